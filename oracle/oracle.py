@@ -1,0 +1,96 @@
+"""numpy/ctypes front-end of oracle/libpvo_oracle.so (the C restatement).
+
+TEST INFRASTRUCTURE ONLY — see oracle/__init__.py.  All arrays are host numpy
+arrays; 16-bit types are carried as numpy float16 or as uint16 bit patterns (bf16).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvo_oracle.so")
+
+O_F32, O_F16, O_BF16, O_F64 = 0, 1, 2, 3
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            import sys
+            sys.path.insert(0, os.path.dirname(_HERE))
+            from pvo_amd.build import build_oracle
+            build_oracle()
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def dtype_code(a, bf16=False):
+    if bf16:
+        assert a.dtype == np.uint16
+        return O_BF16
+    return {np.dtype(np.float32): O_F32, np.dtype(np.float16): O_F16, np.dtype(np.float64): O_F64}[a.dtype]
+
+
+def f32_to_bf16_bits(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    nan = (u & 0x7fffffff) > 0x7f800000
+    r = ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    r[nan] = ((u[nan] >> 16) | 0x40).astype(np.uint16)
+    return r
+
+
+def bf16_bits_to_f32(b):
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def corr_index_forward(volume, coords, radius, contract=True, bf16=False):
+    volume = np.ascontiguousarray(volume); coords = np.ascontiguousarray(coords, dtype=np.float32)
+    N, h1, w1, h2, w2 = volume.shape
+    rd = 2 * radius + 1
+    out = np.zeros((N, rd, rd, h1, w1), dtype=volume.dtype)
+    rc = lib().oracle_corr_index_forward(_p(volume), _p(coords), _p(out), N, h1, w1, h2, w2, radius,
+                                         dtype_code(volume, bf16), int(contract))
+    assert rc == 0
+    return out
+
+
+def corr_index_backward(volume_shape, coords, corr_grad, radius, contract=True, bf16=False):
+    coords = np.ascontiguousarray(coords, dtype=np.float32); corr_grad = np.ascontiguousarray(corr_grad)
+    N, h1, w1, h2, w2 = volume_shape
+    out = np.zeros(volume_shape, dtype=corr_grad.dtype)
+    rc = lib().oracle_corr_index_backward(_p(coords), _p(corr_grad), _p(out), N, h1, w1, h2, w2, radius,
+                                          dtype_code(corr_grad, bf16), int(contract))
+    assert rc == 0
+    return out
+
+
+def corr_pyramid_lookup(pyramid, coords_nhw2, radius, contract=True, bf16=False):
+    pyramid = [np.ascontiguousarray(v) for v in pyramid]
+    coords = np.ascontiguousarray(coords_nhw2, dtype=np.float32)
+    N, h1, w1, h2, w2 = pyramid[0].shape
+    L = len(pyramid)
+    rd = 2 * radius + 1
+    out = np.zeros((N, L * rd * rd, h1, w1), dtype=pyramid[0].dtype)
+    ptrs = (ctypes.c_void_p * L)(*[v.ctypes.data for v in pyramid])
+    rc = lib().oracle_corr_pyramid_lookup(ptrs, _p(coords), _p(out), N, h1, w1, h2, w2, L, radius,
+                                          dtype_code(pyramid[0], bf16), int(contract))
+    assert rc == 0
+    return out
+
+
+def corr_build(fmap1, fmap2, num_levels=4, bf16=False):
+    fmap1 = np.ascontiguousarray(fmap1); fmap2 = np.ascontiguousarray(fmap2)
+    N, C, H, W = fmap1.shape
+    levels = [np.zeros((N, H, W, H >> l, W >> l), dtype=fmap1.dtype) for l in range(num_levels)]
+    ptrs = (ctypes.c_void_p * num_levels)(*[v.ctypes.data for v in levels])
+    rc = lib().oracle_corr_build(_p(fmap1), _p(fmap2), ptrs, N, C, H, W, num_levels, dtype_code(fmap1, bf16))
+    assert rc == 0
+    return levels

@@ -1,0 +1,68 @@
+"""ctypes binding of libpvo_hip.so (the C ABI declared in include/pvo_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is
+missing, or a call returns a non-zero status, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvo_hip.so")
+
+PVO_F32, PVO_F16, PVO_BF16, PVO_F64 = 0, 1, 2, 3
+
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pvo_hip.h one to one
+SIGNATURES = {
+    "pvo_strerror": (_c.c_char_p, [_i]),
+    "pvo_version": (_i, []),
+    "pvo_corr_index_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pvo_corr_index_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pvo_corr_pyramid_lookup": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    # PENDING "pvo_corr_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pvo_frame_distance": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "pvo_projmap": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pvo_iproj": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pvo_depth_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_reproject": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    # PENDING "pvo_ba_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    # PENDING "pvo_ba": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+    # PENDING                 _f, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    # PENDING "pvo_ba_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    # PENDING "pvo_ba_local": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
+    # PENDING                       _i, _vp, _vp, _sz, _vp]),
+    # PENDING "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i,
+    # PENDING                        _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class PvoHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpvo_hip.so, binding every symbol of the header. Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PvoHipError(
+            "libpvo_hip.so not found at %s - build it with `python -m pvo_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pvo_strerror(status).decode()
+        raise PvoHipError("%s failed: %s (status %d)" % (what, msg, status))

@@ -1,0 +1,87 @@
+"""Build libpvo_hip.so (HIP, gfx950 only) and the CPU oracle in-tree.
+
+    python -m pvo_amd.build [--force]
+
+hipcc cross-compiles without a GPU. The shared library has no torch/pybind
+dependency: the drop-in boundary is the C ABI of include/pvo_hip.h.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pvo_amd", "csrc")
+LIB = os.path.join(ROOT, "pvo_amd", "libpvo_hip.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libpvo_oracle.so")
+
+HIP_SOURCES = [
+    "capi_misc.hip",
+    "corr_lookup.hip",
+    "geom.hip",
+]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + "\n")
+        raise RuntimeError("build failed: " + " ".join(cmd[:3]))
+    return r.stdout
+
+
+def build_hip(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "pvo_hip.h"))
+    objs = []
+    procs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            cmd = [hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(" ".join(cmd) + "\n" + out + "\n")
+            raise RuntimeError("hipcc failed on " + cmd[-3])
+        if verbose and out.strip():
+            print(out)
+    if force or procs or _newer(LIB, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in sorted(os.listdir(ORACLE_DIR)) if f.endswith(".c")]
+    hdrs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".h")]
+    if not srcs:
+        return None
+    if force or _newer(ORACLE_LIB, srcs + hdrs):
+        # -ffp-contract=off: the oracle states every rounding explicitly
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+              "-Wall", "-o", ORACLE_LIB] + srcs + ["-lm"])
+    return ORACLE_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_oracle(force)
+
+
+if __name__ == "__main__":
+    f = "--force" in sys.argv
+    print(build_all(force=f, verbose=True))

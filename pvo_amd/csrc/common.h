@@ -1,0 +1,65 @@
+// common.h — shared device/host helpers for libpvo_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pvo_hip.h"
+
+#define PVO_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t _e = hipGetLastError();                       \
+    if (_e != hipSuccess) return PVO_ELAUNCH;                \
+  } while (0)
+
+static inline hipStream_t pvo_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------
+// 16-bit storage types. Arithmetic on them follows the reference's c10::Half
+// model (correlation_kernels.cu:56-65): every * and + is done in fp32 and the
+// result rounded back to the storage type (round-to-nearest-even).
+// ---------------------------------------------------------------------------
+struct pvo_half { _Float16 v; };
+struct pvo_bf16 { uint16_t v; };
+
+__device__ __forceinline__ float pvo_bf16_to_f32(uint16_t h) {
+  return __uint_as_float(static_cast<uint32_t>(h) << 16);
+}
+__device__ __forceinline__ uint16_t pvo_f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x0040u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  using store_t = float;
+  static __device__ __forceinline__ float to_f32(float x) { return x; }
+  static __device__ __forceinline__ float from_f32(float x) { return x; }
+};
+template <> struct Elem<pvo_half> {
+  using store_t = _Float16;
+  static __device__ __forceinline__ float to_f32(_Float16 x) { return static_cast<float>(x); }
+  static __device__ __forceinline__ _Float16 from_f32(float x) { return static_cast<_Float16>(x); }
+};
+template <> struct Elem<pvo_bf16> {
+  using store_t = uint16_t;
+  static __device__ __forceinline__ float to_f32(uint16_t x) { return pvo_bf16_to_f32(x); }
+  static __device__ __forceinline__ uint16_t from_f32(float x) { return pvo_f32_to_bf16(x); }
+};
+
+// floor(x) -> int with saturation (the reference's static_cast<int>(floor(x)),
+// correlation_kernels.cu:49-50; v_cvt_i32_f32 saturates and maps NaN to 0, which
+// is also what the CUDA conversion does). Clamped to +-2^30 so that the +-radius
+// offsets cannot wrap.
+__device__ __forceinline__ int pvo_floor_to_int(float x) {
+  float f = floorf(x);
+  f = fminf(fmaxf(f, -1073741824.0f), 1073741824.0f);
+  return (f != f) ? 0 : static_cast<int>(f);
+}
+
+// wave64 sum via DPP-friendly shuffles
+__device__ __forceinline__ float pvo_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}

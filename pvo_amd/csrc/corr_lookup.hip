@@ -1,0 +1,436 @@
+// corr_lookup.hip — correlation-pyramid lookup for gfx950 (MI355X).
+//
+// Replaces corr_index_forward_kernel / corr_index_backward_kernel
+// (reference VO_Module/src/correlation_kernels.cu:19-70, 73-124) and the Python
+// per-level loop + torch.cat of CorrBlock.__call__ (modules/corr.py:40-50).
+//
+// Design (not a translation of the reference's 16x16 one-thread-per-pixel scatter):
+//   * r == 3 fast path: a 256-thread workgroup owns a strip of 64 consecutive pixels
+//     of one edge.  8 lanes cooperate on one pixel: lane `r` fetches tap ROW r of the
+//     8x8 window as one 16/32-byte segment (dwordx4+dword for 16-bit volumes), the
+//     neighbouring row comes from lane r+1 by a wave shuffle, and the lane produces
+//     the 7 outputs of its row in the reference's accumulation order.  All pyramid
+//     levels are gathered in the same launch; results are transposed through LDS so
+//     that every output channel row is written as one contiguous 64-pixel segment
+//     (the reference does 49 read-modify-writes per pixel on a pre-zeroed tensor).
+//   * generic path (any radius, fp64): one thread per pixel, gather form.
+//
+// Numerics: bit-exact with the reference's arithmetic model.
+//   fp16/bf16: every product and every sum is formed in fp32 and rounded to the
+//              storage type (c10::Half operators), weights are fp32 products rounded
+//              to the storage type; accumulation order per output cell is taps
+//              (a,b), (a,b+1), (a+1,b), (a+1,b+1)   [a: x offset, b: y offset].
+//   fp32/fp64: acc = fma(s, w, acc) — nvcc contracts `corr += s * w` (default
+//              -fmad=true), so the CUDA reference path is an FMA chain.
+// Floating-point contraction is OFF for this file; the FMAs are explicit.
+#pragma clang fp contract(off)
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxLevels = 4;
+constexpr int kStrip = 64;          // pixels per workgroup
+constexpr int kStripPad = 66;       // LDS row stride in elements (keeps 4-byte alignment, spreads banks)
+
+struct LookupLevel {
+  const void* vol;    // [N*HW planes][h2][w2]
+  long long total;    // elements in the level tensor
+  int h2, w2;
+  float scale;        // 1 / 2^level (exact)
+};
+
+struct LookupArgs {
+  LookupLevel lv[kMaxLevels];
+  const float* coords;
+  void* out;
+  int nlev;
+  int coords_interleaved;  // 0: [N,2,h1,w1]   1: [N,h1,w1,2]
+  int HW;                  // h1*w1
+  int N;
+};
+
+template <typename T> struct Arith;  // value domain = float holding a representable value
+template <> struct Arith<float> {
+  static __device__ __forceinline__ float rnd(float x) { return x; }
+  static __device__ __forceinline__ float step(float acc, float s, float w) { return fmaf(s, w, acc); }
+};
+template <> struct Arith<pvo_half> {
+  static __device__ __forceinline__ float rnd(float x) { return static_cast<float>(static_cast<_Float16>(x)); }
+  static __device__ __forceinline__ float step(float acc, float s, float w) { return rnd(acc + rnd(s * w)); }
+};
+template <> struct Arith<pvo_bf16> {
+  static __device__ __forceinline__ float rnd(float x) { return pvo_bf16_to_f32(pvo_f32_to_bf16(x)); }
+  static __device__ __forceinline__ float step(float acc, float s, float w) { return rnd(acc + rnd(s * w)); }
+};
+
+struct __attribute__((packed, aligned(4))) U4A4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ float h16_to_f32(uint32_t bits, pvo_half*) {
+  union { uint16_t u; _Float16 h; } c; c.u = static_cast<uint16_t>(bits);
+  return static_cast<float>(c.h);
+}
+__device__ __forceinline__ float h16_to_f32(uint32_t bits, pvo_bf16*) {
+  return pvo_bf16_to_f32(static_cast<uint16_t>(bits));
+}
+
+// Fetch 8 consecutive 16-bit elements g..g+7 of a level tensor as 4 packed dwords
+// (element 2k in the low half of u[k]).  Elements whose mask bit is clear are never
+// dereferenced outside [0,total); their lanes of u[] hold don't-care bits.
+__device__ __forceinline__ void fetch_row8_16(const uint16_t* base, long long g, long long total,
+                                             uint32_t mask, uint32_t u[4]) {
+  const long long ga = g & ~1LL;
+  u[0] = u[1] = u[2] = u[3] = 0u;
+  if (mask == 0) return;
+  if (ga >= 0 && ga + 10 <= total) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + ga);
+    const U4A4 q = *reinterpret_cast<const U4A4*>(p);
+    const uint32_t q4 = p[4];
+    const uint32_t sh = static_cast<uint32_t>(g & 1) * 2u;  // byte shift
+    u[0] = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
+    u[1] = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
+    u[2] = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+    u[3] = __builtin_amdgcn_alignbyte(q4, q.w, sh);
+  } else {  // first / last few elements of the tensor: guarded element loads
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t e = 0u;
+      if ((mask >> j) & 1u) e = base[g + j];
+      u[j >> 1] |= e << ((j & 1) * 16);
+    }
+  }
+}
+
+__device__ __forceinline__ void fetch_row8_32(const float* base, long long g, uint32_t mask, float v[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = 0.0f;
+    if ((mask >> j) & 1u) v[j] = base[g + j];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack8(const uint32_t u[4], float v[8]) {
+  T* tag = nullptr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[2 * k] = h16_to_f32(u[k] & 0xffffu, tag);
+    v[2 * k + 1] = h16_to_f32(u[k] >> 16, tag);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// r == 3 fast path.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
+  using S = typename Elem<T>::store_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  S* stage = reinterpret_cast<S*>(smem_raw);  // [nlev*49][kStripPad]
+
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int pix0 = blockIdx.x * kStrip;
+  const int row = tid & 7;        // tap row (y offset index) handled by this lane
+  const int HW = a.HW;
+
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int p = pass * 32 + (tid >> 3);
+    const int pix = pix0 + p;
+    const bool pix_ok = pix < HW;
+    float x0 = 0.f, y0 = 0.f;
+    if (pix_ok) {
+      if (a.coords_interleaved) {
+        const float2 c = *reinterpret_cast<const float2*>(a.coords + (static_cast<long long>(n) * HW + pix) * 2);
+        x0 = c.x; y0 = c.y;
+      } else {
+        x0 = a.coords[(static_cast<long long>(n) * 2) * HW + pix];
+        y0 = a.coords[(static_cast<long long>(n) * 2 + 1) * HW + pix];
+      }
+    }
+    const long long plane = static_cast<long long>(n) * HW + pix;
+
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l) {
+      if (l >= a.nlev) break;
+      const LookupLevel L = a.lv[l];
+      const float xs = x0 * L.scale;   // == x0 / 2^l exactly (corr.py:47)
+      const float ys = y0 * L.scale;
+      const float dx = xs - floorf(xs);
+      const float dy = ys - floorf(ys);
+      const int ix = pvo_floor_to_int(xs) - 3;
+      const int iy = pvo_floor_to_int(ys) - 3 + row;
+      const bool rowok = pix_ok && iy >= 0 && iy < L.h2;
+      uint32_t mask = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        mask |= (rowok && static_cast<unsigned>(ix + j) < static_cast<unsigned>(L.w2)) ? (1u << j) : 0u;
+      const long long g = (plane * L.h2 + iy) * L.w2 + ix;
+
+      // own tap row, and the next one (y offset row+1) from lane+1 of this 8-lane group
+      float v[8], vn[8];
+      const uint32_t maskn = __shfl_down(mask, 1, 64);
+      if constexpr (sizeof(S) == 2) {
+        uint32_t u[4], un[4];
+        fetch_row8_16(reinterpret_cast<const uint16_t*>(L.vol), g, L.total, mask, u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) un[k] = __shfl_down(u[k], 1, 64);
+        unpack8<T>(u, v);
+        unpack8<T>(un, vn);
+      } else {
+        fetch_row8_32(reinterpret_cast<const float*>(L.vol), g, mask, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vn[j] = __shfl_down(v[j], 1, 64);
+      }
+
+      // weights: fp32 products rounded to the storage type (correlation_kernels.cu:56-65)
+      const float w11 = Arith<T>::rnd(dx * dy);
+      const float w10 = Arith<T>::rnd(dx * (1.0f - dy));
+      const float w01 = Arith<T>::rnd((1.0f - dx) * dy);
+      const float w00 = Arith<T>::rnd((1.0f - dx) * (1.0f - dy));
+
+      if (row < 7) {
+#pragma unroll
+        for (int ax = 0; ax < 7; ++ax) {
+          // order: taps (ax,row) (ax,row+1) (ax+1,row) (ax+1,row+1); skipped taps leave acc untouched
+          float acc = 0.0f, t;
+          t = Arith<T>::step(acc, v[ax], w00);      acc = ((mask >> ax) & 1u) ? t : acc;
+          t = Arith<T>::step(acc, vn[ax], w01);     acc = ((maskn >> ax) & 1u) ? t : acc;
+          t = Arith<T>::step(acc, v[ax + 1], w10);  acc = ((mask >> (ax + 1)) & 1u) ? t : acc;
+          t = Arith<T>::step(acc, vn[ax + 1], w11); acc = ((maskn >> (ax + 1)) & 1u) ? t : acc;
+          stage[(l * 49 + ax * 7 + row) * kStripPad + p] = Elem<T>::from_f32(acc);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // coalesced write-out: channel rows of 64 pixels
+  const int nch = a.nlev * 49;
+  S* outp = reinterpret_cast<S*>(a.out) + static_cast<long long>(n) * nch * HW;
+  const int npix = min(kStrip, HW - pix0);
+  if constexpr (sizeof(S) == 2) {
+    if (((HW | pix0) & 1) == 0 && (npix & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.out) & 3) == 0)) {
+      const int half = npix >> 1;
+      for (int idx = tid; idx < nch * 32; idx += 256) {
+        const int ch = idx >> 5, c = idx & 31;
+        if (c < half) {
+          const uint32_t val = *reinterpret_cast<const uint32_t*>(&stage[ch * kStripPad + 2 * c]);
+          *reinterpret_cast<uint32_t*>(&outp[static_cast<long long>(ch) * HW + pix0 + 2 * c]) = val;
+        }
+      }
+      return;
+    }
+  }
+  for (int idx = tid; idx < nch * kStrip; idx += 256) {
+    const int ch = idx >> 6, c = idx & 63;
+    if (c < npix) outp[static_cast<long long>(ch) * HW + pix0 + c] = stage[ch * kStripPad + c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// generic path: any radius, also fp64.  One thread per pixel, gather form, same
+// accumulation order and rounding model.
+// ---------------------------------------------------------------------------
+template <typename T> struct GArith {  // 16/32-bit types reuse Arith via float domain
+  using val_t = float;
+  static __device__ __forceinline__ float load(const void* p, long long i) {
+    return Elem<T>::to_f32(reinterpret_cast<const typename Elem<T>::store_t*>(p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, long long i, float v) {
+    reinterpret_cast<typename Elem<T>::store_t*>(p)[i] = Elem<T>::from_f32(v);
+  }
+  static __device__ __forceinline__ float rnd(float x) { return Arith<T>::rnd(x); }
+  static __device__ __forceinline__ float step(float acc, float s, float w) { return Arith<T>::step(acc, s, w); }
+};
+template <> struct GArith<double> {
+  using val_t = double;
+  static __device__ __forceinline__ double load(const void* p, long long i) { return reinterpret_cast<const double*>(p)[i]; }
+  static __device__ __forceinline__ void store(void* p, long long i, double v) { reinterpret_cast<double*>(p)[i] = v; }
+  static __device__ __forceinline__ double rnd(float x) { return static_cast<double>(x); }
+  static __device__ __forceinline__ double step(double acc, double s, double w) { return fma(s, w, acc); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void corr_lookup_generic_kernel(LookupArgs a, int r) {
+  using G = GArith<T>;
+  using V = typename G::val_t;
+  const int HW = a.HW;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (pix >= HW) return;
+  float x0, y0;
+  if (a.coords_interleaved) {
+    x0 = a.coords[(static_cast<long long>(n) * HW + pix) * 2];
+    y0 = a.coords[(static_cast<long long>(n) * HW + pix) * 2 + 1];
+  } else {
+    x0 = a.coords[(static_cast<long long>(n) * 2) * HW + pix];
+    y0 = a.coords[(static_cast<long long>(n) * 2 + 1) * HW + pix];
+  }
+  const int rd = 2 * r + 1;
+  const long long plane = static_cast<long long>(n) * HW + pix;
+  for (int l = 0; l < a.nlev; ++l) {
+    const LookupLevel L = a.lv[l];
+    const float xs = x0 * L.scale, ys = y0 * L.scale;
+    const float dx = xs - floorf(xs), dy = ys - floorf(ys);
+    const int ix = pvo_floor_to_int(xs) - r, iy = pvo_floor_to_int(ys) - r;
+    const V w11 = G::rnd(dx * dy), w10 = G::rnd(dx * (1.0f - dy));
+    const V w01 = G::rnd((1.0f - dx) * dy), w00 = G::rnd((1.0f - dx) * (1.0f - dy));
+    const long long pbase = plane * L.h2 * L.w2;
+    for (int ax = 0; ax < rd; ++ax) {
+      for (int by = 0; by < rd; ++by) {
+        V acc = 0;
+        const int xa = ix + ax, yb = iy + by;
+        const bool x0ok = xa >= 0 && xa < L.w2, x1ok = xa + 1 >= 0 && xa + 1 < L.w2;
+        const bool y0ok = yb >= 0 && yb < L.h2, y1ok = yb + 1 >= 0 && yb + 1 < L.h2;
+        if (x0ok && y0ok) acc = G::step(acc, G::load(L.vol, pbase + static_cast<long long>(yb) * L.w2 + xa), w00);
+        if (x0ok && y1ok) acc = G::step(acc, G::load(L.vol, pbase + static_cast<long long>(yb + 1) * L.w2 + xa), w01);
+        if (x1ok && y0ok) acc = G::step(acc, G::load(L.vol, pbase + static_cast<long long>(yb) * L.w2 + xa + 1), w10);
+        if (x1ok && y1ok) acc = G::step(acc, G::load(L.vol, pbase + static_cast<long long>(yb + 1) * L.w2 + xa + 1), w11);
+        const long long ch = static_cast<long long>(l) * rd * rd + ax * rd + by;
+        G::store(a.out, (static_cast<long long>(n) * a.nlev * rd * rd + ch) * HW + pix, acc);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward: volume_grad[n,y,x,:,:] written densely by one wave per plane
+// (zero outside the (2r+2)^2 window), so no pre-zeroing and no read-modify-write.
+// g accumulates in the reference's order (correlation_kernels.cu:107-118).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void corr_lookup_backward_kernel(
+    const float* __restrict__ coords, const void* __restrict__ corr_grad, void* __restrict__ vol_grad,
+    int N, int HW, int h2, int w2, int r) {
+  using G = GArith<T>;
+  using V = typename G::val_t;
+  const int lane = threadIdx.x & 63;
+  const long long plane = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (plane >= static_cast<long long>(N) * HW) return;
+  const int n = static_cast<int>(plane / HW);
+  const int pix = static_cast<int>(plane - static_cast<long long>(n) * HW);
+  const float x0 = coords[(static_cast<long long>(n) * 2) * HW + pix];
+  const float y0 = coords[(static_cast<long long>(n) * 2 + 1) * HW + pix];
+  const float dx = x0 - floorf(x0), dy = y0 - floorf(y0);
+  const int ix = pvo_floor_to_int(x0) - r, iy = pvo_floor_to_int(y0) - r;
+  const int rd = 2 * r + 1;
+  const V w11 = G::rnd(dx * dy), w10 = G::rnd(dx * (1.0f - dy));
+  const V w01 = G::rnd((1.0f - dx) * dy), w00 = G::rnd((1.0f - dx) * (1.0f - dy));
+  const long long gbase = static_cast<long long>(n) * rd * rd * HW + pix;  // + (i*rd+j)*HW
+  const long long obase = plane * h2 * w2;
+  const int P2 = h2 * w2;
+  for (int e = lane; e < P2; e += 64) {
+    const int y1 = e / w2, x1 = e - y1 * w2;
+    const int i = x1 - ix, j = y1 - iy;   // tap indices in [0, rd]
+    V g = 0;
+    if (i >= 0 && i <= rd && j >= 0 && j <= rd) {
+      if (i > 0 && j > 0)   g = G::step(g, G::load(corr_grad, gbase + static_cast<long long>((i - 1) * rd + (j - 1)) * HW), w11);
+      if (i > 0 && j < rd)  g = G::step(g, G::load(corr_grad, gbase + static_cast<long long>((i - 1) * rd + j) * HW), w10);
+      if (i < rd && j > 0)  g = G::step(g, G::load(corr_grad, gbase + static_cast<long long>(i * rd + (j - 1)) * HW), w01);
+      if (i < rd && j < rd) g = G::step(g, G::load(corr_grad, gbase + static_cast<long long>(i * rd + j) * HW), w00);
+    }
+    G::store(vol_grad, obase + e, g);
+  }
+}
+
+template <typename T>
+int launch_lookup(const LookupArgs& a, int radius, hipStream_t st) {
+  if (a.N == 0 || a.HW == 0) return PVO_OK;
+  if (radius < 0) {  // forced generic path, radius encoded as -(r+1)
+    radius = -radius - 1;
+    dim3 grid((a.HW + 255) / 256, a.N);
+    hipLaunchKernelGGL(corr_lookup_generic_kernel<T>, grid, dim3(256), 0, st, a, radius);
+  } else if (radius == 3) {
+    const size_t lds = static_cast<size_t>(a.nlev) * 49 * kStripPad * sizeof(typename Elem<T>::store_t);
+    dim3 grid((a.HW + kStrip - 1) / kStrip, a.N);
+    hipLaunchKernelGGL(corr_lookup_r3_kernel<T>, grid, dim3(256), lds, st, a);
+  } else {
+    dim3 grid((a.HW + 255) / 256, a.N);
+    hipLaunchKernelGGL(corr_lookup_generic_kernel<T>, grid, dim3(256), 0, st, a, radius);
+  }
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+int launch_lookup_f64(const LookupArgs& a, int radius, hipStream_t st) {
+  if (a.N == 0 || a.HW == 0) return PVO_OK;
+  if (radius < 0) radius = -radius - 1;
+  dim3 grid((a.HW + 255) / 256, a.N);
+  hipLaunchKernelGGL(corr_lookup_generic_kernel<double>, grid, dim3(256), 0, st, a, radius);
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+int dispatch_lookup(const LookupArgs& a, int radius, int dtype, hipStream_t st) {
+  switch (dtype) {
+    case PVO_F32: return launch_lookup<float>(a, radius, st);
+    case PVO_F16: return launch_lookup<pvo_half>(a, radius, st);
+    case PVO_BF16: return launch_lookup<pvo_bf16>(a, radius, st);
+    case PVO_F64: return launch_lookup_f64(a, radius, st);
+    default: return PVO_EINVAL;
+  }
+}
+
+}  // namespace
+
+extern "C" int pvo_corr_index_forward(const void* volume, const float* coords, void* corr,
+                                      int N, int h1, int w1, int h2, int w2,
+                                      int radius, int dtype, void* stream) {
+  if (N < 0 || h1 < 0 || w1 < 0 || h2 < 0 || w2 < 0 || radius < 0) return PVO_EINVAL;
+  if (N == 0 || h1 == 0 || w1 == 0) return PVO_OK;
+  if (!volume && h2 > 0 && w2 > 0) return PVO_EINVAL;
+  if (!coords || !corr) return PVO_EINVAL;
+  if (N > 65535) return PVO_EUNSUPPORTED;
+  LookupArgs a{};
+  a.lv[0] = LookupLevel{volume, static_cast<long long>(N) * h1 * w1 * h2 * w2, h2, w2, 1.0f};
+  a.coords = coords; a.out = corr; a.nlev = 1; a.coords_interleaved = 0; a.HW = h1 * w1; a.N = N;
+  // the 16-bit fast path needs a 4-byte aligned base; odd views use the generic kernel
+  const bool force_generic = (dtype == PVO_F16 || dtype == PVO_BF16) && (reinterpret_cast<uintptr_t>(volume) & 3);
+  return dispatch_lookup(a, force_generic ? -radius - 1 : radius, dtype, pvo_stream(stream));
+}
+
+extern "C" int pvo_corr_pyramid_lookup(const void* const* volumes_host, const float* coords, void* out,
+                                       int N, int h1, int w1, int h2, int w2,
+                                       int num_levels, int radius, int dtype, void* stream) {
+  if (N < 0 || h1 < 0 || w1 < 0 || h2 < 0 || w2 < 0 || radius < 0) return PVO_EINVAL;
+  if (num_levels < 1 || num_levels > kMaxLevels || !volumes_host) return PVO_EINVAL;
+  if (N == 0 || h1 == 0 || w1 == 0) return PVO_OK;
+  if (!coords || !out) return PVO_EINVAL;
+  if (N > 65535) return PVO_EUNSUPPORTED;
+  LookupArgs a{};
+  bool aligned = true;
+  for (int l = 0; l < num_levels; ++l) {
+    const int hl = h2 >> l, wl = w2 >> l;
+    if (!volumes_host[l] && hl > 0 && wl > 0) return PVO_EINVAL;
+    a.lv[l] = LookupLevel{volumes_host[l], static_cast<long long>(N) * h1 * w1 * hl * wl, hl, wl,
+                          1.0f / static_cast<float>(1 << l)};
+    aligned = aligned && ((reinterpret_cast<uintptr_t>(volumes_host[l]) & 3) == 0);
+  }
+  a.coords = coords; a.out = out; a.nlev = num_levels; a.coords_interleaved = 1; a.HW = h1 * w1; a.N = N;
+  if (!aligned && (dtype == PVO_F16 || dtype == PVO_BF16)) return PVO_EINVAL;
+  return dispatch_lookup(a, radius, dtype, pvo_stream(stream));
+}
+
+extern "C" int pvo_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad,
+                                       int N, int h1, int w1, int h2, int w2,
+                                       int radius, int dtype, void* stream) {
+  if (N < 0 || h1 < 0 || w1 < 0 || h2 < 0 || w2 < 0 || radius < 0) return PVO_EINVAL;
+  const long long planes = static_cast<long long>(N) * h1 * w1;
+  if (planes == 0 || h2 == 0 || w2 == 0) return PVO_OK;
+  if (!coords || !corr_grad || !volume_grad) return PVO_EINVAL;
+  const long long nblk = (planes + 3) / 4;
+  if (nblk > 0x7fffffffLL) return PVO_EUNSUPPORTED;
+  hipStream_t st = pvo_stream(stream);
+  dim3 grid(static_cast<unsigned>(nblk)), block(256);
+  switch (dtype) {
+    case PVO_F32: hipLaunchKernelGGL(corr_lookup_backward_kernel<float>, grid, block, 0, st, coords, corr_grad, volume_grad, N, h1 * w1, h2, w2, radius); break;
+    case PVO_F16: hipLaunchKernelGGL(corr_lookup_backward_kernel<pvo_half>, grid, block, 0, st, coords, corr_grad, volume_grad, N, h1 * w1, h2, w2, radius); break;
+    case PVO_BF16: hipLaunchKernelGGL(corr_lookup_backward_kernel<pvo_bf16>, grid, block, 0, st, coords, corr_grad, volume_grad, N, h1 * w1, h2, w2, radius); break;
+    case PVO_F64: hipLaunchKernelGGL(corr_lookup_backward_kernel<double>, grid, block, 0, st, coords, corr_grad, volume_grad, N, h1 * w1, h2, w2, radius); break;
+    default: return PVO_EINVAL;
+  }
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}

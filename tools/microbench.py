@@ -1,0 +1,43 @@
+"""Kernel-level timings on the GPU box (not the contract bench; see bench.py).
+usage: python tools/microbench.py [lookup] [ba] ..."""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pvo_amd import droid_backends as db
+
+
+def timeit(fn, iters=50, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def lookup():
+    dev = torch.device("cuda:0")
+    for dt in (torch.float16, torch.float32):
+        N, H, W = 36, 48, 64
+        pyr = [torch.randn(N, H, W, H >> l, W >> l, device=dev, dtype=dt) for l in range(4)]
+        base = torch.stack(torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy"), -1).float().to(dev)
+        coords = (base[None] + torch.randn(N, H, W, 2, device=dev) * 4).contiguous()
+        us = timeit(lambda: db.corr_pyramid_lookup(pyr, coords, 3))
+        s = pyr[0].element_size()
+        alg = N * H * W * (4 * 64 * s + 8 + 196 * s)
+        print(f"lookup4 {dt} E={N} {H}x{W}: {us:.1f} us  alg {alg/1e6:.1f} MB -> {alg/us/1e6:.3f} TB/s")
+        # per-level reference-style calls
+        cp = coords.permute(0, 3, 1, 2).contiguous()
+        us1 = timeit(lambda: [db.corr_index_forward(pyr[l], cp / 2 ** l, 3) for l in range(4)])
+        print(f"  4x corr_index_forward: {us1:.1f} us")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["lookup"]
+    for w in which:
+        globals()[w]()
