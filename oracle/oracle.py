@@ -94,3 +94,81 @@ def corr_build(fmap1, fmap2, num_levels=4, bf16=False):
     rc = lib().oracle_corr_build(_p(fmap1), _p(fmap2), ptrs, N, C, H, W, num_levels, dtype_code(fmap1, bf16))
     assert rc == 0
     return levels
+
+
+# --------------------------------------------------------------------------- geometry / BA
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64c(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def frame_distance(poses, disps, intrinsics, ii, jj, beta):
+    poses, disps, intrinsics, ii, jj = _f32c(poses), _f32c(disps), _f32c(intrinsics), _i64c(ii), _i64c(jj)
+    out = np.zeros(ii.shape[0], np.float32)
+    lib().oracle_frame_distance(_p(poses), _p(disps), _p(intrinsics), _p(ii), _p(jj), _p(out),
+                                int(ii.shape[0]), disps.shape[1], disps.shape[2], ctypes.c_float(beta))
+    return out
+
+
+def projmap(poses, disps, intrinsics, ii, jj):
+    poses, disps, intrinsics, ii, jj = _f32c(poses), _f32c(disps), _f32c(intrinsics), _i64c(ii), _i64c(jj)
+    E, ht, wd = ii.shape[0], disps.shape[1], disps.shape[2]
+    coords = np.zeros((E, ht, wd, 3), np.float32); valid = np.zeros((E, ht, wd, 1), np.float32)
+    lib().oracle_projmap(_p(poses), _p(disps), _p(intrinsics), _p(ii), _p(jj), _p(coords), _p(valid), E, ht, wd)
+    return coords, valid
+
+
+def iproj(poses, disps, intrinsics):
+    poses, disps, intrinsics = _f32c(poses), _f32c(disps), _f32c(intrinsics)
+    N, ht, wd = disps.shape
+    pts = np.zeros((N, ht, wd, 3), np.float32)
+    lib().oracle_iproj(_p(poses), _p(disps), _p(intrinsics), _p(pts), N, ht, wd)
+    return pts
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    poses, disps, intrinsics, ix, thresh = _f32c(poses), _f32c(disps), _f32c(intrinsics), _i64c(ix), _f32c(thresh)
+    N, (nf, ht, wd) = ix.shape[0], disps.shape
+    out = np.zeros((N, ht, wd), np.float32)
+    lib().oracle_depth_filter(_p(poses), _p(disps), _p(intrinsics), _p(ix), _p(thresh), _p(out), N, nf, ht, wd)
+    return out
+
+
+def reproject(poses, disps, intrinsics, ii, jj):
+    poses, disps, intrinsics, ii, jj = _f32c(poses), _f32c(disps), _f32c(intrinsics), _i64c(ii), _i64c(jj)
+    E, ht, wd = ii.shape[0], disps.shape[1], disps.shape[2]
+    coords = np.zeros((E, ht, wd, 2), np.float32); valid = np.zeros((E, ht, wd, 1), np.float32)
+    lib().oracle_reproject(_p(poses), _p(disps), _p(intrinsics), _p(ii), _p(jj), _p(coords), _p(valid), E, ht, wd)
+    return coords, valid
+
+
+def ba(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep,
+       motion_only=False, xi45_zero=False, evt_skip_first=True, want_sys=False):
+    """Returns dict(poses, disps, dx, dz, K, failed[, sys]); inputs are not modified."""
+    poses, disps = _f32c(poses).copy(), _f32c(disps).copy()
+    intrinsics, targets, weights = _f32c(intrinsics), _f32c(targets), _f32c(weights)
+    ii, jj = _i64c(ii), _i64c(jj)
+    nf, ht, wd = disps.shape
+    E, P = ii.shape[0], t1 - t0
+    if eta is None:
+        eta = np.zeros((1, ht, wd), np.float32)
+    eta = _f32c(eta).reshape(-1, ht, wd)
+    dx = np.zeros((max(P, 0), 6), np.float32)
+    dz = np.zeros((P + E + 1, ht * wd), np.float32)
+    sys_ = np.zeros((6 * P) * (6 * P) + 6 * P, np.float64)
+    status = np.zeros(4, np.int32)
+    f = lib().oracle_ba
+    f.restype = ctypes.c_int
+    K = f(_p(poses), _p(disps), _p(intrinsics), _p(targets), _p(weights), _p(eta), _p(ii), _p(jj),
+          E, nf, ht, wd, eta.shape[0], t0, t1, iterations, ctypes.c_float(lm), ctypes.c_float(ep),
+          int(motion_only), _p(dx), _p(dz), _p(sys_) if want_sys else None, _p(status),
+          int(xi45_zero), int(evt_skip_first))
+    if K < 0:
+        raise ValueError("oracle_ba failed with %d" % K)
+    out = dict(poses=poses, disps=disps, dx=dx, dz=dz[:K], K=K, failed=bool(status[0]))
+    if want_sys:
+        out["sys"] = sys_
+    return out

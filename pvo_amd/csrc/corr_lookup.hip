@@ -56,7 +56,13 @@ template <> struct Arith<float> {
   static __device__ __forceinline__ float step(float acc, float s, float w) { return fmaf(s, w, acc); }
 };
 template <> struct Arith<pvo_half> {
-  static __device__ __forceinline__ float rnd(float x) { return static_cast<float>(static_cast<_Float16>(x)); }
+  // The fp32 value is made opaque before the conversion: hipcc otherwise fuses
+  // `half(a*b)` into v_fma_mixlo_f16, which rounds the exact product ONCE to fp16;
+  // the reference rounds to fp32 first and then to fp16 (scalar_t(dx*dy)).
+  static __device__ __forceinline__ float rnd(float x) {
+    asm volatile("" : "+v"(x));
+    return static_cast<float>(static_cast<_Float16>(x));
+  }
   static __device__ __forceinline__ float step(float acc, float s, float w) { return rnd(acc + rnd(s * w)); }
 };
 template <> struct Arith<pvo_bf16> {

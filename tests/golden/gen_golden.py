@@ -1,0 +1,204 @@
+"""Generate golden fixtures from the REFERENCE's own Python, run in the build container.
+
+    python tests/golden/gen_golden.py          (needs /root/reference; never runs on the GPU box)
+
+What is executed is the reference's code, imported from /root/reference/VO_Module/droid_slam:
+  geom/ba.py (BA, MoBA), geom/chol.py, geom/projective_ops.py      -> ba_python_*.npz, projective_*.npz
+  modules/corr.py  CorrBlock.corr + pyramid construction            -> corr_volume.npz
+  modules/gru.py, droid_net.py (DynamicUpdateModule sub-modules, GraphAgg) -> update_op.npz
+  geom/graph_utils.py graph_to_edge_list                            -> (used for the edge lists)
+
+Three native dependencies of that Python cannot be built in this image (lietorch's C++
+extension needs Eigen/Core, which the vendored Eigen lacks; torch_scatter and the
+droid_backends CUDA extension are absent).  They are substituted at import time:
+  lietorch       -> pvo_amd.geom.se3.SE3 (the product's SE3, itself pinned by lietorch's
+                    property tests, tests/test_se3.py)
+  torch_scatter  -> scatter_sum / scatter_mean written with index_add_
+  droid_backends -> an empty module (corr.py:4 imports it; nothing here calls it)
+Only DATA is written: inputs, outputs and seeds.  No reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/VO_Module/droid_slam"
+sys.path.insert(0, ROOT)
+
+
+def install_substitutes():
+    from pvo_amd.geom import se3 as myse3
+
+    lt = types.ModuleType("lietorch")
+    lt.SE3 = myse3.SE3
+
+    class _Absent:  # Sim3 / SO3 are imported by name but never instantiated on this path
+        pass
+    lt.Sim3 = type("Sim3", (_Absent,), {})
+    lt.SO3 = type("SO3", (_Absent,), {})
+    lt.cat = myse3.cat
+    lt.stack = myse3.stack
+    sys.modules["lietorch"] = lt
+
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
+        dim = dim % src.dim()
+        if dim_size is None:
+            dim_size = int(index.max()) + 1 if index.numel() else 0
+        shape = list(src.shape)
+        shape[dim] = dim_size
+        res = torch.zeros(shape, dtype=src.dtype, device=src.device)
+        return res.index_add_(dim, index.to(src.device), src)
+
+    def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
+        s = scatter_sum(src, index, dim, None, dim_size)
+        cnt = torch.zeros(s.shape[dim % src.dim()], dtype=src.dtype, device=src.device)
+        cnt.index_add_(0, index.to(src.device), torch.ones(index.shape[0], dtype=src.dtype, device=src.device))
+        shape = [1] * s.dim()
+        shape[dim % src.dim()] = -1
+        return s / cnt.clamp(min=1).view(shape)
+
+    ts.scatter_sum, ts.scatter_mean = scatter_sum, scatter_mean
+    sys.modules["torch_scatter"] = ts
+    sys.modules["droid_backends"] = types.ModuleType("droid_backends")
+    for m in ("cv2", "matplotlib", "matplotlib.pyplot"):
+        if m not in sys.modules:
+            try:
+                __import__(m)
+            except Exception:
+                sys.modules[m] = types.ModuleType(m)
+    sys.path.insert(0, REF)
+
+
+def make_scene(seed, P=5, ht=8, wd=10, radius=2, noise=0.05):
+    """A small synthetic window: smooth depth > 0.25 everywhere, gentle motion."""
+    g = torch.Generator().manual_seed(seed)
+    from pvo_amd.geom.se3 import SE3
+    intr = torch.tensor([wd * 0.8, wd * 0.8, wd / 2.0, ht / 2.0])
+    xi = torch.tensor([0.06, 0.01, 0.03, 0.004, 0.012, -0.006])
+    poses_gt = torch.stack([SE3.exp(k * xi).data for k in range(P)], 0)
+    low = torch.rand(1, 1, 3, 4, generator=g) * 0.8 + 0.4
+    disps_gt = torch.nn.functional.interpolate(low, size=(ht, wd), mode="bilinear", align_corners=True)[0, 0]
+    disps_gt = disps_gt[None].repeat(P, 1, 1) * (1.0 + 0.05 * torch.arange(P).view(P, 1, 1))
+    ii, jj = [], []
+    for i in range(P):
+        for j in range(P):
+            if i != j and abs(i - j) <= radius:
+                ii.append(i); jj.append(j)
+    ii, jj = torch.tensor(ii), torch.tensor(jj)
+    import geom.projective_ops as pops
+    coords_gt, _ = pops.projective_transform(SE3(poses_gt[None]), disps_gt[None], intr[None, None].repeat(1, P, 1), ii, jj)
+    E = ii.shape[0]
+    target = coords_gt[0] + noise * torch.randn(E, ht, wd, 2, generator=g)
+    weight = torch.rand(E, ht, wd, 2, generator=g)
+    # initial state: poses lag one frame behind, depth is flat
+    poses0 = torch.stack([SE3.exp(max(k - 1, 0) * xi).data if k > 0 else poses_gt[0] for k in range(P)], 0)
+    poses0[1] = SE3.exp(0.5 * xi).data
+    disps0 = torch.full((P, ht, wd), 0.7)
+    eta = 0.05 + 0.1 * torch.rand(P, ht, wd, generator=g)
+    return dict(intr=intr, poses=poses0, disps=disps0, target=target, weight=weight, eta=eta, ii=ii, jj=jj)
+
+
+def gen_ba():
+    from pvo_amd.geom.se3 import SE3
+    from geom.ba import BA, MoBA
+    import geom.projective_ops as pops
+    for name, seed, P, ht, wd, fixedp in [("a", 0, 5, 8, 10, 1), ("b", 1, 4, 6, 9, 2)]:
+        s = make_scene(seed, P, ht, wd)
+        intr_all = s["intr"][None, None].repeat(1, P, 1)
+        out = {k: v.numpy() for k, v in s.items()}
+        out["fixedp"] = np.int64(fixedp)
+        # one reprojection with Jacobians (pins coords/valid and, through BA, the Jacobians)
+        coords, valid = pops.projective_transform(SE3(s["poses"][None]), s["disps"][None], intr_all, s["ii"], s["jj"])
+        out["reproj_coords"] = coords[0].numpy(); out["reproj_valid"] = valid[0].numpy()
+        Gs, disps = SE3(s["poses"][None].clone()), s["disps"][None].clone()
+        for it in range(2):
+            # the reference adds 1e-7 to C on top of eta (ba.py:91); the native path does not
+            Gs, disps = BA(s["target"][None], s["weight"][None], s["eta"][None] - 1e-7, Gs, disps,
+                           intr_all, s["ii"], s["jj"], fixedp=fixedp)
+            out["ba_poses_%d" % (it + 1)] = Gs.data[0].numpy().copy()
+            out["ba_disps_%d" % (it + 1)] = disps[0].numpy().copy()
+        Gm = MoBA(s["target"][None], s["weight"][None], None, SE3(s["poses"][None].clone()), s["disps"][None],
+                  intr_all, s["ii"], s["jj"], fixedp=fixedp)
+        out["moba_poses_1"] = Gm.data[0].numpy().copy()
+        np.savez_compressed(os.path.join(HERE, "ba_python_%s.npz" % name), **out)
+        print("ba_python_%s: P=%d E=%d %dx%d" % (name, P, s["ii"].shape[0], ht, wd))
+
+
+def gen_corr():
+    from modules.corr import CorrBlock
+    g = torch.Generator().manual_seed(2)
+    N, C, H, W = 1, 32, 16, 16   # the reference pools once more than it keeps (corr.py:35-38): H,W >= 16
+    f1 = torch.randn(1, N, C, H, W, generator=g)
+    f2 = torch.randn(1, N, C, H, W, generator=g)
+    out = dict(fmap1=f1[0].numpy(), fmap2=f2[0].numpy())
+    cb = CorrBlock(f1, f2, num_levels=4, radius=3)
+    for l, lv in enumerate(cb.corr_pyramid):
+        out["level%d_f32" % l] = lv.numpy()
+    cbh = CorrBlock(f1.half(), f2.half(), num_levels=4, radius=3)
+    for l, lv in enumerate(cbh.corr_pyramid):
+        out["level%d_f16" % l] = lv.numpy()
+    np.savez_compressed(os.path.join(HERE, "corr_volume.npz"), **out)
+    print("corr_volume: N=%d C=%d %dx%d" % (N, C, H, W))
+
+
+def gen_update_op():
+    """DynamicUpdateModule, executed sub-module by sub-module in the order of
+    droid_net.py:276-303 (its forward() itself raises on np.range at :295)."""
+    import droid_net
+    torch.manual_seed(0)
+    upd = droid_net.DynamicUpdateModule()
+    upd.eval()
+    g = torch.Generator().manual_seed(3)
+    E, ht, wd = 3, 6, 8
+    net = torch.tanh(torch.randn(1, E, 128, ht, wd, generator=g))
+    inp = torch.relu(torch.randn(1, E, 128, ht, wd, generator=g))
+    corr = torch.randn(1, E, 196, ht, wd, generator=g)
+    motion = torch.randn(1, E, 8, ht, wd, generator=g).clamp(-64, 64)
+    ii = torch.tensor([0, 0, 1])
+    with torch.no_grad():
+        n_ = net.view(E, -1, ht, wd); i_ = inp.view(E, -1, ht, wd)
+        c_ = upd.corr_encoder(corr.view(E, -1, ht, wd))
+        f_ = upd.flow_encoder(motion.view(E, -1, ht, wd))
+        n_ = upd.gru(n_, i_, c_, f_)
+        delta = upd.delta(n_); delta_dy = upd.delta_dy(n_); weight = upd.weight(n_); delta_m = upd.delta_mask(n_)
+        eta, upmask, _, _ = upd.agg(n_.view(1, E, 128, ht, wd), ii)
+    sd = upd.state_dict()
+    keys = sorted(sd.keys())
+    digest = np.array([float(sd[k].double().sum()) for k in keys])
+    np.savez_compressed(os.path.join(HERE, "update_op.npz"),
+                        net=net.numpy(), inp=inp.numpy(), corr=corr.numpy(), motion=motion.numpy(), ii=ii.numpy(),
+                        out_net=n_.numpy(), out_delta=delta.numpy(), out_delta_dy=delta_dy.numpy(),
+                        out_weight=weight.numpy(), out_delta_m=delta_m.numpy(), out_eta=eta.numpy(),
+                        out_upmask=upmask.numpy(), state_keys=np.array(keys), state_sums=digest,
+                        state_shapes=np.array([str(tuple(sd[k].shape)) for k in keys]))
+    print("update_op: %d state tensors, %d params" % (len(keys), sum(v.numel() for v in sd.values())))
+
+
+def gen_graph():
+    """FactorGraph.update glue (factor_graph.py:227-307) with a recorded update operator:
+    inputs/outputs of the arithmetic between the update operator and the BA call."""
+    import geom.graph_utils as gu
+    from collections import OrderedDict
+    graph = OrderedDict()
+    for i in range(4):
+        graph[i] = [j for j in range(4) if i != j and abs(i - j) <= 2]
+    ii, jj, kk = gu.graph_to_edge_list(graph)
+    np.savez_compressed(os.path.join(HERE, "graph_edges.npz"), ii=ii.numpy(), jj=jj.numpy(), kk=kk.numpy())
+    print("graph_edges: E=%d" % ii.shape[0])
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
+    install_substitutes()
+    torch.set_num_threads(4)
+    gen_ba()
+    gen_corr()
+    gen_update_op()
+    gen_graph()

@@ -1,0 +1,91 @@
+"""SE3 facade: the property tests of the reference's lietorch suite
+(thirdparty/lietorch/lietorch/run_tests.py:16-54), fp64, atol 1e-8."""
+import torch
+
+from pvo_amd.geom.se3 import SE3
+
+
+def _rand(n=64, sigma=1.0):
+    torch.manual_seed(0)
+    return SE3.Random(n, sigma=sigma, dtype=torch.float64)
+
+
+def test_exp_log():
+    torch.manual_seed(1)
+    a = 0.2 * torch.randn(256, 6, dtype=torch.float64)
+    assert torch.allclose(SE3.exp(a).log(), a, atol=1e-8)
+    small = 1e-8 * torch.randn(16, 6, dtype=torch.float64)
+    assert torch.allclose(SE3.exp(small).log(), small, atol=1e-12)
+
+
+def test_inv():
+    X = _rand()
+    I = SE3.IdentityLike(X)
+    assert torch.allclose((X * X.inv()).log(), I.log(), atol=1e-8)
+    assert torch.allclose((X.inv() * X).data, I.data, atol=1e-8)
+
+
+def test_adj():
+    X = _rand()
+    torch.manual_seed(2)
+    a = torch.randn(64, 6, dtype=torch.float64)
+    b = X.adj(a)
+    Y1 = X * SE3.exp(a)
+    Y2 = SE3.exp(b) * X
+    assert torch.allclose((Y1 * Y2.inv()).log(), torch.zeros(64, 6, dtype=torch.float64), atol=1e-8)
+
+
+def test_adjT_is_transpose_of_adj():
+    X = _rand()
+    torch.manual_seed(3)
+    a = torch.randn(64, 6, dtype=torch.float64)
+    b = torch.randn(64, 6, dtype=torch.float64)
+    assert torch.allclose((X.adj(a) * b).sum(-1), (a * X.adjT(b)).sum(-1), atol=1e-10)
+
+
+def test_act_matches_matrix():
+    X = _rand()
+    torch.manual_seed(4)
+    p = torch.randn(64, 3, dtype=torch.float64)
+    T = X.matrix()
+    ph = torch.cat([p, torch.ones(64, 1, dtype=torch.float64)], -1)
+    assert torch.allclose(X.act(p), (T @ ph[..., None])[..., :3, 0], atol=1e-10)
+    q = torch.randn(64, 4, dtype=torch.float64)
+    assert torch.allclose(X.act(q), (T @ q[..., None])[..., 0], atol=1e-10)
+
+
+def test_retr_and_broadcast():
+    X = _rand(8)
+    a = torch.zeros(8, 6, dtype=torch.float64)
+    assert torch.allclose(X.retr(a).data, X.data, atol=1e-12)
+    p = torch.randn(8, 5, 7, 4, dtype=torch.float64)
+    out = X[:, None, None] * p
+    assert out.shape == p.shape
+    assert torch.allclose(out[3, 2, 1], (X[3] * p[3, 2, 1]))
+
+
+def test_matches_oracle_se3_helpers():
+    """fp32 agreement with the restated CUDA helpers (droid_kernels.cu:58-107,856-874)."""
+    import ctypes
+    import numpy as np
+    from oracle import oracle as O
+    lib = O.lib()
+    torch.manual_seed(5)
+    Gi, Gj = SE3.Random(1, sigma=0.5).data[0], SE3.Random(1, sigma=0.5).data[0]
+    out = np.zeros(7, np.float32)
+    fp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    gi, gj = Gi.numpy().copy(), Gj.numpy().copy()
+    lib.oracle_relSE3(fp(gi), fp(gj), fp(out))
+    want = (SE3(Gj) * SE3(Gi).inv()).data.numpy()
+    assert np.allclose(out, want, atol=1e-6)
+    a = np.random.default_rng(0).standard_normal(6).astype(np.float32)
+    y = np.zeros(6, np.float32)
+    lib.oracle_adjSE3(fp(gi), fp(a), fp(y))
+    assert np.allclose(y, SE3(Gi).adjT(torch.from_numpy(a)).numpy(), atol=1e-5)
+    xi = (0.05 * np.random.default_rng(1).standard_normal(6)).astype(np.float32)
+    p1 = np.zeros(7, np.float32)
+    lib.oracle_retrSE3(fp(xi), fp(gi), fp(p1), 0)
+    assert np.allclose(p1, SE3(Gi).retr(torch.from_numpy(xi)).data.numpy(), atol=1e-6)
+    # the xi[45] read (droid_kernels.cu:154) as "returned 0": translation differs visibly
+    lib.oracle_retrSE3(fp(xi), fp(gi), fp(p1), 1)
+    assert np.abs(p1[:3] - SE3(Gi).retr(torch.from_numpy(xi)).data.numpy()[:3]).max() > 1e-6
