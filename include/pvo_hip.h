@@ -95,8 +95,8 @@ int pvo_iproj(const float* poses, const float* disps, const float* intrinsics,
               float* points, int N, int ht, int wd, void* stream);
 
 /* droid_backends.depth_filter (droid.cpp:217-231; droid_kernels.cu:640-754,1467-1491).
- * ix [N] int64, thresh [N], counter [N,ht,wd] (must be zero on entry: the six
- * neighbour views vote into it). nframes = disps.size(0). */
+ * ix [N] int64, thresh [N], counter [N,ht,wd] (overwritten: the six neighbour views
+ * are summed in-register instead of six atomicAdd passes). nframes = disps.size(0). */
 int pvo_depth_filter(const float* poses, const float* disps, const float* intrinsics,
                      const int64_t* ix, const float* thresh, float* counter,
                      int N, int nframes, int ht, int wd, void* stream);
@@ -107,6 +107,63 @@ int pvo_depth_filter(const float* poses, const float* disps, const float* intrin
 int pvo_reproject(const float* poses, const float* disps, const float* intrinsics,
                   const int64_t* ii, const int64_t* jj, float* coords, float* valid,
                   int E, int ht, int wd, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Dense bundle adjustment                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* Scratch needed by pvo_ba for a graph of E edges over a pose window of
+ * P = t1 - t0 poses, frame ids < nframes, maps of HW pixels. */
+size_t pvo_ba_workspace_bytes(int E, int P, int nframes, int HW);
+
+/* droid_backends.ba (droid.cpp:87-114; ba_cuda droid_kernels.cu:1293-1410).
+ *   poses [nframes,7] and disps [nframes,ht,wd] are UPDATED IN PLACE
+ *   intrinsics [4]; targets, weights [E,2,ht,wd]; eta [K_eta,ht,wd];
+ *   ii, jj [E] int64; pose window [t0,t1); `iterations` Gauss-Newton steps
+ *   dx_out [t1-t0,6]; dz_out [dz_rows,ht*wd] (may be NULL) receive the last step
+ * K (number of depth maps optimised) = |unique([t0..t1) U ii)|; eta must have K
+ * rows, or 1 row which is then broadcast; dz_rows >= K unless dz_out is NULL.
+ * status_out (device int[4], may be NULL): [0]=0 ok / 1 non-SPD in some iteration
+ * (that step's dx is 0, as droid_kernels.cu:1186-1189), [1]=K found on device,
+ * [2]=1 if K_eta mismatched K, [3] reserved.
+ * The depth back-substitution reproduces EvT6x1_kernel's skip of window pose 0
+ * (droid_kernels.cu:1084).  expSE3 uses xi[5] where the reference reads xi[45] (:154).
+ * No host synchronisation: the factor-graph index structures are built on the
+ * device, the (6P)^2 system is factorised in fp64 by one workgroup. */
+int pvo_ba(float* poses, float* disps, const float* intrinsics,
+           const float* targets, const float* weights, const float* eta,
+           const int64_t* ii, const int64_t* jj,
+           int E, int nframes, int ht, int wd, int K_eta,
+           int t0, int t1, int iterations, float lm, float ep, int motion_only,
+           float* dx_out, float* dz_out, int dz_rows, int* status_out,
+           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Edge-sharded BA: one Gauss-Newton step split at the point where
+ * ranks exchange the reduced pose system.
+ *   pvo_ba_local : assemble this rank's edges, eliminate its depth maps, and write
+ *                  the rank-local reduced system sys[(6P)*(6P) + 6P] (fp64:
+ *                  row-major A-S followed by the rhs), no damping applied yet.
+ *   -- caller all-reduces (sum) `sys` across ranks --
+ *   pvo_ba_finish: damp + factorise + solve on every rank (identical input ->
+ *                  identical dx), retract poses, back-substitute this rank's dz.
+ * With one rank pvo_ba == plan + iterations x (local, finish).  pvo_ba_plan must run
+ * before the first pvo_ba_local of a graph (same workspace); pass K_eta = -1 for a
+ * motion-only plan. */
+int pvo_ba_plan(const int64_t* ii, const int64_t* jj, int E, int nframes, int HW,
+                int K_eta, int t0, int t1, void* workspace, size_t workspace_bytes,
+                void* stream);
+int pvo_ba_local(const float* poses, const float* disps, const float* intrinsics,
+                 const float* targets, const float* weights, const float* eta,
+                 const int64_t* ii, const int64_t* jj,
+                 int E, int nframes, int ht, int wd, int K_eta, int t0, int t1,
+                 int motion_only, double* sys,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int pvo_ba_finish(float* poses, float* disps, const double* sys,
+                  const int64_t* ii, const int64_t* jj,
+                  int E, int nframes, int ht, int wd, int t0, int t1,
+                  float lm, float ep, int motion_only,
+                  float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

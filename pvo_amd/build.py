@@ -19,6 +19,7 @@ HIP_SOURCES = [
     "capi_misc.hip",
     "corr_lookup.hip",
     "geom.hip",
+    "ba.hip",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

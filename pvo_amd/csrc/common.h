@@ -57,9 +57,25 @@ __device__ __forceinline__ int pvo_floor_to_int(float x) {
   return (f != f) ? 0 : static_cast<int>(f);
 }
 
-// wave64 sum via DPP-friendly shuffles
+// wave64 sum without LDS traffic: four DPP butterfly steps inside each 16-lane row
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row sums are
+// combined through v_readlane.  The result is uniform across the wave.
+// (`__shfl_down` lowers to ds_bpermute_b32: measured 270 ns per 6-step reduction in the
+// BA kernels, 3x the cost of everything else in them.)
+template <int CTRL>
+__device__ __forceinline__ float pvo_dpp_step(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(moved);
+}
 __device__ __forceinline__ float pvo_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v = pvo_dpp_step<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = pvo_dpp_step<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = pvo_dpp_step<0x141>(v);   // row_half_mirror
+  v = pvo_dpp_step<0x140>(v);   // row_mirror
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }

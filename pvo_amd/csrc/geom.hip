@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void depth_filter_kernel(
       else if (fabs(idj - 1.0 / static_cast<double>(d11)) < t) votes += 1.0f;
     }
   }
-  counter[static_cast<long long>(b) * HW + k] += votes;
+  counter[static_cast<long long>(b) * HW + k] = votes;
 }
 
 // projective_ops.py:102-130 with jacobian=False; per-frame intrinsics [nframes,4]

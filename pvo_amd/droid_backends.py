@@ -137,3 +137,134 @@ def corr_pyramid_lookup(pyramid, coords, radius):
                                           _dtype_code(pyramid[0], "volume"), _stream(dev)),
               "corr_pyramid_lookup")
     return out
+
+
+# --------------------------------------------------------------------------- reprojection family
+def frame_distance(poses, disps, intrinsics, ii, jj, beta):
+    """droid.cpp:117-133 -> dist [M]."""
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _contig(t, n)
+    dev = _dev(poses, disps, intrinsics, ii, jj)
+    _f32(poses, "poses"); _f32(disps, "disps"); _f32(intrinsics, "intrinsics"); _long(ii, "ii"); _long(jj, "jj")
+    M = ii.shape[0]
+    dist = torch.empty(M, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_frame_distance(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj),
+                                             _ptr(dist), M, disps.shape[1], disps.shape[2], float(beta),
+                                             _stream(dev)), "frame_distance")
+    return dist
+
+
+def projmap(poses, disps, intrinsics, ii, jj):
+    """droid.cpp:136-151 -> [coords [E,ht,wd,3], valid [E,ht,wd,1]]."""
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _contig(t, n)
+    dev = _dev(poses, disps, intrinsics, ii, jj)
+    _long(ii, "ii"); _long(jj, "jj")
+    E, ht, wd = ii.shape[0], disps.shape[1], disps.shape[2]
+    coords = torch.empty(E, ht, wd, 3, dtype=torch.float32, device=dev)
+    valid = torch.empty(E, ht, wd, 1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_projmap(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj),
+                                      _ptr(coords), _ptr(valid), E, ht, wd, _stream(dev)), "projmap")
+    return [coords, valid]
+
+
+def iproj(poses, disps, intrinsics):
+    """droid.cpp:154-163 -> points [N,ht,wd,3]."""
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics")):
+        _contig(t, n)
+    dev = _dev(poses, disps, intrinsics)
+    N, ht, wd = disps.shape
+    pts = torch.empty(N, ht, wd, 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_iproj(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(pts), N, ht, wd,
+                                    _stream(dev)), "iproj")
+    return pts
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """droid.cpp:217-231 -> counter [N,ht,wd]."""
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ix, "ix"), (thresh, "thresh")):
+        _contig(t, n)
+    dev = _dev(poses, disps, intrinsics, ix, thresh)
+    _long(ix, "ix"); _f32(thresh, "thresh")
+    N, (nf, ht, wd) = ix.shape[0], disps.shape
+    counter = torch.empty(N, ht, wd, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_depth_filter(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ix), _ptr(thresh),
+                                           _ptr(counter), N, nf, ht, wd, _stream(dev)), "depth_filter")
+    return counter
+
+
+def reproject(poses, disps, intrinsics, ii, jj):
+    """DepthVideo.reproject (depth_video.py:154-163): poses [F,7], disps [F,ht,wd],
+    intrinsics [F,4] -> coords [E,ht,wd,2], valid [E,ht,wd,1]."""
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _contig(t, n)
+    dev = _dev(poses, disps, intrinsics, ii, jj)
+    _long(ii, "ii"); _long(jj, "jj")
+    E, ht, wd = ii.shape[0], disps.shape[1], disps.shape[2]
+    coords = torch.empty(E, ht, wd, 2, dtype=torch.float32, device=dev)
+    valid = torch.empty(E, ht, wd, 1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_reproject(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj),
+                                        _ptr(coords), _ptr(valid), E, ht, wd, _stream(dev)), "reproject")
+    return coords, valid
+
+
+# --------------------------------------------------------------------------- bundle adjustment
+def ba(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only,
+       status=None):
+    """droid.cpp:87-114 / ba_cuda droid_kernels.cu:1293-1410.
+
+    poses [F,7] and disps [F,ht,wd] are updated IN PLACE; returns [dx [P,6], dz [K,ht*wd]]
+    (dz is an empty tensor when motion_only, where the reference returns an undefined one).
+    Fully asynchronous: no host synchronisation.  `status` (optional int32[4] device tensor)
+    receives [non-SPD seen, K, eta-row mismatch, 0]."""
+    for t, n in ((targets, "targets"), (weights, "weights"), (poses, "poses"), (disps, "disps"),
+                 (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _contig(t, n)      # droid.cpp:103-109 checks exactly these
+    dev = _dev(poses, disps, intrinsics, targets, weights, eta, ii, jj)
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (targets, "targets"),
+                 (weights, "weights")):
+        _f32(t, n)
+    _long(ii, "ii"); _long(jj, "jj")
+    F, ht, wd = disps.shape
+    HW = ht * wd
+    E = ii.shape[0]
+    t0, t1 = int(t0), int(t1)
+    P = t1 - t0
+    if poses.shape[0] < t1 or F < t1:
+        raise PvoHipError("ba: pose window [%d,%d) exceeds the buffers (%d poses, %d depth maps)"
+                          % (t0, t1, poses.shape[0], F))
+    if eta is not None and not motion_only:
+        _f32(eta, "eta")
+        eta = eta.contiguous().view(-1, HW)     # droid_kernels.cu:1376 eta.view({-1, ht*wd})
+        K_eta = eta.shape[0]
+    else:
+        K_eta = 1
+        if not motion_only:
+            raise PvoHipError("ba: eta is required unless motion_only")
+    # K = |unique([t0,t1) U ii)| is only known on the device.  eta carries one row per depth
+    # map (the reference's C + eta broadcast requires it), so K == K_eta unless eta is a single
+    # broadcast row; only then is K read back (one sync) to size dz.
+    if motion_only:
+        K = 0
+    elif K_eta > 1 or E + P == 0:
+        K = K_eta if E + P > 0 else 0
+    else:
+        K = int(torch.unique(torch.cat([torch.arange(t0, t1, device=dev), ii])).numel())
+    dx = torch.zeros(max(P, 0), 6, dtype=torch.float32, device=dev)
+    dz = torch.zeros(K, HW, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.pvo_ba_workspace_bytes(E, P, F, HW)
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        check(lib.pvo_ba(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(targets), _ptr(weights),
+                         _ptr(eta) if eta is not None else ctypes.c_void_p(0), _ptr(ii), _ptr(jj),
+                         E, F, ht, wd, K_eta, t0, t1, int(iterations), float(lm), float(ep),
+                         1 if motion_only else 0, _ptr(dx), _ptr(dz), K,
+                         _ptr(status) if status is not None else ctypes.c_void_p(0),
+                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)), "ba")
+    return [dx, dz]

@@ -37,6 +37,28 @@ def lookup():
         print(f"  4x corr_index_forward: {us1:.1f} us")
 
 
+def ba():
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from test_geom_ba_gpu import _scene
+    dev = torch.device("cuda:0")
+    s = _scene(0, 8, 48, 64, 3, 1)
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()}
+    poses0, disps0 = d["poses"].clone(), d["disps"].clone()
+    def run(iters):
+        poses, disps = poses0.clone(), disps0.clone()
+        db.ba(poses, disps, d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], 1, 8, iters, 1e-4, 0.1, False)
+    for it in (1, 2, 8):
+        us = timeit(lambda: run(it), iters=30)
+        print(f"ba S-B E=36 P=7 48x64 iters={it}: {us:.1f} us per call ({us/it:.1f} us/iter incl. clone+plan)")
+    ii2, jj2 = d["jj"], d["ii"]
+    us = timeit(lambda: db.frame_distance(poses0, disps0, d["intr"], d["ii"], d["jj"], 0.3))
+    print(f"frame_distance M=36: {us:.1f} us")
+    intr_all = d["intr"][None].repeat(8, 1).contiguous()
+    us = timeit(lambda: db.reproject(poses0, disps0, intr_all, d["ii"], d["jj"]))
+    print(f"reproject E=36: {us:.1f} us")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["lookup"]
     for w in which:
