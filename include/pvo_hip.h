@@ -73,6 +73,22 @@ int pvo_corr_pyramid_lookup(const void* const* volumes_host, const float* coords
                             int num_levels, int radius, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Correlation volume build                                                   */
+/* ------------------------------------------------------------------------- */
+
+/* CorrBlock.corr + the avg-pool pyramid (modules/corr.py:24-38,63-71).
+ *   fmap1,fmap2 : features, [N,C,H,W] (channels_last = 0, the reference's layout) or
+ *                 [N,H,W,C] (channels_last = 1, the layout AltCorrBlock already uses, corr.py:104)
+ *   levels_host[l] : device pointer of level l output [N,H,W,H>>l,W>>l] dtype
+ * fp16/bf16 + channels_last + C in {16,32,64,128} + 16-byte aligned features run on the matrix
+ * cores with every level written from the accumulators; anything else takes the generic path.
+ * level0[n,p1,p2] = sum_c (fmap1[n,c,p1]/4)*(fmap2[n,c,p2]/4), fp32 accumulate,
+ * rounded to dtype; level l+1 = 2x2 mean of the ROUNDED level l (floor sizes). */
+int pvo_corr_build(const void* fmap1, const void* fmap2, void* const* levels_host,
+                   int N, int C, int H, int W, int num_levels, int dtype, int channels_last,
+                   void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Reprojection helpers                                                       */
 /* ------------------------------------------------------------------------- */
 

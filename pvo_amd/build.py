@@ -18,6 +18,7 @@ ORACLE_LIB = os.path.join(ORACLE_DIR, "libpvo_oracle.so")
 HIP_SOURCES = [
     "capi_misc.hip",
     "corr_lookup.hip",
+    "corr_build.hip",
     "geom.hip",
     "ba.hip",
 ]

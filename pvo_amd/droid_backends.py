@@ -139,6 +139,28 @@ def corr_pyramid_lookup(pyramid, coords, radius):
     return out
 
 
+def corr_build(fmap1, fmap2, num_levels=4, channels_last=False):
+    """CorrBlock.corr + the avg-pool pyramid (modules/corr.py:24-38,63-71) in one launch.
+
+    fmap1, fmap2: [N,C,H,W] (channels_last=False) or [N,H,W,C] (channels_last=True).
+    Returns the pyramid: level l is [N,H,W,H>>l,W>>l] in the feature dtype."""
+    _contig(fmap1, "fmap1"); _contig(fmap2, "fmap2")
+    dev = _dev(fmap1, fmap2)
+    if fmap1.shape != fmap2.shape or fmap1.dtype != fmap2.dtype:
+        raise PvoHipError("corr_build: fmap1/fmap2 shape or dtype mismatch")
+    if channels_last:
+        N, H, W, C = fmap1.shape
+    else:
+        N, C, H, W = fmap1.shape
+    levels = [torch.empty((N, H, W, H >> l, W >> l), dtype=fmap1.dtype, device=dev) for l in range(num_levels)]
+    ptrs = (ctypes.c_void_p * num_levels)(*[lv.data_ptr() if lv.numel() else 0 for lv in levels])
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_corr_build(_ptr(fmap1), _ptr(fmap2), ptrs, N, C, H, W, num_levels,
+                                         _dtype_code(fmap1, "fmap"), 1 if channels_last else 0, _stream(dev)),
+              "corr_build")
+    return levels
+
+
 # --------------------------------------------------------------------------- reprojection family
 def frame_distance(poses, disps, intrinsics, ii, jj, beta):
     """droid.cpp:117-133 -> dist [M]."""

@@ -1,0 +1,128 @@
+"""Correlation volume + pyramid: oracle vs the reference's CorrBlock fixture (CPU), and the
+HIP build vs the oracle / the fixture / its own pooling identity (GPU).
+
+Tolerances: the reference computes level 0 with torch.matmul (fp32 accumulation in an
+unspecified order) and rounds to the storage type, so level 0 is compared to one unit in the
+last place of the storage type; pooled levels are bit-exact functions of the ROUNDED level
+below, which is checked exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ulp_close(a, b, dtype):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    eps = {np.float16: 2.0 ** -10, np.float32: 2.0 ** -23}[dtype]
+    return np.all(np.abs(a - b) <= 1.01 * eps * np.maximum(np.abs(b), 2.0 ** -14) + 1e-7)
+
+
+def test_oracle_matches_reference_corrblock_fixture():
+    d = np.load(os.path.join(G, "corr_volume.npz"))
+    lv = O.corr_build(d["fmap1"], d["fmap2"], 4)
+    for l in range(4):
+        ref = d["level%d_f32" % l]
+        assert lv[l].shape == ref.shape
+        assert np.allclose(lv[l], ref, rtol=2e-5, atol=2e-5)
+    lh = O.corr_build(d["fmap1"].astype(np.float16), d["fmap2"].astype(np.float16), 4)
+    assert _ulp_close(lh[0], d["level0_f16"], np.float16)
+    for l in range(1, 4):
+        assert np.abs(lh[l].astype(np.float32) - d["level%d_f16" % l].astype(np.float32)).max() < 4e-3
+
+
+def _pool_exact(level, dtype):
+    """2x2 mean of a stored level, fp32 sum in window order, one rounding (ATen avg_pool2d)."""
+    v = level.astype(np.float32)
+    h, w = v.shape[-2] // 2, v.shape[-1] // 2
+    v = v[..., :2 * h, :2 * w]
+    s = ((v[..., 0::2, 0::2] + v[..., 0::2, 1::2]) + v[..., 1::2, 0::2]) + v[..., 1::2, 1::2]
+    return (s * np.float32(0.25)).astype(dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 128, 16, 16), (1, 64, 11, 19), (2, 32, 8, 40), (1, 128, 24, 33), (3, 16, 5, 7)])
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+def test_mfma_build_matches_oracle_and_pools_exactly(cuda, shape, tdt):
+    from pvo_amd import droid_backends as db
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    f1 = torch.randn(N, C, H, W, generator=g).to(tdt)
+    f2 = torch.randn(N, C, H, W, generator=g).to(tdt)
+    got = db.corr_build(f1.permute(0, 2, 3, 1).contiguous().to(cuda), f2.permute(0, 2, 3, 1).contiguous().to(cuda),
+                        4, channels_last=True)
+    assert [tuple(x.shape) for x in got] == [(N, H, W, H >> l, W >> l) for l in range(4)]
+    ref = torch.einsum("ncp,ncq->npq", f1.double().flatten(2) / 4, f2.double().flatten(2) / 4).view(N, H, W, H, W)
+    eps = 2.0 ** -10 if tdt == torch.float16 else 2.0 ** -7
+    l0 = got[0].cpu().double()
+    assert torch.all((l0 - ref).abs() <= 1.01 * eps * ref.abs().clamp(min=2.0 ** -14) + 1e-4)
+    # pooled levels are exact functions of the stored level below
+    for l in range(1, 4):
+        below = got[l - 1].cpu()
+        if tdt == torch.float16:
+            want = _pool_exact(below.numpy(), np.float16)
+            assert np.array_equal(got[l].cpu().numpy().view(np.uint16), want.view(np.uint16))
+        else:
+            v = below.float()
+            h, w = v.shape[-2] // 2, v.shape[-1] // 2
+            v = v[..., :2 * h, :2 * w]
+            s = ((v[..., 0::2, 0::2] + v[..., 0::2, 1::2]) + v[..., 1::2, 0::2]) + v[..., 1::2, 1::2]
+            assert torch.equal(got[l].cpu(), (s * 0.25).to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdt,npd", [(torch.float32, np.float32), (torch.float64, np.float64), (torch.float16, np.float16)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_generic_build_matches_oracle(cuda, tdt, npd, channels_last):
+    from pvo_amd import droid_backends as db
+    N, C, H, W = 2, 24, 9, 13          # C % 16 != 0 forces the generic path for fp16 too
+    g = np.random.default_rng(4)
+    f1 = g.standard_normal((N, C, H, W)).astype(npd)
+    f2 = g.standard_normal((N, C, H, W)).astype(npd)
+    want = O.corr_build(f1, f2, 4)
+    t1, t2 = torch.from_numpy(f1).to(cuda), torch.from_numpy(f2).to(cuda)
+    if channels_last:
+        t1, t2 = t1.permute(0, 2, 3, 1).contiguous(), t2.permute(0, 2, 3, 1).contiguous()
+    got = db.corr_build(t1, t2, 4, channels_last=channels_last)
+    for l in range(4):
+        a, b = got[l].cpu().numpy().astype(np.float64), want[l].astype(np.float64)
+        tol = {np.float32: 1e-5, np.float64: 1e-5, np.float16: 2e-3}[npd]   # the oracle accumulates in fp32
+        assert a.shape == b.shape and np.allclose(a, b, rtol=tol, atol=tol)
+
+
+@pytest.mark.gpu
+def test_build_matches_reference_fixture(cuda):
+    from pvo_amd import droid_backends as db
+    d = np.load(os.path.join(G, "corr_volume.npz"))
+    f1 = torch.from_numpy(d["fmap1"]).half().permute(0, 2, 3, 1).contiguous().to(cuda)
+    f2 = torch.from_numpy(d["fmap2"]).half().permute(0, 2, 3, 1).contiguous().to(cuda)
+    got = db.corr_build(f1, f2, 4, channels_last=True)
+    assert _ulp_close(got[0].cpu().numpy(), d["level0_f16"], np.float16)
+    for l in range(1, 4):
+        assert np.abs(got[l].cpu().float().numpy() - d["level%d_f16" % l].astype(np.float32)).max() < 4e-3
+    f1 = torch.from_numpy(d["fmap1"]).to(cuda); f2 = torch.from_numpy(d["fmap2"]).to(cuda)
+    got = db.corr_build(f1, f2, 4)
+    for l in range(4):
+        assert np.allclose(got[l].cpu().numpy(), d["level%d_f32" % l], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_build_then_lookup_full_size_sb(cuda):
+    """S-B shapes (48x64, C=128, fp16): volume of an edge from a frame to ITSELF peaks on the
+    diagonal, so a lookup at the identity grid returns the self-correlation in the centre tap."""
+    from pvo_amd import droid_backends as db
+    g = torch.Generator().manual_seed(0)
+    N, C, H, W = 4, 128, 48, 64
+    f = torch.randn(N, H, W, C, generator=g).half().to(cuda)
+    pyr = db.corr_build(f, f, 4, channels_last=True)
+    coords = torch.stack(torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy"), -1).float()
+    coords = coords[None].repeat(N, 1, 1, 1).contiguous().to(cuda)
+    out = db.corr_pyramid_lookup(pyr, coords, 3)
+    centre = out[:, 24].float()                       # level 0, offsets (0,0): channel 3*7+3
+    want = (f.float() / 4).pow(2).sum(-1)
+    assert torch.allclose(centre, want, rtol=2e-3, atol=2e-2)
+    assert (out[:, :49].float().argmax(1) == 24).float().mean() > 0.99

@@ -59,6 +59,23 @@ def ba():
     print(f"reproject E=36: {us:.1f} us")
 
 
+def build():
+    dev = torch.device("cuda:0")
+    N, C, H, W = 36, 128, 48, 64
+    f1 = torch.randn(N, H, W, C, device=dev).half(); f2 = torch.randn(N, H, W, C, device=dev).half()
+    us = timeit(lambda: db.corr_build(f1, f2, 4, channels_last=True), iters=20)
+    byts = N * (2 * H * W * C * 2 + (H * W) ** 2 * 2 * (1 + .25 + 1 / 16 + 1 / 64))
+    print(f"corr_build fp16 E={N}: {us:.1f} us  {N*2*(H*W)**2*C/us/1e6:.1f} TFLOP/s  alg {byts/1e6:.0f} MB -> {byts/us/1e6:.2f} TB/s")
+    def ref():
+        a = (f1.view(N, H * W, C) / 4.0) @ (f2.view(N, H * W, C) / 4.0).transpose(1, 2)
+        a = a.view(N * H * W, 1, H, W); out = [a]
+        for i in range(3):
+            a = torch.nn.functional.avg_pool2d(a, 2, stride=2); out.append(a)
+        return out
+    us = timeit(ref, iters=10)
+    print(f"  torch matmul + 3x avg_pool2d (reference formulation on this GPU): {us:.1f} us")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["lookup"]
     for w in which:
