@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""bench.py — VO keyframe updates/sec on the S-B window (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One STEP = one keyframe update of the frontend on an 8-keyframe window at 512x384 (48x64
+maps, 36 edges |i-j|<=3), following droid_frontend.py:36-70 of the reference:
+    re-create the newest keyframe's edges  (volume + pyramid build for 6 edges, reproject)
+    frame distances over the window         (proximity search input, 2 x 56 pairs)
+    4 graph updates, keyframe-distance test, 2 more graph updates
+where one graph update = reproject -> 4-level correlation lookup -> update operator (fp16
+autocast, MIOpen) -> mask/weight glue -> dense BA x2 (factor_graph.py:227-307).
+Inputs are synthetic (seeded), resident in HBM before the timed region; the update operator has
+random-init weights of the reference architecture.  State is restored at the start of every step
+so that K steps do identical work.
+
+N > 1: one process per GPU (torch.distributed, RCCL); every rank tracks its own window
+(independent sequences, no data-path collective), value = N*K / max-over-ranks time.
+
+Extra objects on the JSON line: "roofline" for the dominant hand-written kernel (the fused
+4-level lookup; HBM bound) and "cpu_baseline" (the CPU oracle timed on this host, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H8, W8, NKF, RADIUS = 48, 64, 8, 3
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_window(device, seed=0):
+    """S-B synthetic window."""
+    from pvo_amd.depth_video import DepthVideo
+    from pvo_amd.factor_graph import FactorGraph
+    from pvo_amd.geom.se3 import SE3
+    from pvo_amd.modules.update import DynamicUpdateModule
+    g = torch.Generator().manual_seed(seed)
+    video = DepthVideo(image_size=(H8 * 8, W8 * 8), buffer=16, device=device)
+    xi = torch.tensor([0.05, 0.0, 0.02, 0.0, 0.01, 0.0])
+    low = torch.rand(1, 1, 6, 8, generator=g) * 0.8 + 0.2
+    disp_gt = torch.nn.functional.interpolate(low, size=(H8, W8), mode="bilinear", align_corners=True)[0, 0]
+    intr = torch.tensor([40.0, 40.0, 32.0, 24.0])
+    for k in range(NKF):
+        video.append(float(k), SE3.exp(max(k - 1, 0) * xi).data.to(device), torch.ones(H8, W8, device=device),
+                     intr.to(device), torch.randn(H8, W8, 128, generator=g).half().to(device),
+                     torch.tanh(torch.randn(128, H8, W8, generator=g)).half().to(device),
+                     torch.relu(torch.randn(128, H8, W8, generator=g)).half().to(device))
+    video.disps[:NKF] = 1.0
+    torch.manual_seed(seed)
+    update = DynamicUpdateModule().to(device).eval()
+    graph = FactorGraph(video, update, device=device, max_factors=48)
+    graph.add_neighborhood_factors(0, NKF, r=RADIUS)
+    # targets = ground-truth reprojection + noise, so BA has a well-posed problem
+    gt_poses = torch.stack([SE3.exp(k * xi).data for k in range(NKF)]).to(device)
+    from pvo_amd import droid_backends as db
+    c, _ = db.reproject(torch.cat([gt_poses, video.poses[NKF:]]), disp_gt[None].repeat(16, 1, 1).to(device).contiguous(),
+                        video.intrinsics, graph.ii, graph.jj)
+    graph.target_cam = (c + 0.1 * torch.randn(c.shape, generator=g).to(device))[None]
+    graph.weight = torch.rand(graph.target_cam.shape, generator=g).to(device)
+    return video, graph
+
+
+class Snapshot:
+    """state restored at the start of every step (keeps the K steps identical)"""
+    def __init__(self, video, graph):
+        self.v, self.g = video, graph
+        self.poses, self.disps = video.poses.clone(), video.disps.clone()
+        self.net, self.target, self.weight = graph.net.clone(), graph.target_cam.clone(), graph.weight.clone()
+        self.raw_mask, self.delta_dy, self.damping = graph.raw_mask.clone(), graph.delta_dy.clone(), graph.damping.clone()
+
+    def restore(self):
+        self.v.poses.copy_(self.poses); self.v.disps.copy_(self.disps)
+        self.g.net = self.net.clone(); self.g.target_cam = self.target.clone(); self.g.weight = self.weight.clone()
+        self.g.raw_mask = self.raw_mask.clone(); self.g.delta_dy = self.delta_dy.clone()
+        self.g.damping.copy_(self.damping)
+
+
+def keyframe_update(video, graph, snap, lookup_events=None):
+    """droid_frontend.py:36-70 on a full window"""
+    snap.restore()
+    newest = NKF - 1
+    pairs = [(i, j) for i, j in zip(graph._ii_h, graph._jj_h) if i == newest or j == newest]
+    graph.rm_factors([(i == newest or j == newest) for i, j in zip(graph._ii_h, graph._jj_h)])
+    graph.add_factors([p[0] for p in pairs], [p[1] for p in pairs])
+    snap_edges_fix(graph, snap)
+    d = video.distance(beta=0.3, bidirectional=True)          # NKF x NKF proximity matrix
+    for _ in range(4):
+        graph.update(None, None, use_inactive=True) if lookup_events is None else timed_update(graph, lookup_events)
+    dk = video.distance([newest - 2], [newest - 1], beta=0.3, bidirectional=True)
+    for _ in range(2):
+        graph.update(None, None, use_inactive=True) if lookup_events is None else timed_update(graph, lookup_events)
+    return d, dk
+
+
+def snap_edges_fix(graph, snap):
+    """re-added edges go to the end of the edge list; the restored per-edge state follows the same permutation"""
+    if not hasattr(snap, "perm"):
+        old = snap.edge_list
+        snap.perm = torch.tensor([old.index(e) for e in zip(graph._ii_h, graph._jj_h)], device=graph.device)
+    p = snap.perm
+    graph.net = snap.net[:, p]; graph.target_cam = snap.target[:, p]; graph.weight = snap.weight[:, p]
+    graph.raw_mask = snap.raw_mask[:, p]; graph.delta_dy = snap.delta_dy[:, p]
+
+
+def timed_update(graph, events):
+    """graph.update with HIP events around the correlation lookup (same stream as the kernel)"""
+    corr = graph.corr
+
+    class _Timed:
+        def __call__(self, coords):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = corr(coords)
+            e.record()
+            events.append((s, e))
+            return out
+
+        def __getattr__(self, k):
+            return getattr(corr, k)
+    graph.corr = _Timed()
+    try:
+        graph.update(None, None, use_inactive=True)
+    finally:
+        graph.corr = corr
+
+
+def cpu_baseline():
+    """The CPU oracle (port of the reference algorithm) on this host: ONE graph update's worth of
+    lookup + update operator + BA, plus one edge of volume build, scaled to a keyframe update."""
+    import numpy as np
+    from oracle import oracle as O
+    from pvo_amd.modules.update import DynamicUpdateModule
+    g = np.random.default_rng(0)
+    E = 36
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    # build: 1 edge, fp16 features (scaled x6 edges per keyframe)
+    f1 = g.standard_normal((1, 128, H8, W8)).astype(np.float16); f2 = g.standard_normal((1, 128, H8, W8)).astype(np.float16)
+    t = time.perf_counter(); pyr1 = O.corr_build(f1, f2, 4); t_build = time.perf_counter() - t
+    # lookup: 6 edges (scaled x6 to 36)
+    pyr = [np.repeat(p, 6, 0) for p in pyr1]
+    coords = (np.stack(np.meshgrid(np.arange(W8), np.arange(H8)), -1)[None].astype(np.float32)
+              + g.normal(0, 4, (6, H8, W8, 2)).astype(np.float32))
+    t = time.perf_counter(); O.corr_pyramid_lookup(pyr, coords, 3); t_lookup = (time.perf_counter() - t) * 6
+    # update operator: torch CPU fp32, all cores
+    torch.manual_seed(0)
+    upd = DynamicUpdateModule().eval()
+    with torch.no_grad():
+        a = (torch.randn(1, E, 128, H8, W8), torch.randn(1, E, 128, H8, W8), torch.randn(1, E, 196, H8, W8), torch.randn(1, E, 8, H8, W8))
+        ii = torch.arange(NKF).repeat_interleave(6)[:E]
+        t = time.perf_counter(); upd(*a, ii, None); t_upd = time.perf_counter() - t
+    # BA: 2 iterations on the S-B graph
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_geom_ba_gpu import _scene
+    s = _scene(0, NKF, H8, W8, RADIUS, 1)
+    t = time.perf_counter()
+    O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+         s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, NKF, 2, 1e-4, 0.1)
+    t_ba = time.perf_counter() - t
+    per_kf = 6 * (t_lookup + t_upd + t_ba) + 6 * t_build
+    return {"value": 1.0 / per_kf, "unit": "keyframe updates/s", "cores": nthreads, "kind": "port",
+            "sample": "1 of 6 graph updates (lookup 6 of 36 edges x6, update operator fp32 on %d torch threads, "
+                      "BA 2 iters single thread) + volume build of 1 of 6 edges; scaled to one keyframe update; "
+                      "parts: build %.2fs/edge lookup %.2fs upd %.2fs ba %.2fs" % (nthreads, t_build, t_lookup, t_upd, t_ba)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from pvo_amd import _lib
+    _lib.load()                                         # fail loudly if the HIP library is missing
+    torch.backends.cudnn.benchmark = True               # MIOpen find mode: pick the fastest conv solvers during warm-up
+    video, graph = make_window(device, seed=rank)
+    snap = Snapshot(video, graph)
+    snap.edge_list = list(zip(graph._ii_h, graph._jj_h))
+
+    for _ in range(args.warmup):
+        keyframe_update(video, graph, snap)
+    events = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keyframe_update(video, graph, snap, events)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # the dominant hand-written kernel, back to back on the bench's own inputs: two HIP events on
+    # the launch stream around 50 launches (inside the step, host launch gaps sit between the events)
+    coords1, _ = video.reproject(graph.ii, graph.jj)
+    for _ in range(3):
+        graph.corr(coords1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(50):
+        graph.corr(coords1)
+    ev1.record()
+    torch.cuda.synchronize()
+    lookup_b2b_us = ev0.elapsed_time(ev1) / 50 * 1e3
+
+    if rank == 0:
+        E, HW = len(graph._ii_h), H8 * W8
+        in_region_us = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1) * 1e3
+        lookup_us = lookup_b2b_us
+        alg_bytes = E * HW * (4 * 64 * 2 + 8 + 196 * 2)         # 912*HW bytes per edge, fp16
+        achieved = alg_bytes / (lookup_us * 1e-6) / 1e9 if lookup_us > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_lookup_pmc.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "VO keyframe updates/sec (8-keyframe window, 512x384, 36 edges; 6 graph updates + edge rebuild per keyframe)",
+            "value": world * args.steps / elapsed, "unit": "keyframe updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 (volume, lookup, update operator) / f32 (BA assembly) / f64 (pose solve)",
+            "data": "synthetic",
+            "config": {"workload": "S-B: BASELINE.json configs[1] window (8 keyframes, 48x64 maps, E=36, itrs=2), synthetic",
+                       "edges": E, "graph_updates_per_step": 6, "parallelism": "independent window per GPU"},
+            "graph_updates_per_s": world * args.steps * 6 / elapsed,
+            "roofline": {"kernel": "corr_lookup_r3_kernel<half> (fused 4-level lookup)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": lookup_us, "launches_timed": 50,
+                         "in_step_event_us": in_region_us, "in_step_launches": len(events)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

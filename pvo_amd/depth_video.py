@@ -1,0 +1,101 @@
+"""DepthVideo — keyframe state buffers and the native calls made on them.
+
+Counterpart of the reference's DepthVideo (VO_Module/droid_slam/depth_video.py:13-214):
+same attribute names and shapes (poses [buf,7], disps [buf,H/8,W/8], intrinsics [buf,4],
+fmaps/nets/inps fp16, segms int32), same `reproject` / `distance` / `ba` methods.
+Differences: one process per GPU, so the counter is a plain int and there is no lock;
+feature maps are kept channels-last ([buf,H/8,W/8,128]) because that is the layout both
+the matrix-core volume build and AltCorr read; `reproject` is one HIP kernel instead of the
+lietorch broadcast chain.
+"""
+import torch
+
+from . import droid_backends as db
+
+
+class DepthVideo:
+    def __init__(self, image_size=(480, 640), buffer=1024, device="cuda:0", segm_filter=False, thresh=0.8,
+                 store_images=False):
+        self.counter = 0
+        self.ht, self.wd = ht, wd = int(image_size[0]), int(image_size[1])
+        self.device = torch.device(device)
+        h8, w8 = ht // 8, wd // 8
+        kw = dict(device=self.device)
+        self.tstamp = torch.zeros(buffer, dtype=torch.float, **kw)
+        self.images = torch.zeros(buffer, 3, ht, wd, dtype=torch.uint8, **kw) if store_images else None
+        self.dirty = torch.zeros(buffer, dtype=torch.bool, **kw)
+        self.poses = torch.zeros(buffer, 7, dtype=torch.float, **kw)
+        self.poses[:, 6] = 1.0                                   # identity (depth_video.py:49-50)
+        self.disps = torch.ones(buffer, h8, w8, dtype=torch.float, **kw)
+        self.disps_up = None
+        self.intrinsics = torch.zeros(buffer, 4, dtype=torch.float, **kw)
+        self.fmaps = torch.zeros(buffer, h8, w8, 128, dtype=torch.half, **kw)      # channels-last
+        self.nets = torch.zeros(buffer, 128, h8, w8, dtype=torch.half, **kw)
+        self.inps = torch.zeros(buffer, 128, h8, w8, dtype=torch.half, **kw)
+        self.segms = torch.zeros(buffer, 1, h8, w8, dtype=torch.int, **kw)
+        self.full_flow = torch.ones(buffer, h8, w8, 2, dtype=torch.float, **kw)
+        self.segm_filter, self.thresh = segm_filter, thresh
+        self.max_segments = 1024
+
+    # ------------------------------------------------------------------ bookkeeping
+    def append(self, tstamp, pose, disp, intrinsics, fmap, net, inp, segm=None, image=None):
+        """store one keyframe; fmap may be [128,h,w] (reference layout) or [h,w,128]"""
+        k = self.counter
+        self.tstamp[k] = tstamp
+        if pose is not None:
+            self.poses[k] = pose
+        if disp is not None:
+            self.disps[k] = disp
+        self.intrinsics[k] = intrinsics
+        self.fmaps[k] = fmap.permute(1, 2, 0) if fmap.shape[0] == 128 and fmap.shape[-1] != 128 else fmap
+        self.nets[k] = net
+        self.inps[k] = inp
+        if segm is not None:
+            self.segms[k] = segm
+        if image is not None and self.images is not None:
+            self.images[k] = image
+        self.counter = k + 1
+
+    @staticmethod
+    def format_indicies(ii, jj, device):
+        if not isinstance(ii, torch.Tensor):
+            ii = torch.as_tensor(ii)
+        if not isinstance(jj, torch.Tensor):
+            jj = torch.as_tensor(jj)
+        return (ii.to(device=device, dtype=torch.long).reshape(-1).contiguous(),
+                jj.to(device=device, dtype=torch.long).reshape(-1).contiguous())
+
+    # ------------------------------------------------------------------ native calls
+    def reproject(self, ii, jj):
+        """project points ii -> jj (depth_video.py:154-163): coords [1,E,h,w,2], valid [1,E,h,w,1]"""
+        ii, jj = self.format_indicies(ii, jj, self.device)
+        coords, valid = db.reproject(self.poses, self.disps, self.intrinsics, ii, jj)
+        return coords[None], valid[None]
+
+    def distance(self, ii=None, jj=None, beta=0.3, bidirectional=True):
+        """frame distance metric (depth_video.py:165-195)"""
+        return_matrix = ii is None
+        if return_matrix:
+            N = self.counter
+            ii, jj = torch.meshgrid(torch.arange(N), torch.arange(N), indexing="ij")
+        ii, jj = self.format_indicies(ii, jj, self.device)
+        if bidirectional:
+            poses = self.poses[:self.counter].clone()
+            d1 = db.frame_distance(poses, self.disps, self.intrinsics[0], ii, jj, beta)
+            d2 = db.frame_distance(poses, self.disps, self.intrinsics[0], jj, ii, beta)
+            d = 0.5 * (d1 + d2)
+        else:
+            d = db.frame_distance(self.poses, self.disps, self.intrinsics[0], ii, jj, beta)
+        return d.reshape(N, N) if return_matrix else d
+
+    def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1, motion_only=False,
+           t1_hint=None):
+        """dense bundle adjustment (depth_video.py:197-214); in place on poses / disps"""
+        if t1 is None:
+            t1 = t1_hint if t1_hint is not None else int(max(ii.max().item(), jj.max().item())) + 1
+        if eta is None and not motion_only:
+            k = torch.unique(torch.cat([ii, jj], 0)).shape[0]
+            eta = 1e-7 * torch.ones([k, self.ht // 8, self.wd // 8], device=self.device)
+        db.ba(self.poses, self.disps, self.intrinsics[0], target, weight, eta, ii, jj, t0, t1, itrs, lm, ep,
+              motion_only)
+        self.disps.clamp_(min=0.001)

@@ -1,0 +1,210 @@
+"""FactorGraph — edge bookkeeping and the per-iteration hot loop `update()`.
+
+Counterpart of the reference's FactorGraph (VO_Module/droid_slam/factor_graph.py:12-307):
+same attributes (ii, jj, age, target_cam, weight, raw_mask, delta_dy, full_flow, *_inac,
+damping, corr, net, inp, segm) and methods (add_factors, rm_factors, rm_keyframe,
+add_neighborhood_factors, update).  One `update()` = reproject -> correlation lookup ->
+update operator -> dynamic-mask / weight glue -> dense BA, as factor_graph.py:227-307.
+
+What is different, because it is what costs time once the kernels are fast:
+  * edge lists are mirrored on the host (`_ii_h`, `_jj_h`, `_age_h`): duplicate filtering,
+    the default t0/t1 and the age-based eviction never read device memory back
+    (the reference does `.item()` per edge, factor_graph.py:69-74, :247, depth_video.py:204);
+  * the panoptic segment vote (:256-276) runs on the device (two bincounts keyed by
+    (edge, segment id)) instead of np.unique on the host;
+  * reproject, the 4-level lookup and the whole BA are single calls into libpvo_hip.
+"""
+import torch
+
+from .modules.corr import CorrBlock
+
+
+def coords_grid(ht, wd, device):
+    y, x = torch.meshgrid(torch.arange(ht, device=device).float(), torch.arange(wd, device=device).float(),
+                          indexing="ij")
+    return torch.stack([x, y], dim=-1)
+
+
+class FactorGraph:
+    def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1):
+        self.video, self.update_op = video, update_op
+        self.device = torch.device(device)
+        self.max_factors, self.corr_impl = max_factors, corr_impl
+        self.ht, self.wd = ht, wd = video.ht // 8, video.wd // 8
+        self.dy_thresh, self.mask_num = 0.5, 2
+        self.coords0 = coords_grid(ht, wd, self.device)
+        lng = dict(dtype=torch.long, device=self.device)
+        self.ii, self.jj, self.age = (torch.zeros(0, **lng) for _ in range(3))
+        self._ii_h, self._jj_h, self._age_h = [], [], []
+        self.corr = self.net = self.inp = self.segm = None
+        self.damping = 1e-6 * torch.ones_like(video.disps)
+        z = lambda c: torch.zeros(1, 0, ht, wd, c, device=self.device, dtype=torch.float)
+        self.target_cam, self.weight, self.delta_dy, self.full_flow = z(2), z(2), z(2), z(2)
+        self.raw_mask = z(self.mask_num)
+        self.ii_inac, self.jj_inac = torch.zeros(0, **lng), torch.zeros(0, **lng)
+        self._ii_inac_h, self._jj_inac_h = [], []
+        self.ii_bad, self.jj_bad = torch.zeros(0, **lng), torch.zeros(0, **lng)
+        self.target_cam_inac, self.weight_inac, self.delta_dy_inac, self.full_flow_inac = z(2), z(2), z(2), z(2)
+        self.raw_mask_inac = z(self.mask_num)
+
+    # ------------------------------------------------------------------ edges
+    def _filter_repeated(self, ii, jj):
+        have = set(zip(self._ii_h, self._jj_h)) | set(zip(self._ii_inac_h, self._jj_inac_h))
+        keep = []
+        for k, e in enumerate(zip(ii, jj)):
+            if e not in have:
+                keep.append(k)
+                have.add(e)        # also de-duplicates inside the request
+        return [ii[k] for k in keep], [jj[k] for k in keep]
+
+    @staticmethod
+    def _to_list(x):
+        return [int(v) for v in (x.tolist() if isinstance(x, torch.Tensor) else x)]
+
+    def add_factors(self, ii, jj, remove=False):
+        """add edges (factor_graph.py:106-161)"""
+        ii_l, jj_l = self._filter_repeated(self._to_list(ii), self._to_list(jj))
+        if not ii_l:
+            return
+        if self.max_factors > 0 and len(self._ii_h) + len(ii_l) > self.max_factors and self.corr is not None and remove:
+            order = sorted(range(len(self._age_h)), key=lambda k: self._age_h[k])      # argsort(age), stable
+            rank = [0] * len(order)
+            for pos, k in enumerate(order):
+                rank[k] = pos
+            # the reference masks by POSITION in the age-sorted index list (factor_graph.py:128-129)
+            ix = [order[p] for p in range(len(order))]
+            mask_l = [ix[p] >= self.max_factors - len(ii_l) for p in range(len(order))]
+            self.rm_factors(torch.tensor(mask_l, device=self.device), store=True)
+        ii = torch.tensor(ii_l, dtype=torch.long, device=self.device)
+        jj = torch.tensor(jj_l, dtype=torch.long, device=self.device)
+        net = self.video.nets[ii][None]
+        if self.corr_impl == "volume":
+            corr = CorrBlock(self.video.fmaps[ii][None], self.video.fmaps[jj][None], channels_last=True)
+            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            inp = self.video.inps[ii][None]
+            self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
+        target, _ = self.video.reproject(ii, jj)
+        zeros2 = torch.zeros_like(target)
+        self.ii, self.jj = torch.cat([self.ii, ii]), torch.cat([self.jj, jj])
+        self.age = torch.cat([self.age, torch.zeros_like(ii)])
+        self._ii_h += ii_l; self._jj_h += jj_l; self._age_h += [0] * len(ii_l)
+        self.net = net if self.net is None else torch.cat([self.net, net], 1)
+        self.target_cam = torch.cat([self.target_cam, target], 1)
+        self.weight = torch.cat([self.weight, zeros2], 1)
+        self.raw_mask = torch.cat([self.raw_mask, zeros2[..., :self.mask_num]], 1)
+        self.delta_dy = torch.cat([self.delta_dy, zeros2], 1)
+        segm = self.video.segms[ii][None]
+        self.segm = segm if self.segm is None else torch.cat([self.segm, segm], 1)
+
+    def rm_factors(self, mask, store=False):
+        """drop edges (factor_graph.py:163-200); mask: bool tensor or list over the active edges"""
+        mask_l = [bool(v) for v in (mask.tolist() if isinstance(mask, torch.Tensor) else mask)]
+        mask = torch.tensor(mask_l, dtype=torch.bool, device=self.device)
+        if store:
+            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]])
+            self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
+            self._ii_inac_h += [i for i, m in zip(self._ii_h, mask_l) if m]
+            self._jj_inac_h += [j for j, m in zip(self._jj_h, mask_l) if m]
+            self.target_cam_inac = torch.cat([self.target_cam_inac, self.target_cam[:, mask]], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
+            self.raw_mask_inac = torch.cat([self.raw_mask_inac, self.raw_mask[:, mask]], 1)
+            self.delta_dy_inac = torch.cat([self.delta_dy_inac, self.delta_dy[:, mask]], 1)
+        keep = ~mask
+        self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
+        self._ii_h = [i for i, m in zip(self._ii_h, mask_l) if not m]
+        self._jj_h = [j for j, m in zip(self._jj_h, mask_l) if not m]
+        self._age_h = [a for a, m in zip(self._age_h, mask_l) if not m]
+        if self.corr_impl == "volume" and self.corr is not None:
+            self.corr = self.corr[keep]
+        if self.net is not None:
+            self.net = self.net[:, keep]
+        if self.inp is not None:
+            self.inp = self.inp[:, keep]
+        if self.segm is not None:
+            self.segm = self.segm[:, keep]
+        self.target_cam, self.weight = self.target_cam[:, keep], self.weight[:, keep]
+        self.raw_mask, self.delta_dy = self.raw_mask[:, keep], self.delta_dy[:, keep]
+
+    def clear_edges(self):
+        self.rm_factors([True] * len(self._ii_h))
+        self.net = self.inp = None
+
+    def rm_keyframe(self, ix):
+        """drop keyframe ix and every edge touching it (factor_graph.py:202-225)"""
+        v = self.video
+        for buf in (v.poses, v.disps, v.intrinsics, v.nets, v.inps, v.fmaps) + ((v.segms,) if v.segm_filter else ()):
+            buf[ix] = buf[ix + 1].clone()
+        m = [(i == ix) or (j == ix) for i, j in zip(self._ii_h, self._jj_h)]
+        self.ii[self.ii >= ix] -= 1; self.jj[self.jj >= ix] -= 1
+        self.ii_inac[self.ii_inac >= ix] -= 1; self.jj_inac[self.jj_inac >= ix] -= 1
+        dec = lambda l: [a - 1 if a >= ix else a for a in l]
+        self._ii_h, self._jj_h = dec(self._ii_h), dec(self._jj_h)
+        self._ii_inac_h, self._jj_inac_h = dec(self._ii_inac_h), dec(self._jj_inac_h)
+        self.rm_factors(m, store=False)
+
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        """edges between frames within temporal radius r (factor_graph.py:362-370)"""
+        ii, jj = [], []
+        for i in range(t0, t1):
+            for j in range(t0, t1):
+                if i != j and abs(i - j) <= r:
+                    ii.append(i); jj.append(j)
+        self.add_factors(ii, jj)
+
+    # ------------------------------------------------------------------ hot loop
+    def _segment_vote(self, bin_mask):
+        """factor_graph.py:256-276 on the device: a segment whose dynamic-pixel fraction exceeds
+        video.thresh is forced dynamic on that edge.  Segment id 0 is 'no segment' (label % 1e6 == 0)."""
+        E = bin_mask.shape[1]
+        S = self.video.max_segments
+        seg = self.segm[0, :, 0].long().clamp_(0, S - 1)                       # [E,h,w]
+        dyn = ((bin_mask[0, ..., 0] == 0) | (bin_mask[0, ..., 1] == 0))        # [E,h,w]
+        key = (torch.arange(E, device=seg.device).view(E, 1, 1) * S + seg).reshape(-1)
+        tot = torch.bincount(key, minlength=E * S).float()
+        dcn = torch.bincount(key, weights=dyn.reshape(-1).float(), minlength=E * S)
+        forced = (dcn / tot.clamp(min=1) > self.video.thresh) & (torch.arange(E * S, device=seg.device) % S != 0)
+        keep = ~forced[key].view(1, E, *seg.shape[1:])
+        return bin_mask & keep.unsqueeze(-1)
+
+    @torch.no_grad()
+    def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
+        """one update of the factor graph (factor_graph.py:227-307)"""
+        ht, wd = self.ht, self.wd
+        coords1, _ = self.video.reproject(self.ii, self.jj)
+        motn = torch.cat([self.target_cam - self.coords0, self.target_cam - self.coords0 + self.delta_dy,
+                          self.target_cam - coords1, self.raw_mask], dim=-1)
+        motn = motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+        corr = self.corr(coords1)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
+            self.net, delta, weight, damping, upmask, delta_m = \
+                self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj, False)
+        if t0 is None:
+            t0 = max(1, min(self._ii_h) + 1)
+        if t1 is None:
+            t1 = max(max(self._ii_h), max(self._jj_h)) + 1
+        self.target_cam = coords1 + delta[..., 0:2].float()
+        self.raw_mask = self.raw_mask + delta_m.float()
+        bin_mask = torch.sigmoid(self.raw_mask) >= self.dy_thresh
+        if self.video.segm_filter:
+            bin_mask = self._segment_vote(bin_mask)
+        bin_mask = bin_mask.float()
+        self.delta_dy = delta[..., 2:4].float() * (1 - bin_mask)
+        self.weight = torch.sigmoid(weight.float() + (1 - bin_mask) * 10)
+        src = sorted(set(self._ii_h))                                  # torch.unique(self.ii), host side
+        self.damping[torch.tensor(src, device=self.device)] = damping[0].float()
+        if use_inactive:
+            m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)]
+            m = torch.tensor(m_l, dtype=torch.bool, device=self.device)
+            ii, jj = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
+            target_cam = torch.cat([self.target_cam_inac[:, m], self.target_cam], 1)
+            weight = torch.cat([self.weight_inac[:, m], self.weight], 1)
+            src = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
+        else:
+            ii, jj, target_cam, weight = self.ii, self.jj, self.target_cam, self.weight
+        eta = 0.2 * self.damping[torch.tensor(src, device=self.device)].contiguous() + EP
+        target_cam = target_cam.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+        weight = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+        self.video.ba(target_cam, weight, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
+        self.full_flow = coords1 + self.delta_dy - self.coords0
+        self.age += 1
+        self._age_h = [a + 1 for a in self._age_h]

@@ -1,0 +1,90 @@
+"""CorrBlock — all-pairs correlation volume pyramid + radius-r lookup on the HIP kernels.
+
+API of the reference's CorrBlock / CorrSampler (VO_Module/droid_slam/modules/corr.py:6-71):
+`CorrBlock(fmap1, fmap2, num_levels, radius)(coords)`, `.cat`, `[index]`.  The volume and all
+pyramid levels come from ONE launch of pvo_corr_build, the lookup of all levels from ONE launch
+of pvo_corr_pyramid_lookup (the reference: matmul + 3 pools, then 4 lookups + torch.cat).
+When gradients are required (training) the reference's differentiable formulation is used:
+torch.matmul/avg_pool2d for the volume and CorrSampler (HIP forward + HIP backward) per level.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import droid_backends as db
+
+
+class CorrSampler(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, volume, coords, radius):
+        ctx.save_for_backward(volume, coords)
+        ctx.radius = radius
+        corr, = db.corr_index_forward(volume, coords, radius)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        volume, coords = ctx.saved_tensors
+        grad_volume, = db.corr_index_backward(volume, coords, grad_output.contiguous(), ctx.radius)
+        return grad_volume, None, None
+
+
+class CorrBlock:
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, channels_last=False):
+        """fmap1, fmap2: [B,N,C,H,W] (reference layout) or [B,N,H,W,C] with channels_last=True."""
+        self.num_levels, self.radius = num_levels, radius
+        needs_grad = torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)
+        if needs_grad:
+            if channels_last:
+                fmap1, fmap2 = fmap1.permute(0, 1, 4, 2, 3), fmap2.permute(0, 1, 4, 2, 3)
+            self.corr_pyramid = self._build_differentiable(fmap1, fmap2, num_levels)
+            return
+        if channels_last:
+            B, N, H, W, C = fmap1.shape
+            f1, f2 = fmap1.reshape(B * N, H, W, C), fmap2.reshape(B * N, H, W, C)
+        else:
+            B, N, C, H, W = fmap1.shape
+            f1, f2 = fmap1.reshape(B * N, C, H, W), fmap2.reshape(B * N, C, H, W)
+            if fmap1.dtype in (torch.float16, torch.bfloat16):   # matrix-core path wants channels-last rows
+                f1, f2 = f1.permute(0, 2, 3, 1), f2.permute(0, 2, 3, 1)
+                channels_last = True
+        self.corr_pyramid = db.corr_build(f1.contiguous(), f2.contiguous(), num_levels, channels_last=channels_last)
+
+    @staticmethod
+    def _build_differentiable(fmap1, fmap2, num_levels):
+        corr = CorrBlock.corr(fmap1, fmap2)
+        batch, num, h1, w1, h2, w2 = corr.shape
+        corr = corr.reshape(batch * num * h1 * w1, 1, h2, w2)
+        pyramid = []
+        for i in range(num_levels):
+            pyramid.append(corr.view(batch * num, h1, w1, h2 // 2 ** i, w2 // 2 ** i))
+            if i + 1 < num_levels:
+                corr = F.avg_pool2d(corr, 2, stride=2)
+        return pyramid
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """all-pairs correlation, reference formulation (corr.py:63-71)"""
+        batch, num, dim, ht, wd = fmap1.shape
+        a = fmap1.reshape(batch * num, dim, ht * wd) / 4.0
+        b = fmap2.reshape(batch * num, dim, ht * wd) / 4.0
+        return torch.matmul(a.transpose(1, 2), b).view(batch, num, ht, wd, ht, wd)
+
+    def __call__(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        coords = coords.reshape(batch * num, ht, wd, 2)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.corr_pyramid):
+            c = coords.permute(0, 3, 1, 2).contiguous().float()
+            out = [CorrSampler.apply(self.corr_pyramid[i], c / 2 ** i, self.radius).view(batch, num, -1, ht, wd)
+                   for i in range(self.num_levels)]
+            return torch.cat(out, dim=2)
+        out = db.corr_pyramid_lookup([p.contiguous() for p in self.corr_pyramid], coords.float().contiguous(),
+                                     self.radius)
+        return out.view(batch, num, -1, ht, wd)
+
+    def cat(self, other):
+        self.corr_pyramid = [torch.cat([a, b], 0) for a, b in zip(self.corr_pyramid, other.corr_pyramid)]
+        return self
+
+    def __getitem__(self, index):
+        self.corr_pyramid = [p[index] for p in self.corr_pyramid]
+        return self

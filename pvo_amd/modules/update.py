@@ -1,0 +1,210 @@
+"""Update operator of the VO hot path: ConvGRU + heads + graph aggregation.
+
+State-dict compatible with the reference's `DynamicUpdateModule`
+(VO_Module/droid_slam/droid_net.py:166-314), `ConvGRU` (modules/gru.py:5-34), `GraphAgg`
+(droid_net.py:64-95) and `GradientClip` (modules/clipping.py:7-23): same parameter names,
+shapes and creation order, so a reference checkpoint's `update.*` tensors load unchanged
+and a seeded default init reproduces the reference's weights.
+
+What differs is how the forward pass is issued on MI355X (inference path):
+  * the z and r gate convolutions read the same 448-channel input: one 256-output conv;
+  * the four heads (delta, delta_dy, weight, delta_mask) share their input: one 512-output
+    3x3 conv + ReLU, then one 3x3 conv with a block-diagonal weight producing the 8 outputs;
+  * everything runs channels-last so MIOpen picks its NHWC implicit-GEMM (MFMA) kernels.
+The fused weights are views built from the individual parameters (cached in eval mode).
+Training mode keeps the per-layer path so autograd sees the original parameters.
+The reference's forward() also evaluates `np.range(...)` at droid_net.py:295, which does not
+exist in NumPy (AttributeError); that dead statement is not reproduced.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+GRAD_CLIP = 0.01
+
+
+class _ClipGrad(torch.autograd.Function):
+    """identity forward; backward zeroes gradients with |g| > GRAD_CLIP or NaN (clipping.py:7-18)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        zero = torch.zeros_like(g)
+        g = torch.where(g.abs() > GRAD_CLIP, zero, g)
+        return torch.where(torch.isnan(g), zero, g)
+
+
+class GradientClip(nn.Module):
+    def forward(self, x):
+        return _ClipGrad.apply(x)
+
+
+def scatter_mean(src, index, dim, dim_size=None):
+    """torch_scatter.scatter_mean (droid_net.py:87) with index_add_."""
+    if dim_size is None:
+        dim_size = int(index.max().item()) + 1 if index.numel() else 0
+    shape = list(src.shape)
+    shape[dim] = dim_size
+    out = torch.zeros(shape, dtype=src.dtype, device=src.device).index_add_(dim, index, src)
+    cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add_(
+        0, index, torch.ones(index.shape[0], dtype=src.dtype, device=src.device))
+    view = [1] * src.dim()
+    view[dim] = dim_size
+    return out / cnt.clamp(min=1).view(view)
+
+
+class ConvGRU(nn.Module):
+    def __init__(self, h_planes=128, i_planes=128):
+        super().__init__()
+        self.do_checkpoint = False
+        self.convz = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.convr = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.convq = nn.Conv2d(h_planes + i_planes, h_planes, 3, padding=1)
+        self.w = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+        self.convz_glo = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+        self.convr_glo = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+        self.convq_glo = nn.Conv2d(h_planes, h_planes, 1, padding=0)
+        self._fused = None
+
+    def train(self, mode=True):
+        self._fused = None
+        return super().train(mode)
+
+    def _fused_zr(self):
+        if self._fused is None or self._fused[0].dtype != self.convz.weight.dtype \
+                or self._fused[0].device != self.convz.weight.device:
+            w = torch.cat([self.convz.weight, self.convr.weight], 0).contiguous(memory_format=torch.channels_last)
+            b = torch.cat([self.convz.bias, self.convr.bias], 0)
+            wg = torch.cat([self.convz_glo.weight, self.convr_glo.weight, self.convq_glo.weight], 0)
+            bg = torch.cat([self.convz_glo.bias, self.convr_glo.bias, self.convq_glo.bias], 0)
+            self._fused = (w.detach(), b.detach(), wg.detach(), bg.detach())
+        return self._fused
+
+    def forward(self, net, *inputs):
+        inp = torch.cat(inputs, dim=1)
+        net_inp = torch.cat([net, inp], dim=1)
+        b, c, h, w = net.shape
+        # global context: spatial mean of sigmoid(w(net)) * net   (gru.py:22-24)
+        glo = (torch.sigmoid(self.w(net)) * net).view(b, c, h * w).mean(-1).view(b, c, 1, 1)
+        if self.training or torch.is_grad_enabled():
+            z = torch.sigmoid(self.convz(net_inp) + self.convz_glo(glo))
+            r = torch.sigmoid(self.convr(net_inp) + self.convr_glo(glo))
+            q = torch.tanh(self.convq(torch.cat([r * net, inp], dim=1)) + self.convq_glo(glo))
+        else:
+            wz, bz, wg, bg = self._fused_zr()
+            g = F.conv2d(glo, wg, bg)                       # the three 1x1 context convs at once
+            zr = torch.sigmoid(F.conv2d(net_inp, wz, bz, padding=1) + g[:, :2 * c])
+            z, r = zr[:, :c], zr[:, c:]
+            q = torch.tanh(self.convq(torch.cat([r * net, inp], dim=1)) + g[:, 2 * c:])
+        return (1 - z) * net + z * q
+
+
+class GraphAgg(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(128, 128, 3, padding=1)
+        self.conv2 = nn.Conv2d(128, 128, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.eta = nn.Sequential(nn.Conv2d(128, 1, 3, padding=1), GradientClip(), nn.Softplus())
+        self.upmask_disp = nn.Sequential(nn.Conv2d(128, 8 * 8 * 9, 1, padding=0))
+
+    def forward(self, net, ii):
+        batch, num, ch, ht, wd = net.shape
+        net = net.reshape(batch * num, ch, ht, wd)
+        _, ix = torch.unique(ii, return_inverse=True)
+        net = self.relu(self.conv1(net)).view(batch, num, 128, ht, wd)
+        net = scatter_mean(net, ix, dim=1).view(-1, 128, ht, wd)   # mean over edges sharing a source frame
+        net = self.relu(self.conv2(net))
+        eta = self.eta(net).view(batch, -1, ht, wd)
+        upmask = self.upmask_disp(net).view(batch, -1, 8 * 8 * 9, ht, wd)
+        return 0.01 * eta, upmask, None, None                      # droid_net.py:95
+
+
+def _head(cout):
+    return nn.Sequential(nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True),
+                         nn.Conv2d(128, cout, 3, padding=1), GradientClip())
+
+
+class DynamicUpdateModule(nn.Module):
+    def __init__(self, use_aff_bri=False):
+        super().__init__()
+        cor_planes = 4 * (2 * 3 + 1) ** 2
+        self.mask_num = 2
+        # creation order follows droid_net.py:172-225 so that a seeded init matches the reference
+        self.corr_encoder = nn.Sequential(nn.Conv2d(cor_planes, 128, 1, padding=0), nn.ReLU(inplace=True),
+                                          nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True))
+        self.flow_encoder = nn.Sequential(nn.Conv2d(4 + self.mask_num + 2, 128, 7, padding=3), nn.ReLU(inplace=True),
+                                          nn.Conv2d(128, 64, 3, padding=1), nn.ReLU(inplace=True))
+        self.weight = _head(2)
+        self.delta = _head(2)
+        self.delta_dy = _head(2)
+        self.delta_mask = _head(self.mask_num)
+        if use_aff_bri:
+            self.global_avg_pool = nn.Sequential(nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(inplace=True),
+                                                 nn.AdaptiveAvgPool2d((1, 1)), GradientClip())
+            self.param_linear = nn.Sequential(nn.Linear(128, 2), nn.Sigmoid())
+        self.use_aff_bri = use_aff_bri
+        self.gru = ConvGRU(128, 128 + 128 + 64)
+        self.agg = GraphAgg()
+        self._fused_heads = None
+
+    def train(self, mode=True):
+        self._fused_heads = None
+        return super().train(mode)
+
+    def _heads(self, net):
+        """delta, delta_dy, weight, delta_mask, each [B,2,H,W]"""
+        if self.training or torch.is_grad_enabled():
+            return self.delta(net), self.delta_dy(net), self.weight(net), self.delta_mask(net)
+        hs = (self.delta, self.delta_dy, self.weight, self.delta_mask)
+        f = self._fused_heads
+        if f is None or f[0].dtype != hs[0][0].weight.dtype or f[0].device != hs[0][0].weight.device:
+            w1 = torch.cat([h[0].weight for h in hs], 0).contiguous(memory_format=torch.channels_last)
+            b1 = torch.cat([h[0].bias for h in hs], 0)
+            # second stage as ONE dense conv with a block-diagonal weight (4 x [2,128,3,3] on the
+            # diagonal of [8,512,3,3]): a groups=4 conv with 2 outputs per group has no tuned
+            # MIOpen solver and falls back to its naive kernel (110 ms per call in the profile)
+            w2 = torch.zeros(8, 512, 3, 3, dtype=hs[0][2].weight.dtype, device=hs[0][2].weight.device)
+            for k, h in enumerate(hs):
+                w2[2 * k:2 * k + 2, 128 * k:128 * k + 128] = h[2].weight.detach()
+            w2 = w2.contiguous(memory_format=torch.channels_last)
+            b2 = torch.cat([h[2].bias for h in hs], 0)
+            f = self._fused_heads = (w1.detach(), b1.detach(), w2.detach(), b2.detach())
+        x = F.relu(F.conv2d(net, f[0], f[1], padding=1), inplace=True)      # 128 -> 4*128
+        y = F.conv2d(x, f[2], f[3], padding=1)                              # 4 x (128 -> 2), block diagonal
+        return y[:, 0:2], y[:, 2:4], y[:, 4:6], y[:, 6:8]
+
+    def forward(self, net, inp, corr, flow=None, ii=None, jj=None, use_aff_bri=False, raw_mask=None, segments=None):
+        batch, num, ch, ht, wd = net.shape
+        if flow is None:
+            flow = torch.zeros(batch, num, 4 + self.mask_num + 2, ht, wd, device=net.device, dtype=net.dtype)
+        out_dim = (batch, num, -1, ht, wd)
+        cl = torch.channels_last if net.is_cuda else torch.contiguous_format
+        net = net.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
+        inp = inp.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
+        corr = corr.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
+        flow = flow.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
+
+        corr = self.corr_encoder(corr)
+        flow = self.flow_encoder(flow)
+        net = self.gru(net, inp, corr, flow)
+
+        delta, delta_dy, weight, delta_m = self._heads(net)
+        if use_aff_bri:
+            aff = self.param_linear(self.global_avg_pool(net).view(batch * num, -1)).view(batch, num, -1)
+
+        to_last = lambda t: t.reshape(*out_dim).permute(0, 1, 3, 4, 2).contiguous()
+        delta = torch.cat([to_last(delta), to_last(delta_dy)], dim=-1)      # droid_net.py:299
+        weight, delta_m = to_last(weight), to_last(delta_m)
+        net = net.view(*out_dim)
+
+        if ii is None:
+            return net, delta, weight, delta_m
+        eta, upmask_disp, upmask_flow, upmask_dy = self.agg(net, ii.to(net.device))
+        upmask = {"disp": upmask_disp, "flow": upmask_flow, "dy_mask": upmask_dy}
+        if use_aff_bri:
+            return net, delta, weight, eta, upmask, delta_m, aff
+        return net, delta, weight, eta, upmask, delta_m

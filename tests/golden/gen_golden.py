@@ -6,7 +6,8 @@ What is executed is the reference's code, imported from /root/reference/VO_Modul
   geom/ba.py (BA, MoBA), geom/chol.py, geom/projective_ops.py      -> ba_python_*.npz, projective_*.npz
   modules/corr.py  CorrBlock.corr + pyramid construction            -> corr_volume.npz
   modules/gru.py, droid_net.py (DynamicUpdateModule sub-modules, GraphAgg) -> update_op.npz
-  geom/graph_utils.py graph_to_edge_list                            -> (used for the edge lists)
+  geom/graph_utils.py graph_to_edge_list                            -> graph_edges.npz
+  factor_graph.py FactorGraph.update (with recorded callees)        -> factor_graph_glue_*.npz
 
 Three native dependencies of that Python cannot be built in this image (lietorch's C++
 extension needs Eigen/Core, which the vendored Eigen lacks; torch_scatter and the
@@ -193,6 +194,64 @@ def gen_graph():
     print("graph_edges: E=%d" % ii.shape[0])
 
 
+def gen_factor_graph_glue():
+    """FactorGraph.update (factor_graph.py:227-307) with recorded stand-ins for the three things
+    it calls (video.reproject, the update operator, video.ba): pins the arithmetic in between —
+    motion features, mask / weight / damping glue, the panoptic segment vote, the BA arguments."""
+    import factor_graph as ref_fg
+    g = torch.Generator().manual_seed(5)
+    E, ht, wd, F = 6, 6, 8, 4
+    ii = torch.tensor([0, 0, 1, 1, 2, 3]); jj = torch.tensor([1, 2, 0, 2, 3, 2])
+    rec = dict(
+        coords1=torch.randn(1, E, ht, wd, 2, generator=g) * 3 + 4,
+        target_cam=torch.randn(1, E, ht, wd, 2, generator=g) * 3 + 4,
+        weight0=torch.rand(1, E, ht, wd, 2, generator=g),
+        raw_mask=torch.randn(1, E, ht, wd, 2, generator=g),
+        delta_dy=torch.randn(1, E, ht, wd, 2, generator=g) * 0.2,
+        net=torch.randn(1, E, 128, ht, wd, generator=g), inp=torch.randn(1, E, 128, ht, wd, generator=g),
+        corr=torch.randn(1, E, 196, ht, wd, generator=g),
+        net_out=torch.randn(1, E, 128, ht, wd, generator=g),
+        delta=torch.randn(1, E, ht, wd, 4, generator=g) * 0.5,
+        weight_out=torch.randn(1, E, ht, wd, 2, generator=g),
+        damping_out=torch.rand(1, 4, ht, wd, generator=g) * 0.01,
+        delta_m=torch.randn(1, E, ht, wd, 2, generator=g),
+        segm=torch.randint(0, 4, (1, E, 1, ht, wd), generator=g).int(),
+    )
+    for segm_filter in (False, True):
+        cap = {}
+
+        class Video:
+            pass
+        v = Video()
+        v.ht, v.wd = ht * 8, wd * 8
+        v.disps = torch.ones(F, ht, wd)
+        v.segm_filter, v.thresh = segm_filter, 0.5
+        v.reproject = lambda a, b: (rec["coords1"].clone(), torch.ones(1, E, ht, wd, 1))
+
+        def ba(target, weight, eta, ii_, jj_, t0, t1, itrs=2, lm=1e-4, ep=0.1, motion_only=False):
+            cap.update(ba_target=target.clone(), ba_weight=weight.clone(), ba_eta=eta.clone(), ba_ii=ii_.clone(),
+                       ba_jj=jj_.clone(), ba_t0=torch.tensor(t0), ba_itrs=torch.tensor(itrs))
+        v.ba = ba
+
+        def update_op(net, inp, corr, motn, ii_, jj_, flag):
+            cap["motn"] = motn.clone()
+            return rec["net_out"], rec["delta"], rec["weight_out"], rec["damping_out"], {}, rec["delta_m"]
+        fg = ref_fg.FactorGraph(v, update_op, device="cpu")
+        fg.ii, fg.jj, fg.age = ii.clone(), jj.clone(), torch.zeros(E, dtype=torch.long)
+        fg.net, fg.inp, fg.segm = rec["net"].clone(), rec["inp"].clone(), rec["segm"].clone()
+        fg.target_cam, fg.weight = rec["target_cam"].clone(), rec["weight0"].clone()
+        fg.raw_mask, fg.delta_dy = rec["raw_mask"].clone(), rec["delta_dy"].clone()
+        fg.corr = lambda c: rec["corr"]
+        fg.update(None, 4, itrs=2)
+        out = {k: t.numpy() for k, t in rec.items() if k not in ("net", "inp", "corr", "net_out")}   # opaque to the glue
+        out.update({k: t.numpy() for k, t in cap.items()})
+        out.update(ii=ii.numpy(), jj=jj.numpy(), out_target_cam=fg.target_cam.numpy(), out_weight=fg.weight.numpy(),
+                   out_raw_mask=fg.raw_mask.numpy(), out_delta_dy=fg.delta_dy.numpy(), out_full_flow=fg.full_flow.numpy(),
+                   out_damping=fg.damping.numpy(), out_age=fg.age.numpy())
+        np.savez_compressed(os.path.join(HERE, "factor_graph_glue_%s.npz" % ("segm" if segm_filter else "plain")), **out)
+        print("factor_graph_glue segm_filter=%s" % segm_filter)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -202,3 +261,4 @@ if __name__ == "__main__":
     gen_corr()
     gen_update_op()
     gen_graph()
+    gen_factor_graph_glue()

@@ -1,0 +1,58 @@
+"""FactorGraph.update glue against the reference's FactorGraph.update, both run with the same
+recorded stand-ins for reproject / update operator / BA (fixtures from tests/golden/gen_golden.py).
+CPU only: the three native calls are exactly the parts that are stubbed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pvo_amd.factor_graph import FactorGraph
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name,segm_filter", [("plain", False), ("segm", True)])
+def test_update_glue_matches_reference(name, segm_filter):
+    d = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "factor_graph_glue_%s.npz" % name)).items()}
+    E, ht, wd = d["coords1"].shape[1:4]
+    cap = {}
+
+    class Video:
+        pass
+    v = Video()
+    v.ht, v.wd, v.disps = ht * 8, wd * 8, torch.ones(4, ht, wd)
+    v.segm_filter, v.thresh, v.max_segments = segm_filter, 0.5, 16
+    v.reproject = lambda a, b: (d["coords1"].clone(), torch.ones(1, E, ht, wd, 1))
+
+    def ba(target, weight, eta, ii, jj, t0, t1, itrs=2, lm=1e-4, ep=0.1, motion_only=False):
+        cap.update(target=target, weight=weight, eta=eta, ii=ii, jj=jj, t0=t0, t1=t1, itrs=itrs, lm=lm, ep=ep)
+    v.ba = ba
+
+    def update_op(net, inp, corr, motn, ii, jj, flag):
+        cap["motn"] = motn
+        return torch.zeros(1, E, 128, ht, wd), d["delta"], d["weight_out"], d["damping_out"], {}, d["delta_m"]
+
+    fg = FactorGraph(v, update_op, device="cpu")
+    fg.ii, fg.jj = d["ii"].clone(), d["jj"].clone()
+    fg._ii_h, fg._jj_h, fg._age_h = d["ii"].tolist(), d["jj"].tolist(), [0] * E
+    fg.age = torch.zeros(E, dtype=torch.long)
+    fg.net = fg.inp = torch.zeros(1, E, 128, ht, wd)
+    fg.segm = d["segm"].clone()
+    fg.target_cam, fg.weight = d["target_cam"].clone(), d["weight0"].clone()
+    fg.raw_mask, fg.delta_dy = d["raw_mask"].clone(), d["delta_dy"].clone()
+    fg.corr = lambda c: torch.zeros(1, E, 196, ht, wd)
+    fg.update(None, 4, itrs=2)
+
+    eq = lambda a, b: torch.allclose(a.float(), b.float(), atol=1e-6, rtol=1e-6)
+    assert eq(cap["motn"], d["motn"])
+    assert eq(cap["target"], d["ba_target"]) and eq(cap["weight"], d["ba_weight"]) and eq(cap["eta"], d["ba_eta"])
+    assert torch.equal(cap["ii"], d["ba_ii"]) and torch.equal(cap["jj"], d["ba_jj"])
+    assert cap["t0"] == int(d["ba_t0"]) and cap["itrs"] == int(d["ba_itrs"]) and cap["lm"] == 1e-4 and cap["ep"] == 0.1
+    assert eq(fg.target_cam, d["out_target_cam"]) and eq(fg.weight, d["out_weight"])
+    assert eq(fg.raw_mask, d["out_raw_mask"]) and eq(fg.delta_dy, d["out_delta_dy"])
+    assert eq(fg.full_flow, d["out_full_flow"]) and eq(fg.damping, d["out_damping"])
+    assert torch.equal(fg.age, d["out_age"])
+    if segm_filter:      # the vote must actually have changed something in this fixture
+        plain = np.load(os.path.join(G, "factor_graph_glue_plain.npz"))
+        assert not np.allclose(plain["out_weight"], d["out_weight"].numpy())
