@@ -165,10 +165,32 @@ def ba(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iteratio
     K = f(_p(poses), _p(disps), _p(intrinsics), _p(targets), _p(weights), _p(eta), _p(ii), _p(jj),
           E, nf, ht, wd, eta.shape[0], t0, t1, iterations, ctypes.c_float(lm), ctypes.c_float(ep),
           int(motion_only), _p(dx), _p(dz), _p(sys_) if want_sys else None, _p(status),
-          int(xi45_zero), int(evt_skip_first))
+          int(xi45_zero), int(evt_skip_first), None)
     if K < 0:
         raise ValueError("oracle_ba failed with %d" % K)
     out = dict(poses=poses, disps=disps, dx=dx, dz=dz[:K], K=K, failed=bool(status[0]))
     if want_sys:
         out["sys"] = sys_
     return out
+
+
+def ba_apply(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, dx, motion_only=False):
+    """one BA iteration on these edges with the pose update `dx` imposed (sharded-BA test harness)"""
+    poses, disps = _f32c(poses).copy(), _f32c(disps).copy()
+    intrinsics, targets, weights = _f32c(intrinsics), _f32c(targets), _f32c(weights)
+    ii, jj = _i64c(ii), _i64c(jj)
+    nf, ht, wd = disps.shape
+    E, P = ii.shape[0], t1 - t0
+    if eta is None:
+        eta = np.zeros((1, ht, wd), np.float32)
+    eta = _f32c(eta).reshape(-1, ht, wd)
+    dxo = np.zeros((max(P, 0), 6), np.float32); dz = np.zeros((P + E + 1, ht * wd), np.float32)
+    status = np.zeros(4, np.int32)
+    dxi = _f32c(dx)
+    f = lib().oracle_ba
+    f.restype = ctypes.c_int
+    K = f(_p(poses), _p(disps), _p(intrinsics), _p(targets), _p(weights), _p(eta), _p(ii), _p(jj),
+          E, nf, ht, wd, eta.shape[0], t0, t1, 1, ctypes.c_float(0.0), ctypes.c_float(1.0),
+          int(motion_only), _p(dxo), _p(dz), None, _p(status), 0, 1, _p(dxi))
+    assert K >= 0
+    return dict(poses=poses, disps=disps, dz=dz[:K])

@@ -387,13 +387,15 @@ static void assemble_edge(const float* target, const float* weight, const float*
  * evt_skip_first != 0 reproduces EvT6x1_kernel's `idx <= 0` early return (:1084), which drops
  * window pose 0 from the depth back-substitution; 0 gives the exact Schur back-substitution
  * (what geom/ba.py computes) and is used only to pin this restatement against that file.
+ * dx_in (optional): skip the solve and apply this pose update instead (used by the 2-rank gloo test, where
+ * the reduced system is all-reduced and solved outside).
  * returns K (number of depth maps optimised) or a negative error. status_out[0]=1 when a
  * factorisation failed. */
 int oracle_ba(float* poses, float* disps, const float* intr, const float* targets, const float* weights,
               const float* eta, const int64_t* ii, const int64_t* jj,
               int E, int nframes, int ht, int wd, int K_eta, int t0, int t1, int iterations,
               float lm, float ep, int motion_only, float* dx_out, float* dz_out, double* sys_out,
-              int* status_out, int xi45_zero, int evt_skip_first) {
+              int* status_out, int xi45_zero, int evt_skip_first, const float* dx_in) {
   const int HW = ht * wd, P = t1 - t0, n6 = 6 * P;
   int K = 0, fail_any = 0;
   int64_t* kx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(P + E + 1));
@@ -521,7 +523,9 @@ int oracle_ba(float* poses, float* disps, const float* intr, const float* target
 
     /* solve (:1171-1192): diag += ep + lm*diag; LLT; zeros on failure */
     for (int k = 0; k < n6; k++) A[k * n6 + k] += (double)ep + (double)lm * A[k * n6 + k];
-    if (n6 > 0 && chol_solve(A, b, n6) == 0) {
+    if (dx_in) {                      /* edge-sharded test harness: the globally solved dx is handed in */
+      for (int k = 0; k < n6; k++) dx[k] = dx_in[k];
+    } else if (n6 > 0 && chol_solve(A, b, n6) == 0) {
       for (int k = 0; k < n6; k++) dx[k] = (float)b[k];
     } else {
       for (int k = 0; k < n6; k++) dx[k] = 0.0f;

@@ -290,3 +290,53 @@ def ba(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iteratio
                          _ptr(status) if status is not None else ctypes.c_void_p(0),
                          ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(dev)), "ba")
     return [dx, dz]
+
+
+# --------------------------------------------------------------------------- edge-sharded BA pieces
+def ba_workspace(E, P, nframes, HW, device):
+    """a private workspace tensor for the split BA entry points (one per rank / graph)"""
+    n = _lib.load().pvo_ba_workspace_bytes(int(E), int(P), int(nframes), int(HW))
+    return torch.empty(int(n), dtype=torch.uint8, device=device)
+
+
+def ba_plan(ii, jj, nframes, HW, K_eta, t0, t1, workspace):
+    dev = _dev(ii, jj, workspace)
+    _long(ii, "ii"); _long(jj, "jj")
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_ba_plan(_ptr(ii), _ptr(jj), ii.shape[0], int(nframes), int(HW), int(K_eta), int(t0), int(t1),
+                                      ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(dev)), "ba_plan")
+
+
+def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, motion_only, sys, workspace):
+    """assemble + eliminate this rank's edges; `sys` (fp64 [(6P)^2+6P]) receives the local reduced system"""
+    dev = _dev(poses, disps, intrinsics, targets, weights, eta, ii, jj, sys, workspace)
+    F, ht, wd = disps.shape
+    if sys.dtype != torch.float64 or sys.numel() < (6 * (t1 - t0)) ** 2 + 6 * (t1 - t0):
+        raise PvoHipError("ba_local: sys must be float64 with (6P)^2 + 6P elements")
+    K_eta = 1
+    if eta is not None:
+        eta = eta.contiguous().view(-1, ht * wd)
+        K_eta = eta.shape[0]
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_ba_local(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(targets), _ptr(weights),
+                                       _ptr(eta) if eta is not None else ctypes.c_void_p(0), _ptr(ii), _ptr(jj),
+                                       ii.shape[0], F, ht, wd, K_eta, int(t0), int(t1), 1 if motion_only else 0,
+                                       _ptr(sys), ctypes.c_void_p(workspace.data_ptr()), workspace.numel(),
+                                       _stream(dev)), "ba_local")
+
+
+def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None):
+    """damp + solve the (all-reduced) system, retract poses, back-substitute this rank's depths -> [dx, dz]"""
+    dev = _dev(poses, disps, sys, ii, jj, workspace)
+    F, ht, wd = disps.shape
+    P = int(t1) - int(t0)
+    dx = torch.zeros(max(P, 0), 6, dtype=torch.float32, device=dev)
+    dz = torch.zeros(int(dz_rows), ht * wd, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_ba_finish(_ptr(poses), _ptr(disps), _ptr(sys), _ptr(ii), _ptr(jj), ii.shape[0], F, ht, wd,
+                                        int(t0), int(t1), float(lm), float(ep), 1 if motion_only else 0,
+                                        _ptr(dx), _ptr(dz), int(dz_rows),
+                                        _ptr(status) if status is not None else ctypes.c_void_p(0),
+                                        ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(dev)),
+              "ba_finish")
+    return [dx, dz]

@@ -1,0 +1,133 @@
+"""Edge-sharded BA.
+CPU: two gloo ranks run pvo_amd.parallel.ShardedBA over an ORACLE-backed native layer (the partition,
+eta-row selection and the single all-reduce are the code under test); the result must equal the
+single-process oracle on the whole graph.
+GPU: the HIP split entry points (plan/local/finish) with two shards in one process, summed by hand,
+against pvo_ba on the whole graph."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(__file__))
+from oracle import oracle as O
+from pvo_amd.parallel import ShardedBA, local_eta_rows, partition_by_source
+
+
+class OracleBackend:
+    """the three native steps, computed by the CPU oracle on torch CPU tensors"""
+
+    def ba_workspace(self, E, P, F, HW, device):
+        return {}
+
+    def ba_plan(self, ii, jj, F, HW, K_eta, t0, t1, ws):
+        ws.clear()
+
+    def ba_local(self, poses, disps, intr, targets, weights, eta, ii, jj, t0, t1, motion_only, sys_buf, ws):
+        r = O.ba(poses.numpy(), disps.numpy(), intr.numpy(), targets.numpy(), weights.numpy(),
+                 None if eta is None else eta.numpy(), ii.numpy(), jj.numpy(), t0, t1, 1, 0.0, 1.0,
+                 motion_only=motion_only, want_sys=True)
+        sys_buf.copy_(torch.from_numpy(r["sys"]))
+        ws["args"] = (intr, targets, weights, eta)
+
+    def ba_finish(self, poses, disps, sys_buf, ii, jj, t0, t1, lm, ep, motion_only, ws):
+        # solve the reduced system exactly as oracle_ba does, then let the oracle redo this rank's
+        # iteration with dx forced to the global solution: depth back-substitution is rank-local
+        n = 6 * (t1 - t0)
+        A = sys_buf[:n * n].view(n, n).numpy().copy(); b = sys_buf[n * n:].numpy().copy()
+        A[np.diag_indices(n)] += ep + lm * np.diag(A)
+        dx = np.linalg.solve(A, b).astype(np.float32).reshape(-1, 6)
+        intr, targets, weights, eta = ws["args"]
+        r = O.ba_apply(poses.numpy(), disps.numpy(), intr.numpy(), targets.numpy(), weights.numpy(),
+                       None if eta is None else eta.numpy(), ii.numpy(), jj.numpy(), t0, t1, dx, motion_only)
+        poses.copy_(torch.from_numpy(r["poses"])); disps.copy_(torch.from_numpy(r["disps"]))
+        return [torch.from_numpy(dx), None]
+
+
+def _graph():
+    from test_geom_ba_gpu import _scene
+    return _scene(21, 6, 8, 10, 2, 1)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = _graph()
+    owner, _ = partition_by_source(s["ii"].tolist(), world)
+    mine = torch.tensor([o == rank for o in owner])
+    ii, jj = s["ii"][mine], s["jj"][mine]
+    rows = local_eta_rows(s["ii"].tolist(), ii.tolist(), s["t0"], s["t1"])
+    poses, disps = s["poses"].clone(), s["disps"].clone()
+    before = disps.clone()
+    sb = ShardedBA(backend=OracleBackend())
+    sb.ba(poses, disps, s["intr"], s["target"][mine].contiguous(), s["weight"][mine].contiguous(),
+          s["eta"][rows].contiguous(), ii.contiguous(), jj.contiguous(), s["t0"], s["t1"], itrs=2)
+    sb.sync_disps(disps, before)
+    out[rank] = (poses.numpy().copy(), disps.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_partition_is_deterministic_and_balanced():
+    ii = [0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 3, 4]
+    owner, by_frame = partition_by_source(ii, 2)
+    assert owner == partition_by_source(ii, 2)[0]
+    assert all(owner[k] == by_frame[f] for k, f in enumerate(ii))          # all edges of a source frame together
+    loads = [owner.count(r) for r in range(2)]
+    assert abs(loads[0] - loads[1]) <= 2
+    assert local_eta_rows([0, 1, 2, 3], [0, 2], 1, 4) == [0, 1, 2, 3]      # window frames are always present
+    assert local_eta_rows([0, 5, 6], [6], 1, 4) == [1, 2, 3, 5]
+
+
+def test_two_rank_sharded_ba_equals_single_process_gloo():
+    world = 2
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, 29517, out), nprocs=world, join=True)
+    s = _graph()
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), s["t0"], s["t1"], 2, 1e-4, 0.1)
+    for r in range(world):
+        poses, disps = out[r]
+        assert np.abs(poses - want["poses"]).max() < 2e-5
+        assert np.abs(disps - want["disps"]).max() < 2e-5
+    assert np.array_equal(out[0][0], out[1][0])                           # pose replicas bit-identical
+
+
+@pytest.mark.gpu
+def test_hip_split_entry_points_two_shards_equal_whole_graph(cuda):
+    from pvo_amd import droid_backends as db
+    from test_geom_ba_gpu import _scene
+    s = _scene(5, 8, 24, 32, 3, 1)
+    d = lambda t: t.to(cuda)
+    poses_w, disps_w = d(s["poses"].clone()), d(s["disps"].clone())
+    db.ba(poses_w, disps_w, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]),
+          s["t0"], s["t1"], 2, 1e-4, 0.1, False)
+    owner, _ = partition_by_source(s["ii"].tolist(), 2)
+    F, ht, wd = s["disps"].shape
+    P = s["t1"] - s["t0"]
+    shards = []
+    for r in range(2):
+        m = torch.tensor([o == r for o in owner])
+        rows = local_eta_rows(s["ii"].tolist(), s["ii"][m].tolist(), s["t0"], s["t1"])
+        sh = dict(ii=d(s["ii"][m].contiguous()), jj=d(s["jj"][m].contiguous()), target=d(s["target"][m].contiguous()),
+                  weight=d(s["weight"][m].contiguous()), eta=d(s["eta"][rows].contiguous()),
+                  poses=d(s["poses"].clone()), disps=d(s["disps"].clone()))
+        sh["ws"] = db.ba_workspace(sh["ii"].shape[0], P, F, ht * wd, cuda)
+        sh["sys"] = torch.zeros((6 * P) ** 2 + 6 * P, dtype=torch.float64, device=cuda)
+        db.ba_plan(sh["ii"], sh["jj"], F, ht * wd, sh["eta"].shape[0], s["t0"], s["t1"], sh["ws"])
+        shards.append(sh)
+    for _ in range(2):
+        for sh in shards:
+            db.ba_local(sh["poses"], sh["disps"], d(s["intr"]), sh["target"], sh["weight"], sh["eta"], sh["ii"], sh["jj"],
+                        s["t0"], s["t1"], False, sh["sys"], sh["ws"])
+        total = shards[0]["sys"] + shards[1]["sys"]                        # what the RCCL all-reduce produces
+        for sh in shards:
+            db.ba_finish(sh["poses"], sh["disps"], total, sh["ii"], sh["jj"], s["t0"], s["t1"], 1e-4, 0.1, False, sh["ws"])
+    assert torch.equal(shards[0]["poses"], shards[1]["poses"])            # replicas bit-identical
+    assert (shards[0]["poses"] - poses_w).abs().max() < 2e-5
+    merged = s["disps"].clone().to(cuda) + sum(sh["disps"] - d(s["disps"]) for sh in shards)
+    assert (merged - disps_w).abs().max() < 2e-5
