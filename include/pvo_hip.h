@@ -72,6 +72,23 @@ int pvo_corr_pyramid_lookup(const void* const* volumes_host, const float* coords
                             int N, int h1, int w1, int h2, int w2,
                             int num_levels, int radius, int dtype, void* stream);
 
+/* droid_backends.altcorr_forward (droid.cpp:190-200; altcorr_kernel.cu:27-149, host :290-319):
+ * volume-free lookup.  fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last, coords [B,S,H1,W1,2] f32,
+ * corr [B,S,(2r+1)^2,H1,W1] fully written, channel = iy + (2r+1)*ix.  fp32 only (AltCorrBlock casts
+ * to float, corr.py:120); other dtypes return PVO_EUNSUPPORTED. */
+int pvo_altcorr_forward(const void* fmap1, const void* fmap2, const float* coords, void* corr,
+                        int B, int S, int H1, int W1, int H2, int W2, int C,
+                        int radius, int dtype, void* stream);
+
+/* droid_backends.altcorr_backward (droid.cpp:202-214; altcorr_kernel.cu:152-286, host :321-356; float
+ * only there too).  fmap1_grad [B,H1,W1,C] and fmap2_grad [B,H2,W2,C] are fully written (fmap2_grad is
+ * zeroed on the stream before its atomic accumulation).  The reference's third output, coords_grad, is
+ * all zeros (:340) and is produced by the Python binding. */
+int pvo_altcorr_backward(const void* fmap1, const void* fmap2, const float* coords,
+                         const void* corr_grad, void* fmap1_grad, void* fmap2_grad,
+                         int B, int S, int H1, int W1, int H2, int W2, int C,
+                         int radius, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Correlation volume build                                                   */
 /* ------------------------------------------------------------------------- */

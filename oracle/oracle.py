@@ -194,3 +194,25 @@ def ba_apply(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, dx
           int(motion_only), _p(dxo), _p(dz), None, _p(status), 0, 1, _p(dxi))
     assert K >= 0
     return dict(poses=poses, disps=disps, dz=dz[:K])
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    fmap1, fmap2, coords = _f32c(fmap1), _f32c(fmap2), _f32c(coords)
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    rd = 2 * radius + 1
+    out = np.zeros((B, S, rd * rd, H1, W1), np.float32)
+    assert lib().oracle_altcorr_forward(_p(fmap1), _p(fmap2), _p(coords), _p(out), B, S, H1, W1, H2, W2, C, radius) == 0
+    return out
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    fmap1, fmap2, coords, corr_grad = _f32c(fmap1), _f32c(fmap2), _f32c(coords), _f32c(corr_grad)
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    g1, g2 = np.zeros_like(fmap1), np.zeros_like(fmap2)
+    assert lib().oracle_altcorr_backward(_p(fmap1), _p(fmap2), _p(coords), _p(corr_grad), _p(g1), _p(g2),
+                                         B, S, H1, W1, H2, W2, C, radius) == 0
+    return g1, g2

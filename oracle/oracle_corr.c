@@ -11,6 +11,7 @@
  *   CorrBlock.corr + pyramid    reference VO_Module/droid_slam/modules/corr.py:24-38,63-71
  *   CorrBlock.__call__          reference VO_Module/droid_slam/modules/corr.py:40-50
  *   altcorr_forward_kernel      reference VO_Module/src/altcorr_kernel.cu:27-149
+ *   altcorr_backward_kernel     reference VO_Module/src/altcorr_kernel.cu:152-286
  *
  * PARITY PIN STATUS: the reference CUDA kernels cannot be built in this image
  * (no nvcc; torch's hipify output does not compile against torch 2.10 because of
@@ -289,5 +290,78 @@ int oracle_corr_build(const void* fmap1, const void* fmap2, void* const* levels,
         }
     h = h2; w = w2;
   }
+  return 0;
+}
+
+/* altcorr_forward_kernel (altcorr_kernel.cu:27-149), fp32.  fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C],
+ * coords [B,S,H1,W1,2], corr [B,S,rd*rd,H1,W1] (zeroed here, torch::zeros at :302).
+ * Keeps the reference's accumulation structure: 32-channel slabs outermost, each slab's partial dot
+ * product scattered with the four bilinear weights (channel = iy + rd*ix). */
+int oracle_altcorr_forward(const float* f1, const float* f2, const float* coords, float* corr,
+                           int B, int S, int H1, int W1, int H2, int W2, int C, int r) {
+  const int rd = 2 * r + 1;
+  const long long HW = (long long)H1 * W1;
+  memset(corr, 0, sizeof(float) * (size_t)B * S * rd * rd * HW);
+  for (int b = 0; b < B; b++)
+    for (int c0 = 0; c0 < C; c0 += 32)
+      for (int h1 = 0; h1 < H1; h1++)
+        for (int w1 = 0; w1 < W1; w1++)
+          for (int n = 0; n < S; n++) {
+            const float* cp = coords + ((((long long)b * S + n) * H1 + h1) * W1 + w1) * 2;
+            const float x = cp[0], y = cp[1];
+            const float dx = x - floorf(x), dy = y - floorf(y);
+            float* out = corr + (((long long)b * S + n) * rd * rd) * HW + (long long)h1 * W1 + w1;
+            for (int iy = 0; iy < rd + 1; iy++)
+              for (int ix = 0; ix < rd + 1; ix++) {
+                const int h2 = floor_to_int(y) - r + iy, w2 = floor_to_int(x) - r + ix;
+                float s = 0.0f;
+                if (within(h2, w2, H2, W2)) {
+                  const float* a = f1 + (((long long)b * H1 + h1) * W1 + w1) * C;
+                  const float* q = f2 + (((long long)b * H2 + h2) * W2 + w2) * C;
+                  for (int k = c0; k < c0 + 32 && k < C; k++) s = fmaf(a[k], q[k], s);
+                }
+                if (iy > 0 && ix > 0) out[(long long)((iy - 1) + rd * (ix - 1)) * HW] += s * (dy * dx);
+                if (iy > 0 && ix < rd) out[(long long)((iy - 1) + rd * ix) * HW] += s * (dy * (1 - dx));
+                if (iy < rd && ix > 0) out[(long long)(iy + rd * (ix - 1)) * HW] += s * ((1 - dy) * dx);
+                if (iy < rd && ix < rd) out[(long long)(iy + rd * ix) * HW] += s * ((1 - dy) * (1 - dx));
+              }
+          }
+  return 0;
+}
+
+/* altcorr_backward_kernel (altcorr_kernel.cu:152-286), fp32.  Sums carried in fp64 (the reference's
+ * atomicAdd order is not defined). coords_grad is all zeros in the reference (:340) and is not produced. */
+int oracle_altcorr_backward(const float* f1, const float* f2, const float* coords, const float* cg,
+                            float* g1, float* g2, int B, int S, int H1, int W1, int H2, int W2, int C, int r) {
+  const int rd = 2 * r + 1;
+  const long long HW = (long long)H1 * W1;
+  double* a1 = (double*)calloc((size_t)B * HW * C, sizeof(double));
+  double* a2 = (double*)calloc((size_t)B * H2 * W2 * C + 1, sizeof(double));
+  if (!a1 || !a2) { free(a1); free(a2); return 1; }
+  for (int b = 0; b < B; b++)
+    for (long long p = 0; p < HW; p++)
+      for (int n = 0; n < S; n++) {
+        const float* cp = coords + (((long long)b * S + n) * HW + p) * 2;
+        const float x = cp[0], y = cp[1];
+        const float dx = x - floorf(x), dy = y - floorf(y);
+        const float* gp = cg + (((long long)b * S + n) * rd * rd) * HW + p;
+        for (int iy = 0; iy < rd + 1; iy++)
+          for (int ix = 0; ix < rd + 1; ix++) {
+            const int h2 = floor_to_int(y) - r + iy, w2 = floor_to_int(x) - r + ix;
+            float g = 0.0f;
+            if (!within(h2, w2, H2, W2)) continue;
+            if (iy > 0 && ix > 0) g += gp[(long long)((iy - 1) + rd * (ix - 1)) * HW] * dy * dx;
+            if (iy > 0 && ix < rd) g += gp[(long long)((iy - 1) + rd * ix) * HW] * dy * (1 - dx);
+            if (iy < rd && ix > 0) g += gp[(long long)(iy + rd * (ix - 1)) * HW] * (1 - dy) * dx;
+            if (iy < rd && ix < rd) g += gp[(long long)(iy + rd * ix) * HW] * (1 - dy) * (1 - dx);
+            for (int k = 0; k < C; k++) {
+              a1[((long long)b * HW + p) * C + k] += (double)(g * f2[(((long long)b * H2 + h2) * W2 + w2) * C + k]);
+              a2[(((long long)b * H2 + h2) * W2 + w2) * C + k] += (double)(g * f1[((long long)b * HW + p) * C + k]);
+            }
+          }
+      }
+  for (long long i = 0; i < (long long)B * HW * C; i++) g1[i] = (float)a1[i];
+  for (long long i = 0; i < (long long)B * H2 * W2 * C; i++) g2[i] = (float)a2[i];
+  free(a1); free(a2);
   return 0;
 }

@@ -19,6 +19,7 @@ HIP_SOURCES = [
     "capi_misc.hip",
     "corr_lookup.hip",
     "corr_build.hip",
+    "altcorr.hip",
     "geom.hip",
     "ba.hip",
 ]

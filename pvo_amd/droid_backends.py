@@ -139,6 +139,42 @@ def corr_pyramid_lookup(pyramid, coords, radius):
     return out
 
 
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    """droid.cpp:190-200. fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,S,H1,W1,2] -> [corr [B,S,(2r+1)^2,H1,W1]]"""
+    _contig(fmap1, "fmap1"); _contig(fmap2, "fmap2"); _contig(coords, "coords")
+    dev = _dev(fmap1, fmap2, coords)
+    _f32(coords, "coords")
+    if fmap1.dtype != torch.float32 or fmap2.dtype != torch.float32:
+        raise PvoHipError("altcorr_forward: float32 features only (AltCorrBlock casts with .float(), corr.py:120)")
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    rd = 2 * radius + 1
+    corr = torch.empty(B, S, rd * rd, H1, W1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_altcorr_forward(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr), B, S, H1, W1, H2, W2, C,
+                                              radius, _lib.PVO_F32, _stream(dev)), "altcorr_forward")
+    return [corr]
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    """droid.cpp:202-214 -> [fmap1_grad, fmap2_grad, coords_grad (zeros, as altcorr_kernel.cu:340)]"""
+    for t, n in ((fmap1, "fmap1"), (fmap2, "fmap2"), (coords, "coords"), (corr_grad, "corr_grad")):
+        _contig(t, n)
+    dev = _dev(fmap1, fmap2, coords, corr_grad)
+    if any(t.dtype != torch.float32 for t in (fmap1, fmap2, coords, corr_grad)):
+        raise PvoHipError("altcorr_backward: float32 only (altcorr_kernel.cu:345)")
+    B, H1, W1, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    g1, g2 = torch.empty_like(fmap1), torch.empty_like(fmap2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_altcorr_backward(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr_grad), _ptr(g1), _ptr(g2),
+                                               B, S, H1, W1, H2, W2, C, radius, _lib.PVO_F32, _stream(dev)),
+              "altcorr_backward")
+    return [g1, g2, torch.zeros(B, S, H1, W1, 2, dtype=torch.float32, device=dev)]
+
+
 def corr_build(fmap1, fmap2, num_levels=4, channels_last=False):
     """CorrBlock.corr + the avg-pool pyramid (modules/corr.py:24-38,63-71) in one launch.
 

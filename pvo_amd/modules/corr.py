@@ -88,3 +88,58 @@ class CorrBlock:
     def __getitem__(self, index):
         self.corr_pyramid = [p[index] for p in self.corr_pyramid]
         return self
+
+
+class CorrLayer(torch.autograd.Function):
+    """altcorr forward/backward pair (modules/corr.py:74-88)"""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, coords, r):
+        ctx.r = r
+        ctx.save_for_backward(fmap1, fmap2, coords)
+        corr, = db.altcorr_forward(fmap1, fmap2, coords, r)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad_corr):
+        fmap1, fmap2, coords = ctx.saved_tensors
+        g1, g2, gc = db.altcorr_backward(fmap1, fmap2, coords, grad_corr.contiguous(), ctx.r)
+        return g1, g2, gc, None
+
+
+class AltCorrBlock:
+    """volume-free correlation (modules/corr.py:91-139): features pyramid in channels-last,
+    dot products on the fly.  `fmaps` [B,N,C,H,W] (reference layout) or [B,N,H,W,C]."""
+
+    def __init__(self, fmaps, num_levels=4, radius=3, channels_last=False):
+        self.num_levels, self.radius = num_levels, radius
+        if channels_last:
+            fmaps = fmaps.permute(0, 1, 4, 2, 3)
+        B, N, C, H, W = fmaps.shape
+        f = fmaps.reshape(B * N, C, H, W) / 4.0
+        self.pyramid = []
+        for i in range(num_levels):
+            self.pyramid.append(f.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
+            if i + 1 < num_levels:
+                f = F.avg_pool2d(f, 2, stride=2)
+
+    def corr_fn(self, coords, ii, jj):
+        B, N, H, W, S, _ = coords.shape
+        coords = coords.permute(0, 1, 4, 2, 3, 5)
+        out = []
+        for i in range(self.num_levels):
+            f1 = self.pyramid[0][:, ii]
+            f2 = self.pyramid[i][:, jj]
+            c = (coords / 2 ** i).reshape(B * N, S, H, W, 2).contiguous().float()
+            f1 = f1.reshape((B * N,) + f1.shape[2:]).float().contiguous()
+            f2 = f2.reshape((B * N,) + f2.shape[2:]).float().contiguous()
+            corr = CorrLayer.apply(f1, f2, c, self.radius)
+            out.append(corr.view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2))
+        return torch.cat(out, dim=2)
+
+    def __call__(self, coords, ii, jj):
+        squeeze = coords.dim() == 5
+        if squeeze:
+            coords = coords.unsqueeze(-2)
+        corr = self.corr_fn(coords, ii, jj)
+        return (corr.squeeze(-1) if squeeze else corr).contiguous()
