@@ -106,6 +106,26 @@ int pvo_corr_build(const void* fmap1, const void* fmap2, void* const* levels_hos
                    void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Update operator: fused element-wise half of the ConvGRU                    */
+/* ------------------------------------------------------------------------- */
+
+/* The reference's ConvGRU.forward (modules/gru.py:19-32) around its three 3x3 convolutions.
+ * All feature tensors are channels-last rows [E*HW, C] of fp16/bf16 (`dtype`), 16-byte aligned.
+ *   pvo_gru_glo      glo[E,128] f32 = mean_p( sigmoid(wn) * net )        wn = w(net)      (gru.py:23-24)
+ *   pvo_gru_assemble X[rows,448]   = [net | inp | relu(corr_feat[128]) | relu(flow_feat[64])]
+ *                    (torch.cat of gru.py:20-21 plus the encoders' trailing ReLUs, droid_net.py:176,182)
+ *   pvo_gru_gate     Z = sigmoid(zr[:, :128] + g[e, 0:128]);  X[:, :128] = sigmoid(zr[:,128:] + g[e,128:256]) * net
+ *                    (gru.py:26-28; zr = conv([convz;convr])(X), g[E,384] f32 = context 1x1 convs of glo)
+ *   pvo_gru_out      net_out = (1-Z)*net + Z*tanh(q + g[e,256:384])      q = convq(X)      (gru.py:28-31) */
+int pvo_gru_glo(const void* wn, const void* net, float* glo, int E, int HW, int C, int dtype, void* stream);
+int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
+                     void* X, long long rows, int dtype, void* stream);
+int pvo_gru_gate(const void* zr, const float* g, const void* net, void* Z, void* X,
+                 int E, int HW, int dtype, void* stream);
+int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, void* net_out,
+                int E, int HW, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Reprojection helpers                                                       */
 /* ------------------------------------------------------------------------- */
 

@@ -21,6 +21,7 @@ HIP_SOURCES = [
     "corr_build.hip",
     "altcorr.hip",
     "geom.hip",
+    "gru_fused.hip",
     "ba.hip",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -1,0 +1,226 @@
+// gru_fused.hip — the element-wise half of the ConvGRU update operator, fused for gfx950.
+//
+// The reference's ConvGRU.forward (VO_Module/droid_slam/modules/gru.py:19-32) is, around its
+// three 3x3 convolutions, a chain of ~14 element-wise / concat launches over 28-100 MB tensors
+// (cat, cat, sigmoid, mul, mean, add, sigmoid, mul, cat, add, tanh, mul, mul, add) — 45 % of the
+// GPU time of a graph update once the convolutions run on MIOpen's MFMA kernels.  These four
+// kernels replace that chain; the convolutions stay in MIOpen:
+//
+//   gru_glo      glo[e,c]   = mean_p( sigmoid(wn[e,p,c]) * net[e,p,c] )              gru.py:23-24
+//   gru_assemble X[e,p,:]   = [ net | inp | relu(corr_feat) | relu(flow_feat) ]     gru.py:20-21 + encoder ReLUs
+//   gru_gate     z = sigmoid(zr[..,:128] + gz);  X[e,p,:128] = sigmoid(zr[..,128:] + gr) * net   gru.py:26-28
+//   gru_out      net = (1-z)*net + z*tanh(q + gq)                                    gru.py:28-31
+//
+// X is ONE persistent 448-channel channels-last buffer: the z/r convolution reads it, gru_gate
+// then overwrites its first 128 channels with r*net, and the q convolution reads the same buffer,
+// so neither torch.cat of gru.py:20-21,28 is materialised twice.
+// Layout: channels-last fp16/bf16 rows ([E, H*W, C]); 8 channels (16 B) per thread per access.
+// Arithmetic in fp32, one rounding to the storage type per output.
+#include "common.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct H8 {   // 8 x 16-bit <-> 8 x float
+  static __device__ __forceinline__ void unpack(u32x4 v, float f[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = Elem<T>::to_f32(from_bits(v[k] & 0xffffu));
+      f[2 * k + 1] = Elem<T>::to_f32(from_bits(v[k] >> 16));
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float f[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = to_bits(Elem<T>::from_f32(f[2 * k])) | (to_bits(Elem<T>::from_f32(f[2 * k + 1])) << 16);
+    return v;
+  }
+  static __device__ __forceinline__ typename Elem<T>::store_t from_bits(uint32_t b);
+  static __device__ __forceinline__ uint32_t to_bits(typename Elem<T>::store_t s);
+};
+template <> __device__ __forceinline__ _Float16 H8<pvo_half>::from_bits(uint32_t b) {
+  union { uint16_t u; _Float16 h; } c; c.u = static_cast<uint16_t>(b); return c.h;
+}
+template <> __device__ __forceinline__ uint32_t H8<pvo_half>::to_bits(_Float16 s) {
+  union { uint16_t u; _Float16 h; } c; c.h = s; return c.u;
+}
+template <> __device__ __forceinline__ uint16_t H8<pvo_bf16>::from_bits(uint32_t b) { return static_cast<uint16_t>(b); }
+template <> __device__ __forceinline__ uint32_t H8<pvo_bf16>::to_bits(uint16_t s) { return s; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// glo[e,c] += (1/HW) * sum over this block's pixel chunk; glo zeroed by the host wrapper
+template <typename T>
+__global__ __launch_bounds__(256) void gru_glo_kernel(const uint16_t* __restrict__ wn, const uint16_t* __restrict__ net,
+                                                      float* __restrict__ glo, int HW, int C, int chunk) {
+  __shared__ float red[16][129];
+  const int e = blockIdx.y;
+  const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;      // C == 128: 16 groups of 8 channels
+  const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = p0 + pl; p < p1; p += 16) {
+    const long long o = (static_cast<long long>(e) * HW + p) * C + cg * 8;
+    float a[8], b[8];
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(wn + o), a);
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + o), b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += sigmoidf_(a[k]) * b[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[pl][cg * 8 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+    atomicAdd(glo + static_cast<long long>(e) * C + threadIdx.x, s / static_cast<float>(HW));
+  }
+}
+
+// X [E*HW, 448] <- [net(128) | inp(128) | relu(cf)(128) | relu(ff)(64)]
+template <typename T>
+__global__ __launch_bounds__(256) void gru_assemble_kernel(const uint16_t* __restrict__ net, const uint16_t* __restrict__ inp,
+                                                           const uint16_t* __restrict__ cf, const uint16_t* __restrict__ ff,
+                                                           uint16_t* __restrict__ X, long long rows) {
+  const long long total = rows * 56;                 // 448 / 8 chunks per row
+  for (long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; id < total; id += static_cast<long long>(gridDim.x) * 256) {
+    const long long row = id / 56;
+    const int ch = static_cast<int>(id - row * 56);
+    u32x4 v;
+    if (ch < 16) v = *reinterpret_cast<const u32x4*>(net + row * 128 + ch * 8);
+    else if (ch < 32) v = *reinterpret_cast<const u32x4*>(inp + row * 128 + (ch - 16) * 8);
+    else {
+      v = (ch < 48) ? *reinterpret_cast<const u32x4*>(cf + row * 128 + (ch - 32) * 8)
+                    : *reinterpret_cast<const u32x4*>(ff + row * 64 + (ch - 48) * 8);
+      float f[8];
+      H8<T>::unpack(v, f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.0f);
+      v = H8<T>::pack(f);
+    }
+    *reinterpret_cast<u32x4*>(X + row * 448 + ch * 8) = v;
+  }
+}
+
+// zr [E*HW, 256], g [E, 384] fp32 (z | r | q context), net [E*HW,128]; writes Z [E*HW,128] and X[:, :128] = r*net
+template <typename T>
+__global__ __launch_bounds__(256) void gru_gate_kernel(const uint16_t* __restrict__ zr, const float* __restrict__ g,
+                                                       const uint16_t* __restrict__ net, uint16_t* __restrict__ Z,
+                                                       uint16_t* __restrict__ X, long long rows, int HW) {
+  const long long total = rows * 16;
+  for (long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; id < total; id += static_cast<long long>(gridDim.x) * 256) {
+    const long long row = id >> 4;
+    const int ch = static_cast<int>(id & 15);
+    const int e = static_cast<int>(row / HW);
+    float a[8], b[8], n[8], z[8], rn[8];
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(zr + row * 256 + ch * 8), a);
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(zr + row * 256 + 128 + ch * 8), b);
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + row * 128 + ch * 8), n);
+    const float* ge = g + static_cast<long long>(e) * 384 + ch * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      z[k] = sigmoidf_(a[k] + ge[k]);
+      rn[k] = sigmoidf_(b[k] + ge[128 + k]) * n[k];
+    }
+    *reinterpret_cast<u32x4*>(Z + row * 128 + ch * 8) = H8<T>::pack(z);
+    *reinterpret_cast<u32x4*>(X + row * 448 + ch * 8) = H8<T>::pack(rn);
+  }
+}
+
+// net_out = (1-z)*net + z*tanh(q + gq)
+template <typename T>
+__global__ __launch_bounds__(256) void gru_out_kernel(const uint16_t* __restrict__ q, const float* __restrict__ g,
+                                                      const uint16_t* __restrict__ Z, const uint16_t* __restrict__ net,
+                                                      uint16_t* __restrict__ out, long long rows, int HW) {
+  const long long total = rows * 16;
+  for (long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; id < total; id += static_cast<long long>(gridDim.x) * 256) {
+    const long long row = id >> 4;
+    const int ch = static_cast<int>(id & 15);
+    const int e = static_cast<int>(row / HW);
+    float a[8], z[8], n[8], o[8];
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(q + row * 128 + ch * 8), a);
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(Z + row * 128 + ch * 8), z);
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + row * 128 + ch * 8), n);
+    const float* ge = g + static_cast<long long>(e) * 384 + 256 + ch * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (1.0f - z[k]) * n[k] + z[k] * tanhf(a[k] + ge[k]);
+    *reinterpret_cast<u32x4*>(out + row * 128 + ch * 8) = H8<T>::pack(o);
+  }
+}
+
+inline unsigned grid_for(long long items) {
+  long long b = (items + 255) / 256;
+  return static_cast<unsigned>(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+#define GRU_DISPATCH(dtype, CALL_H, CALL_B)        \
+  do {                                             \
+    if ((dtype) == PVO_F16) { CALL_H; }            \
+    else if ((dtype) == PVO_BF16) { CALL_B; }      \
+    else return PVO_EUNSUPPORTED;                  \
+  } while (0)
+
+extern "C" int pvo_gru_glo(const void* wn, const void* net, float* glo, int E, int HW, int C, int dtype, void* stream) {
+  if (E < 0 || HW < 0 || C != 128) return PVO_EINVAL;
+  if (E == 0 || HW == 0) return PVO_OK;
+  if (!wn || !net || !glo || !aligned16(wn) || !aligned16(net) || E > 65535) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  if (hipMemsetAsync(glo, 0, sizeof(float) * static_cast<size_t>(E) * C, st) != hipSuccess) return PVO_ELAUNCH;
+  const int chunk = 512;
+  dim3 grid((HW + chunk - 1) / chunk, E);
+  GRU_DISPATCH(dtype,
+    hipLaunchKernelGGL(gru_glo_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), glo, HW, C, chunk),
+    hipLaunchKernelGGL(gru_glo_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), glo, HW, C, chunk));
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
+                                void* X, long long rows, int dtype, void* stream) {
+  if (rows < 0) return PVO_EINVAL;
+  if (rows == 0) return PVO_OK;
+  if (!net || !inp || !corr_feat || !flow_feat || !X) return PVO_EINVAL;
+  if (!aligned16(net) || !aligned16(inp) || !aligned16(corr_feat) || !aligned16(flow_feat) || !aligned16(X)) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const unsigned gsz = grid_for(rows * 56);
+  GRU_DISPATCH(dtype,
+    hipLaunchKernelGGL(gru_assemble_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), static_cast<uint16_t*>(X), rows),
+    hipLaunchKernelGGL(gru_assemble_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), static_cast<uint16_t*>(X), rows));
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_gru_gate(const void* zr, const float* g, const void* net, void* Z, void* X,
+                            int E, int HW, int dtype, void* stream) {
+  if (E < 0 || HW < 0) return PVO_EINVAL;
+  const long long rows = static_cast<long long>(E) * HW;
+  if (rows == 0) return PVO_OK;
+  if (!zr || !g || !net || !Z || !X || !aligned16(zr) || !aligned16(net) || !aligned16(Z) || !aligned16(X)) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const unsigned gsz = grid_for(rows * 16);
+  GRU_DISPATCH(dtype,
+    hipLaunchKernelGGL(gru_gate_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW),
+    hipLaunchKernelGGL(gru_gate_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW));
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, void* net_out,
+                           int E, int HW, int dtype, void* stream) {
+  if (E < 0 || HW < 0) return PVO_EINVAL;
+  const long long rows = static_cast<long long>(E) * HW;
+  if (rows == 0) return PVO_OK;
+  if (!q || !g || !Z || !net || !net_out || !aligned16(q) || !aligned16(Z) || !aligned16(net) || !aligned16(net_out)) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const unsigned gsz = grid_for(rows * 16);
+  GRU_DISPATCH(dtype,
+    hipLaunchKernelGGL(gru_out_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW),
+    hipLaunchKernelGGL(gru_out_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW));
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}

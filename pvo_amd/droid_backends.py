@@ -376,3 +376,57 @@ def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace,
                                         ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(dev)),
               "ba_finish")
     return [dx, dz]
+
+
+# --------------------------------------------------------------------------- fused ConvGRU element-wise ops
+def _cl(t, name, C):
+    """a [E,C,H,W] tensor stored channels-last (physically [E,H,W,C]), 16-bit"""
+    if t.dim() != 4 or t.shape[1] != C or not t.is_contiguous(memory_format=torch.channels_last):
+        raise PvoHipError("%s must be a channels-last [E,%d,H,W] tensor" % (name, C))
+    if t.dtype not in (torch.float16, torch.bfloat16):
+        raise PvoHipError("%s must be float16 or bfloat16" % name)
+
+
+def gru_glo(wn, net):
+    """mean over pixels of sigmoid(wn)*net (gru.py:23-24) -> [E,128] float32"""
+    _cl(wn, "wn", 128); _cl(net, "net", 128)
+    dev = _dev(wn, net)
+    E, C, H, W = net.shape
+    glo = torch.empty(E, C, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_glo(_ptr(wn), _ptr(net), _ptr(glo), E, H * W, C, _dtype_code(net, "net"), _stream(dev)), "gru_glo")
+    return glo
+
+
+def gru_assemble(net, inp, corr_feat, flow_feat, X):
+    """X [E,448,H,W] (channels-last) <- [net | inp | relu(corr_feat) | relu(flow_feat)]"""
+    _cl(net, "net", 128); _cl(inp, "inp", 128); _cl(corr_feat, "corr_feat", 128); _cl(flow_feat, "flow_feat", 64); _cl(X, "X", 448)
+    dev = _dev(net, inp, corr_feat, flow_feat, X)
+    E, _, H, W = net.shape
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_assemble(_ptr(net), _ptr(inp), _ptr(corr_feat), _ptr(flow_feat), _ptr(X), E * H * W,
+                                           _dtype_code(net, "net"), _stream(dev)), "gru_assemble")
+
+
+def gru_gate(zr, g, net, Z, X):
+    """Z <- sigmoid(zr[:, :128] + g_z);  X[:, :128] <- sigmoid(zr[:, 128:] + g_r) * net   (gru.py:26-28)"""
+    _cl(zr, "zr", 256); _cl(net, "net", 128); _cl(Z, "Z", 128); _cl(X, "X", 448)
+    dev = _dev(zr, g, net, Z, X)
+    _f32(g, "g"); _contig(g, "g")
+    E, _, H, W = net.shape
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_gate(_ptr(zr), _ptr(g), _ptr(net), _ptr(Z), _ptr(X), E, H * W,
+                                       _dtype_code(net, "net"), _stream(dev)), "gru_gate")
+
+
+def gru_out(q, g, Z, net):
+    """(1-Z)*net + Z*tanh(q + g_q)   (gru.py:28-31) -> new hidden state, channels-last [E,128,H,W]"""
+    _cl(q, "q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
+    dev = _dev(q, g, Z, net)
+    _f32(g, "g"); _contig(g, "g")
+    E, _, H, W = net.shape
+    out = torch.empty_like(net, memory_format=torch.channels_last)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_out(_ptr(q), _ptr(g), _ptr(Z), _ptr(net), _ptr(out), E, H * W,
+                                      _dtype_code(net, "net"), _stream(dev)), "gru_out")
+    return out

@@ -10,7 +10,10 @@ What differs is how the forward pass is issued on MI355X (inference path):
   * the z and r gate convolutions read the same 448-channel input: one 256-output conv;
   * the four heads (delta, delta_dy, weight, delta_mask) share their input: one 512-output
     3x3 conv + ReLU, then one 3x3 conv with a block-diagonal weight producing the 8 outputs;
-  * everything runs channels-last so MIOpen picks its NHWC implicit-GEMM (MFMA) kernels.
+  * everything runs channels-last so MIOpen picks its NHWC implicit-GEMM (MFMA) kernels;
+  * the element-wise half of the GRU (2 concats, gates, context mean, state blend: ~14 launches
+    over 28-100 MB tensors in the reference formulation) is 4 hand-written HIP kernels around one
+    persistent 448-channel buffer (pvo_amd/csrc/gru_fused.hip), under fp16/bf16 autocast.
 The fused weights are views built from the individual parameters (cached in eval mode).
 Training mode keeps the per-layer path so autograd sees the original parameters.
 The reference's forward() also evaluates `np.range(...)` at droid_net.py:295, which does not
@@ -83,6 +86,28 @@ class ConvGRU(nn.Module):
             self._fused = (w.detach(), b.detach(), wg.detach(), bg.detach())
         return self._fused
 
+    def fused_forward(self, net, inp, corr_feat, flow_feat):
+        """inference path on the fused HIP element-wise kernels (pvo_amd/csrc/gru_fused.hip).
+        net, inp [E,128,H,W], corr_feat [E,128,H,W] and flow_feat [E,64,H,W] (both BEFORE their
+        trailing ReLU), all channels-last and 16-bit.  Convolutions stay in MIOpen."""
+        from .. import droid_backends as db
+        E, c, h, w = net.shape
+        dt = net.dtype
+        wz, bz, wg, bg = self._fused_zr()
+        key = (E, h, w, dt, net.device)
+        if getattr(self, "_bufs_key", None) != key:
+            mk = lambda ch: torch.empty(E, h, w, ch, dtype=dt, device=net.device).permute(0, 3, 1, 2)
+            self._bufs, self._bufs_key = (mk(448), mk(128)), key
+        X, Z = self._bufs
+        glo = db.gru_glo(self.w(net), net)                                  # [E,128] fp32
+        with torch.autocast("cuda", enabled=False):
+            g = torch.addmm(bg.float(), glo, wg.view(3 * c, c).float().t())  # context of z | r | q, fp32
+        db.gru_assemble(net, inp, corr_feat, flow_feat, X)
+        zr = F.conv2d(X, wz.to(dt), bz.to(dt), padding=1)
+        db.gru_gate(zr, g, net, Z, X)                                       # X[:, :128] <- r * net
+        q = F.conv2d(X, self.convq.weight.to(dt), self.convq.bias.to(dt), padding=1)
+        return db.gru_out(q, g, Z, net)
+
     def forward(self, net, *inputs):
         inp = torch.cat(inputs, dim=1)
         net_inp = torch.cat([net, inp], dim=1)
@@ -150,6 +175,7 @@ class DynamicUpdateModule(nn.Module):
         self.gru = ConvGRU(128, 128 + 128 + 64)
         self.agg = GraphAgg()
         self._fused_heads = None
+        self.fused_gru = True          # use pvo_amd/csrc/gru_fused.hip on the inference path
 
     def train(self, mode=True):
         self._fused_heads = None
@@ -188,9 +214,18 @@ class DynamicUpdateModule(nn.Module):
         corr = corr.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
         flow = flow.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
 
-        corr = self.corr_encoder(corr)
-        flow = self.flow_encoder(flow)
-        net = self.gru(net, inp, corr, flow)
+        fused = (net.is_cuda and not self.training and not torch.is_grad_enabled() and self.fused_gru
+                 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16))
+        if fused:
+            dt = torch.get_autocast_dtype("cuda")
+            cl_ = lambda t: t.to(dt).contiguous(memory_format=torch.channels_last)
+            cf = self.corr_encoder[2](F.relu(self.corr_encoder[0](corr), inplace=True))      # trailing ReLU fused below
+            ff = self.flow_encoder[2](F.relu(self.flow_encoder[0](flow), inplace=True))
+            net = self.gru.fused_forward(cl_(net), cl_(inp), cl_(cf), cl_(ff))
+        else:
+            corr = self.corr_encoder(corr)
+            flow = self.flow_encoder(flow)
+            net = self.gru(net, inp, corr, flow)
 
         delta, delta_dy, weight, delta_m = self._heads(net)
         if use_aff_bri:
