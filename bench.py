@@ -54,7 +54,7 @@ def make_window(device, seed=0):
                      torch.relu(torch.randn(128, H8, W8, generator=g)).half().to(device))
     video.disps[:NKF] = 1.0
     torch.manual_seed(seed)
-    update = DynamicUpdateModule().to(device).eval()
+    update = DynamicUpdateModule().to(device).eval().half()   # fp16 inference weights (the reference runs this module under fp16 autocast)
     graph = FactorGraph(video, update, device=device, max_factors=48)
     graph.add_neighborhood_factors(0, NKF, r=RADIUS)
     # targets = ground-truth reprojection + noise, so BA has a well-posed problem
@@ -114,10 +114,10 @@ def timed_update(graph, events):
     corr = graph.corr
 
     class _Timed:
-        def __call__(self, coords):
+        def __call__(self, coords, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            out = corr(coords)
+            out = corr(coords, **kw)
             e.record()
             events.append((s, e))
             return out

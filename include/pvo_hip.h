@@ -66,11 +66,13 @@ int pvo_corr_index_backward(const float* coords, const void* corr_grad, void* vo
  * pyramid levels gathered and written straight into the concatenated tensor.
  *   volumes_host[l] : device pointer of level l, [N,h1,w1,h2>>l,w2>>l]
  *   coords [N,h1,w1,2] f32 (the reference's un-permuted layout, x then y)
- *   out    [N,num_levels*(2r+1)^2,h1,w1] dtype
+ *   out    [N,num_levels*(2r+1)^2,h1,w1] dtype, or [N,h1,w1,num_levels*(2r+1)^2] when
+ *          out_channels_last != 0 (the layout the update operator's NHWC convolutions read)
  * Level l is sampled at coords / 2^l exactly as corr.py:47 does. */
 int pvo_corr_pyramid_lookup(const void* const* volumes_host, const float* coords, void* out,
                             int N, int h1, int w1, int h2, int w2,
-                            int num_levels, int radius, int dtype, void* stream);
+                            int num_levels, int radius, int dtype, int out_channels_last,
+                            void* stream);
 
 /* droid_backends.altcorr_forward (droid.cpp:190-200; altcorr_kernel.cu:27-149, host :290-319):
  * volume-free lookup.  fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last, coords [B,S,H1,W1,2] f32,

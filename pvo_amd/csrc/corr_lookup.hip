@@ -46,6 +46,7 @@ struct LookupArgs {
   void* out;
   int nlev;
   int coords_interleaved;  // 0: [N,2,h1,w1]   1: [N,h1,w1,2]
+  int out_channels_last;   // 0: out [N,nch,h1,w1]   1: out [N,h1,w1,nch] (what the NHWC convolutions read)
   int HW;                  // h1*w1
   int N;
 };
@@ -216,6 +217,16 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
   const int nch = a.nlev * 49;
   S* outp = reinterpret_cast<S*>(a.out) + static_cast<long long>(n) * nch * HW;
   const int npix = min(kStrip, HW - pix0);
+  if (a.out_channels_last) {
+    // the strip's outputs are one contiguous run of npix*nch elements: consecutive lanes walk the channels
+    // of a pixel (LDS column reads, stride 33 dwords -> conflict free)
+    S* o = outp + static_cast<long long>(pix0) * nch;
+    for (int idx = tid; idx < npix * nch; idx += 256) {
+      const int c = idx / nch, ch = idx - c * nch;
+      o[idx] = stage[ch * kStripPad + c];
+    }
+    return;
+  }
   if constexpr (sizeof(S) == 2) {
     if (((HW | pix0) & 1) == 0 && (npix & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.out) & 3) == 0)) {
       const int half = npix >> 1;
@@ -295,7 +306,8 @@ __global__ __launch_bounds__(256) void corr_lookup_generic_kernel(LookupArgs a, 
         if (x1ok && y0ok) acc = G::step(acc, G::load(L.vol, pbase + static_cast<long long>(yb) * L.w2 + xa + 1), w10);
         if (x1ok && y1ok) acc = G::step(acc, G::load(L.vol, pbase + static_cast<long long>(yb + 1) * L.w2 + xa + 1), w11);
         const long long ch = static_cast<long long>(l) * rd * rd + ax * rd + by;
-        G::store(a.out, (static_cast<long long>(n) * a.nlev * rd * rd + ch) * HW + pix, acc);
+        if (a.out_channels_last) G::store(a.out, (static_cast<long long>(n) * HW + pix) * (a.nlev * rd * rd) + ch, acc);
+        else G::store(a.out, (static_cast<long long>(n) * a.nlev * rd * rd + ch) * HW + pix, acc);
       }
     }
   }
@@ -399,7 +411,8 @@ extern "C" int pvo_corr_index_forward(const void* volume, const float* coords, v
 
 extern "C" int pvo_corr_pyramid_lookup(const void* const* volumes_host, const float* coords, void* out,
                                        int N, int h1, int w1, int h2, int w2,
-                                       int num_levels, int radius, int dtype, void* stream) {
+                                       int num_levels, int radius, int dtype, int out_channels_last,
+                                       void* stream) {
   if (N < 0 || h1 < 0 || w1 < 0 || h2 < 0 || w2 < 0 || radius < 0) return PVO_EINVAL;
   if (num_levels < 1 || num_levels > kMaxLevels || !volumes_host) return PVO_EINVAL;
   if (N == 0 || h1 == 0 || w1 == 0) return PVO_OK;
@@ -415,6 +428,7 @@ extern "C" int pvo_corr_pyramid_lookup(const void* const* volumes_host, const fl
     aligned = aligned && ((reinterpret_cast<uintptr_t>(volumes_host[l]) & 3) == 0);
   }
   a.coords = coords; a.out = out; a.nlev = num_levels; a.coords_interleaved = 1; a.HW = h1 * w1; a.N = N;
+  a.out_channels_last = out_channels_last ? 1 : 0;
   if (!aligned && (dtype == PVO_F16 || dtype == PVO_BF16)) return PVO_EINVAL;
   return dispatch_lookup(a, radius, dtype, pvo_stream(stream));
 }

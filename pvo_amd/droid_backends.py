@@ -112,12 +112,13 @@ def corr_index_backward(volume, coords, corr_grad, radius):
     return [volume_grad]
 
 
-def corr_pyramid_lookup(pyramid, coords, radius):
+def corr_pyramid_lookup(pyramid, coords, radius, channels_last=False):
     """All levels of CorrBlock.__call__ (modules/corr.py:40-50) in one launch.
 
     pyramid: list of level tensors [N,h1,w1,h2>>l,w2>>l]; coords [N,h1,w1,2] f32
-    -> [N, L*(2r+1)^2, h1, w1].  Not part of the reference surface: it is what the
-    Python loop + torch.cat computes, fused."""
+    -> [N, L*(2r+1)^2, h1, w1]; with channels_last=True the same tensor is returned with
+    channels-last strides (stored [N,h1,w1,L*(2r+1)^2]), ready for NHWC convolutions.
+    Not part of the reference surface: it is what the Python loop + torch.cat computes, fused."""
     dev = _dev(coords, *pyramid)
     _contig(coords, "coords"); _f32(coords, "coords")
     for lv in pyramid:
@@ -129,12 +130,15 @@ def corr_pyramid_lookup(pyramid, coords, radius):
             raise PvoHipError("pyramid level %d has shape %s, expected %s"
                               % (l, tuple(lv.shape), (N, h1, w1, h2 >> l, w2 >> l)))
     rd = 2 * radius + 1
-    out = torch.empty((N, L * rd * rd, h1, w1), dtype=pyramid[0].dtype, device=dev)
+    if channels_last:
+        out = torch.empty((N, h1, w1, L * rd * rd), dtype=pyramid[0].dtype, device=dev).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((N, L * rd * rd, h1, w1), dtype=pyramid[0].dtype, device=dev)
     ptrs = (ctypes.c_void_p * L)(*[lv.data_ptr() if lv.numel() else 0 for lv in pyramid])
     lib = _lib.load()
     with torch.cuda.device(dev):
         check(lib.pvo_corr_pyramid_lookup(ptrs, _ptr(coords), _ptr(out), N, h1, w1, h2, w2, L, radius,
-                                          _dtype_code(pyramid[0], "volume"), _stream(dev)),
+                                          _dtype_code(pyramid[0], "volume"), 1 if channels_last else 0, _stream(dev)),
               "corr_pyramid_lookup")
     return out
 

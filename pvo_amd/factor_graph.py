@@ -46,8 +46,19 @@ class FactorGraph:
         self.ii_bad, self.jj_bad = torch.zeros(0, **lng), torch.zeros(0, **lng)
         self.target_cam_inac, self.weight_inac, self.delta_dy_inac, self.full_flow_inac = z(2), z(2), z(2), z(2)
         self.raw_mask_inac = z(self.mask_num)
+        self._cache = {}            # device index tensors derived from the host edge lists; cleared on any edge change
+        try:
+            self._autocast = next(update_op.parameters()).dtype == torch.float32
+        except (StopIteration, AttributeError, TypeError):
+            self._autocast = True
 
     # ------------------------------------------------------------------ edges
+    def _cached(self, key, make):
+        v = self._cache.get(key)
+        if v is None:
+            v = self._cache[key] = make()
+        return v
+
     def _filter_repeated(self, ii, jj):
         have = set(zip(self._ii_h, self._jj_h)) | set(zip(self._ii_inac_h, self._jj_inac_h))
         keep = []
@@ -75,6 +86,7 @@ class FactorGraph:
             ix = [order[p] for p in range(len(order))]
             mask_l = [ix[p] >= self.max_factors - len(ii_l) for p in range(len(order))]
             self.rm_factors(torch.tensor(mask_l, device=self.device), store=True)
+        self._cache.clear()
         ii = torch.tensor(ii_l, dtype=torch.long, device=self.device)
         jj = torch.tensor(jj_l, dtype=torch.long, device=self.device)
         net = self.video.nets[ii][None]
@@ -100,6 +112,7 @@ class FactorGraph:
         """drop edges (factor_graph.py:163-200); mask: bool tensor or list over the active edges"""
         mask_l = [bool(v) for v in (mask.tolist() if isinstance(mask, torch.Tensor) else mask)]
         mask = torch.tensor(mask_l, dtype=torch.bool, device=self.device)
+        self._cache.clear()
         if store:
             self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]])
             self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
@@ -137,6 +150,7 @@ class FactorGraph:
         m = [(i == ix) or (j == ix) for i, j in zip(self._ii_h, self._jj_h)]
         self.ii[self.ii >= ix] -= 1; self.jj[self.jj >= ix] -= 1
         self.ii_inac[self.ii_inac >= ix] -= 1; self.jj_inac[self.jj_inac >= ix] -= 1
+        self._cache.clear()
         dec = lambda l: [a - 1 if a >= ix else a for a in l]
         self._ii_h, self._jj_h = dec(self._ii_h), dec(self._jj_h)
         self._ii_inac_h, self._jj_inac_h = dec(self._ii_inac_h), dec(self._jj_inac_h)
@@ -174,8 +188,8 @@ class FactorGraph:
         motn = torch.cat([self.target_cam - self.coords0, self.target_cam - self.coords0 + self.delta_dy,
                           self.target_cam - coords1, self.raw_mask], dim=-1)
         motn = motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
-        corr = self.corr(coords1)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
+        corr = self.corr(coords1, channels_last=True) if getattr(self.corr, "supports_channels_last", False) else self.corr(coords1)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self._autocast and self.device.type == "cuda"):
             self.net, delta, weight, damping, upmask, delta_m = \
                 self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj, False)
         if t0 is None:
@@ -191,17 +205,19 @@ class FactorGraph:
         self.delta_dy = delta[..., 2:4].float() * (1 - bin_mask)
         self.weight = torch.sigmoid(weight.float() + (1 - bin_mask) * 10)
         src = sorted(set(self._ii_h))                                  # torch.unique(self.ii), host side
-        self.damping[torch.tensor(src, device=self.device)] = damping[0].float()
-        if use_inactive:
-            m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)]
-            m = torch.tensor(m_l, dtype=torch.bool, device=self.device)
+        src_t = self._cached("src", lambda: torch.tensor(src, device=self.device))
+        self.damping[src_t] = damping[0].float()
+        m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)] if use_inactive else []
+        if any(m_l):
+            m = self._cached(("inac", t0), lambda: torch.tensor(m_l, dtype=torch.bool, device=self.device))
             ii, jj = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
             target_cam = torch.cat([self.target_cam_inac[:, m], self.target_cam], 1)
             weight = torch.cat([self.weight_inac[:, m], self.weight], 1)
-            src = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
+            src2 = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
+            src_t = self._cached(("src2", t0), lambda: torch.tensor(src2, device=self.device))
         else:
             ii, jj, target_cam, weight = self.ii, self.jj, self.target_cam, self.weight
-        eta = 0.2 * self.damping[torch.tensor(src, device=self.device)].contiguous() + EP
+        eta = 0.2 * self.damping[src_t] + EP
         target_cam = target_cam.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
         weight = weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
         self.video.ba(target_cam, weight, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)

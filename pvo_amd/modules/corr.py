@@ -29,6 +29,8 @@ class CorrSampler(torch.autograd.Function):
 
 
 class CorrBlock:
+    supports_channels_last = True      # __call__(coords, channels_last=True) returns NHWC-stored features
+
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3, channels_last=False):
         """fmap1, fmap2: [B,N,C,H,W] (reference layout) or [B,N,H,W,C] with channels_last=True."""
         self.num_levels, self.radius = num_levels, radius
@@ -69,7 +71,8 @@ class CorrBlock:
         b = fmap2.reshape(batch * num, dim, ht * wd) / 4.0
         return torch.matmul(a.transpose(1, 2), b).view(batch, num, ht, wd, ht, wd)
 
-    def __call__(self, coords):
+    def __call__(self, coords, channels_last=False):
+        """[B,N,196,H,W]; channels_last=True returns the same tensor stored [B,N,H,W,196]"""
         batch, num, ht, wd, _ = coords.shape
         coords = coords.reshape(batch * num, ht, wd, 2)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.corr_pyramid):
@@ -78,8 +81,8 @@ class CorrBlock:
                    for i in range(self.num_levels)]
             return torch.cat(out, dim=2)
         out = db.corr_pyramid_lookup([p.contiguous() for p in self.corr_pyramid], coords.float().contiguous(),
-                                     self.radius)
-        return out.view(batch, num, -1, ht, wd)
+                                     self.radius, channels_last=channels_last)
+        return out.unflatten(0, (batch, num))
 
     def cat(self, other):
         self.corr_pyramid = [torch.cat([a, b], 0) for a, b in zip(self.corr_pyramid, other.corr_pyramid)]

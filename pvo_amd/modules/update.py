@@ -143,7 +143,8 @@ class GraphAgg(nn.Module):
         net = self.relu(self.conv1(net)).view(batch, num, 128, ht, wd)
         net = scatter_mean(net, ix, dim=1).view(-1, 128, ht, wd)   # mean over edges sharing a source frame
         net = self.relu(self.conv2(net))
-        eta = self.eta(net).view(batch, -1, ht, wd)
+        # softplus in fp32, as autocast does for the reference (softplus is on its fp32 list)
+        eta = self.eta[2](self.eta[1](self.eta[0](net).float())).view(batch, -1, ht, wd)
         upmask = self.upmask_disp(net).view(batch, -1, 8 * 8 * 9, ht, wd)
         return 0.01 * eta, upmask, None, None                      # droid_net.py:95
 
@@ -214,10 +215,14 @@ class DynamicUpdateModule(nn.Module):
         corr = corr.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
         flow = flow.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
 
+        # 16-bit inference either through autocast (fp32 module) or with a module converted by .half()/.bfloat16()
+        pdt = self.gru.convq.weight.dtype
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else pdt
         fused = (net.is_cuda and not self.training and not torch.is_grad_enabled() and self.fused_gru
-                 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16))
+                 and dt in (torch.float16, torch.bfloat16))
+        if pdt != torch.float32 and not torch.is_autocast_enabled("cuda"):
+            net, inp, corr, flow = (t.to(pdt) for t in (net, inp, corr, flow))
         if fused:
-            dt = torch.get_autocast_dtype("cuda")
             cl_ = lambda t: t.to(dt).contiguous(memory_format=torch.channels_last)
             cf = self.corr_encoder[2](F.relu(self.corr_encoder[0](corr), inplace=True))      # trailing ReLU fused below
             ff = self.flow_encoder[2](F.relu(self.flow_encoder[0](flow), inplace=True))
