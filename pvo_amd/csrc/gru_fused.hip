@@ -53,19 +53,22 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // glo[e,c] += (1/HW) * sum over this block's pixel chunk; glo zeroed by the host wrapper
 template <typename T>
 __global__ __launch_bounds__(256) void gru_glo_kernel(const uint16_t* __restrict__ wn, const uint16_t* __restrict__ net,
-                                                      float* __restrict__ glo, int HW, int C, int chunk) {
+                                                      const float* __restrict__ bias, float* __restrict__ glo, int HW, int C, int chunk) {
   __shared__ float red[16][129];
   const int e = blockIdx.y;
   const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;      // C == 128: 16 groups of 8 channels
   const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float bw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bw[k] = bias ? bias[cg * 8 + k] : 0.0f;
   for (int p = p0 + pl; p < p1; p += 16) {
     const long long o = (static_cast<long long>(e) * HW + p) * C + cg * 8;
     float a[8], b[8];
     H8<T>::unpack(*reinterpret_cast<const u32x4*>(wn + o), a);
     H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + o), b);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += sigmoidf_(a[k]) * b[k];
+    for (int k = 0; k < 8; ++k) acc[k] += sigmoidf_(a[k] + bw[k]) * b[k];
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) red[pl][cg * 8 + k] = acc[k];
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256) void gru_glo_kernel(const uint16_t* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void gru_assemble_kernel(const uint16_t* __restrict__ net, const uint16_t* __restrict__ inp,
                                                            const uint16_t* __restrict__ cf, const uint16_t* __restrict__ ff,
+                                                           const float* __restrict__ bc, const float* __restrict__ bf,
                                                            uint16_t* __restrict__ X, long long rows) {
   const long long total = rows * 56;                 // 448 / 8 chunks per row
   for (long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; id < total; id += static_cast<long long>(gridDim.x) * 256) {
@@ -95,8 +99,9 @@ __global__ __launch_bounds__(256) void gru_assemble_kernel(const uint16_t* __res
                     : *reinterpret_cast<const u32x4*>(ff + row * 64 + (ch - 48) * 8);
       float f[8];
       H8<T>::unpack(v, f);
+      const float* bb = (ch < 48) ? (bc ? bc + (ch - 32) * 8 : nullptr) : (bf ? bf + (ch - 48) * 8 : nullptr);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.0f);
+      for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + (bb ? bb[k] : 0.0f), 0.0f);
       v = H8<T>::pack(f);
     }
     *reinterpret_cast<u32x4*>(X + row * 448 + ch * 8) = v;
@@ -149,6 +154,49 @@ __global__ __launch_bounds__(256) void gru_out_kernel(const uint16_t* __restrict
   }
 }
 
+// x[row, c] = act(x[row, c] + bias[c]) in place; C % 8 == 0
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_kernel(uint16_t* __restrict__ x, const float* __restrict__ bias,
+                                                       long long rows, int C, int relu) {
+  const int cpr = C >> 3;
+  const long long total = rows * cpr;
+  for (long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; id < total; id += static_cast<long long>(gridDim.x) * 256) {
+    const int ch = static_cast<int>(id % cpr);
+    float f[8];
+    H8<T>::unpack(*reinterpret_cast<const u32x4*>(x + id * 8), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      f[k] += bias ? bias[ch * 8 + k] : 0.0f;
+      if (relu) f[k] = fmaxf(f[k], 0.0f);
+    }
+    *reinterpret_cast<u32x4*>(x + id * 8) = H8<T>::pack(f);
+  }
+}
+
+// out[k, p, c] = mean over edges e in [ptr[k], ptr[k+1]) of x[idx[e], p, c]   (GraphAgg's scatter_mean, droid_net.py:87)
+template <typename T>
+__global__ __launch_bounds__(256) void seg_mean_kernel(const uint16_t* __restrict__ x, const int* __restrict__ ptr,
+                                                       const int* __restrict__ idx, uint16_t* __restrict__ out,
+                                                       int HW, int C) {
+  const int k = blockIdx.y;
+  const int e0 = ptr[k], e1 = ptr[k + 1];
+  const int cpr = C >> 3;
+  const long long per = static_cast<long long>(HW) * cpr;
+  const float inv = 1.0f / static_cast<float>(max(e1 - e0, 1));
+  for (long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; id < per; id += static_cast<long long>(gridDim.x) * 256) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int o = e0; o < e1; ++o) {
+      float f[8];
+      H8<T>::unpack(*reinterpret_cast<const u32x4*>(x + (static_cast<long long>(idx[o]) * per + id) * 8), f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += f[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] *= inv;
+    *reinterpret_cast<u32x4*>(out + (static_cast<long long>(k) * per + id) * 8) = H8<T>::pack(acc);
+  }
+}
+
 inline unsigned grid_for(long long items) {
   long long b = (items + 255) / 256;
   return static_cast<unsigned>(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
@@ -165,7 +213,8 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
     else return PVO_EUNSUPPORTED;                  \
   } while (0)
 
-extern "C" int pvo_gru_glo(const void* wn, const void* net, float* glo, int E, int HW, int C, int dtype, void* stream) {
+extern "C" int pvo_gru_glo(const void* wn, const void* net, const float* w_bias, float* glo, int E, int HW, int C, int dtype,
+                           void* stream) {
   if (E < 0 || HW < 0 || C != 128) return PVO_EINVAL;
   if (E == 0 || HW == 0) return PVO_OK;
   if (!wn || !net || !glo || !aligned16(wn) || !aligned16(net) || E > 65535) return PVO_EINVAL;
@@ -174,13 +223,14 @@ extern "C" int pvo_gru_glo(const void* wn, const void* net, float* glo, int E, i
   const int chunk = 512;
   dim3 grid((HW + chunk - 1) / chunk, E);
   GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_glo_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), glo, HW, C, chunk),
-    hipLaunchKernelGGL(gru_glo_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), glo, HW, C, chunk));
+    hipLaunchKernelGGL(gru_glo_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), w_bias, glo, HW, C, chunk),
+    hipLaunchKernelGGL(gru_glo_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), w_bias, glo, HW, C, chunk));
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }
 
 extern "C" int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
+                                const float* corr_bias, const float* flow_bias,
                                 void* X, long long rows, int dtype, void* stream) {
   if (rows < 0) return PVO_EINVAL;
   if (rows == 0) return PVO_OK;
@@ -189,8 +239,8 @@ extern "C" int pvo_gru_assemble(const void* net, const void* inp, const void* co
   hipStream_t st = pvo_stream(stream);
   const unsigned gsz = grid_for(rows * 56);
   GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_assemble_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), static_cast<uint16_t*>(X), rows),
-    hipLaunchKernelGGL(gru_assemble_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), static_cast<uint16_t*>(X), rows));
+    hipLaunchKernelGGL(gru_assemble_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows),
+    hipLaunchKernelGGL(gru_assemble_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows));
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }
@@ -221,6 +271,34 @@ extern "C" int pvo_gru_out(const void* q, const float* g, const void* Z, const v
   GRU_DISPATCH(dtype,
     hipLaunchKernelGGL(gru_out_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW),
     hipLaunchKernelGGL(gru_out_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW));
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream) {
+  if (rows < 0 || C <= 0 || (C & 7)) return PVO_EINVAL;
+  if (rows == 0) return PVO_OK;
+  if (!x || !aligned16(x)) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const unsigned gsz = grid_for(rows * (C >> 3));
+  GRU_DISPATCH(dtype,
+    hipLaunchKernelGGL(bias_act_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<uint16_t*>(x), bias, rows, C, relu),
+    hipLaunchKernelGGL(bias_act_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<uint16_t*>(x), bias, rows, C, relu));
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, void* out,
+                                int K, int HW, int C, int dtype, void* stream) {
+  if (K < 0 || HW < 0 || C <= 0 || (C & 7)) return PVO_EINVAL;
+  if (K == 0 || HW == 0) return PVO_OK;
+  if (!x || !seg_ptr || !seg_idx || !out || !aligned16(x) || !aligned16(out) || K > 65535) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const long long per = static_cast<long long>(HW) * (C >> 3);
+  dim3 grid(static_cast<unsigned>((per + 255) / 256 > 1024 ? 1024 : (per + 255) / 256), K);
+  GRU_DISPATCH(dtype,
+    hipLaunchKernelGGL(seg_mean_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), seg_ptr, seg_idx, static_cast<uint16_t*>(out), HW, C),
+    hipLaunchKernelGGL(seg_mean_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), seg_ptr, seg_idx, static_cast<uint16_t*>(out), HW, C));
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }

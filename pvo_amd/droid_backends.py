@@ -391,24 +391,33 @@ def _cl(t, name, C):
         raise PvoHipError("%s must be float16 or bfloat16" % name)
 
 
-def gru_glo(wn, net):
-    """mean over pixels of sigmoid(wn)*net (gru.py:23-24) -> [E,128] float32"""
+def _bias(b, C, what):
+    if b is None:
+        return ctypes.c_void_p(0)
+    if b.dtype != torch.float32 or b.numel() != C or not b.is_contiguous() or not b.is_cuda:
+        raise PvoHipError("%s must be a contiguous float32 device vector of %d elements" % (what, C))
+    return _ptr(b)
+
+
+def gru_glo(wn, net, w_bias=None):
+    """mean over pixels of sigmoid(wn + w_bias)*net (gru.py:23-24) -> [E,128] float32"""
     _cl(wn, "wn", 128); _cl(net, "net", 128)
     dev = _dev(wn, net)
     E, C, H, W = net.shape
     glo = torch.empty(E, C, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_glo(_ptr(wn), _ptr(net), _ptr(glo), E, H * W, C, _dtype_code(net, "net"), _stream(dev)), "gru_glo")
+        check(_lib.load().pvo_gru_glo(_ptr(wn), _ptr(net), _bias(w_bias, 128, "w_bias"), _ptr(glo), E, H * W, C, _dtype_code(net, "net"), _stream(dev)), "gru_glo")
     return glo
 
 
-def gru_assemble(net, inp, corr_feat, flow_feat, X):
-    """X [E,448,H,W] (channels-last) <- [net | inp | relu(corr_feat) | relu(flow_feat)]"""
+def gru_assemble(net, inp, corr_feat, flow_feat, X, corr_bias=None, flow_bias=None):
+    """X [E,448,H,W] (channels-last) <- [net | inp | relu(corr_feat + corr_bias) | relu(flow_feat + flow_bias)]"""
     _cl(net, "net", 128); _cl(inp, "inp", 128); _cl(corr_feat, "corr_feat", 128); _cl(flow_feat, "flow_feat", 64); _cl(X, "X", 448)
     dev = _dev(net, inp, corr_feat, flow_feat, X)
     E, _, H, W = net.shape
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_assemble(_ptr(net), _ptr(inp), _ptr(corr_feat), _ptr(flow_feat), _ptr(X), E * H * W,
+        check(_lib.load().pvo_gru_assemble(_ptr(net), _ptr(inp), _ptr(corr_feat), _ptr(flow_feat),
+                                           _bias(corr_bias, 128, "corr_bias"), _bias(flow_bias, 64, "flow_bias"), _ptr(X), E * H * W,
                                            _dtype_code(net, "net"), _stream(dev)), "gru_assemble")
 
 
@@ -433,4 +442,31 @@ def gru_out(q, g, Z, net):
     with torch.cuda.device(dev):
         check(_lib.load().pvo_gru_out(_ptr(q), _ptr(g), _ptr(Z), _ptr(net), _ptr(out), E, H * W,
                                       _dtype_code(net, "net"), _stream(dev)), "gru_out")
+    return out
+
+
+def bias_act_(x, bias, relu=True):
+    """in place x <- act(x + bias[c]) on a channels-last 16-bit [N,C,H,W] tensor; returns x"""
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype not in (torch.float16, torch.bfloat16):
+        raise PvoHipError("bias_act_: x must be a channels-last 16-bit [N,C,H,W] tensor")
+    dev = _dev(x)
+    N, C, H, W = x.shape
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_bias_act(_ptr(x), _bias(bias, C, "bias"), N * H * W, C, 1 if relu else 0,
+                                       _dtype_code(x, "x"), _stream(dev)), "bias_act")
+    return x
+
+
+def segment_mean(x, seg_ptr, seg_idx, K):
+    """out[k] = mean of x[seg_idx[e]] for e in [seg_ptr[k], seg_ptr[k+1]); x channels-last [E,C,H,W] -> [K,C,H,W]"""
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype not in (torch.float16, torch.bfloat16):
+        raise PvoHipError("segment_mean: x must be a channels-last 16-bit [E,C,H,W] tensor")
+    dev = _dev(x, seg_ptr, seg_idx)
+    if seg_ptr.dtype != torch.int32 or seg_idx.dtype != torch.int32:
+        raise PvoHipError("segment_mean: seg_ptr / seg_idx must be int32")
+    E, C, H, W = x.shape
+    out = torch.empty(K, H, W, C, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_segment_mean(_ptr(x), _ptr(seg_ptr), _ptr(seg_idx), _ptr(out), K, H * W, C,
+                                           _dtype_code(x, "x"), _stream(dev)), "segment_mean")
     return out

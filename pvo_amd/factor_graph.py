@@ -53,6 +53,13 @@ class FactorGraph:
             self._autocast = True
 
     # ------------------------------------------------------------------ edges
+    def _cl5(self, t):
+        """[1,E,C,H,W] stored channels-last ([E,H,W,C] in memory): the layout the NHWC convolutions and the fused
+        element-wise kernels read, fixed when edges change instead of on every update"""
+        if t is None or self.device.type != "cuda" or t.shape[1] == 0:
+            return t
+        return t[0].contiguous(memory_format=torch.channels_last)[None]
+
     def _cached(self, key, make):
         v = self._cache.get(key)
         if v is None:
@@ -95,12 +102,13 @@ class FactorGraph:
             self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self.video.inps[ii][None]
             self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
+            self.inp = self._cl5(self.inp)       # stored channels-last once, so no update re-lays it out
         target, _ = self.video.reproject(ii, jj)
         zeros2 = torch.zeros_like(target)
         self.ii, self.jj = torch.cat([self.ii, ii]), torch.cat([self.jj, jj])
         self.age = torch.cat([self.age, torch.zeros_like(ii)])
         self._ii_h += ii_l; self._jj_h += jj_l; self._age_h += [0] * len(ii_l)
-        self.net = net if self.net is None else torch.cat([self.net, net], 1)
+        self.net = self._cl5(net if self.net is None else torch.cat([self.net, net], 1))
         self.target_cam = torch.cat([self.target_cam, target], 1)
         self.weight = torch.cat([self.weight, zeros2], 1)
         self.raw_mask = torch.cat([self.raw_mask, zeros2[..., :self.mask_num]], 1)
@@ -130,9 +138,9 @@ class FactorGraph:
         if self.corr_impl == "volume" and self.corr is not None:
             self.corr = self.corr[keep]
         if self.net is not None:
-            self.net = self.net[:, keep]
+            self.net = self._cl5(self.net[:, keep])
         if self.inp is not None:
-            self.inp = self.inp[:, keep]
+            self.inp = self._cl5(self.inp[:, keep])
         if self.segm is not None:
             self.segm = self.segm[:, keep]
         self.target_cam, self.weight = self.target_cam[:, keep], self.weight[:, keep]
@@ -165,6 +173,21 @@ class FactorGraph:
                     ii.append(i); jj.append(j)
         self.add_factors(ii, jj)
 
+    def _agg_segments(self):
+        """CSR of the active edges grouped by source frame, groups in sorted(unique(ii)) order (what
+        torch.unique(ii, return_inverse=True) yields on the device, droid_net.py:83) — built from the host mirror"""
+        frames = sorted(set(self._ii_h))
+        pos = {f: k for k, f in enumerate(frames)}
+        buckets = [[] for _ in frames]
+        for e, i in enumerate(self._ii_h):
+            buckets[pos[i]].append(e)
+        ptr, idx = [0], []
+        for b in buckets:
+            idx += b
+            ptr.append(len(idx))
+        return (torch.tensor(ptr, dtype=torch.int32, device=self.device),
+                torch.tensor(idx, dtype=torch.int32, device=self.device), len(frames))
+
     # ------------------------------------------------------------------ hot loop
     def _segment_vote(self, bin_mask):
         """factor_graph.py:256-276 on the device: a segment whose dynamic-pixel fraction exceeds
@@ -190,8 +213,11 @@ class FactorGraph:
         motn = motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
         corr = self.corr(coords1, channels_last=True) if getattr(self.corr, "supports_channels_last", False) else self.corr(coords1)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self._autocast and self.device.type == "cuda"):
+            kw = {}
+            if getattr(self.update_op, "agg", None) is not None and self.device.type == "cuda":
+                kw["agg_segments"] = self._cached("agg", self._agg_segments)
             self.net, delta, weight, damping, upmask, delta_m = \
-                self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj, False)
+                self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj, False, **kw)
         if t0 is None:
             t0 = max(1, min(self._ii_h) + 1)
         if t1 is None:

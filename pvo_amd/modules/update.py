@@ -74,6 +74,7 @@ class ConvGRU(nn.Module):
 
     def train(self, mode=True):
         self._fused = None
+        self._fb = None
         return super().train(mode)
 
     def _fused_zr(self):
@@ -86,7 +87,7 @@ class ConvGRU(nn.Module):
             self._fused = (w.detach(), b.detach(), wg.detach(), bg.detach())
         return self._fused
 
-    def fused_forward(self, net, inp, corr_feat, flow_feat):
+    def fused_forward(self, net, inp, corr_feat, flow_feat, corr_bias=None, flow_bias=None):
         """inference path on the fused HIP element-wise kernels (pvo_amd/csrc/gru_fused.hip).
         net, inp [E,128,H,W], corr_feat [E,128,H,W] and flow_feat [E,64,H,W] (both BEFORE their
         trailing ReLU), all channels-last and 16-bit.  Convolutions stay in MIOpen."""
@@ -99,14 +100,27 @@ class ConvGRU(nn.Module):
             mk = lambda ch: torch.empty(E, h, w, ch, dtype=dt, device=net.device).permute(0, 3, 1, 2)
             self._bufs, self._bufs_key = (mk(448), mk(128)), key
         X, Z = self._bufs
-        glo = db.gru_glo(self.w(net), net)                                  # [E,128] fp32
+        fb = self._fused_bias()
+        # every convolution below runs WITHOUT bias; the biases ride along in the fused kernels
+        glo = db.gru_glo(F.conv2d(net, self.w.weight.to(dt)), net, fb["w"])      # [E,128] fp32
         with torch.autocast("cuda", enabled=False):
-            g = torch.addmm(bg.float(), glo, wg.view(3 * c, c).float().t())  # context of z | r | q, fp32
-        db.gru_assemble(net, inp, corr_feat, flow_feat, X)
-        zr = F.conv2d(X, wz.to(dt), bz.to(dt), padding=1)
+            g = torch.addmm(fb["g"], glo, fb["wg_t"])                       # context of z | r | q (+ conv biases), fp32
+        db.gru_assemble(net, inp, corr_feat, flow_feat, X, corr_bias, flow_bias)
+        zr = F.conv2d(X, wz.to(dt), None, padding=1)
         db.gru_gate(zr, g, net, Z, X)                                       # X[:, :128] <- r * net
-        q = F.conv2d(X, self.convq.weight.to(dt), self.convq.bias.to(dt), padding=1)
+        q = F.conv2d(X, self.convq.weight.to(dt), None, padding=1)
         return db.gru_out(q, g, Z, net)
+
+    def _fused_bias(self):
+        fb = getattr(self, "_fb", None)
+        if fb is None or fb["w"].device != self.w.weight.device:
+            _, bz, wg, bg = self._fused_zr()
+            c = self.w.weight.shape[0]
+            # g = Wg glo + bg + [bz | br | bq]: the z/r/q convolution biases are per-channel constants too
+            fb = self._fb = {"w": self.w.bias.detach().float().contiguous(),
+                             "g": (bg.float() + torch.cat([bz.float(), self.convq.bias.detach().float()])).contiguous(),
+                             "wg_t": wg.view(3 * c, c).float().t().contiguous()}
+        return fb
 
     def forward(self, net, *inputs):
         inp = torch.cat(inputs, dim=1)
@@ -136,13 +150,28 @@ class GraphAgg(nn.Module):
         self.eta = nn.Sequential(nn.Conv2d(128, 1, 3, padding=1), GradientClip(), nn.Softplus())
         self.upmask_disp = nn.Sequential(nn.Conv2d(128, 8 * 8 * 9, 1, padding=0))
 
-    def forward(self, net, ii):
+    def forward(self, net, ii, segments=None):
+        """segments (optional): (seg_ptr int32 [K+1], seg_idx int32 [E], K) — the CSR of edges grouped by source
+        frame in the order of sorted(unique(ii)).  With it the grouping needs no torch.unique (which synchronises
+        with the host to size its output) and the mean is one HIP kernel instead of zeros + 2 index_add + divide."""
         batch, num, ch, ht, wd = net.shape
         net = net.reshape(batch * num, ch, ht, wd)
-        _, ix = torch.unique(ii, return_inverse=True)
-        net = self.relu(self.conv1(net)).view(batch, num, 128, ht, wd)
-        net = scatter_mean(net, ix, dim=1).view(-1, 128, ht, wd)   # mean over edges sharing a source frame
-        net = self.relu(self.conv2(net))
+        fast = (segments is not None and batch == 1 and net.is_cuda and not torch.is_grad_enabled()
+                and net.dtype in (torch.float16, torch.bfloat16))
+        if fast:
+            from .. import droid_backends as db
+            dt = net.dtype
+            b1, b2 = self.conv1.bias.detach().float(), self.conv2.bias.detach().float()
+            x = F.conv2d(net.contiguous(memory_format=torch.channels_last), self.conv1.weight.to(dt), None, padding=1)
+            x = db.bias_act_(x.contiguous(memory_format=torch.channels_last), b1)
+            x = db.segment_mean(x, segments[0], segments[1], segments[2])
+            net = F.conv2d(x, self.conv2.weight.to(dt), None, padding=1)
+            net = db.bias_act_(net.contiguous(memory_format=torch.channels_last), b2)
+        else:
+            _, ix = torch.unique(ii, return_inverse=True)
+            net = self.relu(self.conv1(net)).view(batch, num, 128, ht, wd)
+            net = scatter_mean(net, ix, dim=1).view(-1, 128, ht, wd)   # mean over edges sharing a source frame
+            net = self.relu(self.conv2(net))
         # softplus in fp32, as autocast does for the reference (softplus is on its fp32 list)
         eta = self.eta[2](self.eta[1](self.eta[0](net).float())).view(batch, -1, ht, wd)
         upmask = self.upmask_disp(net).view(batch, -1, 8 * 8 * 9, ht, wd)
@@ -176,11 +205,23 @@ class DynamicUpdateModule(nn.Module):
         self.gru = ConvGRU(128, 128 + 128 + 64)
         self.agg = GraphAgg()
         self._fused_heads = None
+        self._b32 = None
         self.fused_gru = True          # use pvo_amd/csrc/gru_fused.hip on the inference path
 
     def train(self, mode=True):
         self._fused_heads = None
+        self._b32 = None
         return super().train(mode)
+
+    def _bias32(self):
+        b = getattr(self, "_b32", None)
+        if b is None or b["c0"].device != self.corr_encoder[0].bias.device:
+            f = lambda t: t.detach().float().contiguous()
+            b = self._b32 = {"c0": f(self.corr_encoder[0].bias), "c2": f(self.corr_encoder[2].bias),
+                             "f0": f(self.flow_encoder[0].bias), "f2": f(self.flow_encoder[2].bias),
+                             "h1": torch.cat([f(h[0].bias) for h in (self.delta, self.delta_dy, self.weight, self.delta_mask)]),
+                             "a1": f(self.agg.conv1.bias), "a2": f(self.agg.conv2.bias)}
+        return b
 
     def _heads(self, net):
         """delta, delta_dy, weight, delta_mask, each [B,2,H,W]"""
@@ -200,11 +241,17 @@ class DynamicUpdateModule(nn.Module):
             w2 = w2.contiguous(memory_format=torch.channels_last)
             b2 = torch.cat([h[2].bias for h in hs], 0)
             f = self._fused_heads = (w1.detach(), b1.detach(), w2.detach(), b2.detach())
-        x = F.relu(F.conv2d(net, f[0], f[1], padding=1), inplace=True)      # 128 -> 4*128
-        y = F.conv2d(x, f[2], f[3], padding=1)                              # 4 x (128 -> 2), block diagonal
+        if net.is_cuda and net.dtype in (torch.float16, torch.bfloat16) and net.is_contiguous(memory_format=torch.channels_last):
+            from .. import droid_backends as db
+            x = F.conv2d(net, f[0].to(net.dtype), None, padding=1)          # 128 -> 4*128, bias + ReLU fused in one pass
+            x = db.bias_act_(x.contiguous(memory_format=torch.channels_last), self._bias32()["h1"])
+        else:
+            x = F.relu(F.conv2d(net, f[0], f[1], padding=1), inplace=True)  # 128 -> 4*128
+        y = F.conv2d(x, f[2].to(x.dtype), f[3].to(x.dtype), padding=1)      # 4 x (128 -> 2), block diagonal
         return y[:, 0:2], y[:, 2:4], y[:, 4:6], y[:, 6:8]
 
-    def forward(self, net, inp, corr, flow=None, ii=None, jj=None, use_aff_bri=False, raw_mask=None, segments=None):
+    def forward(self, net, inp, corr, flow=None, ii=None, jj=None, use_aff_bri=False, raw_mask=None, segments=None,
+                agg_segments=None):
         batch, num, ch, ht, wd = net.shape
         if flow is None:
             flow = torch.zeros(batch, num, 4 + self.mask_num + 2, ht, wd, device=net.device, dtype=net.dtype)
@@ -223,10 +270,15 @@ class DynamicUpdateModule(nn.Module):
         if pdt != torch.float32 and not torch.is_autocast_enabled("cuda"):
             net, inp, corr, flow = (t.to(pdt) for t in (net, inp, corr, flow))
         if fused:
+            from .. import droid_backends as db
             cl_ = lambda t: t.to(dt).contiguous(memory_format=torch.channels_last)
-            cf = self.corr_encoder[2](F.relu(self.corr_encoder[0](corr), inplace=True))      # trailing ReLU fused below
-            ff = self.flow_encoder[2](F.relu(self.flow_encoder[0](flow), inplace=True))
-            net = self.gru.fused_forward(cl_(net), cl_(inp), cl_(cf), cl_(ff))
+            b32 = self._bias32()
+            conv = lambda m, x, **kw: F.conv2d(x, m.weight.to(dt), None, **kw)       # bias-free MIOpen convolution
+            c1 = db.bias_act_(cl_(conv(self.corr_encoder[0], cl_(corr))), b32["c0"])                 # + bias, ReLU: one pass
+            f1 = db.bias_act_(cl_(conv(self.flow_encoder[0], cl_(flow), padding=3)), b32["f0"])
+            cf = conv(self.corr_encoder[2], c1, padding=1)                  # their bias + ReLU happen in gru_assemble
+            ff = conv(self.flow_encoder[2], f1, padding=1)
+            net = self.gru.fused_forward(cl_(net), cl_(inp), cl_(cf), cl_(ff), b32["c2"], b32["f2"])
         else:
             corr = self.corr_encoder(corr)
             flow = self.flow_encoder(flow)
@@ -243,7 +295,7 @@ class DynamicUpdateModule(nn.Module):
 
         if ii is None:
             return net, delta, weight, delta_m
-        eta, upmask_disp, upmask_flow, upmask_dy = self.agg(net, ii.to(net.device))
+        eta, upmask_disp, upmask_flow, upmask_dy = self.agg(net, ii.to(net.device), agg_segments)
         upmask = {"disp": upmask_disp, "flow": upmask_flow, "dy_mask": upmask_dy}
         if use_aff_bri:
             return net, delta, weight, eta, upmask, delta_m, aff
