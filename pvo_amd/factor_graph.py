@@ -188,6 +188,49 @@ class FactorGraph:
         return (torch.tensor(ptr, dtype=torch.int32, device=self.device),
                 torch.tensor(idx, dtype=torch.int32, device=self.device), len(frames))
 
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
+        """add edges chosen by frame distance with non-maximum suppression (factor_graph.py:372-429).
+        The distance matrix comes back from the device ONCE (the reference reads it element by element with
+        .item() inside the loop); the greedy selection itself is the reference's, on host lists."""
+        t = self.video.counter
+        ix, jx = list(range(t0, t)), list(range(t1, t))
+        if not ix or not jx:
+            return
+        ii = [i for i in ix for _ in jx]
+        jj = [j for _ in ix for j in jx]
+        d = self.video.distance(ii, jj, beta=beta).float().cpu().tolist()
+        inf = float("inf")
+        nj = t - t1
+        for k, (i, j) in enumerate(zip(ii, jj)):
+            if i - rad < j or d[k] > 100:
+                d[k] = inf
+
+        def suppress(i, j):
+            for di in range(-nms, nms + 1):
+                for dj in range(-nms, nms + 1):
+                    if abs(di) + abs(dj) <= max(min(abs(i - j) - 2, nms), 0):
+                        i1, j1 = i + di, j + dj
+                        if t0 <= i1 < t and t1 <= j1 < t:
+                            d[(i1 - t0) * nj + (j1 - t1)] = inf
+
+        have = list(zip(self._ii_h, self._jj_h)) + list(zip(self.ii_bad.tolist(), self.jj_bad.tolist())) + \
+            list(zip(self._ii_inac_h, self._jj_inac_h))
+        for i, j in have:
+            if abs(i - j) > 2:
+                suppress(i, j)
+        es = []
+        for i in range(t0, t):
+            for j in range(i + 1, min(i + rad + 1, t)):
+                es += [(i, j), (j, i)]
+        for k in sorted(range(len(d)), key=lambda k: d[k]):          # argsort(d), stable
+            if d[k] > thresh:
+                continue
+            i, j = ii[k], jj[k]
+            es += [(i, j), (j, i)]                                    # bidirectional
+            suppress(i, j)
+        if es:
+            self.add_factors([e[0] for e in es], [e[1] for e in es], remove)
+
     # ------------------------------------------------------------------ hot loop
     def _segment_vote(self, bin_mask):
         """factor_graph.py:256-276 on the device: a segment whose dynamic-pixel fraction exceeds
@@ -211,7 +254,12 @@ class FactorGraph:
         motn = torch.cat([self.target_cam - self.coords0, self.target_cam - self.coords0 + self.delta_dy,
                           self.target_cam - coords1, self.raw_mask], dim=-1)
         motn = motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
-        corr = self.corr(coords1, channels_last=True) if getattr(self.corr, "supports_channels_last", False) else self.corr(coords1)
+        if self.corr is None:            # corr_impl != "volume": the update operator gets no correlation features
+            corr = None
+        elif getattr(self.corr, "supports_channels_last", False):
+            corr = self.corr(coords1, channels_last=True)
+        else:
+            corr = self.corr(coords1)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self._autocast and self.device.type == "cuda"):
             kw = {}
             if getattr(self.update_op, "agg", None) is not None and self.device.type == "cuda":

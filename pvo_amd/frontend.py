@@ -1,0 +1,66 @@
+"""DroidFrontend — local-window keyframe optimisation (the caller of the hot path).
+
+Counterpart of the reference's DroidFrontend (VO_Module/droid_slam/droid_frontend.py:9-112): same constants
+(max_factors 48, max_age 25, iters1 4, iters2 2), same initialise / update sequence.  `video.counter` is a plain
+int here (one process per GPU) and the keyframe-distance test reads ONE scalar back per keyframe — the only
+host synchronisation left in a keyframe update.
+"""
+import torch
+
+from .factor_graph import FactorGraph
+
+
+class DroidFrontend:
+    def __init__(self, update_op, video, device="cuda:0", warmup=8, beta=0.3, frontend_nms=1, keyframe_thresh=4.0,
+                 frontend_window=25, frontend_thresh=16.0, frontend_radius=2, max_factors=48):
+        self.video, self.update_op = video, update_op
+        self.graph = FactorGraph(video, update_op, device, max_factors=max_factors)
+        self.t0 = self.t1 = 0
+        self.is_initialized = False
+        self.count = 0
+        self.max_age, self.iters1, self.iters2 = 25, 4, 2
+        self.warmup, self.beta, self.frontend_nms = warmup, beta, frontend_nms
+        self.keyframe_thresh, self.frontend_window = keyframe_thresh, frontend_window
+        self.frontend_thresh, self.frontend_radius = frontend_thresh, frontend_radius
+
+    def _update(self):
+        """add edges, optimise, decide whether the previous frame stays a keyframe (droid_frontend.py:36-70)"""
+        self.count += 1
+        self.t1 += 1
+        if self.graph._ii_h:
+            self.graph.rm_factors([a > self.max_age for a in self.graph._age_h], store=True)
+        self.graph.add_proximity_factors(self.t1 - 5, max(self.t1 - self.frontend_window, 0), rad=self.frontend_radius,
+                                         nms=self.frontend_nms, thresh=self.frontend_thresh, beta=self.beta, remove=True)
+        for _ in range(self.iters1):
+            self.graph.update(None, None, use_inactive=True)
+        d = self.video.distance([self.t1 - 3], [self.t1 - 2], beta=self.beta, bidirectional=True)
+        if d.item() < self.keyframe_thresh:
+            self.graph.rm_keyframe(self.t1 - 2)
+            self.video.counter -= 1
+            self.t1 -= 1
+        else:
+            for _ in range(self.iters2):
+                self.graph.update(None, None, use_inactive=True)
+        self.video.poses[self.t1] = self.video.poses[self.t1 - 1]
+        self.video.disps[self.t1] = self.video.disps[self.t1 - 1].mean()
+        self.video.dirty[min(self.graph._ii_h):self.t1] = True
+
+    def _initialize(self):
+        """bootstrap on the first `warmup` keyframes (droid_frontend.py:72-101)"""
+        self.t0, self.t1 = 0, self.video.counter
+        self.graph.add_neighborhood_factors(self.t0, self.t1, r=3)
+        for _ in range(8):
+            self.graph.update(1, use_inactive=True)
+        self.graph.add_proximity_factors(0, 0, rad=2, nms=2, thresh=self.frontend_thresh)
+        for _ in range(12):
+            self.graph.update(1, use_inactive=True)
+        self.video.poses[self.t1] = self.video.poses[self.t1 - 1].clone()
+        self.video.disps[self.t1] = self.video.disps[self.t1 - 4:self.t1].mean()
+        self.is_initialized = True
+        self.video.dirty[:self.t1] = True
+
+    def __call__(self):
+        if not self.is_initialized and self.video.counter == self.warmup:
+            self._initialize()
+        elif self.is_initialized and self.t1 < self.video.counter:
+            self._update()

@@ -1,0 +1,111 @@
+"""Synthetic closed-loop VO scenes (no dataset or checkpoint is available for the reference:
+/root/reference/checkpoints and datasets hold only READMEs).
+
+A static world made of planes is viewed along a smooth trajectory; depth maps are exact ray/plane
+intersections, so ground-truth correspondences between any two keyframes follow from geometry.  An
+`OracleFlowOperator` stands in for the learned update operator: it answers every graph update with
+the ground-truth correspondence field (+ fixed noise) and a confidence, which turns the frontend +
+dense BA into a closed loop whose trajectory error can be measured (ATE-RMSE after Sim(3) alignment,
+as test_vo.py:162-163 does with evo) and compared between the HIP path and the CPU oracle path.
+"""
+import math
+
+import torch
+
+from .geom.se3 import SE3
+
+
+class PlaneScene:
+    def __init__(self, ht=48, wd=64, n_frames=24, seed=0, step=0.12):
+        g = torch.Generator().manual_seed(seed)
+        self.ht, self.wd, self.n = ht, wd, n_frames
+        self.intr = torch.tensor([wd * 0.625, wd * 0.625, wd / 2.0, ht / 2.0])
+        # planes n.X = d (world): a tilted far wall, a ground plane, a side wall
+        self.planes = [(torch.tensor([0.15, 0.05, 1.0]), 4.0), (torch.tensor([0.0, 1.0, 0.12]), 1.3),
+                       (torch.tensor([1.0, 0.0, 0.35]), 3.2)]
+        xi = []
+        for k in range(n_frames):
+            a = k * step
+            xi.append(torch.tensor([-a, 0.03 * math.sin(1.3 * a), -0.25 * a, 0.02 * math.sin(a), -0.06 * a, 0.01 * a]))
+        self.poses = torch.stack([SE3.exp(x).data for x in xi])         # world-to-camera, frame 0 = identity
+        self.disps = torch.stack([self.render_disp(self.poses[k]) for k in range(n_frames)])
+        self.noise = [torch.randn(ht, wd, 2, generator=g) for _ in range(8)]
+
+    def render_disp(self, pose):
+        ht, wd = self.ht, self.wd
+        fx, fy, cx, cy = self.intr.tolist()
+        y, x = torch.meshgrid(torch.arange(ht).float(), torch.arange(wd).float(), indexing="ij")
+        rays_c = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(x)], -1)       # z_cam = 1
+        G = SE3(pose).inv()                                                                # camera-to-world
+        centre = G.data[:3]
+        rays_w = G.act(torch.cat([rays_c, torch.zeros(ht, wd, 1)], -1))[..., :3]           # rotate only (w = 0)
+        lam = torch.full((ht, wd), float("inf"))
+        for n, d in self.planes:
+            denom = (rays_w * n).sum(-1)
+            l = (d - (centre * n).sum()) / denom
+            l = torch.where((l > 0.05) & (denom.abs() > 1e-6), l, torch.full_like(l, float("inf")))
+            lam = torch.minimum(lam, l)
+        return 1.0 / lam                                                                   # disparity = 1 / depth
+
+
+class OracleFlowOperator:
+    """stand-in for DynamicUpdateModule: returns the ground-truth correspondences as its flow revision.
+    reproject_fn(poses, disps, intrinsics[F,4], ii, jj) -> coords [E,h,w,2] (HIP kernel or CPU oracle)."""
+
+    def __init__(self, scene, video, reproject_fn, noise=0.05, conf=4.0, eta=1e-3):
+        self.scene, self.video, self.reproject_fn = scene, video, reproject_fn
+        self.noise, self.conf, self.eta = noise, conf, eta
+        dev = video.poses.device
+        F = video.poses.shape[0]
+        self.gt_poses = torch.zeros(F, 7); self.gt_poses[:, 6] = 1
+        self.gt_disps = torch.ones(F, scene.ht, scene.wd)
+        self.frame_of = {}            # video slot -> scene frame (slots are renumbered when keyframes are dropped)
+        self.dev = dev
+
+    def parameters(self):
+        return iter(())
+
+    def bind(self, slot, frame):
+        self.frame_of[slot] = frame
+
+    def _gt_tables(self, nslots):
+        for s in range(nslots):
+            f = self.frame_of.get(s, s)
+            self.gt_poses[s] = self.scene.poses[f]; self.gt_disps[s] = self.scene.disps[f]
+        return self.gt_poses.to(self.dev), self.gt_disps.to(self.dev)
+
+    def __call__(self, net, inp, corr, motn, ii, jj, flag=False, **kw):
+        v = self.video
+        E = ii.shape[0]
+        gp, gd = self._gt_tables(v.counter)
+        gt = self.reproject_fn(gp, gd, v.intrinsics, ii, jj)
+        cur = self.reproject_fn(v.poses, v.disps, v.intrinsics, ii, jj)
+        ii_l, jj_l = ii.tolist(), jj.tolist()
+        nz = torch.stack([self.scene.noise[(3 * i + j) % 8] for i, j in zip(ii_l, jj_l)]).to(self.dev)
+        delta = torch.zeros(1, E, self.scene.ht, self.scene.wd, 4, device=self.dev)
+        delta[0, ..., 0:2] = gt + self.noise * nz - cur
+        weight = torch.full((1, E, self.scene.ht, self.scene.wd, 2), self.conf, device=self.dev)
+        K = len(set(ii_l))
+        eta = torch.full((1, K, self.scene.ht, self.scene.wd), self.eta, device=self.dev)
+        delta_m = torch.zeros(1, E, self.scene.ht, self.scene.wd, 2, device=self.dev)
+        return net, delta, weight, eta, {}, delta_m
+
+
+def run_sequence(scene, video, frontend, operator, n_frames=None):
+    """feed the scene's frames as keyframes (the motion filter is outside this path) and run the frontend"""
+    n_frames = n_frames or scene.n
+    dev = video.poses.device
+    h, w = scene.ht, scene.wd
+    g = torch.Generator().manual_seed(1)
+    for k in range(n_frames):
+        slot = video.counter
+        operator.bind(slot, k)
+        video.append(float(k), None if k else scene.poses[0].to(dev), None, scene.intr.to(dev),
+                     torch.randn(h, w, 128, generator=g).half().to(dev),
+                     torch.zeros(128, h, w, dtype=torch.half, device=dev), torch.zeros(128, h, w, dtype=torch.half, device=dev))
+        frontend()
+        # slots above a dropped keyframe move down by one (rm_keyframe)
+        if video.counter <= slot:
+            operator.frame_of.pop(slot, None)
+            operator.bind(video.counter - 1, k)
+    return video.poses[:video.counter].detach().cpu(), [operator.frame_of.get(s, s) for s in range(video.counter)]
