@@ -119,6 +119,11 @@ int pvo_corr_build(const void* fmap1, const void* fmap2, void* const* levels_hos
  *   pvo_gru_gate     Z = sigmoid(zr[:, :128] + g[e, 0:128]);  X[:, :128] = sigmoid(zr[:,128:] + g[e,128:256]) * net
  *                    (gru.py:26-28; zr = conv([convz;convr])(X), g[E,384] f32 = context 1x1 convs of glo)
  *   pvo_gru_out      net_out = (1-Z)*net + Z*tanh(q + g[e,256:384])      q = convq(X)      (gru.py:28-31)
+ * Static-input split: `inp` does not change between updates of an edge, and convolution is linear in its input
+ * channels, so conv(W, [net|inp|corr|flow]) = conv(W[:, dyn], [net|corr|flow]) + conv(W[:, inp], inp).  With
+ * with_inp = 0 / x_channels = 320, X holds only the 320 changing channels and P_zr [rows,256] / P_q [rows,128]
+ * carry the precomputed inp terms (added before the gates' non-linearities).  That removes 128 of the 448 input
+ * channels (29 %) from the two largest convolutions of every update.
  * Convolution biases are folded in: w_bias into pvo_gru_glo (sigmoid(wn + b)), corr_bias/flow_bias into
  * pvo_gru_assemble (relu(x + b)), the z/r/q biases into g; all bias pointers are f32 [C] and may be NULL.
  *   pvo_bias_act     x[rows,C] <- act(x + bias[c]) in place (act = ReLU when relu != 0): the bias add and ReLU that
@@ -129,11 +134,11 @@ int pvo_gru_glo(const void* wn, const void* net, const float* w_bias, float* glo
                 void* stream);
 int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
                      const float* corr_bias, const float* flow_bias,
-                     void* X, long long rows, int dtype, void* stream);
+                     void* X, long long rows, int with_inp, int dtype, void* stream);
 int pvo_gru_gate(const void* zr, const float* g, const void* net, void* Z, void* X,
-                 int E, int HW, int dtype, void* stream);
+                 const void* P_zr, int x_channels, int E, int HW, int dtype, void* stream);
 int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, void* net_out,
-                int E, int HW, int dtype, void* stream);
+                const void* P_q, int E, int HW, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, void* out,
                      int K, int HW, int C, int dtype, void* stream);

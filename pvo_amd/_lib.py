@@ -25,11 +25,11 @@ SIGNATURES = {
     "pvo_altcorr_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_gru_glo": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _vp]),
+    "pvo_gru_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),
     "pvo_bias_act": (_i, [_vp, _vp, _c.c_longlong, _i, _i, _i, _vp]),
     "pvo_segment_mean": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "pvo_gru_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pvo_gru_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_gru_out": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_frame_distance": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "pvo_projmap": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_iproj": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -97,12 +97,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void gru_assemble_kernel(const uint16_t* __restrict__ net, const uint16_t* __restrict__ inp,
                                                            const uint16_t* __restrict__ cf, const uint16_t* __restrict__ ff,
                                                            const float* __restrict__ bc, const float* __restrict__ bf,
-                                                           uint16_t* __restrict__ X, long long rows) {
-  // 32-bit index math (the host checks rows*56 < 2^31): a 64-bit divide per 16-byte chunk made this kernel ALU bound
-  const unsigned total = static_cast<unsigned>(rows) * 56u;   // 448 / 8 chunks per row
+                                                           uint16_t* __restrict__ X, long long rows, int with_inp) {
+  // with_inp == 0: X has 320 channels [net | relu(cf) | relu(ff)] (the inp block's convolution is precomputed)
+  const unsigned cpr = with_inp ? 56u : 40u;                  // 16-byte chunks per row of X
+  const unsigned total = static_cast<unsigned>(rows) * cpr;
   for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
-    const unsigned row = id / 56u;
-    const int ch = static_cast<int>(id - row * 56u);
+    const unsigned row = id / cpr;
+    const int chx = static_cast<int>(id - row * cpr);          // chunk inside X
+    const int ch = (with_inp || chx < 16) ? chx : chx + 16;    // chunk in the 448-channel numbering
     u32x4 v;
     if (ch < 16) v = *reinterpret_cast<const u32x4*>(net + static_cast<size_t>(row) * 128 + ch * 8);
     else if (ch < 32) v = *reinterpret_cast<const u32x4*>(inp + static_cast<size_t>(row) * 128 + (ch - 16) * 8);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void gru_assemble_kernel(const uint16_t* __res
       for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + bb[k], 0.0f);
       v = H8<T>::pack(f);
     }
-    *reinterpret_cast<u32x4*>(X + static_cast<size_t>(row) * 448 + ch * 8) = v;
+    *reinterpret_cast<u32x4*>(X + static_cast<size_t>(row) * (cpr * 8) + chx * 8) = v;
   }
 }
 
@@ -125,7 +127,8 @@ __global__ __launch_bounds__(256) void gru_assemble_kernel(const uint16_t* __res
 template <typename T>
 __global__ __launch_bounds__(256) void gru_gate_kernel(const uint16_t* __restrict__ zr, const float* __restrict__ g,
                                                        const uint16_t* __restrict__ net, uint16_t* __restrict__ Z,
-                                                       uint16_t* __restrict__ X, long long rows, int HW) {
+                                                       uint16_t* __restrict__ X, long long rows, int HW,
+                                                       const uint16_t* __restrict__ P, int xc) {
   const unsigned total = static_cast<unsigned>(rows) * 16u;
   for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
     const size_t row = id >> 4;
@@ -138,13 +141,20 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const uint16_t* __restric
     float gz[8], gr[8];
     load8f(g + static_cast<long long>(e) * 384 + ch * 8, gz);
     load8f(g + static_cast<long long>(e) * 384 + 128 + ch * 8, gr);
+    if (P) {   // precomputed convolution of the (static) inp block, [rows, 256]
+      float pz[8], pr[8];
+      H8<T>::unpack(*reinterpret_cast<const u32x4*>(P + row * 256 + ch * 8), pz);
+      H8<T>::unpack(*reinterpret_cast<const u32x4*>(P + row * 256 + 128 + ch * 8), pr);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { gz[k] += pz[k]; gr[k] += pr[k]; }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       z[k] = sigmoidf_(a[k] + gz[k]);
       rn[k] = sigmoidf_(b[k] + gr[k]) * n[k];
     }
     *reinterpret_cast<u32x4*>(Z + row * 128 + ch * 8) = H8<T>::pack(z);
-    *reinterpret_cast<u32x4*>(X + row * 448 + ch * 8) = H8<T>::pack(rn);
+    *reinterpret_cast<u32x4*>(X + row * xc + ch * 8) = H8<T>::pack(rn);
   }
 }
 
@@ -152,7 +162,8 @@ __global__ __launch_bounds__(256) void gru_gate_kernel(const uint16_t* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void gru_out_kernel(const uint16_t* __restrict__ q, const float* __restrict__ g,
                                                       const uint16_t* __restrict__ Z, const uint16_t* __restrict__ net,
-                                                      uint16_t* __restrict__ out, long long rows, int HW) {
+                                                      uint16_t* __restrict__ out, long long rows, int HW,
+                                                      const uint16_t* __restrict__ P) {
   const unsigned total = static_cast<unsigned>(rows) * 16u;
   for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
     const size_t row = id >> 4;
@@ -164,6 +175,12 @@ __global__ __launch_bounds__(256) void gru_out_kernel(const uint16_t* __restrict
     H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + row * 128 + ch * 8), n);
     float gq[8];
     load8f(g + static_cast<long long>(e) * 384 + 256 + ch * 8, gq);
+    if (P) {
+      float pq[8];
+      H8<T>::unpack(*reinterpret_cast<const u32x4*>(P + row * 128 + ch * 8), pq);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gq[k] += pq[k];
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = (1.0f - z[k]) * n[k] + z[k] * tanhf(a[k] + gq[k]);
     *reinterpret_cast<u32x4*>(out + row * 128 + ch * 8) = H8<T>::pack(o);
@@ -262,23 +279,26 @@ extern "C" int pvo_gru_glo(const void* wn, const void* net, const float* w_bias,
 
 extern "C" int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
                                 const float* corr_bias, const float* flow_bias,
-                                void* X, long long rows, int dtype, void* stream) {
+                                void* X, long long rows, int with_inp, int dtype, void* stream) {
   if (rows < 0) return PVO_EINVAL;
   if (rows == 0) return PVO_OK;
-  if (!net || !inp || !corr_feat || !flow_feat || !X) return PVO_EINVAL;
+  if (!net || (with_inp && !inp) || !corr_feat || !flow_feat || !X) return PVO_EINVAL;
+  if (!inp) inp = net;   // unused when with_inp == 0
   if (rows * 56 >= (1LL << 31)) return PVO_EUNSUPPORTED;
   if (!aligned16(net) || !aligned16(inp) || !aligned16(corr_feat) || !aligned16(flow_feat) || !aligned16(X)) return PVO_EINVAL;
   hipStream_t st = pvo_stream(stream);
   const unsigned gsz = grid_for(rows * 56);
   GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_assemble_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows),
-    hipLaunchKernelGGL(gru_assemble_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows));
+    hipLaunchKernelGGL(gru_assemble_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows, with_inp),
+    hipLaunchKernelGGL(gru_assemble_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows, with_inp));
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }
 
 extern "C" int pvo_gru_gate(const void* zr, const float* g, const void* net, void* Z, void* X,
-                            int E, int HW, int dtype, void* stream) {
+                            const void* P_zr, int x_channels, int E, int HW, int dtype, void* stream) {
+  if (x_channels != 448 && x_channels != 320) return PVO_EINVAL;
+  if (P_zr && !aligned16(P_zr)) return PVO_EINVAL;
   if (E < 0 || HW < 0) return PVO_EINVAL;
   const long long rows = static_cast<long long>(E) * HW;
   if (rows == 0) return PVO_OK;
@@ -287,14 +307,15 @@ extern "C" int pvo_gru_gate(const void* zr, const float* g, const void* net, voi
   hipStream_t st = pvo_stream(stream);
   const unsigned gsz = grid_for(rows * 16);
   GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_gate_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW),
-    hipLaunchKernelGGL(gru_gate_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW));
+    hipLaunchKernelGGL(gru_gate_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW, static_cast<const uint16_t*>(P_zr), x_channels),
+    hipLaunchKernelGGL(gru_gate_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW, static_cast<const uint16_t*>(P_zr), x_channels));
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }
 
 extern "C" int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, void* net_out,
-                           int E, int HW, int dtype, void* stream) {
+                           const void* P_q, int E, int HW, int dtype, void* stream) {
+  if (P_q && !aligned16(P_q)) return PVO_EINVAL;
   if (E < 0 || HW < 0) return PVO_EINVAL;
   const long long rows = static_cast<long long>(E) * HW;
   if (rows == 0) return PVO_OK;
@@ -303,8 +324,8 @@ extern "C" int pvo_gru_out(const void* q, const float* g, const void* Z, const v
   hipStream_t st = pvo_stream(stream);
   const unsigned gsz = grid_for(rows * 16);
   GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_out_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW),
-    hipLaunchKernelGGL(gru_out_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW));
+    hipLaunchKernelGGL(gru_out_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW, static_cast<const uint16_t*>(P_q)),
+    hipLaunchKernelGGL(gru_out_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW, static_cast<const uint16_t*>(P_q)));
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }

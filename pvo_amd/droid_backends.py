@@ -411,36 +411,46 @@ def gru_glo(wn, net, w_bias=None):
 
 
 def gru_assemble(net, inp, corr_feat, flow_feat, X, corr_bias=None, flow_bias=None):
-    """X [E,448,H,W] (channels-last) <- [net | inp | relu(corr_feat + corr_bias) | relu(flow_feat + flow_bias)]"""
-    _cl(net, "net", 128); _cl(inp, "inp", 128); _cl(corr_feat, "corr_feat", 128); _cl(flow_feat, "flow_feat", 64); _cl(X, "X", 448)
+    """X [E,448,H,W] (channels-last) <- [net | inp | relu(corr_feat + corr_bias) | relu(flow_feat + flow_bias)];
+    with inp=None, X is [E,320,H,W] without the inp block (its convolution is precomputed, see gru_gate)."""
+    _cl(net, "net", 128); _cl(corr_feat, "corr_feat", 128); _cl(flow_feat, "flow_feat", 64)
+    if inp is not None:
+        _cl(inp, "inp", 128)
+    _cl(X, "X", 448 if inp is not None else 320)
     dev = _dev(net, inp, corr_feat, flow_feat, X)
     E, _, H, W = net.shape
     with torch.cuda.device(dev):
         check(_lib.load().pvo_gru_assemble(_ptr(net), _ptr(inp), _ptr(corr_feat), _ptr(flow_feat),
                                            _bias(corr_bias, 128, "corr_bias"), _bias(flow_bias, 64, "flow_bias"), _ptr(X), E * H * W,
+                                           1 if inp is not None else 0,
                                            _dtype_code(net, "net"), _stream(dev)), "gru_assemble")
 
 
-def gru_gate(zr, g, net, Z, X):
-    """Z <- sigmoid(zr[:, :128] + g_z);  X[:, :128] <- sigmoid(zr[:, 128:] + g_r) * net   (gru.py:26-28)"""
-    _cl(zr, "zr", 256); _cl(net, "net", 128); _cl(Z, "Z", 128); _cl(X, "X", 448)
-    dev = _dev(zr, g, net, Z, X)
+def gru_gate(zr, g, net, Z, X, P_zr=None):
+    """Z <- sigmoid(zr[:, :128] + P_zr[:, :128] + g_z);  X[:, :128] <- sigmoid(zr[:, 128:] + P_zr[:, 128:] + g_r) * net
+    (gru.py:26-28); X has 448 or 320 channels"""
+    _cl(zr, "zr", 256); _cl(net, "net", 128); _cl(Z, "Z", 128); _cl(X, "X", X.shape[1])
+    if P_zr is not None:
+        _cl(P_zr, "P_zr", 256)
+    dev = _dev(zr, g, net, Z, X, P_zr)
     _f32(g, "g"); _contig(g, "g")
     E, _, H, W = net.shape
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_gate(_ptr(zr), _ptr(g), _ptr(net), _ptr(Z), _ptr(X), E, H * W,
+        check(_lib.load().pvo_gru_gate(_ptr(zr), _ptr(g), _ptr(net), _ptr(Z), _ptr(X), _ptr(P_zr), X.shape[1], E, H * W,
                                        _dtype_code(net, "net"), _stream(dev)), "gru_gate")
 
 
-def gru_out(q, g, Z, net):
-    """(1-Z)*net + Z*tanh(q + g_q)   (gru.py:28-31) -> new hidden state, channels-last [E,128,H,W]"""
+def gru_out(q, g, Z, net, P_q=None):
+    """(1-Z)*net + Z*tanh(q + P_q + g_q)   (gru.py:28-31) -> new hidden state, channels-last [E,128,H,W]"""
     _cl(q, "q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
-    dev = _dev(q, g, Z, net)
+    if P_q is not None:
+        _cl(P_q, "P_q", 128)
+    dev = _dev(q, g, Z, net, P_q)
     _f32(g, "g"); _contig(g, "g")
     E, _, H, W = net.shape
     out = torch.empty_like(net, memory_format=torch.channels_last)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_out(_ptr(q), _ptr(g), _ptr(Z), _ptr(net), _ptr(out), E, H * W,
+        check(_lib.load().pvo_gru_out(_ptr(q), _ptr(g), _ptr(Z), _ptr(net), _ptr(out), _ptr(P_q), E, H * W,
                                       _dtype_code(net, "net"), _stream(dev)), "gru_out")
     return out
 

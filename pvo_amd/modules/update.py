@@ -75,6 +75,8 @@ class ConvGRU(nn.Module):
     def train(self, mode=True):
         self._fused = None
         self._fb = None
+        self._ws = None
+        self._P_key = None
         return super().train(mode)
 
     def _fused_zr(self):
@@ -98,18 +100,39 @@ class ConvGRU(nn.Module):
         key = (E, h, w, dt, net.device)
         if getattr(self, "_bufs_key", None) != key:
             mk = lambda ch: torch.empty(E, h, w, ch, dtype=dt, device=net.device).permute(0, 3, 1, 2)
-            self._bufs, self._bufs_key = (mk(448), mk(128)), key
+            self._bufs, self._bufs_key = (mk(320), mk(128)), key
         X, Z = self._bufs
         fb = self._fused_bias()
+        ws = self._split_weights(dt)
+        # `inp` is constant over the life of an edge and convolution is linear in its input channels:
+        # conv(W, [net|inp|corr|flow]) = conv(W[:, dyn], [net|corr|flow]) + conv(W[:, inp], inp).  The second term
+        # is computed once per edge set and added inside the gate kernels: 128 of 448 input channels (29 %)
+        # leave the two largest convolutions of every update.
+        pk = (inp.data_ptr(), inp._version, tuple(inp.shape), dt)
+        if getattr(self, "_P_key", None) != pk:
+            self._P = (F.conv2d(inp, ws["zr_inp"], None, padding=1).contiguous(memory_format=torch.channels_last),
+                       F.conv2d(inp, ws["q_inp"], None, padding=1).contiguous(memory_format=torch.channels_last))
+            self._P_key = pk
+        P_zr, P_q = self._P
         # every convolution below runs WITHOUT bias; the biases ride along in the fused kernels
         glo = db.gru_glo(F.conv2d(net, self.w.weight.to(dt)), net, fb["w"])      # [E,128] fp32
         with torch.autocast("cuda", enabled=False):
             g = torch.addmm(fb["g"], glo, fb["wg_t"])                       # context of z | r | q (+ conv biases), fp32
-        db.gru_assemble(net, inp, corr_feat, flow_feat, X, corr_bias, flow_bias)
-        zr = F.conv2d(X, wz.to(dt), None, padding=1)
-        db.gru_gate(zr, g, net, Z, X)                                       # X[:, :128] <- r * net
-        q = F.conv2d(X, self.convq.weight.to(dt), None, padding=1)
-        return db.gru_out(q, g, Z, net)
+        db.gru_assemble(net, None, corr_feat, flow_feat, X, corr_bias, flow_bias)   # X = [net | relu(cf) | relu(ff)]
+        zr = F.conv2d(X, ws["zr_dyn"], None, padding=1)
+        db.gru_gate(zr, g, net, Z, X, P_zr)                                 # X[:, :128] <- r * net
+        q = F.conv2d(X, ws["q_dyn"], None, padding=1)
+        return db.gru_out(q, g, Z, net, P_q)
+
+    def _split_weights(self, dt):
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws["q_dyn"].dtype != dt or ws["q_dyn"].device != self.convq.weight.device:
+            wz = self._fused_zr()[0]
+            dyn = lambda w: torch.cat([w[:, :128], w[:, 256:]], 1).to(dt).contiguous(memory_format=torch.channels_last)
+            sta = lambda w: w[:, 128:256].to(dt).contiguous(memory_format=torch.channels_last)
+            wq = self.convq.weight.detach()
+            ws = self._ws = {"zr_dyn": dyn(wz), "zr_inp": sta(wz), "q_dyn": dyn(wq), "q_inp": sta(wq)}
+        return ws
 
     def _fused_bias(self):
         fb = getattr(self, "_fb", None)

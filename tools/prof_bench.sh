@@ -9,7 +9,7 @@ rm -rf /tmp/pb
 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /tmp/pb_bench.log 2>&1
 mkdir -p $OUT
 cp /tmp/pb/*/*kernel_stats.csv $OUT/kernel_stats_full_run.csv
-tail -1 /tmp/pb_bench.log > $OUT/bench_line.json
+grep "^{\"metric\"" /tmp/pb_bench.log | tail -1 > $OUT/bench_line.json
 python - <<PY
 import csv, glob, collections
 rows = list(csv.DictReader(open(glob.glob("/tmp/pb/*/*kernel_trace.csv")[0])))
