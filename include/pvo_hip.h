@@ -139,6 +139,12 @@ int pvo_gru_gate(const void* zr, const float* g, const void* net, void* Z, void*
                  const void* P_zr, int x_channels, int E, int HW, int dtype, void* stream);
 int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, void* net_out,
                 const void* P_q, int E, int HW, int dtype, void* stream);
+/* Second stage of the four output heads (droid_net.py:184-210) in one launch: y[E,H,W,8] =
+ * Conv3x3(128->2) per head applied to relu(h1[..., head*128:(head+1)*128] + bias1), zero padding.
+ * h1 [E,H,W,512] is the bias-free output of the four first-stage convolutions; w2 is
+ * [4 heads][2 outputs][9 taps (ky*3+kx)][128 channels] in `dtype`; bias1 [512], bias2 [8] f32. */
+int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const float* bias2, void* y,
+                  int E, int H, int W, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, void* out,
                      int K, int HW, int C, int dtype, void* stream);

@@ -26,6 +26,7 @@ SIGNATURES = {
     "pvo_corr_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_gru_glo": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),
+    "pvo_heads_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_bias_act": (_i, [_vp, _vp, _c.c_longlong, _i, _i, _i, _vp]),
     "pvo_segment_mean": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -358,3 +358,126 @@ extern "C" int pvo_segment_mean(const void* x, const int* seg_ptr, const int* se
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }
+
+// ---------------------------------------------------------------------------
+// heads_out: second stage of the four output heads in one kernel.
+//   reference: delta / delta_dy / weight / delta_mask = Conv3x3(128->2)(ReLU(Conv3x3(128->128)(net)))   droid_net.py:184-210
+//   input  h1 [E,H,W,512] = the four first-stage convolutions side by side, WITHOUT bias and ReLU (a bias-free MIOpen
+//          conv); bias1 [512] f32 and the ReLU are applied while the tile is staged, zero padding outside the image
+//   w2     [4 heads][2 outputs][9 taps][128 channels] 16-bit, bias2 [8] f32
+//   output y [E,H,W,8] (head-major: delta, delta_dy, weight, delta_mask)
+// A 512->8 convolution is a poor fit for an implicit-GEMM kernel (N = 8 of a 128/256-wide tile: 57 TFLOP/s measured);
+// here one workgroup owns an 8x16 pixel tile, stages the 10x18 halo of one head (128 channels) in LDS with a padded
+// row stride, and every thread accumulates one (pixel, output) with packed fp16 dot products (v_dot2_f32_f16).
+// Waves 0-1 compute output 0, waves 2-3 output 1, so weight reads are wave-uniform LDS broadcasts.
+// ---------------------------------------------------------------------------
+namespace {
+
+typedef __fp16 h2_t __attribute__((ext_vector_type(2)));   // the operand type of __builtin_amdgcn_fdot2
+
+constexpr int kHT = 8, kWT = 16;                 // pixel tile
+constexpr int kHaloW = kWT + 2, kHaloPos = (kHT + 2) * kHaloW;   // 180 positions
+constexpr int kPosStride = 128 * 2 + 16;         // bytes per halo position (padded against b128 bank conflicts)
+
+template <typename T>
+__device__ __forceinline__ float dot8(u32x4 a, u32x4 b, float acc);
+template <>
+__device__ __forceinline__ float dot8<pvo_half>(u32x4 a, u32x4 b, float acc) {
+  // explicit lanes: indexing the ext-vector inside __builtin_bit_cast made hipcc feed lane 0 to all four dot2s
+  const uint32_t a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a0), __builtin_bit_cast(h2_t, b0), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a1), __builtin_bit_cast(h2_t, b1), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a2), __builtin_bit_cast(h2_t, b2), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a3), __builtin_bit_cast(h2_t, b3), acc, false);
+  return acc;
+}
+template <>
+__device__ __forceinline__ float dot8<pvo_bf16>(u32x4 a, u32x4 b, float acc) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc = fmaf(__uint_as_float(a[k] << 16), __uint_as_float(b[k] << 16), acc);
+    acc = fmaf(__uint_as_float(a[k] & 0xffff0000u), __uint_as_float(b[k] & 0xffff0000u), acc);
+  }
+  return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void heads_out_kernel(const uint16_t* __restrict__ h1, const float* __restrict__ bias1,
+                                                        const uint16_t* __restrict__ w2, const float* __restrict__ bias2,
+                                                        uint16_t* __restrict__ y, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xs = smem;                                   // [180][272 B]
+  unsigned char* ws = smem + kHaloPos * kPosStride;           // [2][9][128] 16-bit for the current head
+  float* ys = reinterpret_cast<float*>(ws + 2 * 9 * 128 * 2); // [128 px][8]
+  const int e = blockIdx.z;
+  const int y0 = blockIdx.y * kHT, x0 = blockIdx.x * kWT;
+  const int tid = threadIdx.x;
+  const int o = tid >> 7;                                     // output channel of this thread's head (wave-uniform)
+  const int p = tid & 127, py = p >> 4, px = p & 15;
+
+  for (int head = 0; head < 4; ++head) {
+    __syncthreads();                                          // previous head's tile fully consumed
+    // stage relu(h1 + bias1) for this head's 128 channels: 180 positions x 16 chunks of 8 channels
+    for (int id = tid; id < kHaloPos * 16; id += 256) {
+      const int pos = id >> 4, ch = id & 15;
+      const int hy = y0 - 1 + pos / kHaloW, hx = x0 - 1 + pos % kHaloW;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (hy >= 0 && hy < H && hx >= 0 && hx < W) {
+        float f[8], bb[8];
+        H8<T>::unpack(*reinterpret_cast<const u32x4*>(h1 + ((static_cast<size_t>(e) * H + hy) * W + hx) * 512 + head * 128 + ch * 8), f);
+        load8f(bias1 + head * 128 + ch * 8, bb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + bb[k], 0.0f);
+        v = H8<T>::pack(f);
+      }
+      *reinterpret_cast<u32x4*>(xs + pos * kPosStride + ch * 16) = v;
+    }
+    for (int id = tid; id < 2 * 9 * 16; id += 256)            // this head's weights: 2 x 9 x 128 halves
+      *reinterpret_cast<u32x4*>(ws + id * 16) = *reinterpret_cast<const u32x4*>(w2 + static_cast<size_t>(head) * 2 * 9 * 128 + id * 8);
+    __syncthreads();
+    float acc = bias2[head * 2 + o];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const unsigned char* xp = xs + ((py + t / 3) * kHaloW + (px + t % 3)) * kPosStride;
+      const unsigned char* wp = ws + (o * 9 + t) * 256;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        acc = dot8<T>(*reinterpret_cast<const u32x4*>(xp + c * 16), *reinterpret_cast<const u32x4*>(wp + c * 16), acc);
+    }
+    ys[p * 8 + head * 2 + o] = acc;
+  }
+  __syncthreads();
+  if (tid < 128) {                                            // one 16-byte store per pixel
+    const int gy = y0 + (tid >> 4), gx = x0 + (tid & 15);
+    if (gy < H && gx < W) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = ys[tid * 8 + k];
+      *reinterpret_cast<u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * 8) = H8<T>::pack(f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const float* bias2, void* y,
+                             int E, int H, int W, int dtype, void* stream) {
+  if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
+  if (E == 0 || H == 0 || W == 0) return PVO_OK;
+  if (!h1 || !bias1 || !w2 || !bias2 || !y || !aligned16(h1) || !aligned16(w2) || !aligned16(y) ||
+      (reinterpret_cast<uintptr_t>(bias1) & 15) || E > 65535) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const size_t lds = static_cast<size_t>(kHaloPos) * kPosStride + 2 * 9 * 128 * 2 + 128 * 8 * sizeof(float);
+  dim3 grid((W + kWT - 1) / kWT, (H + kHT - 1) / kHT, E);
+  if (dtype == PVO_F16) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_out_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+    hipLaunchKernelGGL(heads_out_kernel<pvo_half>, grid, dim3(256), lds, st, static_cast<const uint16_t*>(h1), bias1, static_cast<const uint16_t*>(w2), bias2, static_cast<uint16_t*>(y), H, W);
+  } else if (dtype == PVO_BF16) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_out_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+    hipLaunchKernelGGL(heads_out_kernel<pvo_bf16>, grid, dim3(256), lds, st, static_cast<const uint16_t*>(h1), bias1, static_cast<const uint16_t*>(w2), bias2, static_cast<uint16_t*>(y), H, W);
+  } else {
+    return PVO_EUNSUPPORTED;
+  }
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}

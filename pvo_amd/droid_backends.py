@@ -480,3 +480,18 @@ def segment_mean(x, seg_ptr, seg_idx, K):
         check(_lib.load().pvo_segment_mean(_ptr(x), _ptr(seg_ptr), _ptr(seg_idx), _ptr(out), K, H * W, C,
                                            _dtype_code(x, "x"), _stream(dev)), "segment_mean")
     return out
+
+
+def heads_out(h1, bias1, w2, bias2):
+    """y [E,8,H,W] (channels-last) = the four heads' second 3x3 convolutions of relu(h1 + bias1);
+    h1 [E,512,H,W] channels-last 16-bit, w2 [4,2,9,128] same dtype, bias1 [512] / bias2 [8] float32"""
+    _cl(h1, "h1", 512)
+    dev = _dev(h1, bias1, w2, bias2)
+    if tuple(w2.shape) != (4, 2, 9, 128) or w2.dtype != h1.dtype or not w2.is_contiguous():
+        raise PvoHipError("heads_out: w2 must be a contiguous [4,2,9,128] tensor of the feature dtype")
+    E, _, H, W = h1.shape
+    y = torch.empty(E, H, W, 8, dtype=h1.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_heads_out(_ptr(h1), _bias(bias1, 512, "bias1"), _ptr(w2), _bias(bias2, 8, "bias2"), _ptr(y),
+                                        E, H, W, _dtype_code(h1, "h1"), _stream(dev)), "heads_out")
+    return y

@@ -229,11 +229,13 @@ class DynamicUpdateModule(nn.Module):
         self.agg = GraphAgg()
         self._fused_heads = None
         self._b32 = None
+        self._w2r = None
         self.fused_gru = True          # use pvo_amd/csrc/gru_fused.hip on the inference path
 
     def train(self, mode=True):
         self._fused_heads = None
         self._b32 = None
+        self._w2r = None
         return super().train(mode)
 
     def _bias32(self):
@@ -243,8 +245,17 @@ class DynamicUpdateModule(nn.Module):
             b = self._b32 = {"c0": f(self.corr_encoder[0].bias), "c2": f(self.corr_encoder[2].bias),
                              "f0": f(self.flow_encoder[0].bias), "f2": f(self.flow_encoder[2].bias),
                              "h1": torch.cat([f(h[0].bias) for h in (self.delta, self.delta_dy, self.weight, self.delta_mask)]),
+                             "h2": torch.cat([f(h[2].bias) for h in (self.delta, self.delta_dy, self.weight, self.delta_mask)]),
                              "a1": f(self.agg.conv1.bias), "a2": f(self.agg.conv2.bias)}
         return b
+
+    def _heads_w2(self, dt):
+        w = getattr(self, "_w2r", None)
+        if w is None or w.dtype != dt or w.device != self.delta[2].weight.device:
+            hs = (self.delta, self.delta_dy, self.weight, self.delta_mask)
+            # [head][out][tap = ky*3+kx][channel]
+            w = self._w2r = torch.stack([h[2].weight.detach().permute(0, 2, 3, 1).reshape(2, 9, 128) for h in hs]).to(dt).contiguous()
+        return w
 
     def _heads(self, net):
         """delta, delta_dy, weight, delta_mask, each [B,2,H,W]"""
@@ -266,8 +277,12 @@ class DynamicUpdateModule(nn.Module):
             f = self._fused_heads = (w1.detach(), b1.detach(), w2.detach(), b2.detach())
         if net.is_cuda and net.dtype in (torch.float16, torch.bfloat16) and net.is_contiguous(memory_format=torch.channels_last):
             from .. import droid_backends as db
-            x = F.conv2d(net, f[0].to(net.dtype), None, padding=1)          # 128 -> 4*128, bias + ReLU fused in one pass
-            x = db.bias_act_(x.contiguous(memory_format=torch.channels_last), self._bias32()["h1"])
+            # first stage 128 -> 4*128 as one bias-free MIOpen conv; bias, ReLU and the four 128 -> 2 second-stage
+            # convolutions happen in ONE hand-written kernel (a 512 -> 8 conv has no efficient GEMM shape)
+            x = F.conv2d(net, f[0].to(net.dtype), None, padding=1).contiguous(memory_format=torch.channels_last)
+            b32 = self._bias32()
+            y = db.heads_out(x, b32["h1"], self._heads_w2(net.dtype), b32["h2"])
+            return y[:, 0:2], y[:, 2:4], y[:, 4:6], y[:, 6:8]
         else:
             x = F.relu(F.conv2d(net, f[0], f[1], padding=1), inplace=True)  # 128 -> 4*128
         y = F.conv2d(x, f[2].to(x.dtype), f[3].to(x.dtype), padding=1)      # 4 x (128 -> 2), block diagonal
