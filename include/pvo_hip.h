@@ -149,6 +149,20 @@ int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, in
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, void* out,
                      int K, int HW, int C, int dtype, void* stream);
 
+/* FactorGraph.update's arithmetic around the update operator (factor_graph.py:231-306, segm_filter off), two launches
+ * instead of ~25 element-wise PyTorch launches.  All [E,H,W,2] tensors are f32.
+ *   pvo_graph_motion  motn [E,H,W,8] (`dtype`, channels-last) = clamp([target-coords0 | target-coords0+delta_dy |
+ *                     target-coords1 | raw_mask], +-64)                                   (:233-237)
+ *   pvo_graph_post    heads [E,H,W,8] (`dtype`) = delta | delta_dy | weight logits | delta_mask as pvo_heads_out writes them:
+ *                     raw_mask += delta_mask (in place); bin = sigmoid(raw_mask) >= dy_thresh; target = coords1 + delta;
+ *                     delta_dy = delta_dy_raw (1-bin); weight = sigmoid(logits + 10 (1-bin)); full_flow = coords1 + delta_dy - coords0;
+ *                     target_ba / weight_ba [E,2,H,W] are the layouts pvo_ba reads                (:249-306) */
+int pvo_graph_motion(const float* target, const float* coords1, const float* delta_dy, const float* raw_mask,
+                     void* motn, int E, int H, int W, int dtype, void* stream);
+int pvo_graph_post(const float* coords1, const void* heads, float* raw_mask, float* target, float* delta_dy,
+                   float* weight, float* target_ba, float* weight_ba, float* full_flow,
+                   int E, int H, int W, float dy_thresh, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Reprojection helpers                                                       */
 /* ------------------------------------------------------------------------- */

@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "altcorr.hip",
     "geom.hip",
     "gru_fused.hip",
+    "graph_glue.hip",
     "ba.hip",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -495,3 +495,34 @@ def heads_out(h1, bias1, w2, bias2):
         check(_lib.load().pvo_heads_out(_ptr(h1), _bias(bias1, 512, "bias1"), _ptr(w2), _bias(bias2, 8, "bias2"), _ptr(y),
                                         E, H, W, _dtype_code(h1, "h1"), _stream(dev)), "heads_out")
     return y
+
+
+# --------------------------------------------------------------------------- FactorGraph.update glue
+def graph_motion(target, coords1, delta_dy, raw_mask, dtype):
+    """motion features (factor_graph.py:233-237): [1,E,H,W,2] f32 x4 -> [1,E,8,H,W] in `dtype`, stored channels-last"""
+    for t, n in ((target, "target"), (coords1, "coords1"), (delta_dy, "delta_dy"), (raw_mask, "raw_mask")):
+        _contig(t, n); _f32(t, n)
+    dev = _dev(target, coords1, delta_dy, raw_mask)
+    _, E, H, W, _ = target.shape
+    motn = torch.empty(E, H, W, 8, dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_graph_motion(_ptr(target), _ptr(coords1), _ptr(delta_dy), _ptr(raw_mask), _ptr(motn), E, H, W,
+                                           _DT[dtype], _stream(dev)), "graph_motion")
+    return motn.permute(0, 3, 1, 2)[None]
+
+
+def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5):
+    """factor_graph.py:249-306 after the update operator.  heads [E,8,H,W] channels-last 16-bit (delta | delta_dy |
+    weight | delta_mask); raw_mask [1,E,H,W,2] is updated IN PLACE; target_ba / weight_ba [E,2,H,W] f32 are filled.
+    Returns (target_cam, delta_dy, weight, full_flow), each [1,E,H,W,2] f32."""
+    _cl(heads, "heads", 8)
+    _contig(coords1, "coords1"); _contig(raw_mask, "raw_mask"); _contig(target_ba, "target_ba"); _contig(weight_ba, "weight_ba")
+    dev = _dev(coords1, heads, raw_mask, target_ba, weight_ba)
+    _, E, H, W, _ = coords1.shape
+    new = lambda: torch.empty(1, E, H, W, 2, dtype=torch.float32, device=dev)
+    target, delta_dy, weight, full_flow = new(), new(), new(), new()
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_graph_post(_ptr(coords1), _ptr(heads), _ptr(raw_mask), _ptr(target), _ptr(delta_dy), _ptr(weight),
+                                         _ptr(target_ba), _ptr(weight_ba), _ptr(full_flow), E, H, W, float(dy_thresh),
+                                         _dtype_code(heads, "heads"), _stream(dev)), "graph_post")
+    return target, delta_dy, weight, full_flow

@@ -46,6 +46,7 @@ class FactorGraph:
         self.ii_bad, self.jj_bad = torch.zeros(0, **lng), torch.zeros(0, **lng)
         self.target_cam_inac, self.weight_inac, self.delta_dy_inac, self.full_flow_inac = z(2), z(2), z(2), z(2)
         self.raw_mask_inac = z(self.mask_num)
+        self.fused_glue = True      # use the two-kernel glue path when the update operator supports it
         self._cache = {}            # device index tensors derived from the host edge lists; cleared on any edge change
         try:
             self._autocast = next(update_op.parameters()).dtype == torch.float32
@@ -246,9 +247,60 @@ class FactorGraph:
         keep = ~forced[key].view(1, E, *seg.shape[1:])
         return bin_mask & keep.unsqueeze(-1)
 
+    def _fused_ok(self):
+        """the two-kernel glue path: HIP device, no panoptic vote, an update operator that exposes raw_heads in 16 bit"""
+        if self.device.type != "cuda" or self.video.segm_filter or self.corr is None:
+            return False
+        op = self.update_op
+        if not hasattr(op, "_heads_w2") or getattr(op, "training", True) or not getattr(op, "fused_gru", False):
+            return False
+        return next(op.parameters()).dtype in (torch.float16, torch.bfloat16)
+
+    @torch.no_grad()
+    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only):
+        from . import droid_backends as db
+        ht, wd = self.ht, self.wd
+        E = len(self._ii_h)
+        dt = next(self.update_op.parameters()).dtype
+        coords1, _ = self.video.reproject(self.ii, self.jj)
+        motn = db.graph_motion(self.target_cam.contiguous(), coords1, self.delta_dy.contiguous(), self.raw_mask.contiguous(), dt)
+        corr = self.corr(coords1, channels_last=True)
+        seg = self._cached("agg", self._agg_segments)
+        self.net, heads, damping, upmask = self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj, False,
+                                                          agg_segments=seg, raw_heads=True)
+        if t0 is None:
+            t0 = max(1, min(self._ii_h) + 1)
+        if t1 is None:
+            t1 = max(max(self._ii_h), max(self._jj_h)) + 1
+        src = sorted(set(self._ii_h))
+        src_t = self._cached("src", lambda: torch.tensor(src, device=self.device))
+        m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)] if use_inactive else []
+        n_in = sum(m_l)
+        target_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
+        weight_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
+        self.raw_mask = self.raw_mask.contiguous()
+        self.target_cam, self.delta_dy, self.weight, self.full_flow = db.graph_post(
+            coords1, heads, self.raw_mask, target_ba[n_in:], weight_ba[n_in:], self.dy_thresh)
+        self.damping[src_t] = damping[0].float()
+        if n_in:
+            m = self._cached(("inac", t0), lambda: torch.tensor(m_l, dtype=torch.bool, device=self.device))
+            ii, jj = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
+            target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)
+            weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
+            src2 = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
+            src_t = self._cached(("src2", t0), lambda: torch.tensor(src2, device=self.device))
+        else:
+            ii, jj = self.ii, self.jj
+        eta = 0.2 * self.damping[src_t] + EP
+        self.video.ba(target_ba, weight_ba, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
+        self.age += 1
+        self._age_h = [a + 1 for a in self._age_h]
+
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
         """one update of the factor graph (factor_graph.py:227-307)"""
+        if self.fused_glue and self._fused_ok():
+            return self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only)
         ht, wd = self.ht, self.wd
         coords1, _ = self.video.reproject(self.ii, self.jj)
         motn = torch.cat([self.target_cam - self.coords0, self.target_cam - self.coords0 + self.delta_dy,

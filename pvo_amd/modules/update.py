@@ -282,6 +282,7 @@ class DynamicUpdateModule(nn.Module):
             x = F.conv2d(net, f[0].to(net.dtype), None, padding=1).contiguous(memory_format=torch.channels_last)
             b32 = self._bias32()
             y = db.heads_out(x, b32["h1"], self._heads_w2(net.dtype), b32["h2"])
+            self._last_heads = y                       # [E,8,H,W] channels-last: delta | delta_dy | weight | delta_mask
             return y[:, 0:2], y[:, 2:4], y[:, 4:6], y[:, 6:8]
         else:
             x = F.relu(F.conv2d(net, f[0], f[1], padding=1), inplace=True)  # 128 -> 4*128
@@ -289,7 +290,9 @@ class DynamicUpdateModule(nn.Module):
         return y[:, 0:2], y[:, 2:4], y[:, 4:6], y[:, 6:8]
 
     def forward(self, net, inp, corr, flow=None, ii=None, jj=None, use_aff_bri=False, raw_mask=None, segments=None,
-                agg_segments=None):
+                agg_segments=None, raw_heads=False):
+        """raw_heads=True (inference on the HIP path): returns (net, heads [E,8,H,W] channels-last, eta, upmask) with the
+        four head outputs side by side, for pvo_graph_post; raises if the fused head kernel was not used."""
         batch, num, ch, ht, wd = net.shape
         if flow is None:
             flow = torch.zeros(batch, num, 4 + self.mask_num + 2, ht, wd, device=net.device, dtype=net.dtype)
@@ -322,7 +325,13 @@ class DynamicUpdateModule(nn.Module):
             flow = self.flow_encoder(flow)
             net = self.gru(net, inp, corr, flow)
 
+        self._last_heads = None
         delta, delta_dy, weight, delta_m = self._heads(net)
+        if raw_heads:
+            if self._last_heads is None or ii is None:
+                raise RuntimeError("raw_heads needs the fused 16-bit inference path and ii")
+            eta, upmask_disp, _, _ = self.agg(net.view(*out_dim), ii.to(net.device), agg_segments)
+            return net.view(*out_dim), self._last_heads, eta, {"disp": upmask_disp, "flow": None, "dy_mask": None}
         if use_aff_bri:
             aff = self.param_linear(self.global_avg_pool(net).view(batch * num, -1)).view(batch, num, -1)
 
