@@ -39,7 +39,7 @@ namespace {
 constexpr float kMinDepth = 0.25f;
 constexpr int kPPT = 2;                 // pixels per thread in assemble
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
-constexpr int kLdsCholMax = 138;        // (6P) up to which the fp64 system lives in LDS (138*141*8 + 16 = 156 KB < 160 KB)
+constexpr int kLdsCholMax = 138;        // (6P) up to which the fp64 system lives in LDS (138*139*8 + 23*21*8 + 208 = 157.5 KB < 160 KB)
 
 struct Plan {            // int region of the workspace
   int* kidx;             // [F]   frame -> depth index, -1 if none
@@ -84,7 +84,7 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.w = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(Kmax) * HW));
   w.dx = reinterpret_cast<float*>(take(sizeof(float) * (n6 + 8)));
   w.sys = reinterpret_cast<double*>(take(sizeof(double) * (n6 * n6 + n6 + 8)));
-  w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + 3 * n6 + 8 : 8)));
+  w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + n6 + 21 * (n6 / 6) + 32 : 8)));
   w.bytes = off;
   return w;
 }
@@ -539,47 +539,127 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
 // ---------------------------------------------------------------------------
 // solve: damping + fp64 Cholesky + substitution + pose retraction, one workgroup
 // ---------------------------------------------------------------------------
-// In-place LL^T of the SPD matrix A (row-major n x n, lower triangle read) with the
-// forward substitution folded in: b is carried as one more row of the trailing update,
-// so one barrier per column and no separate L y = b pass.  L^T is written into the UPPER
-// triangle (A[j][i] = L[i][j]), pivots and y into diag[0..2n), which keeps every location
-// read in step j disjoint from every location written in step j.
-__device__ void chol_solve_block(double* A, double* b, double* diag, int n, int* fail_flag) {
+// Blocked LL^T (6x6 blocks: the natural granularity of the pose system) of the SPD matrix in A, rhs carried as
+// row n of A (so the forward substitution is just one more row of every panel / trailing update).
+//   per block column kb:  (a) every thread factors the 6x6 diagonal block redundantly in registers (21 broadcast LDS reads,
+//                             no communication);  (b) one thread per remaining row solves its 1x6 panel in place;
+//                         barrier;  (c) rank-6 trailing update over a 16x16 thread grid;  barrier.
+// 2 barriers per 6 columns (the column-at-a-time version needed 6, and a serial fp64 sqrt/div in front of each).
+// Ld[kb][21] keeps the factored diagonal blocks (row-major lower) for the back substitution.
+// 1/sqrt(d) in fp64: hardware estimate (v_rsq_f64) + two Newton steps; the library sqrt and divide are ~30-instruction
+// software sequences each and sit on the serial critical path of the factorisation
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y;
+}
+
+__device__ __forceinline__ bool chol6(const double D[21], double L[21], double rdiag[6]) {
+  // index (r,c), r >= c:  r*(r+1)/2 + c
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = D[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+    ok = ok && (d > 0.0);
+    const double rs = ok ? rsqrt_nr(d) : 0.0;
+    rdiag[j] = rs;
+    L[j * (j + 1) / 2 + j] = d * rs;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = D[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      L[i * (i + 1) / 2 + j] = v * rs;
+    }
+  }
+  return ok;
+}
+
+__device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, int* fail_flag) {
+  // A: (n+1) x n row-major, row n = rhs.  On return row n holds the solution x.
   const int tid = threadIdx.x, nt = blockDim.x;
   const int tx = tid & 15, ty = tid >> 4, nty = nt >> 4;
-  for (int j = 0; j < n; ++j) {
+  const int P = n / 6;
+  for (int kb = 0; kb < P; ++kb) {
+    const int j0 = 6 * kb;
+    double D[21], L[21], rd[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) D[r * (r + 1) / 2 + c] = A[(j0 + r) * n + j0 + c];
+    const bool ok = chol6(D, L, rd);
+    if (!ok) { if (tid == 0) *fail_flag = 1; __syncthreads(); return; }      // uniform: every thread saw the same block
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < 21; ++q) Ld[kb * 21 + q] = L[q];
+    }
+    // (b) panel rows j0+6 .. n (inclusive: the rhs row)
+    for (int i = j0 + 6 + tid; i <= n; i += nt) {
+      double x[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = A[i * n + j0 + c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= x[k] * L[c * (c + 1) / 2 + k];
+        x[c] = v * rd[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) A[i * n + j0 + c] = x[c];
+    }
     __syncthreads();
-    const double djj = A[j * n + j];
-    if (!(djj > 0.0)) { if (tid == 0) *fail_flag = 1; __syncthreads(); return; }
-    const double inv = 1.0 / djj;
-    const double rs = 1.0 / sqrt(djj);
-    // trailing update A[i][c] -= A[i][j] A[c][j] / djj   (j < c <= i), rows i over ty, cols c over tx
-    for (int i = j + 1 + ty; i < n; i += nty) {
-      const double lij = A[i * n + j] * inv;
-      for (int c = j + 1 + tx; c <= i; c += 16) A[i * n + c] -= lij * A[c * n + j];
+    // (c) trailing update, rows i in (j0+6 .. n], columns c in (j0+6 .. min(i, n-1)]
+    for (int i = j0 + 6 + ty; i <= n; i += nty) {
+      double li[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) li[t] = A[i * n + j0 + t];
+      const int cmax = (i < n) ? i : n - 1;
+      for (int c = j0 + 6 + tx; c <= cmax; c += 16) {
+        double acc = A[i * n + c];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc -= li[t] * A[c * n + j0 + t];
+        A[i * n + c] = acc;
+      }
     }
-    // b as row n of the same update; y_j = b_j / L_jj
-    const double bj = b[j];
-    for (int c = j + 1 + tid; c < n; c += nt) b[c] -= bj * inv * A[c * n + j];
-    // L^T column -> upper triangle, pivot
-    for (int i = j + 1 + tid; i < n; i += nt) A[j * n + i] = A[i * n + j] * rs;
-    if (tid == 0) { diag[j] = djj * rs; diag[n + j] = bj * rs; }   // pivot, y_j (kept apart from b: no 2nd barrier)
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = tid; i < n; i += nt) b[i] = diag[n + i];
-  __syncthreads();
-  if (tid < 64) {
-    // back substitution L^T x = y by one wave: lane L owns rows i == L (mod 64); x_j is
-    // broadcast with a shuffle, so every b[i] is only touched by its owner lane.
-    for (int j = n - 1; j >= 0; --j) {
-      const int owner = j & 63;
-      double xj = (tid == owner) ? b[j] / diag[j] : 0.0;
-      xj = __shfl(xj, owner, 64);
-      if (tid == owner) b[j] = xj;
-      for (int i = tid; i < j; i += 64) b[i] -= A[i * n + j] * xj;   // L^T[i][j] = A[i][j] (upper)
+  // back substitution L^T x = y (y in row n), block rows from the bottom; x overwrites y
+  double* y = A + static_cast<long long>(n) * n;
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  for (int kb = P - 1; kb >= 0; --kb) {
+    const int j0 = 6 * kb;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = j0 + 6 + tid; i < n; i += nt) {
+      const double xi = y[i];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s[c] += A[i * n + j0 + c] * xi;
     }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double v = s[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave * 6 + c] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double x[6];
+      const double* L = Ld + kb * 21;
+#pragma unroll
+      for (int c = 5; c >= 0; --c) {
+        double v = y[j0 + c];
+        for (int w = 0; w < nw; ++w) v -= red[w * 6 + c];
+#pragma unroll
+        for (int k = c + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + c] * x[k];
+        x[c] = v / L[c * (c + 1) / 2 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) y[j0 + c] = x[c];
+    }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void ba_solve_kernel(
@@ -589,9 +669,10 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs]
   int& fail = *reinterpret_cast<int*>(smem);
   const int n = 6 * P;
-  double* A = use_lds ? reinterpret_cast<double*>(smem + 16) : chol_global;
+  double* A = use_lds ? reinterpret_cast<double*>(smem + 16) : chol_global;     // (n+1) x n: system, then the rhs row
   double* b = A + static_cast<long long>(n) * n;
-  double* diag = b + n;
+  double* Ld = b + n;                                                            // [P][21] factored diagonal blocks
+  double* red = Ld + 21 * P;                                                     // [4][6] wave partials
   if (threadIdx.x == 0) fail = 0;
   for (int idx = threadIdx.x; idx < n * n + n; idx += blockDim.x) {
     double v = sys[idx];
@@ -602,7 +683,7 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
     A[idx] = v;
   }
   __syncthreads();
-  chol_solve_block(A, b, diag, n, &fail);
+  chol_solve_blocked(A, Ld, red, n, &fail);
   __syncthreads();
   const int failed = fail;
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
@@ -737,7 +818,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, const double* sys,
   hipStream_t st = pvo_stream(stream);
   const int n6 = 6 * P;
   const int use_lds = n6 <= kLdsCholMax;
-  const size_t lds = 16 + (use_lds ? sizeof(double) * (static_cast<size_t>(n6) * n6 + 3 * n6) : 0);
+  const size_t lds = 16 + (use_lds ? sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 21 * P + 24) : 0);
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 64) != hipSuccess) return PVO_ELAUNCH;
