@@ -68,11 +68,14 @@ int pvo_corr_index_backward(const float* coords, const void* corr_grad, void* vo
  *   coords [N,h1,w1,2] f32 (the reference's un-permuted layout, x then y)
  *   out    [N,num_levels*(2r+1)^2,h1,w1] dtype, or [N,h1,w1,num_levels*(2r+1)^2] when
  *          out_channels_last != 0 (the layout the update operator's NHWC convolutions read)
- * Level l is sampled at coords / 2^l exactly as corr.py:47 does. */
+ * Level l is sampled at coords / 2^l exactly as corr.py:47 does.
+ * slots (device int[N], may be NULL): the volume of edge n is slot slots[n] of level tensors holding num_slots
+ * volumes each — a resident pool, so adding / dropping factor-graph edges never moves a 25 MB volume (the
+ * reference re-indexes and torch.cat's the whole pyramid on every edge change, factor_graph.py:135,177). */
 int pvo_corr_pyramid_lookup(const void* const* volumes_host, const float* coords, void* out,
                             int N, int h1, int w1, int h2, int w2,
                             int num_levels, int radius, int dtype, int out_channels_last,
-                            void* stream);
+                            const int* slots, int num_slots, void* stream);
 
 /* droid_backends.altcorr_forward (droid.cpp:190-200; altcorr_kernel.cu:27-149, host :290-319):
  * volume-free lookup.  fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C] channels-last, coords [B,S,H1,W1,2] f32,
@@ -101,11 +104,12 @@ int pvo_altcorr_backward(const void* fmap1, const void* fmap2, const float* coor
  *   levels_host[l] : device pointer of level l output [N,H,W,H>>l,W>>l] dtype
  * fp16/bf16 + channels_last + C in {16,32,64,128} + 16-byte aligned features run on the matrix
  * cores with every level written from the accumulators; anything else takes the generic path.
+ * out_slots (device int[N], may be NULL): edge n is written into slot out_slots[n] of the level tensors (pool).
  * level0[n,p1,p2] = sum_c (fmap1[n,c,p1]/4)*(fmap2[n,c,p2]/4), fp32 accumulate,
  * rounded to dtype; level l+1 = 2x2 mean of the ROUNDED level l (floor sizes). */
 int pvo_corr_build(const void* fmap1, const void* fmap2, void* const* levels_host,
                    int N, int C, int H, int W, int num_levels, int dtype, int channels_last,
-                   void* stream);
+                   const int* out_slots, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Update operator: fused element-wise half of the ConvGRU                    */

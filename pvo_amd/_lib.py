@@ -20,10 +20,10 @@ SIGNATURES = {
     "pvo_version": (_i, []),
     "pvo_corr_index_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_index_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "pvo_corr_pyramid_lookup": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pvo_corr_pyramid_lookup": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "pvo_altcorr_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_altcorr_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "pvo_corr_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pvo_corr_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "pvo_gru_glo": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),
     "pvo_heads_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

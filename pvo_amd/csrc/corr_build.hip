@@ -37,6 +37,7 @@ struct BuildArgs {
   const void* f1; const void* f2;   // [N,H,W,C]
   void* lv[4];                      // level l: [N, HW, H>>l, W>>l]
   int N, C, H, W, nlev;
+  const int* out_slots;             // optional: edge n is written to slot out_slots[n] of the level tensors
 };
 
 template <typename T> struct Cvt16;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void corr_build_mfma_kernel(BuildArgs a) {
   }
   __syncthreads();
 
-  const long long plane0 = static_cast<long long>(n) * HW + m0;   // plane of this wave's row 0
+  const long long plane0 = static_cast<long long>(a.out_slots ? a.out_slots[n] : n) * HW + m0;   // plane of this wave's row 0
   const int rows_ok = min(32, HW - m0);                            // valid source pixels of this wave
   if (rows_ok <= 0) return;
   // aligned: every level's row segments are 16-byte (level 3: 8-byte) aligned and complete
@@ -376,7 +377,7 @@ int build_mfma(const BuildArgs& a, hipStream_t st) {
 
 extern "C" int pvo_corr_build(const void* fmap1, const void* fmap2, void* const* levels_host,
                               int N, int C, int H, int W, int num_levels, int dtype, int channels_last,
-                              void* stream) {
+                              const int* out_slots, void* stream) {
   if (N < 0 || C <= 0 || H < 0 || W < 0 || num_levels < 1 || num_levels > 4 || !levels_host) return PVO_EINVAL;
   if (N == 0 || H == 0 || W == 0) return PVO_OK;
   if (!fmap1 || !fmap2 || N > 65535) return PVO_EINVAL;
@@ -387,10 +388,11 @@ extern "C" int pvo_corr_build(const void* fmap1, const void* fmap2, void* const*
                     ((reinterpret_cast<uintptr_t>(fmap1) | reinterpret_cast<uintptr_t>(fmap2)) & 15) == 0;
   if (fast) {
     BuildArgs a{};
-    a.f1 = fmap1; a.f2 = fmap2; a.N = N; a.C = C; a.H = H; a.W = W; a.nlev = num_levels;
+    a.f1 = fmap1; a.f2 = fmap2; a.N = N; a.C = C; a.H = H; a.W = W; a.nlev = num_levels; a.out_slots = out_slots;
     for (int l = 0; l < num_levels; ++l) a.lv[l] = levels_host[l];
     return dtype == PVO_F16 ? build_mfma<pvo_half>(a, st) : build_mfma<pvo_bf16>(a, st);
   }
+  if (out_slots) return PVO_EUNSUPPORTED;   // slot-pool output is a feature of the matrix-core path
   switch (dtype) {
     case PVO_F32: return build_generic<float>(fmap1, fmap2, levels_host, N, C, H, W, num_levels, channels_last, st);
     case PVO_F16: return build_generic<pvo_half>(fmap1, fmap2, levels_host, N, C, H, W, num_levels, channels_last, st);

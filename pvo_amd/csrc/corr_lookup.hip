@@ -47,6 +47,7 @@ struct LookupArgs {
   int nlev;
   int coords_interleaved;  // 0: [N,2,h1,w1]   1: [N,h1,w1,2]
   int out_channels_last;   // 0: out [N,nch,h1,w1]   1: out [N,h1,w1,nch] (what the NHWC convolutions read)
+  const int* slots;        // optional: volume of edge n lives in slot slots[n] of a pool (NULL: slot n)
   int HW;                  // h1*w1
   int N;
 };
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
         y0 = a.coords[(static_cast<long long>(n) * 2 + 1) * HW + pix];
       }
     }
-    const long long plane = static_cast<long long>(n) * HW + pix;
+    const long long plane = static_cast<long long>(a.slots ? a.slots[n] : n) * HW + pix;
 
 #pragma unroll
     for (int l = 0; l < kMaxLevels; ++l) {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void corr_lookup_generic_kernel(LookupArgs a, 
     y0 = a.coords[(static_cast<long long>(n) * 2 + 1) * HW + pix];
   }
   const int rd = 2 * r + 1;
-  const long long plane = static_cast<long long>(n) * HW + pix;
+  const long long plane = static_cast<long long>(a.slots ? a.slots[n] : n) * HW + pix;
   for (int l = 0; l < a.nlev; ++l) {
     const LookupLevel L = a.lv[l];
     const float xs = x0 * L.scale, ys = y0 * L.scale;
@@ -412,7 +413,7 @@ extern "C" int pvo_corr_index_forward(const void* volume, const float* coords, v
 extern "C" int pvo_corr_pyramid_lookup(const void* const* volumes_host, const float* coords, void* out,
                                        int N, int h1, int w1, int h2, int w2,
                                        int num_levels, int radius, int dtype, int out_channels_last,
-                                       void* stream) {
+                                       const int* slots, int num_slots, void* stream) {
   if (N < 0 || h1 < 0 || w1 < 0 || h2 < 0 || w2 < 0 || radius < 0) return PVO_EINVAL;
   if (num_levels < 1 || num_levels > kMaxLevels || !volumes_host) return PVO_EINVAL;
   if (N == 0 || h1 == 0 || w1 == 0) return PVO_OK;
@@ -423,12 +424,14 @@ extern "C" int pvo_corr_pyramid_lookup(const void* const* volumes_host, const fl
   for (int l = 0; l < num_levels; ++l) {
     const int hl = h2 >> l, wl = w2 >> l;
     if (!volumes_host[l] && hl > 0 && wl > 0) return PVO_EINVAL;
-    a.lv[l] = LookupLevel{volumes_host[l], static_cast<long long>(N) * h1 * w1 * hl * wl, hl, wl,
+    a.lv[l] = LookupLevel{volumes_host[l], static_cast<long long>(slots ? num_slots : N) * h1 * w1 * hl * wl, hl, wl,
                           1.0f / static_cast<float>(1 << l)};
     aligned = aligned && ((reinterpret_cast<uintptr_t>(volumes_host[l]) & 3) == 0);
   }
   a.coords = coords; a.out = out; a.nlev = num_levels; a.coords_interleaved = 1; a.HW = h1 * w1; a.N = N;
   a.out_channels_last = out_channels_last ? 1 : 0;
+  a.slots = slots;
+  if (slots && num_slots <= 0) return PVO_EINVAL;
   if (!aligned && (dtype == PVO_F16 || dtype == PVO_BF16)) return PVO_EINVAL;
   return dispatch_lookup(a, radius, dtype, pvo_stream(stream));
 }

@@ -112,7 +112,7 @@ def corr_index_backward(volume, coords, corr_grad, radius):
     return [volume_grad]
 
 
-def corr_pyramid_lookup(pyramid, coords, radius, channels_last=False):
+def corr_pyramid_lookup(pyramid, coords, radius, channels_last=False, slots=None):
     """All levels of CorrBlock.__call__ (modules/corr.py:40-50) in one launch.
 
     pyramid: list of level tensors [N,h1,w1,h2>>l,w2>>l]; coords [N,h1,w1,2] f32
@@ -123,12 +123,18 @@ def corr_pyramid_lookup(pyramid, coords, radius, channels_last=False):
     _contig(coords, "coords"); _f32(coords, "coords")
     for lv in pyramid:
         _contig(lv, "volume")
-    N, h1, w1, h2, w2 = pyramid[0].shape
+    NV, h1, w1, h2, w2 = pyramid[0].shape
     L = len(pyramid)
     for l, lv in enumerate(pyramid):
-        if tuple(lv.shape) != (N, h1, w1, h2 >> l, w2 >> l) or lv.dtype != pyramid[0].dtype:
+        if tuple(lv.shape) != (NV, h1, w1, h2 >> l, w2 >> l) or lv.dtype != pyramid[0].dtype:
             raise PvoHipError("pyramid level %d has shape %s, expected %s"
-                              % (l, tuple(lv.shape), (N, h1, w1, h2 >> l, w2 >> l)))
+                              % (l, tuple(lv.shape), (NV, h1, w1, h2 >> l, w2 >> l)))
+    N = coords.shape[0]
+    if slots is None:
+        if N != NV:
+            raise PvoHipError("coords has %d edges but the pyramid holds %d volumes" % (N, NV))
+    elif slots.dtype != torch.int32 or slots.numel() != N or not slots.is_cuda:
+        raise PvoHipError("slots must be a device int32 tensor with one entry per edge")
     rd = 2 * radius + 1
     if channels_last:
         out = torch.empty((N, h1, w1, L * rd * rd), dtype=pyramid[0].dtype, device=dev).permute(0, 3, 1, 2)
@@ -138,7 +144,8 @@ def corr_pyramid_lookup(pyramid, coords, radius, channels_last=False):
     lib = _lib.load()
     with torch.cuda.device(dev):
         check(lib.pvo_corr_pyramid_lookup(ptrs, _ptr(coords), _ptr(out), N, h1, w1, h2, w2, L, radius,
-                                          _dtype_code(pyramid[0], "volume"), 1 if channels_last else 0, _stream(dev)),
+                                          _dtype_code(pyramid[0], "volume"), 1 if channels_last else 0,
+                                          _ptr(slots), NV, _stream(dev)),
               "corr_pyramid_lookup")
     return out
 
@@ -179,11 +186,12 @@ def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
     return [g1, g2, torch.zeros(B, S, H1, W1, 2, dtype=torch.float32, device=dev)]
 
 
-def corr_build(fmap1, fmap2, num_levels=4, channels_last=False):
+def corr_build(fmap1, fmap2, num_levels=4, channels_last=False, out=None, out_slots=None):
     """CorrBlock.corr + the avg-pool pyramid (modules/corr.py:24-38,63-71) in one launch.
 
     fmap1, fmap2: [N,C,H,W] (channels_last=False) or [N,H,W,C] (channels_last=True).
-    Returns the pyramid: level l is [N,H,W,H>>l,W>>l] in the feature dtype."""
+    Returns the pyramid: level l is [N,H,W,H>>l,W>>l] in the feature dtype.
+    out / out_slots: write edge n into slot out_slots[n] (device int32) of the existing level tensors `out`."""
     _contig(fmap1, "fmap1"); _contig(fmap2, "fmap2")
     dev = _dev(fmap1, fmap2)
     if fmap1.shape != fmap2.shape or fmap1.dtype != fmap2.dtype:
@@ -192,11 +200,16 @@ def corr_build(fmap1, fmap2, num_levels=4, channels_last=False):
         N, H, W, C = fmap1.shape
     else:
         N, C, H, W = fmap1.shape
-    levels = [torch.empty((N, H, W, H >> l, W >> l), dtype=fmap1.dtype, device=dev) for l in range(num_levels)]
+    if out is not None:
+        levels = out
+        if out_slots is None or out_slots.dtype != torch.int32 or out_slots.numel() != N:
+            raise PvoHipError("corr_build: out needs out_slots (device int32, one per edge)")
+    else:
+        levels = [torch.empty((N, H, W, H >> l, W >> l), dtype=fmap1.dtype, device=dev) for l in range(num_levels)]
     ptrs = (ctypes.c_void_p * num_levels)(*[lv.data_ptr() if lv.numel() else 0 for lv in levels])
     with torch.cuda.device(dev):
         check(_lib.load().pvo_corr_build(_ptr(fmap1), _ptr(fmap2), ptrs, N, C, H, W, num_levels,
-                                         _dtype_code(fmap1, "fmap"), 1 if channels_last else 0, _stream(dev)),
+                                         _dtype_code(fmap1, "fmap"), 1 if channels_last else 0, _ptr(out_slots), _stream(dev)),
               "corr_build")
     return levels
 

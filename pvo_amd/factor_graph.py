@@ -16,7 +16,7 @@ What is different, because it is what costs time once the kernels are fast:
 """
 import torch
 
-from .modules.corr import CorrBlock
+from .modules.corr import CorrBlock, CorrVolumePool
 
 
 def coords_grid(ht, wd, device):
@@ -99,8 +99,14 @@ class FactorGraph:
         jj = torch.tensor(jj_l, dtype=torch.long, device=self.device)
         net = self.video.nets[ii][None]
         if self.corr_impl == "volume":
-            corr = CorrBlock(self.video.fmaps[ii][None], self.video.fmaps[jj][None], channels_last=True)
-            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            if self.device.type == "cuda" and self.video.fmaps.dtype in (torch.float16, torch.bfloat16):
+                if self.corr is None:          # resident slot pool: edge changes never move a volume
+                    cap = (self.max_factors if self.max_factors > 0 else 96) + 32
+                    self.corr = CorrVolumePool(cap, self.ht, self.wd, self.device, self.video.fmaps.dtype)
+                self.corr.add(self.video.fmaps[ii], self.video.fmaps[jj])
+            else:
+                corr = CorrBlock(self.video.fmaps[ii][None], self.video.fmaps[jj][None], channels_last=True)
+                self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self.video.inps[ii][None]
             self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
             self.inp = self._cl5(self.inp)       # stored channels-last once, so no update re-lays it out
@@ -137,7 +143,10 @@ class FactorGraph:
         self._jj_h = [j for j, m in zip(self._jj_h, mask_l) if not m]
         self._age_h = [a for a, m in zip(self._age_h, mask_l) if not m]
         if self.corr_impl == "volume" and self.corr is not None:
-            self.corr = self.corr[keep]
+            if isinstance(self.corr, CorrVolumePool):
+                self.corr.keep([not m for m in mask_l])
+            else:
+                self.corr = self.corr[keep]
         if self.net is not None:
             self.net = self._cl5(self.net[:, keep])
         if self.inp is not None:

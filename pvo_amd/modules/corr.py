@@ -146,3 +146,52 @@ class AltCorrBlock:
             coords = coords.unsqueeze(-2)
         corr = self.corr_fn(coords, ii, jj)
         return (corr.squeeze(-1) if squeeze else corr).contiguous()
+
+
+class CorrVolumePool:
+    """Resident pool of correlation-volume pyramids for a factor graph whose edge set changes every keyframe.
+
+    The reference keeps one dense pyramid tensor and, whenever edges are dropped or added, re-indexes it and
+    torch.cat's the new edges onto it (factor_graph.py:135,177, modules/corr.py:52-60): at 25 MB per edge that is a
+    ~1.5 GB copy per keyframe for a 36-edge window.  Here every edge owns a SLOT of preallocated level tensors
+    (capacity x 25 MB: 1.6 GB for 64 slots, irrelevant against 288 GB of HBM); the build kernel writes new edges
+    straight into free slots and the lookup kernel follows a per-edge slot index.  No volume is ever moved."""
+    supports_channels_last = True
+
+    def __init__(self, capacity, ht, wd, device, dtype=torch.float16, num_levels=4, radius=3):
+        self.num_levels, self.radius, self.capacity = num_levels, radius, capacity
+        self.levels = [torch.empty(capacity, ht, wd, ht >> l, wd >> l, dtype=dtype, device=device) for l in range(num_levels)]
+        self.free = list(range(capacity - 1, -1, -1))
+        self.slots = []                       # slot of each active edge, in edge order
+        self._slots_t = None
+        self.device = device
+
+    def __len__(self):
+        return len(self.slots)
+
+    def add(self, fmap1, fmap2):
+        """fmap1, fmap2: [n,H,W,C] channels-last features of the new edges (appended in order)"""
+        n = fmap1.shape[0]
+        if n > len(self.free):
+            raise RuntimeError("CorrVolumePool is full (%d slots)" % self.capacity)
+        new = [self.free.pop() for _ in range(n)]
+        st = torch.tensor(new, dtype=torch.int32, device=self.device)
+        db.corr_build(fmap1.contiguous(), fmap2.contiguous(), self.num_levels, channels_last=True, out=self.levels, out_slots=st)
+        self.slots += new
+        self._slots_t = None
+
+    def keep(self, mask):
+        """drop the edges whose mask entry is False"""
+        for s, m in zip(self.slots, mask):
+            if not m:
+                self.free.append(s)
+        self.slots = [s for s, m in zip(self.slots, mask) if m]
+        self._slots_t = None
+
+    def __call__(self, coords, channels_last=False):
+        batch, num, ht, wd, _ = coords.shape
+        if self._slots_t is None:
+            self._slots_t = torch.tensor(self.slots, dtype=torch.int32, device=self.device)
+        out = db.corr_pyramid_lookup(self.levels, coords.reshape(batch * num, ht, wd, 2).float().contiguous(), self.radius,
+                                     channels_last=channels_last, slots=self._slots_t)
+        return out.unflatten(0, (batch, num))

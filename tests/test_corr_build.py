@@ -126,3 +126,26 @@ def test_build_then_lookup_full_size_sb(cuda):
     want = (f.float() / 4).pow(2).sum(-1)
     assert torch.allclose(centre, want, rtol=2e-3, atol=2e-2)
     assert (out[:, :49].float().argmax(1) == 24).float().mean() > 0.99
+
+
+@pytest.mark.gpu
+def test_volume_pool_matches_corrblock_through_edge_changes(cuda):
+    """CorrVolumePool (resident slots + slot-indexed build/lookup) == CorrBlock (dense pyramid, cat / index) after
+    adding, dropping and re-adding edges; bit-exact (same kernels, different addressing)."""
+    from pvo_amd.modules.corr import CorrBlock, CorrVolumePool
+    g = torch.Generator().manual_seed(3)
+    H, W, C = 16, 24, 64
+    f = torch.randn(6, H, W, C, generator=g).half().to(cuda)
+    ii, jj = [0, 1, 2, 3, 4], [1, 2, 3, 4, 5]
+    pool = CorrVolumePool(8, H, W, cuda)
+    pool.add(f[ii], f[jj])
+    blk = CorrBlock(f[ii][None], f[jj][None], channels_last=True)
+    keep = [True, False, True, True, False]
+    pool.keep(keep)
+    blk = blk[torch.tensor(keep, device=cuda)]
+    pool.add(f[[5, 0]], f[[0, 3]])
+    blk = blk.cat(CorrBlock(f[[5, 0]][None], f[[0, 3]][None], channels_last=True))
+    assert len(pool) == 5 and sorted(pool.slots + pool.free) == list(range(8))
+    coords = (torch.rand(1, 5, H, W, 2, generator=g) * 24 - 2).to(cuda)
+    a, b = pool(coords, channels_last=True), blk(coords, channels_last=True)
+    assert a.shape == b.shape == (1, 5, 196, H, W) and torch.equal(a, b)
