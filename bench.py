@@ -175,7 +175,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -198,6 +198,10 @@ def main():
     snap = Snapshot(video, graph)
     snap.edge_list = list(zip(graph._ii_h, graph._jj_h))
 
+    # one-time library initialisation, before the counted warm-up: MIOpen's solver search (find mode) and its on-disk
+    # kernel cache are cold on a fresh machine and otherwise leak into the first timed steps (75 vs 89 steps/s measured)
+    for _ in range(8):
+        keyframe_update(video, graph, snap)
     for _ in range(args.warmup):
         keyframe_update(video, graph, snap)
     events = []

@@ -379,80 +379,101 @@ constexpr int kHT = 8, kWT = 16;                 // pixel tile
 constexpr int kHaloW = kWT + 2, kHaloPos = (kHT + 2) * kHaloW;   // 180 positions
 constexpr int kPosStride = 128 * 2 + 16;         // bytes per halo position (padded against b128 bank conflicts)
 
+// one dword pair (2 channels) of x against the same 2 channels of the weights of output 0 and output 1
 template <typename T>
-__device__ __forceinline__ float dot8(u32x4 a, u32x4 b, float acc);
+__device__ __forceinline__ void mac2(uint32_t x, uint32_t w0, uint32_t w1, float& a0, float& a1);
 template <>
-__device__ __forceinline__ float dot8<pvo_half>(u32x4 a, u32x4 b, float acc) {
-  // explicit lanes: indexing the ext-vector inside __builtin_bit_cast made hipcc feed lane 0 to all four dot2s
-  const uint32_t a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a0), __builtin_bit_cast(h2_t, b0), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a1), __builtin_bit_cast(h2_t, b1), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a2), __builtin_bit_cast(h2_t, b2), acc, false);
-  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a3), __builtin_bit_cast(h2_t, b3), acc, false);
-  return acc;
+__device__ __forceinline__ void mac2<pvo_half>(uint32_t x, uint32_t w0, uint32_t w1, float& a0, float& a1) {
+  a0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x), __builtin_bit_cast(h2_t, w0), a0, false);
+  a1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x), __builtin_bit_cast(h2_t, w1), a1, false);
 }
 template <>
-__device__ __forceinline__ float dot8<pvo_bf16>(u32x4 a, u32x4 b, float acc) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    acc = fmaf(__uint_as_float(a[k] << 16), __uint_as_float(b[k] << 16), acc);
-    acc = fmaf(__uint_as_float(a[k] & 0xffff0000u), __uint_as_float(b[k] & 0xffff0000u), acc);
-  }
-  return acc;
+__device__ __forceinline__ void mac2<pvo_bf16>(uint32_t x, uint32_t w0, uint32_t w1, float& a0, float& a1) {
+  const float xl = __uint_as_float(x << 16), xh = __uint_as_float(x & 0xffff0000u);
+  a0 = fmaf(xl, __uint_as_float(w0 << 16), a0); a0 = fmaf(xh, __uint_as_float(w0 & 0xffff0000u), a0);
+  a1 = fmaf(xl, __uint_as_float(w1 << 16), a1); a1 = fmaf(xh, __uint_as_float(w1 & 0xffff0000u), a1);
 }
 
+// Thread = (pixel of the 8x16 tile, half of the 128 channels); it accumulates BOTH outputs of the head, so every
+// activation dword read from LDS feeds two dot products.  The channel half is wave-uniform (waves 0-1: channels
+// 0-63, waves 2-3: 64-127), so the weights are read with scalar loads (SGPR operands of v_dot2c) and cost no LDS
+// bandwidth at all: the first version read x AND w through LDS and was LDS-bandwidth bound (80 us).
 template <typename T>
 __global__ __launch_bounds__(256) void heads_out_kernel(const uint16_t* __restrict__ h1, const float* __restrict__ bias1,
-                                                        const uint16_t* __restrict__ w2, const float* __restrict__ bias2,
+                                                        const uint32_t* __restrict__ w2, const float* __restrict__ bias2,
                                                         uint16_t* __restrict__ y, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xs = smem;                                   // [180][272 B]
-  unsigned char* ws = smem + kHaloPos * kPosStride;           // [2][9][128] 16-bit for the current head
-  float* ys = reinterpret_cast<float*>(ws + 2 * 9 * 128 * 2); // [128 px][8]
+  float* ys = reinterpret_cast<float*>(smem + kHaloPos * kPosStride);   // [2 halves][128 px][8]
   const int e = blockIdx.z;
   const int y0 = blockIdx.y * kHT, x0 = blockIdx.x * kWT;
   const int tid = threadIdx.x;
-  const int o = tid >> 7;                                     // output channel of this thread's head (wave-uniform)
+  const int kh = __builtin_amdgcn_readfirstlane(tid >> 7);    // channel half, wave-uniform
   const int p = tid & 127, py = p >> 4, px = p & 15;
 
   for (int head = 0; head < 4; ++head) {
     __syncthreads();                                          // previous head's tile fully consumed
-    // stage relu(h1 + bias1) for this head's 128 channels: 180 positions x 16 chunks of 8 channels
-    for (int id = tid; id < kHaloPos * 16; id += 256) {
-      const int pos = id >> 4, ch = id & 15;
-      const int hy = y0 - 1 + pos / kHaloW, hx = x0 - 1 + pos % kHaloW;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (hy >= 0 && hy < H && hx >= 0 && hx < W) {
-        float f[8], bb[8];
-        H8<T>::unpack(*reinterpret_cast<const u32x4*>(h1 + ((static_cast<size_t>(e) * H + hy) * W + hx) * 512 + head * 128 + ch * 8), f);
-        load8f(bias1 + head * 128 + ch * 8, bb);
+    {
+      constexpr int kIters = (kHaloPos * 16 + 255) / 256;     // 12 independent 16-byte loads in flight per thread
+      u32x4 raw[kIters];
+      const int ch = tid & 15;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + bb[k], 0.0f);
-        v = H8<T>::pack(f);
+      for (int it = 0; it < kIters; ++it) {
+        const int pos = (tid >> 4) + 16 * it;
+        raw[it] = u32x4{0u, 0u, 0u, 0u};
+        if (pos < kHaloPos) {
+          const int hy = y0 - 1 + pos / kHaloW, hx = x0 - 1 + pos % kHaloW;
+          if (hy >= 0 && hy < H && hx >= 0 && hx < W)
+            raw[it] = *reinterpret_cast<const u32x4*>(h1 + ((static_cast<size_t>(e) * H + hy) * W + hx) * 512 + head * 128 + ch * 8);
+        }
       }
-      *reinterpret_cast<u32x4*>(xs + pos * kPosStride + ch * 16) = v;
+      float bb[8];
+      load8f(bias1 + head * 128 + ch * 8, bb);
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int pos = (tid >> 4) + 16 * it;
+        if (pos < kHaloPos) {
+          const int hy = y0 - 1 + pos / kHaloW, hx = x0 - 1 + pos % kHaloW;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (hy >= 0 && hy < H && hx >= 0 && hx < W) {      // zero padding is applied AFTER bias + ReLU
+            float f[8];
+            H8<T>::unpack(raw[it], f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + bb[k], 0.0f);
+            v = H8<T>::pack(f);
+          }
+          *reinterpret_cast<u32x4*>(xs + pos * kPosStride + ch * 16) = v;
+        }
+      }
     }
-    for (int id = tid; id < 2 * 9 * 16; id += 256)            // this head's weights: 2 x 9 x 128 halves
-      *reinterpret_cast<u32x4*>(ws + id * 16) = *reinterpret_cast<const u32x4*>(w2 + static_cast<size_t>(head) * 2 * 9 * 128 + id * 8);
     __syncthreads();
-    float acc = bias2[head * 2 + o];
+    float a0[2] = {0.0f, 0.0f}, a1[2] = {0.0f, 0.0f};         // two accumulators per output break the dot2 dependency chain
+    // weights of this (head, half): [out][tap][64 channels] = dwords w2[((head*2+o)*9+t)*64 + kh*32 + k], wave-uniform
+    const uint32_t* __restrict__ wq = w2 + static_cast<size_t>(head) * 2 * 9 * 64 + kh * 32;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const unsigned char* xp = xs + ((py + t / 3) * kHaloW + (px + t % 3)) * kPosStride;
-      const unsigned char* wp = ws + (o * 9 + t) * 256;
+      const unsigned char* xp = xs + ((py + t / 3) * kHaloW + (px + t % 3)) * kPosStride + kh * 128;
 #pragma unroll
-      for (int c = 0; c < 16; ++c)
-        acc = dot8<T>(*reinterpret_cast<const u32x4*>(xp + c * 16), *reinterpret_cast<const u32x4*>(wp + c * 16), acc);
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(xp + c * 16);
+        const uint32_t* w0 = wq + t * 64 + c * 4;              // output 0
+        const uint32_t* w1 = wq + (9 + t) * 64 + c * 4;        // output 1
+        mac2<T>(xv.x, w0[0], w1[0], a0[0], a1[0]);
+        mac2<T>(xv.y, w0[1], w1[1], a0[1], a1[1]);
+        mac2<T>(xv.z, w0[2], w1[2], a0[0], a1[0]);
+        mac2<T>(xv.w, w0[3], w1[3], a0[1], a1[1]);
+      }
     }
-    ys[p * 8 + head * 2 + o] = acc;
+    ys[(kh * 128 + p) * 8 + head * 2 + 0] = a0[0] + a0[1];
+    ys[(kh * 128 + p) * 8 + head * 2 + 1] = a1[0] + a1[1];
   }
   __syncthreads();
-  if (tid < 128) {                                            // one 16-byte store per pixel
+  if (tid < 128) {                                            // sum the two channel halves, add bias, one 16-byte store per pixel
     const int gy = y0 + (tid >> 4), gx = x0 + (tid & 15);
     if (gy < H && gx < W) {
       float f[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = ys[tid * 8 + k];
+      for (int k = 0; k < 8; ++k) f[k] = ys[tid * 8 + k] + ys[(128 + tid) * 8 + k] + bias2[k];
       *reinterpret_cast<u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * 8) = H8<T>::pack(f);
     }
   }
@@ -467,14 +488,14 @@ extern "C" int pvo_heads_out(const void* h1, const float* bias1, const void* w2,
   if (!h1 || !bias1 || !w2 || !bias2 || !y || !aligned16(h1) || !aligned16(w2) || !aligned16(y) ||
       (reinterpret_cast<uintptr_t>(bias1) & 15) || E > 65535) return PVO_EINVAL;
   hipStream_t st = pvo_stream(stream);
-  const size_t lds = static_cast<size_t>(kHaloPos) * kPosStride + 2 * 9 * 128 * 2 + 128 * 8 * sizeof(float);
+  const size_t lds = static_cast<size_t>(kHaloPos) * kPosStride + 2 * 128 * 8 * sizeof(float);
   dim3 grid((W + kWT - 1) / kWT, (H + kHT - 1) / kHT, E);
   if (dtype == PVO_F16) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_out_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-    hipLaunchKernelGGL(heads_out_kernel<pvo_half>, grid, dim3(256), lds, st, static_cast<const uint16_t*>(h1), bias1, static_cast<const uint16_t*>(w2), bias2, static_cast<uint16_t*>(y), H, W);
+    hipLaunchKernelGGL(heads_out_kernel<pvo_half>, grid, dim3(256), lds, st, static_cast<const uint16_t*>(h1), bias1, static_cast<const uint32_t*>(w2), bias2, static_cast<uint16_t*>(y), H, W);
   } else if (dtype == PVO_BF16) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_out_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-    hipLaunchKernelGGL(heads_out_kernel<pvo_bf16>, grid, dim3(256), lds, st, static_cast<const uint16_t*>(h1), bias1, static_cast<const uint16_t*>(w2), bias2, static_cast<uint16_t*>(y), H, W);
+    hipLaunchKernelGGL(heads_out_kernel<pvo_bf16>, grid, dim3(256), lds, st, static_cast<const uint16_t*>(h1), bias1, static_cast<const uint32_t*>(w2), bias2, static_cast<uint16_t*>(y), H, W);
   } else {
     return PVO_EUNSUPPORTED;
   }
