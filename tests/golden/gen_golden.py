@@ -127,6 +127,18 @@ def gen_ba():
         Gm = MoBA(s["target"][None], s["weight"][None], None, SE3(s["poses"][None].clone()), s["disps"][None],
                   intr_all, s["ii"], s["jj"], fixedp=fixedp)
         out["moba_poses_1"] = Gm.data[0].numpy().copy()
+        # training path: gradients of a fixed linear functional of two BA steps (chol.py:22-30 backward)
+        g = torch.Generator().manual_seed(100 + seed)
+        leaves = {k: s[k][None].clone().requires_grad_(True) for k in ("target", "weight", "eta", "disps")}
+        Gs, disps = SE3(s["poses"][None].clone()), leaves["disps"]
+        for it in range(2):
+            Gs, disps = BA(leaves["target"], leaves["weight"], leaves["eta"] - 1e-7, Gs, disps,
+                           intr_all, s["ii"], s["jj"], fixedp=fixedp)
+        cp, cd = torch.randn(Gs.data.shape, generator=g), torch.randn(disps.shape, generator=g)
+        ((Gs.data * cp).sum() + (disps * cd).sum()).backward()
+        out["grad_cp"], out["grad_cd"] = cp[0].numpy(), cd[0].numpy()
+        for k, v in leaves.items():
+            out["grad_" + k] = v.grad[0].numpy().copy()
         np.savez_compressed(os.path.join(HERE, "ba_python_%s.npz" % name), **out)
         print("ba_python_%s: P=%d E=%d %dx%d" % (name, P, s["ii"].shape[0], ht, wd))
 
