@@ -1,0 +1,131 @@
+"""DroidNet: encoders + update operator + the unrolled training loop, and the upsampling helpers.
+
+Mirror of the reference's ``droid_net.py`` (VO_Module/droid_slam/droid_net.py): `cvx_upsample`
+(:23-37), `upsample_dim_1/_x`, `upsample_inter` (:40-65) and `DroidNet` (:317-439) with the same
+sub-module names (`fnet`, `cnet`, `update`), so checkpoints load unchanged.  `forward` is the
+training-time unroll (config 5): differentiable CorrBlock (HIP lookup forward/backward), the
+update operator and the PyTorch BA of `pvo_amd.geom.ba`; inference goes through
+`FactorGraph.update` and the HIP solver instead.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .geom import projective_ops as pops
+from .geom.ba import BA
+from .geom.graph_utils import graph_to_edge_list, keyframe_indicies
+from .modules.corr import CorrBlock
+from .modules.extractor import BasicEncoder
+from .modules.update import DynamicUpdateModule
+
+
+def cvx_upsample(data, mask):
+    """8x convex upsampling of a [B,H,W,D] field with [B,9*64,H,W] logits (droid_net.py:23-37):
+    every fine pixel is a softmax-weighted combination of the 3x3 coarse neighbourhood."""
+    batch, ht, wd, dim = data.shape
+    wgt = torch.softmax(mask.view(batch, 1, 9, 8, 8, ht, wd), dim=2)
+    nbr = F.unfold(data.permute(0, 3, 1, 2), [3, 3], padding=1).view(batch, dim, 9, 1, 1, ht, wd)
+    up = (wgt * nbr).sum(dim=2)                                   # [B,D,8,8,H,W]
+    return up.permute(0, 4, 2, 5, 3, 1).reshape(batch, 8 * ht, 8 * wd, dim)
+
+
+def upsample_dim_1(disp, mask):
+    batch, num, ht, wd = disp.shape
+    up = cvx_upsample(disp.reshape(batch * num, ht, wd, 1), mask.reshape(batch * num, -1, ht, wd))
+    return up.view(batch, num, 8 * ht, 8 * wd)
+
+
+def upsample_dim_x(flow, mask):
+    batch, num, ht, wd, dim = flow.shape
+    up = cvx_upsample(flow.reshape(batch * num, ht, wd, dim), mask.reshape(batch * num, -1, ht, wd))
+    return up.view(batch, num, 8 * ht, 8 * wd, dim)
+
+
+def upsample_inter(mask):
+    """8x bilinear (align_corners) upsampling of a [B,N,H,W,D] field (droid_net.py:56-65)."""
+    batch, num, ht, wd, dim = mask.shape
+    x = mask.permute(0, 1, 4, 2, 3).reshape(batch * num, dim, ht, wd)
+    x = F.interpolate(x, scale_factor=8, mode="bilinear", align_corners=True, recompute_scale_factor=True)
+    return x.permute(0, 2, 3, 1).reshape(batch, num, 8 * ht, 8 * wd, dim)
+
+
+class DroidNet(nn.Module):
+    def __init__(self, use_aff_bri=False):
+        super().__init__()
+        self.fnet = BasicEncoder(output_dim=128, norm_fn="instance")
+        self.cnet = BasicEncoder(output_dim=256, norm_fn="none")
+        self.update = DynamicUpdateModule(use_aff_bri)
+        self.use_aff_bri = use_aff_bri
+
+    def extract_features(self, images):
+        """[B,N,3,H,W] BGR 0..255 -> fmaps [B,N,128,h,w], net = tanh, inp = relu (droid_net.py:325-340).
+        Unlike the reference the caller's image tensor is not modified in place."""
+        mean = torch.as_tensor([0.485, 0.456, 0.406], device=images.device)[:, None, None]
+        std = torch.as_tensor([0.229, 0.224, 0.225], device=images.device)[:, None, None]
+        x = (images[:, :, [2, 1, 0]] / 255.0 - mean) / std
+        fmaps = self.fnet(x)
+        net, inp = self.cnet(x).split([128, 128], dim=2)
+        return fmaps, torch.tanh(net), torch.relu(inp)
+
+    def forward(self, Gs, images, disps, intrinsics, graph=None, num_steps=12, fixedp=2, ret_flow=False,
+                downsample=False, segments=None):
+        """Unrolled estimation over a frame graph (droid_net.py:342-439).  Returns per-step lists
+        (Gs, upsampled disps, residuals[, full flows], masks[, affine-brightness params])."""
+        ii, jj, _ = graph_to_edge_list(graph)
+        ii = ii.to(device=images.device, dtype=torch.long)
+        jj = jj.to(device=images.device, dtype=torch.long)
+        dy_thresh, mask_num = 0.5, 2
+
+        fmaps, net, inp = self.extract_features(images)
+        net, inp = net[:, ii], inp[:, ii]
+        corr_fn = CorrBlock(fmaps[:, ii], fmaps[:, jj], num_levels=4, radius=3)
+
+        ht, wd = images.shape[-2:]
+        coords0 = pops.coords_grid(ht // 8, wd // 8, device=images.device)
+        coords1, _ = pops.projective_transform(Gs, disps, intrinsics, ii, jj)
+        target_cam = coords1.clone()
+        delta_dy = torch.zeros_like(coords1)
+        raw_mask = torch.zeros_like(coords1)[..., :mask_num]
+
+        Gs_list, disp_list, residual_list, flow_list, mask_list, aff_list = [], [], [], [], [], []
+        for _ in range(num_steps):
+            Gs, disps = Gs.detach(), disps.detach()
+            coords1, target_cam = coords1.detach(), target_cam.detach()
+            delta_dy, raw_mask = delta_dy.detach(), raw_mask.detach()
+
+            corr = corr_fn(coords1)
+            cam_flow = coords1 - coords0
+            motion = torch.cat([cam_flow, cam_flow + delta_dy, target_cam - coords1, raw_mask], dim=-1)
+            motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+
+            out = self.update(net, inp, corr, motion, ii, jj, self.use_aff_bri)
+            net, delta, weight, eta, upmask, delta_m = out[:6]
+
+            raw_mask = raw_mask + delta_m                         # 1: static, 0: dynamic
+            mask = torch.sigmoid(raw_mask)
+            bin_mask = (mask >= dy_thresh).float()
+            target_cam = coords1 + delta[..., 0:2]
+            weight = torch.sigmoid(weight + (1 - bin_mask) * 10)
+
+            for _ in range(2):                                    # droid_net.py:408-410 (fixedp=2 hard-wired)
+                Gs, disps = BA(target_cam, weight, eta, Gs, disps, intrinsics, ii, jj, fixedp=2)
+
+            coords1, valid = pops.projective_transform(Gs, disps, intrinsics, ii, jj)
+            residual = (target_cam - coords1) * valid
+            delta_dy = delta[..., 2:4] * (1 - bin_mask)
+            target_all = coords1 + delta_dy
+
+            Gs_list.append(Gs)
+            disp_list.append(upsample_dim_1(disps, upmask["disp"]))
+            residual_list.append(residual)
+            mask_list.append(upsample_inter(mask))
+            if ret_flow:
+                flow = target_all - coords0
+                flow_list.append(flow if downsample else upsample_inter(flow * 8))
+            if self.use_aff_bri:
+                aff_list.append(out[6])
+
+        res = [Gs_list, disp_list, residual_list] + ([flow_list] if ret_flow else []) + [mask_list]
+        if ret_flow and self.use_aff_bri:
+            res.append(aff_list)
+        return tuple(res)

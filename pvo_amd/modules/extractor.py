@@ -1,0 +1,85 @@
+"""Feature / context encoders (1/8 resolution), state-dict compatible with the reference's
+``modules/extractor.py`` (VO_Module/droid_slam/modules/extractor.py:6-56 ResidualBlock,
+:116-201 BasicEncoder): same sub-module names, creation order and initialisation (kaiming-normal
+fan_out for convs, unit/zero for norm affine parameters :166-173), so a reference checkpoint loads
+with `load_state_dict` and a seeded construction gives identical weights.
+
+These run once per frame (MotionFilter) and are vendor-library convolutions (MIOpen); they are
+caller-side plumbing of the hot path, not a hand-written kernel.
+"""
+import torch.nn as nn
+
+DIM = 32
+
+
+def _norm(kind, planes, groups=None):
+    if kind == "group":
+        return nn.GroupNorm(num_groups=groups if groups is not None else planes // 8, num_channels=planes)
+    if kind == "batch":
+        return nn.BatchNorm2d(planes)
+    if kind == "instance":
+        return nn.InstanceNorm2d(planes)
+    if kind == "none":
+        return nn.Sequential()
+    raise ValueError("unknown norm_fn %r" % (kind,))
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_planes, planes, norm_fn="group", stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1 = _norm(norm_fn, planes)
+        self.norm2 = _norm(norm_fn, planes)
+        self.downsample = None
+        if stride != 1:
+            self.norm3 = _norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class BasicEncoder(nn.Module):
+    """[B,N,3,H,W] -> [B,N,output_dim,H/8,W/8]  (extractor.py:183-201)."""
+
+    def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0, multidim=False):
+        super().__init__()
+        if multidim:
+            raise NotImplementedError("multidim encoders are never constructed on the VO path (droid_net.py:320-321)")
+        self.norm_fn = norm_fn
+        self.multidim = multidim
+        self.norm1 = _norm(norm_fn, DIM, groups=8)
+        self.conv1 = nn.Conv2d(3, DIM, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = DIM
+        self.layer1 = self._make_layer(DIM, stride=1)
+        self.layer2 = self._make_layer(2 * DIM, stride=2)
+        self.layer3 = self._make_layer(4 * DIM, stride=2)
+        self.conv2 = nn.Conv2d(4 * DIM, output_dim, kernel_size=1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, dim, stride=1):
+        blocks = (ResidualBlock(self.in_planes, dim, self.norm_fn, stride=stride),
+                  ResidualBlock(dim, dim, self.norm_fn, stride=1))
+        self.in_planes = dim
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        b, n, c, h, w = x.shape
+        x = self.relu1(self.norm1(self.conv1(x.reshape(b * n, c, h, w))))
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        return x.view(b, n, *x.shape[1:])

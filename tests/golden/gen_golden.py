@@ -264,6 +264,84 @@ def gen_factor_graph_glue():
         print("factor_graph_glue segm_filter=%s" % segm_filter)
 
 
+def _oracle_backed_lookup():
+    """droid_backends.corr_index_forward/backward for the reference's CorrSampler at fixture time:
+    the CPU oracle (oracle/oracle_corr.c), fp32."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    mod = sys.modules["droid_backends"]
+
+    def fwd(volume, coords, radius):
+        return [torch.from_numpy(O.corr_index_forward(volume.detach().numpy(), coords.detach().numpy(), radius))]
+
+    def bwd(volume, coords, grad, radius):
+        return [torch.from_numpy(O.corr_index_backward(tuple(volume.shape), coords.detach().numpy(),
+                                                       grad.detach().numpy(), radius))]
+    mod.corr_index_forward, mod.corr_index_backward = fwd, bwd
+
+
+def droidnet_inputs(N, H, W, seed=12):
+    """Inputs of the DroidNet.forward fixture, regenerated from the seed by the generator and the tests
+    alike (CPU generator streams are reproducible), so the images need not be stored."""
+    from pvo_amd.geom.se3 import SE3
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randint(0, 256, (1, N, 3, H, W), generator=g).float()
+    xi = torch.tensor([0.05, 0.01, 0.02, 0.003, 0.01, -0.004])
+    Gs = SE3(torch.stack([SE3.exp(k * xi).data for k in range(N)], 0)[None])
+    disps = 0.5 + 0.5 * torch.rand(1, N, H // 8, W // 8, generator=g)
+    intr = torch.tensor([W * 0.1, W * 0.1, W / 16.0, H / 16.0])[None, None].repeat(1, N, 1)
+    return images, Gs, disps, intr
+
+
+def gen_droidnet():
+    """The reference's DroidNet.forward (droid_net.py:342-439), run unmodified on a 4-frame graph.
+    Fixture-time substitutes on top of install_substitutes(): the lookup extension is the CPU oracle, and
+    numpy gets a `range` attribute aliasing `arange` so the dead line droid_net.py:295 (whose result is never
+    used) does not raise.  Weights are the seeded default initialisation; only inputs/outputs are stored."""
+    from collections import OrderedDict
+    import droid_net as ref_net
+    from modules.extractor import BasicEncoder
+    from pvo_amd.geom.se3 import SE3
+    _oracle_backed_lookup()
+    np.range = np.arange
+    out = {}
+    # encoders: seeded construction, one small input
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 2, 3, 32, 48, generator=g)
+    for norm, od in (("instance", 128), ("none", 256)):
+        torch.manual_seed(0)
+        enc = BasicEncoder(output_dim=od, norm_fn=norm).eval()
+        out["enc_%s" % norm] = enc(x).detach().numpy()
+        out["enc_%s_keys" % norm] = np.array(list(enc.state_dict().keys()))
+    out["enc_x"] = x.numpy()
+    # convex upsampling
+    data, mask = torch.randn(2, 5, 6, 3, generator=g), torch.randn(2, 576, 5, 6, generator=g)
+    out["cvx_data"], out["cvx_mask"] = data.numpy(), mask.numpy()
+    out["cvx_up"] = ref_net.cvx_upsample(data, mask).numpy()
+    fl = torch.randn(1, 2, 4, 5, 2, generator=g)
+    out["inter_in"], out["inter_up"] = fl.numpy(), ref_net.upsample_inter(fl).numpy()
+    # the unrolled loop
+    torch.manual_seed(0)
+    net = ref_net.DroidNet().eval()
+    N, H, W = 4, 128, 160
+    images, Gs, disps, intr = droidnet_inputs(N, H, W)
+    graph = OrderedDict((i, [j for j in range(N) if j != i and abs(i - j) <= 2]) for i in range(N))
+    with torch.no_grad():
+        res = net(SE3(Gs.data.clone()), images.clone(), disps.clone(), intr, graph, num_steps=3, fixedp=2, ret_flow=True,
+                  downsample=True)
+    Gs_l, disp_l, resid_l, flow_l, mask_l = res
+    out.update(shape=np.array([N, H, W]), num_steps=np.int64(3), state_keys=np.array(list(net.state_dict().keys())),
+               state_sums=np.array([float(v.double().sum()) for v in net.state_dict().values()]))
+    for s in range(3):
+        out["Gs_%d" % s] = Gs_l[s].data[0].numpy()
+        out["disp_up_%d" % s] = disp_l[s][0, :, ::4, ::4].numpy()
+        out["resid_%d" % s] = resid_l[s][0].numpy()
+        out["flow_%d" % s] = flow_l[s][0].numpy()
+        out["mask_%d" % s] = mask_l[s][0, :, ::8, ::8].numpy()
+    np.savez_compressed(os.path.join(HERE, "droidnet_forward.npz"), **out)
+    print("droidnet_forward: %d frames %dx%d, %d state tensors" % (N, H, W, len(net.state_dict())))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -274,3 +352,4 @@ if __name__ == "__main__":
     gen_update_op()
     gen_graph()
     gen_factor_graph_glue()
+    gen_droidnet()

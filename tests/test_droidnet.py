@@ -1,0 +1,134 @@
+"""Encoders, upsampling helpers and the unrolled DroidNet.forward against outputs of the reference's
+own droid_net.py / modules/extractor.py (tests/golden/gen_golden.py: gen_droidnet)."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+
+from pvo_amd import droid_net as dn
+from pvo_amd.geom.se3 import SE3
+from pvo_amd.modules.extractor import BasicEncoder
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "droidnet_forward.npz")
+
+
+def _inputs(N, H, W, seed=12):
+    """same stream as gen_golden.droidnet_inputs (kept in sync by test_inputs_helper_matches_generator)"""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randint(0, 256, (1, N, 3, H, W), generator=g).float()
+    xi = torch.tensor([0.05, 0.01, 0.02, 0.003, 0.01, -0.004])
+    Gs = SE3(torch.stack([SE3.exp(k * xi).data for k in range(N)], 0)[None])
+    disps = 0.5 + 0.5 * torch.rand(1, N, H // 8, W // 8, generator=g)
+    intr = torch.tensor([W * 0.1, W * 0.1, W / 16.0, H / 16.0])[None, None].repeat(1, N, 1)
+    return images, Gs, disps, intr
+
+
+def test_encoders_match_reference():
+    z = np.load(GOLD)
+    x = torch.from_numpy(z["enc_x"])
+    for norm, od in (("instance", 128), ("none", 256)):
+        torch.manual_seed(0)
+        enc = BasicEncoder(output_dim=od, norm_fn=norm).eval()
+        assert list(enc.state_dict().keys()) == list(z["enc_%s_keys" % norm])
+        with torch.no_grad():
+            y = enc(x)
+        assert torch.allclose(y, torch.from_numpy(z["enc_%s" % norm]), atol=1e-5)
+
+
+def test_upsampling_matches_reference():
+    z = np.load(GOLD)
+    up = dn.cvx_upsample(torch.from_numpy(z["cvx_data"]), torch.from_numpy(z["cvx_mask"]))
+    assert torch.allclose(up, torch.from_numpy(z["cvx_up"]), atol=1e-6)
+    assert torch.allclose(dn.upsample_inter(torch.from_numpy(z["inter_in"])), torch.from_numpy(z["inter_up"]), atol=1e-6)
+    d = torch.from_numpy(z["cvx_data"])[..., 0][None]
+    assert dn.upsample_dim_1(d, torch.from_numpy(z["cvx_mask"])[None]).shape == (1, 2, 40, 48)
+    # convexity: a constant field stays constant
+    c = dn.cvx_upsample(torch.full((1, 4, 4, 1), 2.5), torch.randn(1, 576, 4, 4))
+    assert torch.allclose(c[:, 8:-8, 8:-8], torch.full_like(c[:, 8:-8, 8:-8], 2.5), atol=1e-6)
+
+
+def test_state_dict_layout_matches_reference():
+    z = np.load(GOLD)
+    torch.manual_seed(0)
+    net = dn.DroidNet()
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(z["state_keys"])
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    assert np.allclose(sums, z["state_sums"], rtol=0, atol=1e-9)
+
+
+class _OracleCorrBlock:
+    """CPU stand-in for the HIP CorrBlock in the no-GPU test: torch volume + oracle lookup."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+        import oracle as O
+        self.O, self.radius = O, radius
+        from pvo_amd.modules.corr import CorrBlock
+        self.pyr = CorrBlock._build_differentiable(fmap1, fmap2, num_levels)
+
+    def __call__(self, coords):
+        b, n, h, w, _ = coords.shape
+        c = coords.reshape(b * n, h, w, 2).permute(0, 3, 1, 2).contiguous().numpy()
+        out = [torch.from_numpy(self.O.corr_index_forward(p.contiguous().numpy(), c / 2 ** i, self.radius)).view(b, n, -1, h, w)
+               for i, p in enumerate(self.pyr)]
+        return torch.cat(out, dim=2)
+
+
+def _run_forward(device, corr_cls=None, atol=None):
+    z = np.load(GOLD)
+    N, H, W = [int(v) for v in z["shape"]]
+    images, Gs, disps, intr = _inputs(N, H, W)
+    torch.manual_seed(0)
+    net = dn.DroidNet().eval().to(device)
+    graph = OrderedDict((i, [j for j in range(N) if j != i and abs(i - j) <= 2]) for i in range(N))
+    old = dn.CorrBlock
+    if corr_cls is not None:
+        dn.CorrBlock = corr_cls
+    try:
+        with torch.no_grad():
+            res = net(SE3(Gs.data.clone().to(device)), images.to(device), disps.to(device), intr.to(device), graph,
+                      num_steps=int(z["num_steps"]), fixedp=2, ret_flow=True, downsample=True)
+    finally:
+        dn.CorrBlock = old
+    Gs_l, disp_l, resid_l, flow_l, mask_l = res
+    for s in range(int(z["num_steps"])):
+        assert torch.allclose(Gs_l[s].data[0].cpu(), torch.from_numpy(z["Gs_%d" % s]), atol=atol), s
+        assert torch.allclose(disp_l[s][0, :, ::4, ::4].cpu(), torch.from_numpy(z["disp_up_%d" % s]), atol=atol), s
+        assert torch.allclose(resid_l[s][0].cpu(), torch.from_numpy(z["resid_%d" % s]), atol=10 * atol), s
+        assert torch.allclose(flow_l[s][0].cpu(), torch.from_numpy(z["flow_%d" % s]), atol=10 * atol), s
+        assert torch.allclose(mask_l[s][0, :, ::8, ::8].cpu(), torch.from_numpy(z["mask_%d" % s]), atol=atol), s
+
+
+def test_forward_matches_reference_cpu():
+    _run_forward("cpu", _OracleCorrBlock, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_forward_matches_reference_gpu():
+    """same unroll with the HIP correlation kernels and MIOpen convolutions (fp32)"""
+    _run_forward("cuda:0", None, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_training_step_backpropagates_through_hip_lookup_and_ba():
+    N, H, W = 3, 128, 128
+    images, Gs, disps, intr = _inputs(N, H, W, seed=5)
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    net = dn.DroidNet().train().to(dev)
+    graph = OrderedDict((i, [j for j in range(N) if j != i]) for i in range(N))
+    res = net(SE3(Gs.data[:, :N].to(dev)), images.to(dev), disps.to(dev), intr.to(dev), graph, num_steps=2, fixedp=2)
+    Gs_l, disp_l, resid_l, mask_l = res
+    loss = sum(r.abs().mean() for r in resid_l) + sum(d.mean() for d in disp_l) + sum((g.data ** 2).sum() for g in Gs_l)
+    loss.backward()
+    grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert any(k.startswith("fnet.") for k in grads), "no gradient reached the feature encoder through the lookup backward"
+    assert any(k.startswith("update.gru.") for k in grads)
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    assert sum(float(g.abs().sum()) for k, g in grads.items() if k.startswith("fnet.")) > 0
