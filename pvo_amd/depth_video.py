@@ -56,6 +56,49 @@ class DepthVideo:
             self.images[k] = image
         self.counter = k + 1
 
+    def __setitem__(self, index, item):
+        """video[index] = (tstamp, image, pose, disp, intrinsics[, fmap[, net[, inp[, segm]]]]) with None = keep
+        (depth_video.py:64-101).  The counter grows to cover an int index; fmap may be NCHW or channels-last."""
+        if isinstance(index, int) and index >= self.counter:
+            self.counter = index + 1
+        self.tstamp[index] = torch.as_tensor(item[0], dtype=torch.float, device=self.device)
+        if item[1] is not None and self.images is not None:
+            self.images[index] = item[1].to(self.images.dtype)
+        for buf, val in ((self.poses, item[2]), (self.disps, item[3]), (self.intrinsics, item[4])):
+            if val is not None:
+                buf[index] = val
+        if len(item) > 5 and item[5] is not None:
+            f = item[5]
+            self.fmaps[index] = f.movedim(-3, -1) if f.shape[-1] != 128 else f
+        if len(item) > 6:
+            self.nets[index] = item[6]
+        if len(item) > 7:
+            self.inps[index] = item[7]
+        if self.segm_filter and len(item) > 8 and item[8] is not None:
+            self.segms[index] = item[8]
+
+    def __getitem__(self, index):
+        """(pose, disp, intrinsics, fmap, net, inp) of a keyframe; negative ints count from the end (:103-121)"""
+        if isinstance(index, int) and index < 0:
+            index = self.counter + index
+        return (self.poses[index], self.disps[index], self.intrinsics[index], self.fmaps[index], self.nets[index],
+                self.inps[index])
+
+    def normalize(self):
+        """rescale so the mean inverse depth of the stored keyframes is 1 (depth_video.py:145-152)"""
+        n = self.counter
+        s = self.disps[:n].mean()
+        self.disps[:n] /= s
+        self.poses[:n, :3] *= s
+        self.dirty[:n] = True
+
+    def upsample(self, ix, mask):
+        """convex 8x upsampling of the inverse depth of keyframes ix (depth_video.py:139-143)"""
+        from .droid_net import cvx_upsample
+        if self.disps_up is None:
+            self.disps_up = torch.zeros(self.disps.shape[0], self.ht, self.wd, dtype=torch.float, device=self.device)
+        self.disps_up[ix] = cvx_upsample(self.disps[ix].unsqueeze(-1), mask).squeeze(-1)
+
     @staticmethod
     def format_indicies(ii, jj, device):
         if not isinstance(ii, torch.Tensor):

@@ -1,0 +1,78 @@
+"""Droid - the VO system object: motion filter -> frontend (local BA) -> backend (global BA) -> trajectory filler.
+
+Counterpart of the reference's Droid (VO_Module/droid_slam/droid.py:19-124): same constructor argument object
+(the fields of evaluation_scripts/test_vo.py:58-83), `track`, `terminate`, `get_traj`, `get_depth`, `get_flow`.
+There is no visualiser process and no shared-memory video: one process owns one GPU.  With `args.weights = None`
+the network keeps its seeded default initialisation (this image has no checkpoints).
+"""
+from argparse import Namespace
+from collections import OrderedDict
+
+import torch
+
+from .backend import DroidBackend
+from .depth_video import DepthVideo
+from .droid_net import DroidNet, upsample_inter
+from .frontend import DroidFrontend
+from .geom.se3 import SE3
+from .motion_filter import MotionFilter
+from .trajectory_filler import PoseTrajectoryFiller
+
+
+def default_args(**over):
+    """the defaults of evaluation_scripts/test_vo.py:58-83"""
+    a = dict(device="cuda:0", weights=None, buffer=1024, image_size=[240, 808], disable_vis=True, use_aff_bri=False,
+             beta=0.6, filter_thresh=1.75, warmup=12, keyframe_thresh=2.25, frontend_thresh=12.0, frontend_window=25,
+             frontend_radius=2, frontend_nms=1, backend_thresh=15.0, backend_radius=2, backend_nms=3,
+             segm_filter=False, thresh=0.8, half_update=True)
+    a.update(over)
+    return Namespace(**a)
+
+
+class Droid:
+    def __init__(self, args):
+        self.args = args
+        self.load_weights(args.weights, args.use_aff_bri)
+        self.video = DepthVideo(args.image_size, args.buffer, args.device, args.segm_filter, args.thresh)
+        self.filterx = MotionFilter(self.net, self.video, thresh=args.filter_thresh, device=args.device)
+        self.frontend = DroidFrontend(self.net.update, self.video, args.device, warmup=args.warmup, beta=args.beta,
+                                      frontend_nms=args.frontend_nms, keyframe_thresh=args.keyframe_thresh,
+                                      frontend_window=args.frontend_window, frontend_thresh=args.frontend_thresh,
+                                      frontend_radius=args.frontend_radius)
+        self.backend = DroidBackend(self.net, self.video, args)
+        self.traj_filler = PoseTrajectoryFiller(self.net, self.video, args.device)
+
+    def load_weights(self, weights, use_aff_bri=False):
+        """droid.py:55-62; DataParallel's "module." prefix is stripped"""
+        self.net = DroidNet(use_aff_bri)
+        if weights is not None:
+            sd = torch.load(weights, map_location=self.args.device)
+            self.net.load_state_dict(OrderedDict((k.replace("module.", ""), v) for k, v in sd.items()))
+        self.net.to(self.args.device).eval()
+        if getattr(self.args, "half_update", True) and torch.device(self.args.device).type == "cuda":
+            self.net.update.half()          # the fused 16-bit operator path; encoders stay fp32 under autocast
+
+    def track(self, tstamp, image, depth=None, intrinsics=None, segments=None):
+        with torch.no_grad():
+            self.filterx.track(tstamp, image, depth, intrinsics, segments)
+            self.frontend()
+
+    def terminate(self, stream=None, need_inv=True):
+        """two global BA passes, then fill in every frame's pose; returns [num_frames, 7] (t, q) (droid.py:77-98)"""
+        del self.frontend
+        torch.cuda.empty_cache()
+        self.backend(7)
+        torch.cuda.empty_cache()
+        self.backend(12)
+        traj = self.traj_filler(stream)
+        return (traj.inv() if need_inv else traj).data.cpu().numpy()
+
+    def get_traj(self):
+        return SE3(self.video.poses[:self.video.counter]).data.cpu().numpy()
+
+    def get_depth(self):
+        d = self.video.disps[:self.video.counter]
+        return upsample_inter(d[None, ..., None]).squeeze(4).squeeze(0)
+
+    def get_flow(self):
+        return upsample_inter(self.video.full_flow[:self.video.counter][None] * 8)

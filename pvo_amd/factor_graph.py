@@ -174,6 +174,48 @@ class FactorGraph:
         self._ii_inac_h, self._jj_inac_h = dec(self._ii_inac_h), dec(self._jj_inac_h)
         self.rm_factors(m, store=False)
 
+    @torch.no_grad()
+    def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8):
+        """global-BA update without correlation volumes (factor_graph.py:309-360): features are correlated on the
+        fly by the alt-corr kernel, the update operator runs over source-frame chunks of 8, then ONE dense BA over
+        all keyframes [1, t) with lm=1e-5, ep=1e-2.  As in the reference the motion features are built from
+        `target_cam - coords0` (not the fresh reprojection) and the damping is the raw eta (no 0.2 factor)."""
+        from .modules.corr import AltCorrBlock
+        t = self.video.counter
+        ht, wd = self.ht, self.wd
+        corr_op = AltCorrBlock(self.video.fmaps[None, :t], channels_last=True)
+        jmax = max(self._jj_h)
+        chunks = []
+        for i in range(0, jmax + 1, 8):
+            sel = [k for k, a in enumerate(self._ii_h) if i <= a < i + 8]
+            if sel:
+                chunks.append((torch.tensor(sel, device=self.device), sorted({self._ii_h[k] for k in sel})))
+        src = torch.tensor(sorted(set(self._ii_h)), device=self.device)
+        for _ in range(steps):
+            coords1, _ = self.video.reproject(self.ii, self.jj)
+            cam = self.target_cam - self.coords0
+            motn = torch.cat([cam, cam + self.delta_dy, self.target_cam - coords1, self.raw_mask], dim=-1)
+            motn = motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+            for v, srcs in chunks:
+                iis, jjs = self.ii[v], self.jj[v]
+                corr1 = corr_op(coords1[:, v], iis, jjs)
+                with torch.autocast("cuda", dtype=torch.float16, enabled=self._autocast and self.device.type == "cuda"):
+                    net, delta, weight, damping, _, delta_m = self.update_op(
+                        self.net[:, v], self.video.inps[iis][None], corr1, motn[:, v], iis, jjs, False)
+                self.net[:, v] = net.to(self.net.dtype)
+                self.target_cam[:, v] = coords1[:, v] + delta[..., 0:2].float()
+                self.damping[torch.tensor(srcs, device=self.device)] = damping[0].float()
+                raw = self.raw_mask[:, v] + delta_m.float()
+                self.raw_mask[:, v] = raw
+                bin_mask = (torch.sigmoid(raw) >= self.dy_thresh).float()
+                self.delta_dy[:, v] = delta[..., 2:4].float() * (1 - bin_mask)
+                self.weight[:, v] = torch.sigmoid(weight.float() + (1 - bin_mask) * 10)
+            eta = self.damping[src].contiguous() + EP
+            target = self.target_cam.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+            weight = self.weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+            self.video.ba(target, weight, eta, self.ii, self.jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
+            self.video.dirty[:t] = True
+
     def add_neighborhood_factors(self, t0, t1, r=3):
         """edges between frames within temporal radius r (factor_graph.py:362-370)"""
         ii, jj = [], []

@@ -1,0 +1,67 @@
+"""PoseTrajectoryFiller - poses of the non-keyframe images (VO_Module/droid_slam/trajectory_filler.py:12-112).
+
+Frames are processed in chunks of 16: each gets a pose interpolated on se(3) between its neighbouring keyframes,
+is written temporarily behind the keyframes in the video buffers, connected to those two keyframes, and refined
+by six motion-only updates (update operator + HIP BA with `motion_only=True`).
+"""
+import torch
+
+from .factor_graph import FactorGraph
+from .geom import se3 as lie
+from .geom.se3 import SE3
+
+
+class PoseTrajectoryFiller:
+    def __init__(self, net, video, device="cuda:0"):
+        self.cnet, self.fnet, self.update = net.cnet, net.fnet, net.update
+        self.count, self.video, self.device = 0, video, torch.device(device)
+        self.MEAN = torch.as_tensor([0.485, 0.456, 0.406], device=self.device)[:, None, None]
+        self.STDV = torch.as_tensor([0.229, 0.224, 0.225], device=self.device)[:, None, None]
+
+    def _features(self, images):
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
+            x = images[None, :, [2, 1, 0]].to(self.device).float() / 255.0
+            return self.fnet((x - self.MEAN) / self.STDV).squeeze(0)
+
+    def _fill(self, tstamps, images, intrinsics):
+        v = self.video
+        tt = torch.as_tensor(tstamps, device=self.device, dtype=torch.float)
+        images = torch.stack(images, 0)
+        intrinsics = torch.stack(intrinsics, 0).to(self.device)
+        N, M = v.counter, len(tstamps)
+        ts = v.tstamp[:N]
+        Ps = SE3(v.poses[:N])
+
+        # bracket each time stamp by keyframes t0 <= t < t1 and interpolate with constant twist
+        t0 = ((ts[None, :] <= tt[:, None]).sum(dim=1) - 1).clamp(min=0)
+        t1 = torch.where(t0 < N - 1, t0 + 1, t0)
+        dt = ts[t1] - ts[t0] + 1e-3
+        vel = (Ps[t1] * Ps[t0].inv()).log() / dt.unsqueeze(-1)
+        Gs = SE3.exp(vel * (tt - ts[t0]).unsqueeze(-1)) * Ps[t0]
+
+        fmap = self._features(images)
+        v.counter += M
+        v[N:N + M] = (tt, images, Gs.data, 1.0, intrinsics / 8.0, fmap)
+
+        graph = FactorGraph(v, self.update, self.device)
+        new = torch.arange(N, N + M, device=self.device)
+        graph.add_factors(t0, new)
+        graph.add_factors(t1, new)
+        for _ in range(6):
+            graph.update(N, N + M, motion_only=True)
+        Gs = SE3(v.poses[N:N + M].clone())
+        v.counter -= M
+        return [Gs]
+
+    @torch.no_grad()
+    def __call__(self, image_stream):
+        """image_stream yields (tstamp, image, intrinsics, segments); returns SE3 [num_frames]"""
+        pose_list, tstamps, images, intrinsics = [], [], [], []
+        for (tstamp, image, intrinsic, _segments) in image_stream:
+            tstamps.append(tstamp); images.append(image); intrinsics.append(intrinsic)
+            if len(tstamps) == 16:
+                pose_list += self._fill(tstamps, images, intrinsics)
+                tstamps, images, intrinsics = [], [], []
+        if tstamps:
+            pose_list += self._fill(tstamps, images, intrinsics)
+        return lie.cat(pose_list, 0)

@@ -1,15 +1,12 @@
 """Encoders, upsampling helpers and the unrolled DroidNet.forward against outputs of the reference's
 own droid_net.py / modules/extractor.py (tests/golden/gen_golden.py: gen_droidnet)."""
 import os
-import sys
 from collections import OrderedDict
 
 import numpy as np
 import pytest
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
 
 from pvo_amd import droid_net as dn
 from pvo_amd.geom.se3 import SE3
@@ -67,7 +64,7 @@ class _OracleCorrBlock:
     """CPU stand-in for the HIP CorrBlock in the no-GPU test: torch volume + oracle lookup."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
-        import oracle as O
+        from oracle import oracle as O
         self.O, self.radius = O, radius
         from pvo_amd.modules.corr import CorrBlock
         self.pyr = CorrBlock._build_differentiable(fmap1, fmap2, num_levels)
