@@ -255,7 +255,7 @@ def main():
             "config": {"workload": "S-B: BASELINE.json configs[1] window (8 keyframes, 48x64 maps, E=36, itrs=2), synthetic",
                        "edges": E, "graph_updates_per_step": 6, "parallelism": "independent window per GPU"},
             "graph_updates_per_s": world * args.steps * 6 / elapsed,
-            "roofline": {"kernel": "corr_lookup_r3_kernel<half> (fused 4-level lookup)", "bound": "hbm",
+            "roofline": {"kernel": "corr_lookup_r3_kernel<half, tiled> (fused 4-level lookup, 8x8-tiled resident volumes)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": lookup_us, "launches_timed": 50,

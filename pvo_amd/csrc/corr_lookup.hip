@@ -32,12 +32,15 @@ namespace {
 constexpr int kMaxLevels = 4;
 constexpr int kStrip = 64;          // pixels per workgroup
 constexpr int kStripPad = 66;       // LDS row stride in elements (keeps 4-byte alignment, spreads banks)
+constexpr int kPixPad = 4;          // channels-last staging: row of nch + 4 elements per pixel (8-byte aligned rows)
 
 struct LookupLevel {
   const void* vol;    // [N*HW planes][h2][w2]
   long long total;    // elements in the level tensor
   int h2, w2;
   float scale;        // 1 / 2^level (exact)
+  int tw;             // tiled layout only: 8x8 tiles per row of a plane
+  long long plane_elems;  // tiled layout only: elements per plane = th * tw * 64
 };
 
 struct LookupArgs {
@@ -109,6 +112,33 @@ __device__ __forceinline__ void fetch_row8_16(const uint16_t* base, long long g,
   }
 }
 
+// Tiled level layout [plane][th][tw][8][8] (16-bit elements: one tile = one 128-byte line, so an 8x8 tap
+// window touches at most 4 lines instead of 8 row segments in 8 different lines).  Fetch row iy, columns
+// ix..ix+7: they live in row (iy & 7) of tiles c0 = ix >> 3 and c0 + 1; two aligned 16-byte loads and a
+// funnel shift by (ix & 7) elements.  Elements outside [0, w2) hold don't-care bits (masked by the caller).
+typedef uint32_t lk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fetch_row8_tiled(const uint16_t* base, long long pbase, int tw, int iy, int ix,
+                                                bool rowok, uint32_t u[4]) {
+  const int c0 = ix >> 3, s = ix & 7;
+  lk_u32x4 A = {0u, 0u, 0u, 0u}, B = {0u, 0u, 0u, 0u};
+  if (rowok) {
+    const uint16_t* rowp = base + pbase + static_cast<long long>(iy >> 3) * tw * 64 + (iy & 7) * 8;
+    if (static_cast<unsigned>(c0) < static_cast<unsigned>(tw)) A = *reinterpret_cast<const lk_u32x4*>(rowp + c0 * 64);
+    if (static_cast<unsigned>(c0 + 1) < static_cast<unsigned>(tw)) B = *reinterpret_cast<const lk_u32x4*>(rowp + (c0 + 1) * 64);
+  }
+  // funnel shift of the 8 dwords (A:B) by s elements, written with scalars only (local arrays of the
+  // selects end up in scratch memory: 64 B/lane and 5x the HBM write traffic, measured)
+  const bool by2 = (s & 4) != 0, by1 = (s & 2) != 0;
+  const uint32_t p0 = by2 ? A.z : A.x, p1 = by2 ? A.w : A.y, p2 = by2 ? B.x : A.z, p3 = by2 ? B.y : A.w,
+                 p4 = by2 ? B.z : B.x, p5 = by2 ? B.w : B.y;
+  const uint32_t q0 = by1 ? p1 : p0, q1 = by1 ? p2 : p1, q2 = by1 ? p3 : p2, q3 = by1 ? p4 : p3, q4 = by1 ? p5 : p4;
+  const uint32_t sh = static_cast<uint32_t>(s & 1) * 2u;
+  u[0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
+  u[1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
+  u[2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
+  u[3] = __builtin_amdgcn_alignbyte(q4, q3, sh);
+}
+
 __device__ __forceinline__ void fetch_row8_32(const float* base, long long g, uint32_t mask, float v[8]) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -130,7 +160,7 @@ __device__ __forceinline__ void unpack8(const uint32_t u[4], float v[8]) {
 // ---------------------------------------------------------------------------
 // r == 3 fast path.
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool TILED>
 __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
   using S = typename Elem<T>::store_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -141,6 +171,7 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
   const int pix0 = blockIdx.x * kStrip;
   const int row = tid & 7;        // tap row (y offset index) handled by this lane
   const int HW = a.HW;
+  const int cl_stride = a.nlev * 49 + kPixPad;   // channels-last staging is pixel-major
 
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
@@ -181,7 +212,10 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
       const uint32_t maskn = __shfl_down(mask, 1, 64);
       if constexpr (sizeof(S) == 2) {
         uint32_t u[4], un[4];
-        fetch_row8_16(reinterpret_cast<const uint16_t*>(L.vol), g, L.total, mask, u);
+        if constexpr (TILED)
+          fetch_row8_tiled(reinterpret_cast<const uint16_t*>(L.vol), plane * L.plane_elems, L.tw, iy, ix, rowok, u);
+        else
+          fetch_row8_16(reinterpret_cast<const uint16_t*>(L.vol), g, L.total, mask, u);
 #pragma unroll
         for (int k = 0; k < 4; ++k) un[k] = __shfl_down(u[k], 1, 64);
         unpack8<T>(u, v);
@@ -207,7 +241,8 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
           t = Arith<T>::step(acc, vn[ax], w01);     acc = ((maskn >> ax) & 1u) ? t : acc;
           t = Arith<T>::step(acc, v[ax + 1], w10);  acc = ((mask >> (ax + 1)) & 1u) ? t : acc;
           t = Arith<T>::step(acc, vn[ax + 1], w11); acc = ((maskn >> (ax + 1)) & 1u) ? t : acc;
-          stage[(l * 49 + ax * 7 + row) * kStripPad + p] = Elem<T>::from_f32(acc);
+          const int ch = l * 49 + ax * 7 + row;
+          stage[a.out_channels_last ? p * cl_stride + ch : ch * kStripPad + p] = Elem<T>::from_f32(acc);
         }
       }
     }
@@ -219,12 +254,25 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
   S* outp = reinterpret_cast<S*>(a.out) + static_cast<long long>(n) * nch * HW;
   const int npix = min(kStrip, HW - pix0);
   if (a.out_channels_last) {
-    // the strip's outputs are one contiguous run of npix*nch elements: consecutive lanes walk the channels
-    // of a pixel (LDS column reads, stride 33 dwords -> conflict free)
+    // the strip's outputs are one contiguous run of npix*nch elements, staged pixel-major.  16-bit: 8-byte
+    // (4-channel) stores, nch = 49*nlev so a pixel is a whole number of them only when nlev is even; a wave then
+    // writes 512 contiguous, 512-byte aligned bytes per instruction (2-byte stores cost 5x the HBM write traffic:
+    // partial-line writes, measured with WRITE_SIZE).
     S* o = outp + static_cast<long long>(pix0) * nch;
+    if constexpr (sizeof(S) == 2) {
+      if ((nch & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0) {
+        const int qpp = nch >> 2;                              // 8-byte chunks per pixel
+        for (int idx = tid; idx < npix * qpp; idx += 256) {
+          const int c = idx / qpp, q = idx - c * qpp;
+          *reinterpret_cast<uint2*>(o + static_cast<long long>(idx) * 4) =
+              *reinterpret_cast<const uint2*>(&stage[c * cl_stride + q * 4]);
+        }
+        return;
+      }
+    }
     for (int idx = tid; idx < npix * nch; idx += 256) {
       const int c = idx / nch, ch = idx - c * nch;
-      o[idx] = stage[ch * kStripPad + c];
+      o[idx] = stage[c * cl_stride + ch];
     }
     return;
   }
@@ -362,9 +410,17 @@ int launch_lookup(const LookupArgs& a, int radius, hipStream_t st) {
     dim3 grid((a.HW + 255) / 256, a.N);
     hipLaunchKernelGGL(corr_lookup_generic_kernel<T>, grid, dim3(256), 0, st, a, radius);
   } else if (radius == 3) {
-    const size_t lds = static_cast<size_t>(a.nlev) * 49 * kStripPad * sizeof(typename Elem<T>::store_t);
+    const size_t lds = static_cast<size_t>(max(a.nlev * 49 * kStripPad, kStrip * (a.nlev * 49 + kPixPad))) *
+                       sizeof(typename Elem<T>::store_t);
     dim3 grid((a.HW + kStrip - 1) / kStrip, a.N);
-    hipLaunchKernelGGL(corr_lookup_r3_kernel<T>, grid, dim3(256), lds, st, a);
+    if (a.lv[0].plane_elems != 0) {
+      if constexpr (sizeof(typename Elem<T>::store_t) == 2)
+        hipLaunchKernelGGL((corr_lookup_r3_kernel<T, true>), grid, dim3(256), lds, st, a);
+      else
+        return PVO_EUNSUPPORTED;
+    } else {
+      hipLaunchKernelGGL((corr_lookup_r3_kernel<T, false>), grid, dim3(256), lds, st, a);
+    }
   } else {
     dim3 grid((a.HW + 255) / 256, a.N);
     hipLaunchKernelGGL(corr_lookup_generic_kernel<T>, grid, dim3(256), 0, st, a, radius);
@@ -434,6 +490,33 @@ extern "C" int pvo_corr_pyramid_lookup(const void* const* volumes_host, const fl
   if (slots && num_slots <= 0) return PVO_EINVAL;
   if (!aligned && (dtype == PVO_F16 || dtype == PVO_BF16)) return PVO_EINVAL;
   return dispatch_lookup(a, radius, dtype, pvo_stream(stream));
+}
+
+extern "C" int pvo_corr_pyramid_lookup_tiled(const void* const* volumes_host, const float* coords, void* out,
+                                             int N, int h1, int w1, int h2, int w2,
+                                             int num_levels, int dtype, int out_channels_last,
+                                             const int* slots, int num_slots, void* stream) {
+  if (N < 0 || h1 < 0 || w1 < 0 || h2 < 0 || w2 < 0) return PVO_EINVAL;
+  if (num_levels < 1 || num_levels > kMaxLevels || !volumes_host) return PVO_EINVAL;
+  if (dtype != PVO_F16 && dtype != PVO_BF16) return PVO_EUNSUPPORTED;
+  if (N == 0 || h1 == 0 || w1 == 0) return PVO_OK;
+  if (!coords || !out) return PVO_EINVAL;
+  if (N > 65535) return PVO_EUNSUPPORTED;
+  if (slots && num_slots <= 0) return PVO_EINVAL;
+  LookupArgs a{};
+  for (int l = 0; l < num_levels; ++l) {
+    const int hl = h2 >> l, wl = w2 >> l;
+    if (hl <= 0 || wl <= 0) return PVO_EUNSUPPORTED;
+    if (!volumes_host[l] || (reinterpret_cast<uintptr_t>(volumes_host[l]) & 15)) return PVO_EINVAL;
+    const int th = (hl + 7) >> 3, tw = (wl + 7) >> 3;
+    const long long pe = static_cast<long long>(th) * tw * 64;
+    a.lv[l] = LookupLevel{volumes_host[l], static_cast<long long>(slots ? num_slots : N) * h1 * w1 * pe, hl, wl,
+                          1.0f / static_cast<float>(1 << l), tw, pe};
+  }
+  a.coords = coords; a.out = out; a.nlev = num_levels; a.coords_interleaved = 1; a.HW = h1 * w1; a.N = N;
+  a.out_channels_last = out_channels_last ? 1 : 0;
+  a.slots = slots;
+  return dispatch_lookup(a, 3, dtype, pvo_stream(stream));
 }
 
 extern "C" int pvo_corr_index_backward(const float* coords, const void* corr_grad, void* volume_grad,

@@ -150,6 +150,64 @@ def corr_pyramid_lookup(pyramid, coords, radius, channels_last=False, slots=None
     return out
 
 
+def tiled_level_shape(ht, wd, level):
+    """trailing dims (th, tw, 8, 8) of level `level` of an 8x8-tiled pyramid over an ht x wd target image"""
+    return (((ht >> level) + 7) // 8, ((wd >> level) + 7) // 8, 8, 8)
+
+
+def tiled_supported(ht, wd, dtype):
+    return dtype in (torch.float16, torch.bfloat16) and wd % 64 == 0 and ht % 8 == 0
+
+
+def corr_build_tiled(fmap1, fmap2, out, out_slots):
+    """pvo_corr_build_tiled: edge n -> slot out_slots[n] of the tiled level tensors `out`
+    ([slots, H, W, th, tw, 8, 8] per level); fmap1/fmap2 [N,H,W,C] channels-last 16-bit."""
+    _contig(fmap1, "fmap1"); _contig(fmap2, "fmap2")
+    dev = _dev(fmap1, fmap2, out_slots, *out)
+    N, H, W, C = fmap1.shape
+    if fmap1.shape != fmap2.shape or fmap1.dtype != fmap2.dtype or len(out) != 4:
+        raise PvoHipError("corr_build_tiled: fmap mismatch or not 4 levels")
+    for l, lv in enumerate(out):
+        if tuple(lv.shape[1:]) != (H, W) + tiled_level_shape(H, W, l) or lv.dtype != fmap1.dtype or not lv.is_contiguous():
+            raise PvoHipError("corr_build_tiled: level %d has shape %s" % (l, tuple(lv.shape)))
+    if out_slots.dtype != torch.int32 or out_slots.numel() != N:
+        raise PvoHipError("corr_build_tiled: out_slots must be device int32, one per edge")
+    ptrs = (ctypes.c_void_p * 4)(*[lv.data_ptr() for lv in out])
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_corr_build_tiled(_ptr(fmap1), _ptr(fmap2), ptrs, N, C, H, W, _dtype_code(fmap1, "fmap"),
+                                               _ptr(out_slots), _stream(dev)), "corr_build_tiled")
+    return out
+
+
+def corr_pyramid_lookup_tiled(pyramid, coords, channels_last=False, slots=None):
+    """radius-3 lookup of all levels of an 8x8-tiled pyramid (see corr_build_tiled); same result as
+    corr_pyramid_lookup on the row-major pyramid."""
+    dev = _dev(coords, *pyramid)
+    _contig(coords, "coords"); _f32(coords, "coords")
+    NV, h1, w1 = pyramid[0].shape[:3]
+    th0, tw0 = pyramid[0].shape[3:5]
+    L = len(pyramid)
+    N = coords.shape[0]
+    if slots is None:
+        if N != NV:
+            raise PvoHipError("coords has %d edges but the pyramid holds %d volumes" % (N, NV))
+    elif slots.dtype != torch.int32 or slots.numel() != N or not slots.is_cuda:
+        raise PvoHipError("slots must be a device int32 tensor with one entry per edge")
+    for l, lv in enumerate(pyramid):
+        if tuple(lv.shape) != (NV, h1, w1) + tiled_level_shape(h1, w1, l) or not lv.is_contiguous():
+            raise PvoHipError("tiled pyramid level %d has shape %s" % (l, tuple(lv.shape)))
+    if channels_last:
+        out = torch.empty((N, h1, w1, L * 49), dtype=pyramid[0].dtype, device=dev).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((N, L * 49, h1, w1), dtype=pyramid[0].dtype, device=dev)
+    ptrs = (ctypes.c_void_p * L)(*[lv.data_ptr() for lv in pyramid])
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_corr_pyramid_lookup_tiled(ptrs, _ptr(coords), _ptr(out), N, h1, w1, h1, w1, L,
+                                                        _dtype_code(pyramid[0], "volume"), 1 if channels_last else 0,
+                                                        _ptr(slots), NV, _stream(dev)), "corr_pyramid_lookup_tiled")
+    return out
+
+
 def altcorr_forward(fmap1, fmap2, coords, radius):
     """droid.cpp:190-200. fmap1 [B,H1,W1,C], fmap2 [B,H2,W2,C], coords [B,S,H1,W1,2] -> [corr [B,S,(2r+1)^2,H1,W1]]"""
     _contig(fmap1, "fmap1"); _contig(fmap2, "fmap2"); _contig(coords, "coords")

@@ -160,7 +160,13 @@ class CorrVolumePool:
 
     def __init__(self, capacity, ht, wd, device, dtype=torch.float16, num_levels=4, radius=3):
         self.num_levels, self.radius, self.capacity = num_levels, radius, capacity
-        self.levels = [torch.empty(capacity, ht, wd, ht >> l, wd >> l, dtype=dtype, device=device) for l in range(num_levels)]
+        # 8x8-tiled planes when the shape allows it: an 8x8 tap window then spans <= 4 cache lines instead of 8
+        self.tiled = num_levels == 4 and radius == 3 and db.tiled_supported(ht, wd, dtype)
+        if self.tiled:
+            self.levels = [torch.empty((capacity, ht, wd) + db.tiled_level_shape(ht, wd, l), dtype=dtype, device=device)
+                           for l in range(num_levels)]
+        else:
+            self.levels = [torch.empty(capacity, ht, wd, ht >> l, wd >> l, dtype=dtype, device=device) for l in range(num_levels)]
         self.free = list(range(capacity - 1, -1, -1))
         self.slots = []                       # slot of each active edge, in edge order
         self._slots_t = None
@@ -176,7 +182,10 @@ class CorrVolumePool:
             raise RuntimeError("CorrVolumePool is full (%d slots)" % self.capacity)
         new = [self.free.pop() for _ in range(n)]
         st = torch.tensor(new, dtype=torch.int32, device=self.device)
-        db.corr_build(fmap1.contiguous(), fmap2.contiguous(), self.num_levels, channels_last=True, out=self.levels, out_slots=st)
+        if self.tiled:
+            db.corr_build_tiled(fmap1.contiguous(), fmap2.contiguous(), self.levels, st)
+        else:
+            db.corr_build(fmap1.contiguous(), fmap2.contiguous(), self.num_levels, channels_last=True, out=self.levels, out_slots=st)
         self.slots += new
         self._slots_t = None
 
@@ -192,6 +201,9 @@ class CorrVolumePool:
         batch, num, ht, wd, _ = coords.shape
         if self._slots_t is None:
             self._slots_t = torch.tensor(self.slots, dtype=torch.int32, device=self.device)
-        out = db.corr_pyramid_lookup(self.levels, coords.reshape(batch * num, ht, wd, 2).float().contiguous(), self.radius,
-                                     channels_last=channels_last, slots=self._slots_t)
+        c = coords.reshape(batch * num, ht, wd, 2).float().contiguous()
+        if self.tiled:
+            out = db.corr_pyramid_lookup_tiled(self.levels, c, channels_last=channels_last, slots=self._slots_t)
+        else:
+            out = db.corr_pyramid_lookup(self.levels, c, self.radius, channels_last=channels_last, slots=self._slots_t)
         return out.unflatten(0, (batch, num))

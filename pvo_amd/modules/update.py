@@ -59,6 +59,17 @@ def scatter_mean(src, index, dim, dim_size=None):
     return out / cnt.clamp(min=1).view(view)
 
 
+def _w16(owner, conv, dt):
+    """conv.weight in `dt`, channels-last, cached on `owner` (MIOpen's NHWC solvers want NHWC filters; without the
+    cache PyTorch re-lays the filter out on every call - a 5 us copy kernel per convolution)."""
+    cache = owner.__dict__.setdefault("_w16_cache", {})
+    w = conv.weight
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] is not w or hit[1] != w._version or hit[2].dtype != dt or hit[2].device != w.device:
+        hit = cache[id(conv)] = (w, w._version, w.detach().to(dt).contiguous(memory_format=torch.channels_last))
+    return hit[2]
+
+
 class ConvGRU(nn.Module):
     def __init__(self, h_planes=128, i_planes=128):
         super().__init__()
@@ -115,7 +126,7 @@ class ConvGRU(nn.Module):
             self._P_key = pk
         P_zr, P_q = self._P
         # every convolution below runs WITHOUT bias; the biases ride along in the fused kernels
-        glo = db.gru_glo(F.conv2d(net, self.w.weight.to(dt)), net, fb["w"])      # [E,128] fp32
+        glo = db.gru_glo(F.conv2d(net, _w16(self, self.w, dt)), net, fb["w"])      # [E,128] fp32
         with torch.autocast("cuda", enabled=False):
             g = torch.addmm(fb["g"], glo, fb["wg_t"])                       # context of z | r | q (+ conv biases), fp32
         db.gru_assemble(net, None, corr_feat, flow_feat, X, corr_bias, flow_bias)   # X = [net | relu(cf) | relu(ff)]
@@ -184,12 +195,22 @@ class GraphAgg(nn.Module):
         if fast:
             from .. import droid_backends as db
             dt = net.dtype
-            b1, b2 = self.conv1.bias.detach().float(), self.conv2.bias.detach().float()
-            x = F.conv2d(net.contiguous(memory_format=torch.channels_last), self.conv1.weight.to(dt), None, padding=1)
-            x = db.bias_act_(x.contiguous(memory_format=torch.channels_last), b1)
+            fb = self.__dict__.get("_fb32")
+            if fb is None or fb[0].device != net.device:
+                f32 = lambda t: t.detach().float().contiguous()
+                fb = self.__dict__["_fb32"] = (f32(self.conv1.bias), f32(self.conv2.bias), f32(self.eta[0].bias),
+                                               f32(self.upmask_disp[0].bias))
+            x = F.conv2d(net.contiguous(memory_format=torch.channels_last), _w16(self, self.conv1, dt), None, padding=1)
+            x = db.bias_act_(x.contiguous(memory_format=torch.channels_last), fb[0])
             x = db.segment_mean(x, segments[0], segments[1], segments[2])
-            net = F.conv2d(x, self.conv2.weight.to(dt), None, padding=1)
-            net = db.bias_act_(net.contiguous(memory_format=torch.channels_last), b2)
+            net = F.conv2d(x, _w16(self, self.conv2, dt), None, padding=1)
+            net = db.bias_act_(net.contiguous(memory_format=torch.channels_last), fb[1])
+            # bias-free convolutions (MIOpen adds a bias in a separate pass): eta's bias joins the fp32 softplus input,
+            # upmask's is added by the in-place bias kernel
+            eta = F.softplus(F.conv2d(net, _w16(self, self.eta[0], dt), None, padding=1).float().add_(fb[2]))
+            up = F.conv2d(net, _w16(self, self.upmask_disp[0], dt), None).contiguous(memory_format=torch.channels_last)
+            upmask = db.bias_act_(up, fb[3], relu=False).view(batch, -1, 8 * 8 * 9, ht, wd)
+            return eta.view(batch, -1, ht, wd).mul_(0.01), upmask, None, None
         else:
             _, ix = torch.unique(ii, return_inverse=True)
             net = self.relu(self.conv1(net)).view(batch, num, 128, ht, wd)
@@ -314,7 +335,7 @@ class DynamicUpdateModule(nn.Module):
             from .. import droid_backends as db
             cl_ = lambda t: t.to(dt).contiguous(memory_format=torch.channels_last)
             b32 = self._bias32()
-            conv = lambda m, x, **kw: F.conv2d(x, m.weight.to(dt), None, **kw)       # bias-free MIOpen convolution
+            conv = lambda m, x, **kw: F.conv2d(x, _w16(self, m, dt), None, **kw)      # bias-free MIOpen convolution
             c1 = db.bias_act_(cl_(conv(self.corr_encoder[0], cl_(corr))), b32["c0"])                 # + bias, ReLU: one pass
             f1 = db.bias_act_(cl_(conv(self.flow_encoder[0], cl_(flow), padding=3)), b32["f0"])
             cf = conv(self.corr_encoder[2], c1, padding=1)                  # their bias + ReLU happen in gru_assemble

@@ -149,3 +149,58 @@ def test_volume_pool_matches_corrblock_through_edge_changes(cuda):
     coords = (torch.rand(1, 5, H, W, 2, generator=g) * 24 - 2).to(cuda)
     a, b = pool(coords, channels_last=True), blk(coords, channels_last=True)
     assert a.shape == b.shape == (1, 5, 196, H, W) and torch.equal(a, b)
+
+
+def _tile(level, th, tw):
+    """row-major [..., h, w] -> 8x8-tiled [..., th, tw, 8, 8] (zero padded)"""
+    h, w = level.shape[-2:]
+    pad = torch.zeros(level.shape[:-2] + (th * 8, tw * 8), dtype=level.dtype, device=level.device)
+    pad[..., :h, :w] = level
+    return pad.unflatten(-2, (th, 8)).unflatten(-1, (tw, 8)).transpose(-3, -2).contiguous()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (24, 128)])
+def test_tiled_pool_layout_is_bit_identical_to_row_major(cuda, dtype, H, W):
+    """the 8x8-tiled build writes exactly the row-major pyramid's values at the tiled addresses, and the tiled
+    lookup returns exactly what the row-major lookup returns (out-of-range, negative and border coordinates)"""
+    from pvo_amd import droid_backends as db
+    from pvo_amd.modules.corr import CorrVolumePool
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    C, N = 64, 3
+    f1 = torch.randn(N, H, W, C, generator=g).to(dtype).to(cuda)
+    f2 = torch.randn(N, H, W, C, generator=g).to(dtype).to(cuda)
+    ref = db.corr_build(f1, f2, 4, channels_last=True)
+    pool = CorrVolumePool(5, H, W, cuda, dtype)
+    assert pool.tiled
+    for lv in pool.levels:
+        lv.view(torch.int16).fill_(0x7e01)                      # NaN bit pattern in every padding element
+    pool.add(f1, f2)
+    slots = pool.slots
+    for l in range(4):
+        th, tw = db.tiled_level_shape(H, W, l)[:2]
+        want = _tile(ref[l], th, tw)
+        got = pool.levels[l][slots]
+        hl, wl = H >> l, W >> l
+        inside = _tile(torch.ones(hl, wl, device=cuda), th, tw).bool()
+        assert torch.equal(got[..., inside].view(torch.int16), want[..., inside].view(torch.int16)), l
+    coords = torch.rand(1, N, H, W, 2, generator=g) * torch.tensor([W + 12.0, H + 12.0]) - 6.0
+    coords[0, 0, 0, :4] = torch.tensor([[-3.0, -3.0], [W + 2.5, H + 2.5], [0.0, 0.0], [W - 1.0, H - 1.0]])
+    coords = coords.to(cuda)
+    for cl in (False, True):
+        a = pool(coords, channels_last=cl)[0]
+        b = db.corr_pyramid_lookup(ref, coords[0].contiguous(), 3, channels_last=cl)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.gpu
+def test_tiled_entry_points_reject_unsupported_shapes(cuda):
+    from pvo_amd import droid_backends as db
+    from pvo_amd.modules.corr import CorrVolumePool
+    assert not db.tiled_supported(30, 101, torch.float16) and not db.tiled_supported(48, 64, torch.float32)
+    assert not CorrVolumePool(2, 16, 24, cuda).tiled          # falls back to row-major planes
+    f = torch.randn(1, 16, 24, 64, device=cuda).half()
+    lv = [torch.empty((1, 16, 24) + db.tiled_level_shape(16, 24, l), dtype=torch.half, device=cuda) for l in range(4)]
+    with pytest.raises(db.PvoHipError):
+        db.corr_build_tiled(f, f, lv, torch.zeros(1, dtype=torch.int32, device=cuda))

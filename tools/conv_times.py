@@ -28,6 +28,8 @@ with torch.no_grad():
         ("gru w 1x1 128->128", lambda a=x(128): m.gru.w(a), 128*128),
         ("gru zr 3x3 448->256 (fused)", lambda a=x(448): F.conv2d(a, *m.gru._fused_zr()[:2], padding=1), 448*256*9),
         ("gru q 3x3 448->128", lambda a=x(448): m.gru.convq(a), 448*128*9),
+        ("gru zr 3x3 320->256 (dyn split)", lambda a=x(320), w=torch.randn(256, 320, 3, 3, device=dev, dtype=torch.half).contiguous(memory_format=cl): F.conv2d(a, w, None, padding=1), 320*256*9),
+        ("gru q 3x3 320->128 (dyn split)", lambda a=x(320), w=torch.randn(128, 320, 3, 3, device=dev, dtype=torch.half).contiguous(memory_format=cl): F.conv2d(a, w, None, padding=1), 320*128*9),
         ("heads 3x3 128->512 (fused)", lambda a=x(128): F.conv2d(a, torch.cat([h[0].weight for h in (m.delta, m.delta_dy, m.weight, m.delta_mask)]).contiguous(memory_format=cl), None, padding=1), 128*512*9),
         ("heads 3x3 512->8 blockdiag", lambda a=x(512): F.conv2d(a, torch.zeros(8, 512, 3, 3, device=dev, dtype=torch.half).contiguous(memory_format=cl), None, padding=1), 512*8*9),
         ("agg conv1 3x3 128->128", lambda a=x(128): m.agg.conv1(a), 128*128*9),

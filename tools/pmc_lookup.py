@@ -18,6 +18,17 @@ for _ in range(3):
 flush = torch.empty(600 * 1024 * 1024, device=dev, dtype=torch.uint8)
 for _ in range(5):
     flush.zero_()             # evict the volume from the 256 MiB Infinity Cache between launches
-    out = db.corr_pyramid_lookup(pyr, coords, 3)
+    out = db.corr_pyramid_lookup(pyr, coords, 3)          # row-major planes (kernel <pvo_half, false>)
+    torch.cuda.synchronize()
+# the resident pool's 8x8-tiled planes (kernel <pvo_half, true>): what FactorGraph.update launches at this shape
+from pvo_amd.modules.corr import CorrVolumePool
+pool = CorrVolumePool(N, H, W, dev)
+f1 = torch.randn(N, H, W, 128, device=dev, generator=g).half()
+f2 = torch.randn(N, H, W, 128, device=dev, generator=g).half()
+pool.add(f1, f2)
+assert pool.tiled
+for _ in range(5):
+    flush.zero_()
+    out = pool(coords[None], channels_last=True)
     torch.cuda.synchronize()
 print("done", out.shape)
