@@ -200,8 +200,17 @@ def main():
 
     # one-time library initialisation, before the counted warm-up: MIOpen's solver search (find mode) and its on-disk
     # kernel cache are cold on a fresh machine and otherwise leak into the first timed steps (75 vs 89 steps/s measured)
-    for _ in range(8):
-        keyframe_update(video, graph, snap)
+    # ... and so are the GPU's clocks and the host's caches: keep priming (bounded: 3 s) until a block of 8 steps is no
+    # faster than the block before it.  None of this is timed or counted; the timed region below is exactly K steps.
+    prev, t_prime = None, time.perf_counter()
+    while True:
+        torch.cuda.synchronize(); tb = time.perf_counter()
+        for _ in range(8):
+            keyframe_update(video, graph, snap)
+        torch.cuda.synchronize(); blk = time.perf_counter() - tb
+        if (prev is not None and blk > 0.97 * prev) or time.perf_counter() - t_prime > 3.0:
+            break
+        prev = blk
     for _ in range(args.warmup):
         keyframe_update(video, graph, snap)
     events = []
