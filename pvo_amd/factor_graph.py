@@ -48,6 +48,9 @@ class FactorGraph:
         self.raw_mask_inac = z(self.mask_num)
         self.fused_glue = True      # use the two-kernel glue path when the update operator supports it
         self._cache = {}            # device index tensors derived from the host edge lists; cleared on any edge change
+        self._version = 0           # bumped on every edge change
+        self.use_graphs = False     # replay repeated updates of an unchanged edge set from a captured HIP graph
+        self._graph_state = None
         try:
             self._autocast = next(update_op.parameters()).dtype == torch.float32
         except (StopIteration, AttributeError, TypeError):
@@ -94,7 +97,7 @@ class FactorGraph:
             ix = [order[p] for p in range(len(order))]
             mask_l = [ix[p] >= self.max_factors - len(ii_l) for p in range(len(order))]
             self.rm_factors(torch.tensor(mask_l, device=self.device), store=True)
-        self._cache.clear()
+        self._cache.clear(); self._version += 1
         ii = torch.tensor(ii_l, dtype=torch.long, device=self.device)
         jj = torch.tensor(jj_l, dtype=torch.long, device=self.device)
         net = self.video.nets[ii][None]
@@ -127,7 +130,7 @@ class FactorGraph:
         """drop edges (factor_graph.py:163-200); mask: bool tensor or list over the active edges"""
         mask_l = [bool(v) for v in (mask.tolist() if isinstance(mask, torch.Tensor) else mask)]
         mask = torch.tensor(mask_l, dtype=torch.bool, device=self.device)
-        self._cache.clear()
+        self._cache.clear(); self._version += 1
         if store:
             self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]])
             self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
@@ -168,7 +171,7 @@ class FactorGraph:
         m = [(i == ix) or (j == ix) for i, j in zip(self._ii_h, self._jj_h)]
         self.ii[self.ii >= ix] -= 1; self.jj[self.jj >= ix] -= 1
         self.ii_inac[self.ii_inac >= ix] -= 1; self.jj_inac[self.jj_inac >= ix] -= 1
-        self._cache.clear()
+        self._cache.clear(); self._version += 1
         dec = lambda l: [a - 1 if a >= ix else a for a in l]
         self._ii_h, self._jj_h = dec(self._ii_h), dec(self._jj_h)
         self._ii_inac_h, self._jj_inac_h = dec(self._ii_inac_h), dec(self._jj_inac_h)
@@ -307,8 +310,46 @@ class FactorGraph:
             return False
         return next(op.parameters()).dtype in (torch.float16, torch.bfloat16)
 
+    _GRAPH_STATE = ("net", "target_cam", "delta_dy", "weight", "raw_mask", "full_flow")
+
     @torch.no_grad()
-    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only):
+    def _update_graphed(self, t0, t1, itrs, use_inactive, EP, motion_only):
+        """The frontend runs 4 + 2 updates on an unchanged edge set (droid_frontend.py:50-62).  The first one runs
+        eagerly (it fills the index caches and lets MIOpen pick its solvers); the second is captured into a HIP graph
+        whose inputs and outputs are the same static state buffers; it and every further update of this edge set are
+        graph replays: ~60 kernel launches become one hipGraphLaunch, which is what keeps the GPU busy after the one
+        host synchronisation per keyframe."""
+        key = (self._version, t0, t1, itrs, use_inactive, EP, motion_only, len(self._ii_h))
+        st = self._graph_state
+        if st is None or st["key"] != key:
+            # the previous edge set's graph stays alive until the next capture so that its memory pool can be handed on
+            prev = st.get("graph") or st.get("prev") if st else None
+            self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only)
+            self._graph_state = {"key": key, "graph": None, "prev": prev}
+            return
+        if st["graph"] is None:
+            static = {n: getattr(self, n).clone() for n in self._GRAPH_STATE}
+            for n, b in static.items():
+                setattr(self, n, b)
+            g = torch.cuda.CUDAGraph()
+            prev = st.pop("prev", None)         # same shapes every keyframe: the pool is reused, nothing is hipMalloc'ed
+            with torch.cuda.graph(g, pool=prev.pool() if prev is not None else None):
+                self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only, host_age=False)
+                for n, b in static.items():
+                    b.copy_(getattr(self, n))
+            for n, b in static.items():
+                setattr(self, n, b)
+            st["graph"], st["static"] = g, static
+        else:
+            for n, b in st["static"].items():      # a caller may have re-assigned state tensors (bench snapshot)
+                cur = getattr(self, n)
+                if cur is not b:
+                    b.copy_(cur); setattr(self, n, b)
+        st["graph"].replay()
+        self._age_h = [a + 1 for a in self._age_h]
+
+    @torch.no_grad()
+    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only, host_age=True):
         from . import droid_backends as db
         ht, wd = self.ht, self.wd
         E = len(self._ii_h)
@@ -334,7 +375,8 @@ class FactorGraph:
             coords1, heads, self.raw_mask, target_ba[n_in:], weight_ba[n_in:], self.dy_thresh)
         self.damping[src_t] = damping[0].float()
         if n_in:
-            m = self._cached(("inac", t0), lambda: torch.tensor(m_l, dtype=torch.bool, device=self.device))
+            # integer indices from the host mirror: a boolean mask would synchronise to size its result
+            m = self._cached(("inac_idx", t0), lambda: torch.tensor([k for k, v in enumerate(m_l) if v], device=self.device))
             ii, jj = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
             target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)
             weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
@@ -345,12 +387,15 @@ class FactorGraph:
         eta = 0.2 * self.damping[src_t] + EP
         self.video.ba(target_ba, weight_ba, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
         self.age += 1
-        self._age_h = [a + 1 for a in self._age_h]
+        if host_age:
+            self._age_h = [a + 1 for a in self._age_h]
 
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
         """one update of the factor graph (factor_graph.py:227-307)"""
         if self.fused_glue and self._fused_ok():
+            if self.use_graphs:
+                return self._update_graphed(t0, t1, itrs, use_inactive, EP, motion_only)
             return self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only)
         ht, wd = self.ht, self.wd
         coords1, _ = self.video.reproject(self.ii, self.jj)
