@@ -367,75 +367,83 @@ extern "C" int pvo_segment_mean(const void* x, const int* seg_ptr, const int* se
 //   w2     [4 heads][2 outputs][9 taps][128 channels] 16-bit, bias2 [8] f32
 //   output y [E,H,W,8] (head-major: delta, delta_dy, weight, delta_mask)
 // A 512->8 convolution is a poor fit for an implicit-GEMM kernel (N = 8 of a 128/256-wide tile: 57 TFLOP/s measured);
-// here one workgroup owns an 8x16 pixel tile, stages the 10x18 halo of one head (128 channels) in LDS with a padded
-// row stride, and every thread accumulates one (pixel, output) with packed fp16 dot products (v_dot2_f32_f16).
-// Waves 0-1 compute output 0, waves 2-3 output 1, so weight reads are wave-uniform LDS broadcasts.
+// here one workgroup owns an 8x16 pixel tile and, head by head, stages the 10x18 halo (128 channels) in LDS with a padded
+// row stride while the next head's loads are in flight; each wave multiplies two tile rows on the matrix cores
+// (v_mfma_f32_16x16x32: 16 pixels x 32 channels x 16 columns of which 2 are the head's outputs).
 // ---------------------------------------------------------------------------
 namespace {
 
-typedef __fp16 h2_t __attribute__((ext_vector_type(2)));   // the operand type of __builtin_amdgcn_fdot2
 
 constexpr int kHT = 8, kWT = 16;                 // pixel tile
 constexpr int kHaloW = kWT + 2, kHaloPos = (kHT + 2) * kHaloW;   // 180 positions
 constexpr int kPosStride = 128 * 2 + 16;         // bytes per halo position (padded against b128 bank conflicts)
 
-// one dword pair (2 channels) of x against the same 2 channels of the weights of output 0 and output 1
-template <typename T>
-__device__ __forceinline__ void mac2(uint32_t x, uint32_t w0, uint32_t w1, float& a0, float& a1);
-template <>
-__device__ __forceinline__ void mac2<pvo_half>(uint32_t x, uint32_t w0, uint32_t w1, float& a0, float& a1) {
-  a0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x), __builtin_bit_cast(h2_t, w0), a0, false);
-  a1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x), __builtin_bit_cast(h2_t, w1), a1, false);
+typedef float ho_v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 ho_v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 ho_v8b __attribute__((ext_vector_type(8)));
+template <typename T> __device__ __forceinline__ ho_v4f ho_mfma(u32x4 a, u32x4 b, ho_v4f c);
+template <> __device__ __forceinline__ ho_v4f ho_mfma<pvo_half>(u32x4 a, u32x4 b, ho_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ho_v8h, a), __builtin_bit_cast(ho_v8h, b), c, 0, 0, 0);
 }
-template <>
-__device__ __forceinline__ void mac2<pvo_bf16>(uint32_t x, uint32_t w0, uint32_t w1, float& a0, float& a1) {
-  const float xl = __uint_as_float(x << 16), xh = __uint_as_float(x & 0xffff0000u);
-  a0 = fmaf(xl, __uint_as_float(w0 << 16), a0); a0 = fmaf(xh, __uint_as_float(w0 & 0xffff0000u), a0);
-  a1 = fmaf(xl, __uint_as_float(w1 << 16), a1); a1 = fmaf(xh, __uint_as_float(w1 & 0xffff0000u), a1);
+template <> __device__ __forceinline__ ho_v4f ho_mfma<pvo_bf16>(u32x4 a, u32x4 b, ho_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ho_v8b, a), __builtin_bit_cast(ho_v8b, b), c, 0, 0, 0);
 }
 
-// Thread = (pixel of the 8x16 tile, half of the 128 channels); it accumulates BOTH outputs of the head, so every
-// activation dword read from LDS feeds two dot products.  The channel half is wave-uniform (waves 0-1: channels
-// 0-63, waves 2-3: 64-127), so the weights are read with scalar loads (SGPR operands of v_dot2c) and cost no LDS
-// bandwidth at all: the first version read x AND w through LDS and was LDS-bandwidth bound (80 us).
+// History (all measured on MI355X, S-B): packed-dot versions (v_dot2c, weights through LDS, SGPRs, ...) sat at 72-86 us
+// whatever their memory schedule: probe builds showed 31 us of HBM streaming, 20 us of staging and the rest dot issue.
+// Matrix cores + per-tap global weight fragments: 62 us (20 us of it the fragment loads); weights through LDS: 44 us.
 template <typename T>
 __global__ __launch_bounds__(256) void heads_out_kernel(const uint16_t* __restrict__ h1, const float* __restrict__ bias1,
                                                         const uint32_t* __restrict__ w2, const float* __restrict__ bias2,
                                                         uint16_t* __restrict__ y, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* xs = smem;                                   // [180][272 B]
-  float* ys = reinterpret_cast<float*>(smem + kHaloPos * kPosStride);   // [2 halves][128 px][8]
+  unsigned char* xs = smem;                                   // [180][272 B]; reused for the final transpose
+  unsigned char* wl = smem + kHaloPos * kPosStride;           // this head's second-stage weights [2][9][128] 16-bit
+  unsigned char* wzero = wl + 2 * 9 * 256;                    // 16 zero bytes: the B fragment of the 14 padding columns
   const int e = blockIdx.z;
   const int y0 = blockIdx.y * kHT, x0 = blockIdx.x * kWT;
   const int tid = threadIdx.x;
-  const int kh = __builtin_amdgcn_readfirstlane(tid >> 7);    // channel half, wave-uniform
-  const int p = tid & 127, py = p >> 4, px = p & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  constexpr int kIters = (kHaloPos * 16 + 255) / 256;         // 12 independent 16-byte loads in flight per thread
+  const int ch = tid & 15;
 
+  // halo positions of this thread: fixed over the heads, so the offsets are computed once (-1: outside the image)
+  const uint16_t* __restrict__ h1e = h1 + static_cast<size_t>(e) * H * W * 512;   // this edge's image (32-bit offsets below)
+  int off[kIters];
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int pos = (tid >> 4) + 16 * it;
+    off[it] = -1;
+    if (pos < kHaloPos) {
+      const int hy = y0 - 1 + pos / kHaloW, hx = x0 - 1 + pos % kHaloW;
+      if (hy >= 0 && hy < H && hx >= 0 && hx < W) off[it] = (hy * W + hx) * 512 + ch * 8;
+    }
+  }
+  // software pipeline: the global loads of head h+1 are in flight while head h is being computed from LDS
+  u32x4 raw[kIters];
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    raw[it] = u32x4{0u, 0u, 0u, 0u};
+    if (off[it] >= 0) raw[it] = *reinterpret_cast<const u32x4*>(h1e + off[it]);
+  }
+  u32x4 wr0 = *reinterpret_cast<const u32x4*>(w2 + tid * 4), wr1 = {0u, 0u, 0u, 0u};
+  if (tid < 32) wr1 = *reinterpret_cast<const u32x4*>(w2 + (256 + tid) * 4);
+  if (tid == 0) *reinterpret_cast<u32x4*>(wzero) = u32x4{0u, 0u, 0u, 0u};
+  float acc[32];                                              // [head][tile row of the wave][4 pixels] of D column li
+#pragma unroll
   for (int head = 0; head < 4; ++head) {
     __syncthreads();                                          // previous head's tile fully consumed
     {
-      constexpr int kIters = (kHaloPos * 16 + 255) / 256;     // 12 independent 16-byte loads in flight per thread
-      u32x4 raw[kIters];
-      const int ch = tid & 15;
-#pragma unroll
-      for (int it = 0; it < kIters; ++it) {
-        const int pos = (tid >> 4) + 16 * it;
-        raw[it] = u32x4{0u, 0u, 0u, 0u};
-        if (pos < kHaloPos) {
-          const int hy = y0 - 1 + pos / kHaloW, hx = x0 - 1 + pos % kHaloW;
-          if (hy >= 0 && hy < H && hx >= 0 && hx < W)
-            raw[it] = *reinterpret_cast<const u32x4*>(h1 + ((static_cast<size_t>(e) * H + hy) * W + hx) * 512 + head * 128 + ch * 8);
-        }
-      }
       float bb[8];
       load8f(bias1 + head * 128 + ch * 8, bb);
+
 #pragma unroll
       for (int it = 0; it < kIters; ++it) {
         const int pos = (tid >> 4) + 16 * it;
         if (pos < kHaloPos) {
-          const int hy = y0 - 1 + pos / kHaloW, hx = x0 - 1 + pos % kHaloW;
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (hy >= 0 && hy < H && hx >= 0 && hx < W) {      // zero padding is applied AFTER bias + ReLU
+          if (off[it] >= 0) {                                 // zero padding is applied AFTER bias + ReLU
             float f[8];
             H8<T>::unpack(raw[it], f);
 #pragma unroll
@@ -445,35 +453,62 @@ __global__ __launch_bounds__(256) void heads_out_kernel(const uint16_t* __restri
           *reinterpret_cast<u32x4*>(xs + pos * kPosStride + ch * 16) = v;
         }
       }
+      *reinterpret_cast<u32x4*>(wl + tid * 16) = wr0;
+      if (tid < 32) *reinterpret_cast<u32x4*>(wl + (256 + tid) * 16) = wr1;
     }
     __syncthreads();
-    float a0[2] = {0.0f, 0.0f}, a1[2] = {0.0f, 0.0f};         // two accumulators per output break the dot2 dependency chain
-    // weights of this (head, half): [out][tap][64 channels] = dwords w2[((head*2+o)*9+t)*64 + kh*32 + k], wave-uniform
-    const uint32_t* __restrict__ wq = w2 + static_cast<size_t>(head) * 2 * 9 * 64 + kh * 32;
+    if (head < 3) {
+#pragma unroll
+      for (int it = 0; it < kIters; ++it)
+        if (off[it] >= 0) raw[it] = *reinterpret_cast<const u32x4*>(h1e + off[it] + (head + 1) * 128);
+      wr0 = *reinterpret_cast<const u32x4*>(w2 + (head + 1) * 1152 + tid * 4);
+      if (tid < 32) wr1 = *reinterpret_cast<const u32x4*>(w2 + (head + 1) * 1152 + (256 + tid) * 4);
+    }
+    // matrix cores: D[16 pixels of a tile row][16 columns, 2 real = the head's outputs] += A[16 px][32 ch] B[32 ch][16]
+    // per (tap, 32-channel chunk).  7/8 of the columns multiply zeros - still 4x cheaper than 576 v_dot2c per thread
+    // (the packed-dot version sat at 75 us whatever its memory schedule was: it was dot-issue bound).
+    // wave w owns tile rows 2w, 2w+1; lane: pixel li = lane & 15, channel group lk = lane >> 4 (8 channels).
+    ho_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    // B fragments come from the head's weights in LDS ([out][tap][128 ch]); columns >= 2 read a zero row (a per-tap
+    // global load of the fragments cost 20 us of the 62: measured with probe builds)
+    const unsigned char* wrow = li < 2 ? wl + li * 9 * 256 + lk * 16 : wzero;
+    const int wstep = li < 2 ? 1 : 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const unsigned char* xp = xs + ((py + t / 3) * kHaloW + (px + t % 3)) * kPosStride + kh * 128;
+      u32x4 bf[4];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(xp + c * 16);
-        const uint32_t* w0 = wq + t * 64 + c * 4;              // output 0
-        const uint32_t* w1 = wq + (9 + t) * 64 + c * 4;        // output 1
-        mac2<T>(xv.x, w0[0], w1[0], a0[0], a1[0]);
-        mac2<T>(xv.y, w0[1], w1[1], a0[1], a1[1]);
-        mac2<T>(xv.z, w0[2], w1[2], a0[0], a1[0]);
-        mac2<T>(xv.w, w0[3], w1[3], a0[1], a1[1]);
+      for (int kc = 0; kc < 4; ++kc) {
+        bf[kc] = *reinterpret_cast<const u32x4*>(wrow + wstep * (t * 256 + kc * 64));
+      }
+      const unsigned char* xp0 = xs + ((2 * wave + t / 3) * kHaloW + (li + t % 3)) * kPosStride + lk * 16;
+      const unsigned char* xp1 = xp0 + kHaloW * kPosStride;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        d0 = ho_mfma<T>(*reinterpret_cast<const u32x4*>(xp0 + kc * 64), bf[kc], d0);
+        d1 = ho_mfma<T>(*reinterpret_cast<const u32x4*>(xp1 + kc * 64), bf[kc], d1);
       }
     }
-    ys[(kh * 128 + p) * 8 + head * 2 + 0] = a0[0] + a0[1];
-    ys[(kh * 128 + p) * 8 + head * 2 + 1] = a1[0] + a1[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[head * 8 + r] = d0[r]; acc[head * 8 + 4 + r] = d1[r]; }
+  }
+  __syncthreads();                                            // the last tile is consumed: its LDS carries the transpose
+  float* ys = reinterpret_cast<float*>(xs);                   // [128 px][8]
+  if (li < 2) {                                               // D column li = output li; rows lk*4 + r = pixels of the tile row
+#pragma unroll
+    for (int head = 0; head < 4; ++head)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ys[((2 * wave) * 16 + lk * 4 + r) * 8 + head * 2 + li] = acc[head * 8 + r];
+        ys[((2 * wave + 1) * 16 + lk * 4 + r) * 8 + head * 2 + li] = acc[head * 8 + 4 + r];
+      }
   }
   __syncthreads();
-  if (tid < 128) {                                            // sum the two channel halves, add bias, one 16-byte store per pixel
+  if (tid < 128) {                                            // add bias, one 16-byte store per pixel
     const int gy = y0 + (tid >> 4), gx = x0 + (tid & 15);
     if (gy < H && gx < W) {
       float f[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = ys[tid * 8 + k] + ys[(128 + tid) * 8 + k] + bias2[k];
+      for (int k = 0; k < 8; ++k) f[k] = ys[tid * 8 + k] + bias2[k];
       *reinterpret_cast<u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * 8) = H8<T>::pack(f);
     }
   }
@@ -487,8 +522,9 @@ extern "C" int pvo_heads_out(const void* h1, const float* bias1, const void* w2,
   if (E == 0 || H == 0 || W == 0) return PVO_OK;
   if (!h1 || !bias1 || !w2 || !bias2 || !y || !aligned16(h1) || !aligned16(w2) || !aligned16(y) ||
       (reinterpret_cast<uintptr_t>(bias1) & 15) || E > 65535) return PVO_EINVAL;
+  if (static_cast<long long>(H) * W * 512 > 0x7fffffffLL) return PVO_EUNSUPPORTED;   // per-image offsets are 32-bit
   hipStream_t st = pvo_stream(stream);
-  const size_t lds = static_cast<size_t>(kHaloPos) * kPosStride + 2 * 128 * 8 * sizeof(float);
+  const size_t lds = static_cast<size_t>(kHaloPos) * kPosStride + 2 * 9 * 256 + 16;   // 53584 B
   dim3 grid((W + kWT - 1) / kWT, (H + kHT - 1) / kHT, E);
   if (dtype == PVO_F16) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_out_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
