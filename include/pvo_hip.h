@@ -161,6 +161,11 @@ int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, v
  * [4 heads][2 outputs][9 taps (ky*3+kx)][128 channels] in `dtype`; bias1 [512], bias2 [8] f32. */
 int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const float* bias2, void* y,
                   int E, int H, int W, int dtype, void* stream);
+/* y[E,H,W,128] = relu(conv7x7(x[E,H,W,8], zero padding 3) + bias): the first layer of the update operator's
+ * flow encoder (droid_net.py:176-180) on the matrix cores; 16-bit channels-last in and out.  w_taps is the filter
+ * re-arranged to [52 taps (ky*7+kx; 49 real + 3 zero)][128 outputs][8 input channels] in `dtype`; bias f32 [128]. */
+int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
+                   int E, int H, int W, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, void* out,
                      int K, int HW, int C, int dtype, void* stream);

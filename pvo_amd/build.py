@@ -23,6 +23,7 @@ HIP_SOURCES = [
     "geom.hip",
     "gru_fused.hip",
     "graph_glue.hip",
+    "conv_small.hip",
     "ba.hip",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -1,0 +1,127 @@
+// conv_small.hip — the update operator's small-K convolutions on the matrix cores.
+//
+// pvo_conv7x7_c8: y = relu(conv7x7(x, w) + bias), x [E,H,W,8] -> y [E,H,W,128], zero padding 3.
+//   reference: flow_encoder[0:2] = Conv2d(4+2+2, 128, 7, padding=3) + ReLU (VO_Module/droid_slam/droid_net.py:176-180),
+//   applied to the motion features of factor_graph.py:233-237.
+//   MIOpen needs 27 us for this convolution (K = 392, 8 input channels: a poor implicit-GEMM shape) plus a 9 us
+//   bias+ReLU pass; here it is one kernel bound by its 28 MB output write.
+//   Mapping: 8 input channels in 16-bit = 16 bytes = exactly one lane's k-group of v_mfma_f32_16x16x32, so one MFMA
+//   consumes 4 taps (lane group lk = lane >> 4 selects the tap) of 16 pixels against 16 output channels.  49 taps = 13
+//   MFMAs (the last one padded with zero weights).  A workgroup owns an 8x16 pixel tile whose 14x22 halo (4.9 KB) sits
+//   in LDS; wave w owns output channels [32w, 32w+32) and keeps its 26 weight fragments in registers for all 8 tile rows.
+//   Weights arrive pre-arranged as [52 taps (49 + 3 zero)][128 outputs][8 channels] 16-bit.
+#include "common.h"
+
+namespace {
+
+typedef uint32_t cs_u32x4 __attribute__((ext_vector_type(4)));
+typedef float cs_v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 cs_v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 cs_v8b __attribute__((ext_vector_type(8)));
+
+template <typename T> __device__ __forceinline__ cs_v4f cs_mfma(cs_u32x4 a, cs_u32x4 b, cs_v4f c);
+template <> __device__ __forceinline__ cs_v4f cs_mfma<pvo_half>(cs_u32x4 a, cs_u32x4 b, cs_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cs_v8h, a), __builtin_bit_cast(cs_v8h, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ cs_v4f cs_mfma<pvo_bf16>(cs_u32x4 a, cs_u32x4 b, cs_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cs_v8b, a), __builtin_bit_cast(cs_v8b, b), c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ uint32_t cs_bits(float x);
+template <> __device__ __forceinline__ uint32_t cs_bits<pvo_half>(float x) {
+  union { _Float16 h; uint16_t u; } c; c.h = static_cast<_Float16>(x); return c.u;
+}
+template <> __device__ __forceinline__ uint32_t cs_bits<pvo_bf16>(float x) { return pvo_f32_to_bf16(x); }
+
+constexpr int kTH = 8, kTW = 16, kR = 3;
+constexpr int kHW_ = kTW + 2 * kR, kHH_ = kTH + 2 * kR;       // 22 x 14 halo
+constexpr int kTaps = 49, kSteps = 13;                        // 13 MFMAs x 4 taps
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                         const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                         int H, int W) {
+  __shared__ __attribute__((aligned(16))) unsigned char halo[kHH_ * kHW_ * 16];
+  __shared__ __attribute__((aligned(16))) unsigned char slab[4][16 * 80];      // per wave: 16 pixels x 32 channels (+16 B pad)
+  const int e = blockIdx.z, y0 = blockIdx.y * kTH, x0 = blockIdx.x * kTW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  // weight fragments of this wave's two 16-channel column tiles: B[k = (tap, ch)][n]; lane (li, lk) holds column li,
+  // k-group lk = tap 4*s + lk of step s, all 8 channels
+  cs_u32x4 bf[kSteps][2];
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      bf[s][nt] = *reinterpret_cast<const cs_u32x4*>(wt + (static_cast<size_t>(4 * s + lk) * 128 + wave * 32 + nt * 16 + li) * 8);
+
+  const uint16_t* xe = x + static_cast<size_t>(e) * H * W * 8;
+  for (int pos = tid; pos < kHH_ * kHW_; pos += 256) {
+    const int hy = y0 - kR + pos / kHW_, hx = x0 - kR + pos % kHW_;
+    cs_u32x4 v = {0u, 0u, 0u, 0u};
+    if (hy >= 0 && hy < H && hx >= 0 && hx < W) v = *reinterpret_cast<const cs_u32x4*>(xe + (static_cast<size_t>(hy) * W + hx) * 8);
+    *reinterpret_cast<cs_u32x4*>(halo + pos * 16) = v;
+  }
+  // LDS offset of this lane's tap in step s, relative to the tile row: taps >= 49 have zero weights, any address does
+  int toff[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) {
+    const int tap = min(4 * s + lk, kTaps - 1);
+    toff[s] = ((tap / 7) * kHW_ + (tap % 7) + li) * 16;
+  }
+  float bb[2];
+  bb[0] = bias[wave * 32 + li];
+  bb[1] = bias[wave * 32 + 16 + li];
+  __syncthreads();
+
+  unsigned char* myslab = slab[wave];
+  for (int py = 0; py < kTH; ++py) {
+    cs_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned char* rowp = halo + py * kHW_ * 16;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+      const cs_u32x4 a = *reinterpret_cast<const cs_u32x4*>(rowp + toff[s]);
+      d0 = cs_mfma<T>(a, bf[s][0], d0);
+      d1 = cs_mfma<T>(a, bf[s][1], d1);
+    }
+    // D: column li = channel, rows lk*4 + r = pixels.  bias + ReLU, transpose through the wave's slab, 16-byte stores
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = lk * 4 + r;
+      *reinterpret_cast<uint16_t*>(myslab + p * 80 + li * 2) = static_cast<uint16_t>(cs_bits<T>(fmaxf(d0[r] + bb[0], 0.0f)));
+      *reinterpret_cast<uint16_t*>(myslab + p * 80 + (16 + li) * 2) = static_cast<uint16_t>(cs_bits<T>(fmaxf(d1[r] + bb[1], 0.0f)));
+    }
+    // same wave: LDS operations retire in order, only the compiler must not move the loads above the stores
+    asm volatile("" ::: "memory");
+    const int p = lane >> 2, c = lane & 3;
+    const cs_u32x4 v = *reinterpret_cast<const cs_u32x4*>(myslab + p * 80 + c * 16);
+    const int gy = y0 + py, gx = x0 + p;
+    if (gy < H && gx < W)
+      *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * 128 + wave * 32 + c * 8) = v;
+    asm volatile("" ::: "memory");
+  }
+}
+
+}  // namespace
+
+extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
+                              int E, int H, int W, int dtype, void* stream) {
+  if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
+  if (E == 0 || H == 0 || W == 0) return PVO_OK;
+  if (!x || !w_taps || !bias || !y || E > 65535) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_taps) | reinterpret_cast<uintptr_t>(y)) & 15) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, E);
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(conv7x7_c8_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x),
+                       static_cast<const uint16_t*>(w_taps), bias, static_cast<uint16_t*>(y), H, W);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(conv7x7_c8_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x),
+                       static_cast<const uint16_t*>(w_taps), bias, static_cast<uint16_t*>(y), H, W);
+  else
+    return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}

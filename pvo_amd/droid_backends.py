@@ -538,6 +538,30 @@ def bias_act_(x, bias, relu=True):
     return x
 
 
+def conv7x7_c8_weights(weight, dtype):
+    """[128,8,7,7] conv filter -> the [52,128,8] tap-major layout pvo_conv7x7_c8 reads (3 zero taps of padding)"""
+    co, ci, kh, kw = weight.shape
+    if (co, ci, kh, kw) != (128, 8, 7, 7):
+        raise PvoHipError("conv7x7_c8: filter must be [128,8,7,7]")
+    w = torch.zeros(52, 128, 8, dtype=dtype, device=weight.device)
+    w[:49] = weight.detach().permute(2, 3, 0, 1).reshape(49, 128, 8).to(dtype)
+    return w.contiguous()
+
+
+def conv7x7_c8(x, w_taps, bias):
+    """relu(conv7x7(x) + bias): x [E,8,H,W] channels-last 16-bit -> [E,128,H,W] channels-last (flow_encoder[0:2])"""
+    _cl(x, "x", 8)
+    dev = _dev(x, w_taps, bias)
+    E, _, H, W = x.shape
+    if w_taps.dtype != x.dtype or tuple(w_taps.shape) != (52, 128, 8) or not w_taps.is_contiguous():
+        raise PvoHipError("conv7x7_c8: w_taps must be the [52,128,8] tensor of conv7x7_c8_weights in x's dtype")
+    y = torch.empty(E, H, W, 128, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_conv7x7_c8(_ptr(x), _ptr(w_taps), _bias(bias, 128, "bias"), _ptr(y), E, H, W,
+                                         _dtype_code(x, "x"), _stream(dev)), "conv7x7_c8")
+    return y
+
+
 def segment_mean(x, seg_ptr, seg_idx, K):
     """out[k] = mean of x[seg_idx[e]] for e in [seg_ptr[k], seg_ptr[k+1]); x channels-last [E,C,H,W] -> [K,C,H,W]"""
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype not in (torch.float16, torch.bfloat16):

@@ -270,6 +270,14 @@ class DynamicUpdateModule(nn.Module):
                              "a1": f(self.agg.conv1.bias), "a2": f(self.agg.conv2.bias)}
         return b
 
+    def _flow_taps(self, dt):
+        w = self.flow_encoder[0].weight
+        hit = self.__dict__.get("_ftaps")
+        if hit is None or hit[0] is not w or hit[1] != w._version or hit[2].dtype != dt or hit[2].device != w.device:
+            from .. import droid_backends as db
+            hit = self.__dict__["_ftaps"] = (w, w._version, db.conv7x7_c8_weights(w, dt))
+        return hit[2]
+
     def _heads_w2(self, dt):
         w = getattr(self, "_w2r", None)
         if w is None or w.dtype != dt or w.device != self.delta[2].weight.device:
@@ -337,7 +345,7 @@ class DynamicUpdateModule(nn.Module):
             b32 = self._bias32()
             conv = lambda m, x, **kw: F.conv2d(x, _w16(self, m, dt), None, **kw)      # bias-free MIOpen convolution
             c1 = db.bias_act_(cl_(conv(self.corr_encoder[0], cl_(corr))), b32["c0"])                 # + bias, ReLU: one pass
-            f1 = db.bias_act_(cl_(conv(self.flow_encoder[0], cl_(flow), padding=3)), b32["f0"])
+            f1 = db.conv7x7_c8(cl_(flow), self._flow_taps(dt), b32["f0"])     # 7x7, 8 -> 128, + bias + ReLU: one MFMA kernel
             cf = conv(self.corr_encoder[2], c1, padding=1)                  # their bias + ReLU happen in gru_assemble
             ff = conv(self.flow_encoder[2], f1, padding=1)
             net = self.gru.fused_forward(cl_(net), cl_(inp), cl_(cf), cl_(ff), b32["c2"], b32["f2"])
