@@ -148,6 +148,10 @@ int pvo_corr_pyramid_lookup_tiled(const void* const* volumes_host, const float* 
  *                    over edges sharing a source frame (droid_net.py:83-87); x [E,HW,C], out [K,HW,C] */
 int pvo_gru_glo(const void* wn, const void* net, const float* w_bias, float* glo, int E, int HW, int C, int dtype,
                 void* stream);
+/* pvo_gru_glo with the 1x1 convolution `w` folded in: glo[e,c] = mean_px sigmoid((W net)[c] + b[c]) * net[c];
+ * net [E,HW,128] 16-bit, w_weight [128 out][128 in] in `dtype`, w_bias f32 [128] or NULL, glo f32 [E,128]. */
+int pvo_gru_glo_fused(const void* net, const void* w_weight, const float* w_bias, float* glo,
+                      int E, int HW, int dtype, void* stream);
 int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
                      const float* corr_bias, const float* flow_bias,
                      void* X, long long rows, int with_inp, int dtype, void* stream);

@@ -104,6 +104,72 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// pvo_gru_glo_fused: glo[e,c] = mean over pixels of sigmoid(w(net) + b)[c] * net[c]   (ConvGRU's global context,
+// VO_Module/droid_slam/modules/gru.py:22-24) with the 1x1 convolution `w` (128 -> 128) done in the kernel.
+//   Before: a 13 us MIOpen 1x1 convolution writing wn (28 MB) + a 20 us reduction kernel reading wn and net.
+//   Here: net is read once; 64-pixel tiles go through LDS, wave w owns output channels [32w, 32w+32) with its 8 weight
+//   fragments in registers (v_mfma_f32_16x16x32), the sigmoid gate and the pixel sum stay in registers in the
+//   accumulator layout (lane = channel), one atomicAdd per channel per workgroup.  glo is zeroed by the host entry.
+// ---------------------------------------------------------------------------
+constexpr int kGloTile = 64, kGloStride = 272;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gru_glo_mfma_kernel(const uint16_t* __restrict__ net, const uint16_t* __restrict__ ww,
+                                                           const float* __restrict__ bias, float* __restrict__ glo,
+                                                           int HW, int chunk) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[kGloTile * kGloStride];
+  const int e = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  cs_u32x4 bf[4][2];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      bf[kc][nt] = *reinterpret_cast<const cs_u32x4*>(ww + static_cast<size_t>(wave * 32 + nt * 16 + li) * 128 + kc * 32 + lk * 8);
+  const float b0 = bias ? bias[wave * 32 + li] : 0.0f, b1 = bias ? bias[wave * 32 + 16 + li] : 0.0f;
+  float s0 = 0.0f, s1 = 0.0f;
+  const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, HW);
+  const uint16_t* ne = net + static_cast<size_t>(e) * HW * 128;
+  for (int p0 = p_begin; p0 < p_end; p0 += kGloTile) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                      // 64 px x 16 chunks of 16 B
+      const int id = tid + 256 * it, px = id >> 4, c = id & 15;
+      cs_u32x4 v = {0u, 0u, 0u, 0u};
+      if (p0 + px < p_end) v = *reinterpret_cast<const cs_u32x4*>(ne + static_cast<size_t>(p0 + px) * 128 + c * 8);
+      *reinterpret_cast<cs_u32x4*>(tile + px * kGloStride + c * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      cs_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const cs_u32x4 a = *reinterpret_cast<const cs_u32x4*>(tile + (g * 16 + li) * kGloStride + kc * 64 + lk * 16);
+        d0 = cs_mfma<T>(a, bf[kc][0], d0);
+        d1 = cs_mfma<T>(a, bf[kc][1], d1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                       // D rows lk*4 + r = pixels, column li = channel
+        const unsigned char* row = tile + (g * 16 + lk * 4 + r) * kGloStride + (wave * 32 + li) * 2;
+        const float n0 = Elem<T>::to_f32(*reinterpret_cast<const typename Elem<T>::store_t*>(row));
+        const float n1 = Elem<T>::to_f32(*reinterpret_cast<const typename Elem<T>::store_t*>(row + 32));
+        s0 += n0 / (1.0f + __expf(-(d0[r] + b0)));        // padded pixels carry net = 0
+        s1 += n1 / (1.0f + __expf(-(d1[r] + b1)));
+      }
+    }
+  }
+  s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+  if (lk == 0) {
+    const float inv = 1.0f / static_cast<float>(HW);
+    atomicAdd(glo + static_cast<size_t>(e) * 128 + wave * 32 + li, s0 * inv);
+    atomicAdd(glo + static_cast<size_t>(e) * 128 + wave * 32 + 16 + li, s1 * inv);
+  }
+}
+
 }  // namespace
 
 extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
@@ -120,6 +186,28 @@ extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bi
   else if (dtype == PVO_BF16)
     hipLaunchKernelGGL(conv7x7_c8_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x),
                        static_cast<const uint16_t*>(w_taps), bias, static_cast<uint16_t*>(y), H, W);
+  else
+    return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_gru_glo_fused(const void* net, const void* w_weight, const float* w_bias, float* glo,
+                                 int E, int HW, int dtype, void* stream) {
+  if (E < 0 || HW < 0) return PVO_EINVAL;
+  if (E == 0 || HW == 0) return PVO_OK;
+  if (!net || !w_weight || !glo || E > 65535) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(w_weight)) & 15) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  if (hipMemsetAsync(glo, 0, sizeof(float) * static_cast<size_t>(E) * 128, st) != hipSuccess) return PVO_ELAUNCH;
+  const int chunk = 256;
+  dim3 grid((HW + chunk - 1) / chunk, E);
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(gru_glo_mfma_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(net),
+                       static_cast<const uint16_t*>(w_weight), w_bias, glo, HW, chunk);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(gru_glo_mfma_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(net),
+                       static_cast<const uint16_t*>(w_weight), w_bias, glo, HW, chunk);
   else
     return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();

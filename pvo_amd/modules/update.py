@@ -126,7 +126,7 @@ class ConvGRU(nn.Module):
             self._P_key = pk
         P_zr, P_q = self._P
         # every convolution below runs WITHOUT bias; the biases ride along in the fused kernels
-        glo = db.gru_glo(F.conv2d(net, _w16(self, self.w, dt)), net, fb["w"])      # [E,128] fp32
+        glo = db.gru_glo_fused(net, _w16(self, self.w, dt), fb["w"])              # [E,128] fp32; the 1x1 conv runs in the kernel
         with torch.autocast("cuda", enabled=False):
             g = torch.addmm(fb["g"], glo, fb["wg_t"])                       # context of z | r | q (+ conv biases), fp32
         db.gru_assemble(net, None, corr_feat, flow_feat, X, corr_bias, flow_bias)   # X = [net | relu(cf) | relu(ff)]
