@@ -148,9 +148,13 @@ int pvo_corr_pyramid_lookup_tiled(const void* const* volumes_host, const float* 
  *                    over edges sharing a source frame (droid_net.py:83-87); x [E,HW,C], out [K,HW,C] */
 int pvo_gru_glo(const void* wn, const void* net, const float* w_bias, float* glo, int E, int HW, int C, int dtype,
                 void* stream);
-/* pvo_gru_glo with the 1x1 convolution `w` folded in: glo[e,c] = mean_px sigmoid((W net)[c] + b[c]) * net[c];
- * net [E,HW,128] 16-bit, w_weight [128 out][128 in] in `dtype`, w_bias f32 [128] or NULL, glo f32 [E,128]. */
-int pvo_gru_glo_fused(const void* net, const void* w_weight, const float* w_bias, float* glo,
+/* pvo_gru_glo with the 1x1 convolution `w` folded in, as per-chunk partial means:
+ *   glo_part[e, k, c] = (1/HW) * sum over pixels of chunk k (256 pixels) of sigmoid((W net)[c] + b[c]) * net[c]
+ * so glo[e,c] = sum_k glo_part[e,k,c]; K = pvo_gru_glo_chunks(HW).  No zero fill and no atomics: the consumer's GEMM
+ * against row-tiled weights sums the chunks.  net [E,HW,128] 16-bit, w_weight [128 out][128 in] in `dtype`,
+ * w_bias f32 [128] or NULL, glo_part f32 [E,K,128]. */
+int pvo_gru_glo_chunks(int HW);
+int pvo_gru_glo_fused(const void* net, const void* w_weight, const float* w_bias, float* glo_part,
                       int E, int HW, int dtype, void* stream);
 int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
                      const float* corr_bias, const float* flow_bias,

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
                                                          const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                          int H, int W) {
   __shared__ __attribute__((aligned(16))) unsigned char halo[kHH_ * kHW_ * 16];
-  __shared__ __attribute__((aligned(16))) unsigned char slab[4][16 * 80];      // per wave: 16 pixels x 32 channels (+16 B pad)
+  __shared__ __attribute__((aligned(16))) unsigned char slab[2][16 * 272];     // one tile row: 16 pixels x 128 channels (+16 B pad), double buffered
   const int e = blockIdx.z, y0 = blockIdx.y * kTH, x0 = blockIdx.x * kTW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
   bb[1] = bias[wave * 32 + 16 + li];
   __syncthreads();
 
-  unsigned char* myslab = slab[wave];
   for (int py = 0; py < kTH; ++py) {
     cs_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
     const unsigned char* rowp = halo + py * kHW_ * 16;
@@ -86,21 +85,22 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
       d0 = cs_mfma<T>(a, bf[s][0], d0);
       d1 = cs_mfma<T>(a, bf[s][1], d1);
     }
-    // D: column li = channel, rows lk*4 + r = pixels.  bias + ReLU, transpose through the wave's slab, 16-byte stores
+    // D: column li = channel, rows lk*4 + r = pixels.  bias + ReLU, then the four waves' 32-channel slices meet in a
+    // workgroup slab so that every pixel leaves as one contiguous 256-byte row (a wave storing its own 64-byte slice
+    // writes half cache lines: 1.3 TB/s measured)
+    unsigned char* sl = slab[py & 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int p = lk * 4 + r;
-      *reinterpret_cast<uint16_t*>(myslab + p * 80 + li * 2) = static_cast<uint16_t>(cs_bits<T>(fmaxf(d0[r] + bb[0], 0.0f)));
-      *reinterpret_cast<uint16_t*>(myslab + p * 80 + (16 + li) * 2) = static_cast<uint16_t>(cs_bits<T>(fmaxf(d1[r] + bb[1], 0.0f)));
+      *reinterpret_cast<uint16_t*>(sl + p * 272 + (wave * 32 + li) * 2) = static_cast<uint16_t>(cs_bits<T>(fmaxf(d0[r] + bb[0], 0.0f)));
+      *reinterpret_cast<uint16_t*>(sl + p * 272 + (wave * 32 + 16 + li) * 2) = static_cast<uint16_t>(cs_bits<T>(fmaxf(d1[r] + bb[1], 0.0f)));
     }
-    // same wave: LDS operations retire in order, only the compiler must not move the loads above the stores
-    asm volatile("" ::: "memory");
-    const int p = lane >> 2, c = lane & 3;
-    const cs_u32x4 v = *reinterpret_cast<const cs_u32x4*>(myslab + p * 80 + c * 16);
+    __syncthreads();                                          // (double buffered: one barrier per tile row)
+    const int p = tid >> 4, c = tid & 15;
+    const cs_u32x4 v = *reinterpret_cast<const cs_u32x4*>(sl + p * 272 + c * 16);
     const int gy = y0 + py, gx = x0 + p;
     if (gy < H && gx < W)
-      *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * 128 + wave * 32 + c * 8) = v;
-    asm volatile("" ::: "memory");
+      *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * 128 + c * 8) = v;
   }
 }
 
@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
 //   Before: a 13 us MIOpen 1x1 convolution writing wn (28 MB) + a 20 us reduction kernel reading wn and net.
 //   Here: net is read once; 64-pixel tiles go through LDS, wave w owns output channels [32w, 32w+32) with its 8 weight
 //   fragments in registers (v_mfma_f32_16x16x32), the sigmoid gate and the pixel sum stay in registers in the
-//   accumulator layout (lane = channel), one atomicAdd per channel per workgroup.  glo is zeroed by the host entry.
+//   accumulator layout (lane = channel), and each workgroup writes the partial means of its 256-pixel chunk: glo_part [E][chunks][128]; the
+//   consumer (a [E, chunks*128] x [chunks*128, 384] GEMM against row-tiled gate weights) sums the chunks for free.
 // ---------------------------------------------------------------------------
 constexpr int kGloTile = 64, kGloStride = 272;
 
@@ -163,10 +164,11 @@ __global__ __launch_bounds__(256) void gru_glo_mfma_kernel(const uint16_t* __res
   }
   s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
   s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-  if (lk == 0) {
+  if (lk == 0) {                                          // this workgroup's partial mean: no zero fill, no atomics
     const float inv = 1.0f / static_cast<float>(HW);
-    atomicAdd(glo + static_cast<size_t>(e) * 128 + wave * 32 + li, s0 * inv);
-    atomicAdd(glo + static_cast<size_t>(e) * 128 + wave * 32 + 16 + li, s1 * inv);
+    float* o = glo + (static_cast<size_t>(e) * gridDim.x + blockIdx.x) * 128 + wave * 32;
+    o[li] = s0 * inv;
+    o[16 + li] = s1 * inv;
   }
 }
 
@@ -192,22 +194,23 @@ extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bi
   return PVO_OK;
 }
 
-extern "C" int pvo_gru_glo_fused(const void* net, const void* w_weight, const float* w_bias, float* glo,
+extern "C" int pvo_gru_glo_chunks(int HW) { return HW <= 0 ? 0 : (HW + 255) / 256; }
+
+extern "C" int pvo_gru_glo_fused(const void* net, const void* w_weight, const float* w_bias, float* glo_part,
                                  int E, int HW, int dtype, void* stream) {
   if (E < 0 || HW < 0) return PVO_EINVAL;
   if (E == 0 || HW == 0) return PVO_OK;
-  if (!net || !w_weight || !glo || E > 65535) return PVO_EINVAL;
+  if (!net || !w_weight || !glo_part || E > 65535) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(w_weight)) & 15) return PVO_EINVAL;
   hipStream_t st = pvo_stream(stream);
-  if (hipMemsetAsync(glo, 0, sizeof(float) * static_cast<size_t>(E) * 128, st) != hipSuccess) return PVO_ELAUNCH;
   const int chunk = 256;
-  dim3 grid((HW + chunk - 1) / chunk, E);
+  dim3 grid(pvo_gru_glo_chunks(HW), E);
   if (dtype == PVO_F16)
     hipLaunchKernelGGL(gru_glo_mfma_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(net),
-                       static_cast<const uint16_t*>(w_weight), w_bias, glo, HW, chunk);
+                       static_cast<const uint16_t*>(w_weight), w_bias, glo_part, HW, chunk);
   else if (dtype == PVO_BF16)
     hipLaunchKernelGGL(gru_glo_mfma_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(net),
-                       static_cast<const uint16_t*>(w_weight), w_bias, glo, HW, chunk);
+                       static_cast<const uint16_t*>(w_weight), w_bias, glo_part, HW, chunk);
   else
     return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();

@@ -539,7 +539,8 @@ def bias_act_(x, bias, relu=True):
 
 
 def gru_glo_fused(net, w_weight, w_bias=None):
-    """global context with the 1x1 conv folded in: mean_px sigmoid(w(net) + b) * net -> [E,128] f32.
+    """global context with the 1x1 conv folded in, as partial means over 256-pixel chunks:
+    returns [E, K, 128] f32 with mean_px sigmoid(w(net) + b) * net == result.sum(1).
     net [E,128,H,W] channels-last 16-bit; w_weight [128,128] (or [128,128,1,1]) in net's dtype."""
     _cl(net, "net", 128)
     dev = _dev(net, w_weight)
@@ -547,11 +548,12 @@ def gru_glo_fused(net, w_weight, w_bias=None):
     w2d = w_weight.reshape(128, 128)
     if w2d.dtype != net.dtype or not w2d.is_contiguous():
         raise PvoHipError("gru_glo_fused: w_weight must be a contiguous [128,128] tensor in net's dtype")
-    glo = torch.empty(E, C, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    part = torch.empty(E, lib.pvo_gru_glo_chunks(H * W), C, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_glo_fused(_ptr(net), _ptr(w2d), _bias(w_bias, C, "w_bias"), _ptr(glo), E, H * W,
-                                            _dtype_code(net, "net"), _stream(dev)), "gru_glo_fused")
-    return glo
+        check(lib.pvo_gru_glo_fused(_ptr(net), _ptr(w2d), _bias(w_bias, C, "w_bias"), _ptr(part), E, H * W,
+                                    _dtype_code(net, "net"), _stream(dev)), "gru_glo_fused")
+    return part
 
 
 def conv7x7_c8_weights(weight, dtype):

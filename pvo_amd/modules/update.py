@@ -126,9 +126,12 @@ class ConvGRU(nn.Module):
             self._P_key = pk
         P_zr, P_q = self._P
         # every convolution below runs WITHOUT bias; the biases ride along in the fused kernels
-        glo = db.gru_glo_fused(net, _w16(self, self.w, dt), fb["w"])              # [E,128] fp32; the 1x1 conv runs in the kernel
+        part = db.gru_glo_fused(net, _w16(self, self.w, dt), fb["w"])             # [E,K,128] partial means; 1x1 conv in the kernel
+        K = part.shape[1]
+        if fb.get("K") != K:                                                # gate weights tiled K times: the GEMM sums the chunks
+            fb["wg_t_tiled"], fb["K"] = fb["wg_t"].repeat(K, 1).contiguous(), K
         with torch.autocast("cuda", enabled=False):
-            g = torch.addmm(fb["g"], glo, fb["wg_t"])                       # context of z | r | q (+ conv biases), fp32
+            g = torch.addmm(fb["g"], part.view(E, K * c), fb["wg_t_tiled"])   # context of z | r | q (+ conv biases), fp32
         db.gru_assemble(net, None, corr_feat, flow_feat, X, corr_bias, flow_bias)   # X = [net | relu(cf) | relu(ff)]
         zr = F.conv2d(X, ws["zr_dyn"], None, padding=1)
         db.gru_gate(zr, g, net, Z, X, P_zr)                                 # X[:, :128] <- r * net
