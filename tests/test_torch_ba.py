@@ -145,3 +145,56 @@ def test_hip_ba_agrees_with_torch_ba(name):
               t["fixedp"], P, iters, 1e-4, 0.1, False)
         assert torch.allclose(poses.cpu(), Gs.data[0], atol=ptol), iters
         assert torch.allclose(d.cpu(), disps[0], atol=dtol), iters
+
+
+def _depth_only_case(H=12, W=20, seed=0):
+    """BASELINE config 0 in miniature (S-1): two frames, two edges, both poses fixed -> a depth-only update"""
+    g = torch.Generator().manual_seed(seed)
+    intr = torch.tensor([W * 0.8, W * 0.8, W / 2.0, H / 2.0])
+    xi = torch.tensor([0.06, 0.01, 0.03, 0.004, 0.012, -0.006])
+    poses = torch.stack([SE3.exp(0 * xi).data, SE3.exp(xi).data])
+    gt = 0.4 + 0.6 * torch.rand(2, H, W, generator=g)
+    ii, jj = torch.tensor([0, 1]), torch.tensor([1, 0])
+    c, _ = pops.projective_transform(SE3(poses[None]), gt[None], intr[None, None].repeat(1, 2, 1), ii, jj)
+    weight = 200.0 * torch.rand(2, H, W, 2, generator=g)       # large confidences so that one step moves the depths visibly
+    eta = 1e-3 + 1e-3 * torch.rand(2, H, W, generator=g)
+    return dict(intr=intr, poses=poses, gt=gt, ii=ii, jj=jj, target=c[0], weight=weight, eta=eta, d0=torch.full((2, H, W), 0.7))
+
+
+def test_depth_only_ba_with_all_poses_fixed_matches_oracle():
+    from oracle import oracle as O
+    s = _depth_only_case()
+    intr_all = s["intr"][None, None].repeat(1, 2, 1)
+    Gs, d = BA(s["target"][None], s["weight"][None], s["eta"][None] - 1e-7, SE3(s["poses"][None].clone()), s["d0"][None].clone(),
+               intr_all, s["ii"], s["jj"], fixedp=2)
+    assert torch.equal(Gs.data[0], s["poses"])                           # no free pose
+    assert (d[0] - s["d0"]).abs().max() > 0.05                            # the depths did move ...
+    assert (d[0] - s["gt"]).abs().mean() < 0.6 * (s["d0"] - s["gt"]).abs().mean()   # ... towards the truth
+    r = O.ba(s["poses"].numpy().copy(), s["d0"].numpy().copy(), s["intr"].numpy(),
+             s["target"].permute(0, 3, 1, 2).contiguous().numpy(), s["weight"].permute(0, 3, 1, 2).contiguous().numpy(),
+             s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 2, 2, 1, 1e-4, 0.1)
+    assert np.array_equal(r["poses"], s["poses"].numpy())
+    assert np.abs(r["disps"] - d[0].numpy()).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_depth_only_ba_on_the_gpu_matches_oracle_and_torch():
+    """P = t1 - t0 = 0: no pose block, no Schur complement, no solve - only dz = w / (C + eta)"""
+    from oracle import oracle as O
+    from pvo_amd import droid_backends as db
+    s = _depth_only_case(H=47, W=156, seed=1)                            # the reference's CPU-runnable shape (config 0)
+    dev = torch.device("cuda:0")
+    poses, d = s["poses"].clone().to(dev), s["d0"].clone().to(dev)
+    tg = s["target"].permute(0, 3, 1, 2).contiguous()
+    wg = s["weight"].permute(0, 3, 1, 2).contiguous()
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    dx, dz = db.ba(poses, d, s["intr"].to(dev), tg.to(dev), wg.to(dev), s["eta"].to(dev), s["ii"].to(dev), s["jj"].to(dev),
+                   2, 2, 1, 1e-4, 0.1, False, status=status)
+    assert dx.shape == (0, 6) and dz.shape == (2, 47 * 156) and int(status[0]) == 0
+    r = O.ba(s["poses"].numpy().copy(), s["d0"].numpy().copy(), s["intr"].numpy(), tg.numpy(), wg.numpy(), s["eta"].numpy(),
+             s["ii"].numpy(), s["jj"].numpy(), 2, 2, 1, 1e-4, 0.1)
+    assert torch.equal(poses.cpu(), s["poses"])
+    assert np.abs(d.cpu().numpy() - r["disps"]).max() < 1e-4
+    Gs, dt = BA(s["target"][None], s["weight"][None], s["eta"][None] - 1e-7, SE3(s["poses"][None].clone()), s["d0"][None].clone(),
+                s["intr"][None, None].repeat(1, 2, 1), s["ii"], s["jj"], fixedp=2)
+    assert (dt[0] - d.cpu()).abs().max() < 1e-4
