@@ -123,6 +123,16 @@ int pvo_corr_pyramid_lookup_tiled(const void* const* volumes_host, const float* 
                                   int N, int h1, int w1, int h2, int w2, int num_levels, int dtype,
                                   int out_channels_last, const int* slots, int num_slots, void* stream);
 
+/* Lookup + first correlation-encoder layer in one kernel: out[N,h1,w1,128] = relu(W corr + b), where corr is the
+ * 196-channel result of pvo_corr_pyramid_lookup_tiled (4 levels, radius 3) and W/b are the weights of the update
+ * operator's Conv2d(196,128,1) (droid_net.py:172-175).  The 196 channels never reach HBM.  enc_weight is
+ * [128 outputs][224] in `dtype` (input channel k < 196 in the lookup's channel order, 28 zero columns of padding),
+ * enc_bias f32 [128].  Same shape/dtype restrictions as the tiled lookup. */
+int pvo_corr_lookup_encode_tiled(const void* const* volumes_host, const float* coords,
+                                 const void* enc_weight, const float* enc_bias, void* out,
+                                 int N, int h1, int w1, int dtype,
+                                 const int* slots, int num_slots, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Update operator: fused element-wise half of the ConvGRU                    */
 /* ------------------------------------------------------------------------- */

@@ -28,6 +28,7 @@ SIGNATURES = {
     "pvo_gru_glo_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_conv7x7_c8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_corr_build_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pvo_corr_lookup_encode_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "pvo_corr_pyramid_lookup_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "pvo_gru_glo": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),

@@ -32,6 +32,9 @@ namespace {
 constexpr int kMaxLevels = 4;
 constexpr int kStrip = 64;          // pixels per workgroup
 constexpr int kStripPad = 66;       // LDS row stride in elements (keeps 4-byte alignment, spreads banks)
+constexpr int kEncK = 224;          // ENC: 196 lookup channels padded to 7 MFMA k-steps of 32
+constexpr int kEncStride = 232;     // ENC: staging row of a pixel in elements (464 B: 16-byte aligned, odd multiple of 16 B)
+constexpr int kEncOutStride = 136;  // ENC: output slab row in elements (272 B)
 constexpr int kPixPad = 4;          // channels-last staging: row of nch + 4 elements per pixel (8-byte aligned rows)
 
 struct LookupLevel {
@@ -51,6 +54,8 @@ struct LookupArgs {
   int coords_interleaved;  // 0: [N,2,h1,w1]   1: [N,h1,w1,2]
   int out_channels_last;   // 0: out [N,nch,h1,w1]   1: out [N,h1,w1,nch] (what the NHWC convolutions read)
   const int* slots;        // optional: volume of edge n lives in slot slots[n] of a pool (NULL: slot n)
+  const void* enc_w;       // ENC kernels: 1x1 encoder weights [128 outputs][224 = 196 + 28 zero] in the volume dtype
+  const float* enc_b;      // ENC kernels: encoder bias f32 [128]
   int HW;                  // h1*w1
   int N;
 };
@@ -160,7 +165,23 @@ __device__ __forceinline__ void unpack8(const uint32_t u[4], float v[8]) {
 // ---------------------------------------------------------------------------
 // r == 3 fast path.
 // ---------------------------------------------------------------------------
-template <typename T, bool TILED>
+typedef float lk_v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 lk_v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 lk_v8b __attribute__((ext_vector_type(8)));
+template <typename T> __device__ __forceinline__ lk_v4f lk_mfma(lk_u32x4 x, lk_u32x4 w, lk_v4f c);
+template <> __device__ __forceinline__ lk_v4f lk_mfma<pvo_half>(lk_u32x4 x, lk_u32x4 w, lk_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(lk_v8h, x), __builtin_bit_cast(lk_v8h, w), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ lk_v4f lk_mfma<pvo_bf16>(lk_u32x4 x, lk_u32x4 w, lk_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lk_v8b, x), __builtin_bit_cast(lk_v8b, w), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ lk_v4f lk_mfma<float>(lk_u32x4, lk_u32x4, lk_v4f c) { return c; }   // never instantiated with ENC
+
+// ENC: the lookup's 196 channels never leave the workgroup; they feed the update operator's first correlation-encoder
+// layer, relu(W corr + b) with W [128,196] (droid_net.py:172-175: Conv2d(196,128,1) + ReLU), on the matrix cores, and the
+// 128 encoded channels are written instead: 28 MB of output instead of 43 MB, and the 1x1 convolution's 27 us + 9 us
+// (conv, bias/ReLU pass) with their 43 + 28 + 56 MB of traffic disappear.
+template <typename T, bool TILED, bool ENC>
 __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
   using S = typename Elem<T>::store_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -171,7 +192,13 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
   const int pix0 = blockIdx.x * kStrip;
   const int row = tid & 7;        // tap row (y offset index) handled by this lane
   const int HW = a.HW;
-  const int cl_stride = a.nlev * 49 + kPixPad;   // channels-last staging is pixel-major
+  const int cl_stride = ENC ? kEncStride : a.nlev * 49 + kPixPad;   // channels-last staging is pixel-major
+  if constexpr (ENC) {     // zero the k-padding columns 196..231 of every pixel row (0 x garbage could be NaN)
+    uint32_t* z = reinterpret_cast<uint32_t*>(smem_raw) + (tid >> 2) * (kEncStride / 2) + 98 + (tid & 3);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (98 + (tid & 3) + 4 * q < kEncStride / 2) z[4 * q] = 0u;
+  }
 
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
@@ -242,13 +269,62 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
           t = Arith<T>::step(acc, v[ax + 1], w10);  acc = ((mask >> (ax + 1)) & 1u) ? t : acc;
           t = Arith<T>::step(acc, vn[ax + 1], w11); acc = ((maskn >> (ax + 1)) & 1u) ? t : acc;
           const int ch = l * 49 + ax * 7 + row;
-          stage[a.out_channels_last ? p * cl_stride + ch : ch * kStripPad + p] = Elem<T>::from_f32(acc);
+          stage[(ENC || a.out_channels_last) ? p * cl_stride + ch : ch * kStripPad + p] = Elem<T>::from_f32(acc);
         }
       }
     }
   }
   __syncthreads();
 
+  if constexpr (ENC && sizeof(S) == 2) {
+    // encoded[px][n] = relu(sum_k corr[px][k] W[n][k] + b[n]); wave w owns outputs [32w, 32w+32), 16 at a time so that
+    // only 7 weight fragments are live (they are fetched here, after the gather phase, to keep its occupancy)
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const uint16_t* W16 = reinterpret_cast<const uint16_t*>(a.enc_w);
+    unsigned char* oslab = smem_raw;                                     // [64 px][272 B], over the staging once it is consumed
+    lk_v4f dd[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int nn = wave * 32 + nt * 16 + li;
+      lk_u32x4 wf[kEncK / 32];
+#pragma unroll
+      for (int ks = 0; ks < kEncK / 32; ++ks)
+        wf[ks] = *reinterpret_cast<const lk_u32x4*>(W16 + static_cast<size_t>(nn) * kEncK + ks * 32 + lk * 8);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        lk_v4f d = {0.f, 0.f, 0.f, 0.f};
+        const unsigned char* arow = smem_raw + (g * 16 + li) * (kEncStride * 2) + lk * 16;
+#pragma unroll
+        for (int ks = 0; ks < kEncK / 32; ++ks)
+          d = lk_mfma<T>(*reinterpret_cast<const lk_u32x4*>(arow + ks * 64), wf[ks], d);
+        dd[nt][g] = d;
+      }
+      asm volatile("" ::: "memory");      // keep the second tile's weight loads below the first tile's MFMAs (registers)
+    }
+    __syncthreads();                                                  // every wave has read its A fragments
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int nn = wave * 32 + nt * 16 + li;
+      const float bn = a.enc_b[nn];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                                   // D rows lk*4 + r = pixels, column li = output nn
+          *reinterpret_cast<S*>(oslab + (g * 16 + lk * 4 + r) * (kEncOutStride * 2) + nn * 2) =
+              Elem<T>::from_f32(fmaxf(dd[nt][g][r] + bn, 0.0f));
+    }
+    __syncthreads();
+    const int npix = min(kStrip, HW - pix0);
+    S* o = reinterpret_cast<S*>(a.out) + (static_cast<long long>(n) * HW + pix0) * 128;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                                  // 64 px x 16 chunks of 16 B: whole 256-byte pixel rows
+      const int id = tid + 256 * it, px = id >> 4, c = id & 15;
+      if (px < npix)
+        *reinterpret_cast<lk_u32x4*>(o + static_cast<long long>(px) * 128 + c * 8) =
+            *reinterpret_cast<const lk_u32x4*>(oslab + px * (kEncOutStride * 2) + c * 16);
+    }
+    return;
+  }
   // coalesced write-out: channel rows of 64 pixels
   const int nch = a.nlev * 49;
   S* outp = reinterpret_cast<S*>(a.out) + static_cast<long long>(n) * nch * HW;
@@ -414,12 +490,18 @@ int launch_lookup(const LookupArgs& a, int radius, hipStream_t st) {
                        sizeof(typename Elem<T>::store_t);
     dim3 grid((a.HW + kStrip - 1) / kStrip, a.N);
     if (a.lv[0].plane_elems != 0) {
-      if constexpr (sizeof(typename Elem<T>::store_t) == 2)
-        hipLaunchKernelGGL((corr_lookup_r3_kernel<T, true>), grid, dim3(256), lds, st, a);
-      else
+      if constexpr (sizeof(typename Elem<T>::store_t) == 2) {
+        if (a.enc_w) {
+          const size_t lds_enc = static_cast<size_t>(kStrip) * kEncStride * 2;   // 29.7 KB; the output slab reuses it
+          hipLaunchKernelGGL((corr_lookup_r3_kernel<T, true, true>), grid, dim3(256), lds_enc, st, a);
+        } else {
+          hipLaunchKernelGGL((corr_lookup_r3_kernel<T, true, false>), grid, dim3(256), lds, st, a);
+        }
+      } else {
         return PVO_EUNSUPPORTED;
+      }
     } else {
-      hipLaunchKernelGGL((corr_lookup_r3_kernel<T, false>), grid, dim3(256), lds, st, a);
+      hipLaunchKernelGGL((corr_lookup_r3_kernel<T, false, false>), grid, dim3(256), lds, st, a);
     }
   } else {
     dim3 grid((a.HW + 255) / 256, a.N);
@@ -516,6 +598,34 @@ extern "C" int pvo_corr_pyramid_lookup_tiled(const void* const* volumes_host, co
   a.coords = coords; a.out = out; a.nlev = num_levels; a.coords_interleaved = 1; a.HW = h1 * w1; a.N = N;
   a.out_channels_last = out_channels_last ? 1 : 0;
   a.slots = slots;
+  return dispatch_lookup(a, 3, dtype, pvo_stream(stream));
+}
+
+extern "C" int pvo_corr_lookup_encode_tiled(const void* const* volumes_host, const float* coords,
+                                            const void* enc_weight, const float* enc_bias, void* out,
+                                            int N, int h1, int w1, int dtype,
+                                            const int* slots, int num_slots, void* stream) {
+  if (N < 0 || h1 < 0 || w1 < 0 || !volumes_host) return PVO_EINVAL;
+  if (dtype != PVO_F16 && dtype != PVO_BF16) return PVO_EUNSUPPORTED;
+  if (N == 0 || h1 == 0 || w1 == 0) return PVO_OK;
+  if (!coords || !out || !enc_weight || !enc_bias) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(enc_weight) | reinterpret_cast<uintptr_t>(out)) & 15) return PVO_EINVAL;
+  if (N > 65535) return PVO_EUNSUPPORTED;
+  if (slots && num_slots <= 0) return PVO_EINVAL;
+  LookupArgs a{};
+  for (int l = 0; l < kMaxLevels; ++l) {
+    const int hl = h1 >> l, wl = w1 >> l;
+    if (hl <= 0 || wl <= 0) return PVO_EUNSUPPORTED;
+    if (!volumes_host[l] || (reinterpret_cast<uintptr_t>(volumes_host[l]) & 15)) return PVO_EINVAL;
+    const int th = (hl + 7) >> 3, tw = (wl + 7) >> 3;
+    const long long pe = static_cast<long long>(th) * tw * 64;
+    a.lv[l] = LookupLevel{volumes_host[l], static_cast<long long>(slots ? num_slots : N) * h1 * w1 * pe, hl, wl,
+                          1.0f / static_cast<float>(1 << l), tw, pe};
+  }
+  a.coords = coords; a.out = out; a.nlev = kMaxLevels; a.coords_interleaved = 1; a.HW = h1 * w1; a.N = N;
+  a.out_channels_last = 1;
+  a.slots = slots;
+  a.enc_w = enc_weight; a.enc_b = enc_bias;
   return dispatch_lookup(a, 3, dtype, pvo_stream(stream));
 }
 

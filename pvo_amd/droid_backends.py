@@ -43,6 +43,15 @@ def _dev(*ts):
     return dev
 
 
+def to_device_async(values, dtype, device):
+    """host sequence -> device tensor through a pinned staging buffer and an asynchronous copy: unlike
+    torch.tensor(values, device=...) this does not drain the stream"""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type != "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -205,6 +214,43 @@ def corr_pyramid_lookup_tiled(pyramid, coords, channels_last=False, slots=None):
         check(_lib.load().pvo_corr_pyramid_lookup_tiled(ptrs, _ptr(coords), _ptr(out), N, h1, w1, h1, w1, L,
                                                         _dtype_code(pyramid[0], "volume"), 1 if channels_last else 0,
                                                         _ptr(slots), NV, _stream(dev)), "corr_pyramid_lookup_tiled")
+    return out
+
+
+def corr_encoder_weights(weight, dtype):
+    """Conv2d(196,128,1) filter [128,196,1,1] -> the zero-padded [128,224] matrix pvo_corr_lookup_encode_tiled reads"""
+    if tuple(weight.shape[:2]) != (128, 196):
+        raise PvoHipError("corr_encoder_weights: filter must be [128,196,1,1]")
+    w = torch.zeros(128, 224, dtype=dtype, device=weight.device)
+    w[:, :196] = weight.detach().reshape(128, 196).to(dtype)
+    return w
+
+
+def corr_lookup_encode_tiled(pyramid, coords, enc_weight, enc_bias, slots=None):
+    """relu(W corr + b) with corr = the radius-3 lookup of the 8x8-tiled pyramid, in one kernel
+    -> [N,128,h1,w1] stored channels-last (the input of corr_encoder[2])."""
+    dev = _dev(coords, enc_weight, enc_bias, *pyramid)
+    _contig(coords, "coords"); _f32(coords, "coords")
+    NV, h1, w1 = pyramid[0].shape[:3]
+    N = coords.shape[0]
+    if len(pyramid) != 4:
+        raise PvoHipError("corr_lookup_encode_tiled: 4 levels required")
+    if slots is None:
+        if N != NV:
+            raise PvoHipError("coords has %d edges but the pyramid holds %d volumes" % (N, NV))
+    elif slots.dtype != torch.int32 or slots.numel() != N or not slots.is_cuda:
+        raise PvoHipError("slots must be a device int32 tensor with one entry per edge")
+    for l, lv in enumerate(pyramid):
+        if tuple(lv.shape) != (NV, h1, w1) + tiled_level_shape(h1, w1, l) or not lv.is_contiguous():
+            raise PvoHipError("tiled pyramid level %d has shape %s" % (l, tuple(lv.shape)))
+    if tuple(enc_weight.shape) != (128, 224) or enc_weight.dtype != pyramid[0].dtype or not enc_weight.is_contiguous():
+        raise PvoHipError("enc_weight must be the [128,224] tensor of corr_encoder_weights in the volume dtype")
+    out = torch.empty((N, h1, w1, 128), dtype=pyramid[0].dtype, device=dev).permute(0, 3, 1, 2)
+    ptrs = (ctypes.c_void_p * 4)(*[lv.data_ptr() for lv in pyramid])
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_corr_lookup_encode_tiled(ptrs, _ptr(coords), _ptr(enc_weight), _bias(enc_bias, 128, "enc_bias"),
+                                                       _ptr(out), N, h1, w1, _dtype_code(pyramid[0], "volume"),
+                                                       _ptr(slots), NV, _stream(dev)), "corr_lookup_encode_tiled")
     return out
 
 

@@ -49,6 +49,7 @@ class FactorGraph:
         self.fused_glue = True      # use the two-kernel glue path when the update operator supports it
         self._cache = {}            # device index tensors derived from the host edge lists; cleared on any edge change
         self._version = 0           # bumped on every edge change
+        self.fused_encoder = True   # tiled pools: run the lookup fused with the operator's first correlation-encoder layer
         self.use_graphs = False     # replay repeated updates of an unchanged edge set from a captured HIP graph
         self._graph_state = None
         try:
@@ -96,10 +97,10 @@ class FactorGraph:
             # the reference masks by POSITION in the age-sorted index list (factor_graph.py:128-129)
             ix = [order[p] for p in range(len(order))]
             mask_l = [ix[p] >= self.max_factors - len(ii_l) for p in range(len(order))]
-            self.rm_factors(torch.tensor(mask_l, device=self.device), store=True)
+            self.rm_factors(mask_l, store=True)
         self._cache.clear(); self._version += 1
-        ii = torch.tensor(ii_l, dtype=torch.long, device=self.device)
-        jj = torch.tensor(jj_l, dtype=torch.long, device=self.device)
+        both = self._idx(ii_l + jj_l)
+        ii, jj = both[:len(ii_l)], both[len(ii_l):]
         net = self.video.nets[ii][None]
         if self.corr_impl == "volume":
             if self.device.type == "cuda" and self.video.fmaps.dtype in (torch.float16, torch.bfloat16):
@@ -126,25 +127,35 @@ class FactorGraph:
         segm = self.video.segms[ii][None]
         self.segm = segm if self.segm is None else torch.cat([self.segm, segm], 1)
 
+    def _idx(self, values):
+        """host list -> device int64 tensor without draining the stream (pinned staging buffer, asynchronous copy);
+        `torch.tensor(list, device=...)` is a synchronous copy, and boolean-mask indexing synchronises again to size
+        its result - a dozen pipeline drains per keyframe in the reference's bookkeeping"""
+        t = torch.tensor(values, dtype=torch.long)
+        if self.device.type != "cuda":
+            return t
+        return t.pin_memory().to(self.device, non_blocking=True)
+
     def rm_factors(self, mask, store=False):
         """drop edges (factor_graph.py:163-200); mask: bool tensor or list over the active edges"""
         mask_l = [bool(v) for v in (mask.tolist() if isinstance(mask, torch.Tensor) else mask)]
-        mask = torch.tensor(mask_l, dtype=torch.bool, device=self.device)
         self._cache.clear(); self._version += 1
+        keep_l = [k for k, m in enumerate(mask_l) if not m]
+        keep = self._idx(keep_l)
         if store:
-            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]])
-            self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]])
+            rm = self._idx([k for k, m in enumerate(mask_l) if m])
+            self.ii_inac = torch.cat([self.ii_inac, self.ii[rm]])
+            self.jj_inac = torch.cat([self.jj_inac, self.jj[rm]])
             self._ii_inac_h += [i for i, m in zip(self._ii_h, mask_l) if m]
             self._jj_inac_h += [j for j, m in zip(self._jj_h, mask_l) if m]
-            self.target_cam_inac = torch.cat([self.target_cam_inac, self.target_cam[:, mask]], 1)
-            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
-            self.raw_mask_inac = torch.cat([self.raw_mask_inac, self.raw_mask[:, mask]], 1)
-            self.delta_dy_inac = torch.cat([self.delta_dy_inac, self.delta_dy[:, mask]], 1)
-        keep = ~mask
+            self.target_cam_inac = torch.cat([self.target_cam_inac, self.target_cam[:, rm]], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, rm]], 1)
+            self.raw_mask_inac = torch.cat([self.raw_mask_inac, self.raw_mask[:, rm]], 1)
+            self.delta_dy_inac = torch.cat([self.delta_dy_inac, self.delta_dy[:, rm]], 1)
         self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
-        self._ii_h = [i for i, m in zip(self._ii_h, mask_l) if not m]
-        self._jj_h = [j for j, m in zip(self._jj_h, mask_l) if not m]
-        self._age_h = [a for a, m in zip(self._age_h, mask_l) if not m]
+        self._ii_h = [self._ii_h[k] for k in keep_l]
+        self._jj_h = [self._jj_h[k] for k in keep_l]
+        self._age_h = [self._age_h[k] for k in keep_l]
         if self.corr_impl == "volume" and self.corr is not None:
             if isinstance(self.corr, CorrVolumePool):
                 self.corr.keep([not m for m in mask_l])
@@ -169,8 +180,8 @@ class FactorGraph:
         for buf in (v.poses, v.disps, v.intrinsics, v.nets, v.inps, v.fmaps) + ((v.segms,) if v.segm_filter else ()):
             buf[ix] = buf[ix + 1].clone()
         m = [(i == ix) or (j == ix) for i, j in zip(self._ii_h, self._jj_h)]
-        self.ii[self.ii >= ix] -= 1; self.jj[self.jj >= ix] -= 1
-        self.ii_inac[self.ii_inac >= ix] -= 1; self.jj_inac[self.jj_inac >= ix] -= 1
+        for t in (self.ii, self.jj, self.ii_inac, self.jj_inac):     # (masked in-place updates would synchronise)
+            t -= (t >= ix).long()
         self._cache.clear(); self._version += 1
         dec = lambda l: [a - 1 if a >= ix else a for a in l]
         self._ii_h, self._jj_h = dec(self._ii_h), dec(self._jj_h)
@@ -240,8 +251,9 @@ class FactorGraph:
         for b in buckets:
             idx += b
             ptr.append(len(idx))
-        return (torch.tensor(ptr, dtype=torch.int32, device=self.device),
-                torch.tensor(idx, dtype=torch.int32, device=self.device), len(frames))
+        from .droid_backends import to_device_async
+        both = to_device_async(ptr + idx, torch.int32, self.device)
+        return both[:len(ptr)], both[len(ptr):], len(frames)
 
     def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
         """add edges chosen by frame distance with non-maximum suppression (factor_graph.py:372-429).
@@ -356,7 +368,11 @@ class FactorGraph:
         dt = next(self.update_op.parameters()).dtype
         coords1, _ = self.video.reproject(self.ii, self.jj)
         motn = db.graph_motion(self.target_cam.contiguous(), coords1, self.delta_dy.contiguous(), self.raw_mask.contiguous(), dt)
-        corr = self.corr(coords1, channels_last=True)
+        if getattr(self.corr, "tiled", False) and self.fused_encoder:
+            pool = self.corr
+            corr = lambda w, b: pool.encoded(coords1, w, b)       # lookup + corr_encoder[0] + ReLU in one kernel
+        else:
+            corr = self.corr(coords1, channels_last=True)
         seg = self._cached("agg", self._agg_segments)
         self.net, heads, damping, upmask = self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj, False,
                                                           agg_segments=seg, raw_heads=True)
@@ -365,7 +381,7 @@ class FactorGraph:
         if t1 is None:
             t1 = max(max(self._ii_h), max(self._jj_h)) + 1
         src = sorted(set(self._ii_h))
-        src_t = self._cached("src", lambda: torch.tensor(src, device=self.device))
+        src_t = self._cached("src", lambda: self._idx(src))
         m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)] if use_inactive else []
         n_in = sum(m_l)
         target_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
@@ -376,12 +392,12 @@ class FactorGraph:
         self.damping[src_t] = damping[0].float()
         if n_in:
             # integer indices from the host mirror: a boolean mask would synchronise to size its result
-            m = self._cached(("inac_idx", t0), lambda: torch.tensor([k for k, v in enumerate(m_l) if v], device=self.device))
+            m = self._cached(("inac_idx", t0), lambda: self._idx([k for k, v in enumerate(m_l) if v]))
             ii, jj = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
             target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)
             weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
             src2 = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
-            src_t = self._cached(("src2", t0), lambda: torch.tensor(src2, device=self.device))
+            src_t = self._cached(("src2", t0), lambda: self._idx(src2))
         else:
             ii, jj = self.ii, self.jj
         eta = 0.2 * self.damping[src_t] + EP

@@ -181,7 +181,7 @@ class CorrVolumePool:
         if n > len(self.free):
             raise RuntimeError("CorrVolumePool is full (%d slots)" % self.capacity)
         new = [self.free.pop() for _ in range(n)]
-        st = torch.tensor(new, dtype=torch.int32, device=self.device)
+        st = db.to_device_async(new, torch.int32, self.device)
         if self.tiled:
             db.corr_build_tiled(fmap1.contiguous(), fmap2.contiguous(), self.levels, st)
         else:
@@ -197,10 +197,19 @@ class CorrVolumePool:
         self.slots = [s for s, m in zip(self.slots, mask) if m]
         self._slots_t = None
 
+    def encoded(self, coords, enc_weight, enc_bias):
+        """relu(W lookup(coords) + b): the lookup fused with the update operator's first correlation-encoder layer
+        (tiled pools only); [batch*num, 128, ht, wd] channels-last"""
+        batch, num, ht, wd, _ = coords.shape
+        if self._slots_t is None:
+            self._slots_t = db.to_device_async(self.slots, torch.int32, self.device)
+        return db.corr_lookup_encode_tiled(self.levels, coords.reshape(batch * num, ht, wd, 2).float().contiguous(),
+                                           enc_weight, enc_bias, slots=self._slots_t)
+
     def __call__(self, coords, channels_last=False):
         batch, num, ht, wd, _ = coords.shape
         if self._slots_t is None:
-            self._slots_t = torch.tensor(self.slots, dtype=torch.int32, device=self.device)
+            self._slots_t = db.to_device_async(self.slots, torch.int32, self.device)
         c = coords.reshape(batch * num, ht, wd, 2).float().contiguous()
         if self.tiled:
             out = db.corr_pyramid_lookup_tiled(self.levels, c, channels_last=channels_last, slots=self._slots_t)

@@ -273,6 +273,14 @@ class DynamicUpdateModule(nn.Module):
                              "a1": f(self.agg.conv1.bias), "a2": f(self.agg.conv2.bias)}
         return b
 
+    def _enc0_w(self, dt):
+        w = self.corr_encoder[0].weight
+        hit = self.__dict__.get("_enc0")
+        if hit is None or hit[0] is not w or hit[1] != w._version or hit[2].dtype != dt or hit[2].device != w.device:
+            from .. import droid_backends as db
+            hit = self.__dict__["_enc0"] = (w, w._version, db.corr_encoder_weights(w, dt))
+        return hit[2]
+
     def _flow_taps(self, dt):
         w = self.flow_encoder[0].weight
         hit = self.__dict__.get("_ftaps")
@@ -332,7 +340,8 @@ class DynamicUpdateModule(nn.Module):
         cl = torch.channels_last if net.is_cuda else torch.contiguous_format
         net = net.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
         inp = inp.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
-        corr = corr.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
+        if not callable(corr):
+            corr = corr.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
         flow = flow.reshape(batch * num, -1, ht, wd).contiguous(memory_format=cl)
 
         # 16-bit inference either through autocast (fp32 module) or with a module converted by .half()/.bfloat16()
@@ -341,13 +350,19 @@ class DynamicUpdateModule(nn.Module):
         fused = (net.is_cuda and not self.training and not torch.is_grad_enabled() and self.fused_gru
                  and dt in (torch.float16, torch.bfloat16))
         if pdt != torch.float32 and not torch.is_autocast_enabled("cuda"):
-            net, inp, corr, flow = (t.to(pdt) for t in (net, inp, corr, flow))
+            net, inp, flow = (t.to(pdt) for t in (net, inp, flow))
+            corr = corr if callable(corr) else corr.to(pdt)
+        if callable(corr) and not fused:
+            raise RuntimeError("a fused lookup+encoder callable needs the 16-bit inference path")
         if fused:
             from .. import droid_backends as db
             cl_ = lambda t: t.to(dt).contiguous(memory_format=torch.channels_last)
             b32 = self._bias32()
             conv = lambda m, x, **kw: F.conv2d(x, _w16(self, m, dt), None, **kw)      # bias-free MIOpen convolution
-            c1 = db.bias_act_(cl_(conv(self.corr_encoder[0], cl_(corr))), b32["c0"])                 # + bias, ReLU: one pass
+            if callable(corr):        # a (coords-bound) fused lookup + first encoder layer: the 196 channels stay on chip
+                c1 = corr(self._enc0_w(dt), b32["c0"])
+            else:
+                c1 = db.bias_act_(cl_(conv(self.corr_encoder[0], cl_(corr))), b32["c0"])             # + bias, ReLU: one pass
             f1 = db.conv7x7_c8(cl_(flow), self._flow_taps(dt), b32["f0"])     # 7x7, 8 -> 128, + bias + ReLU: one MFMA kernel
             cf = conv(self.corr_encoder[2], c1, padding=1)                  # their bias + ReLU happen in gru_assemble
             ff = conv(self.flow_encoder[2], f1, padding=1)

@@ -204,3 +204,30 @@ def test_tiled_entry_points_reject_unsupported_shapes(cuda):
     lv = [torch.empty((1, 16, 24) + db.tiled_level_shape(16, 24, l), dtype=torch.half, device=cuda) for l in range(4)]
     with pytest.raises(db.PvoHipError):
         db.corr_build_tiled(f, f, lv, torch.zeros(1, dtype=torch.int32, device=cuda))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(48, 64), (8, 64)])
+def test_fused_lookup_encoder_matches_lookup_then_conv(cuda, dtype, H, W):
+    """pvo_corr_lookup_encode_tiled == relu(conv1x1(lookup) + b): the lookup half is bit-exact (tested above), the
+    encoder half is an fp32-accumulated GEMM rounded once to the 16-bit type"""
+    import torch.nn.functional as F
+    from pvo_amd import droid_backends as db
+    from pvo_amd.modules.corr import CorrVolumePool
+    g = torch.Generator().manual_seed(H + W)
+    C, N = 64, 3
+    f1 = torch.randn(N, H, W, C, generator=g).to(dtype).to(cuda)
+    f2 = torch.randn(N, H, W, C, generator=g).to(dtype).to(cuda)
+    pool = CorrVolumePool(4, H, W, cuda, dtype)
+    pool.add(f1, f2)
+    coords = (torch.rand(1, N, H, W, 2, generator=g) * torch.tensor([W + 8.0, H + 8.0]) - 4.0).to(cuda)
+    w = (torch.randn(128, 196, 1, 1, generator=g) * 0.05).to(dtype).to(cuda)
+    b = torch.randn(128, generator=g).to(cuda)
+    got = pool.encoded(coords, db.corr_encoder_weights(w, dtype), b)
+    corr = pool(coords, channels_last=True)[0]
+    ref = torch.relu(F.conv2d(corr.float(), w.float(), b))
+    assert got.shape == (N, 128, H, W) and got.is_contiguous(memory_format=torch.channels_last)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert torch.allclose(got.float(), ref, atol=tol, rtol=tol)
+    assert (got.float() - ref).abs().mean().item() < tol / 8

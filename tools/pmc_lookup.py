@@ -31,4 +31,11 @@ for _ in range(5):
     flush.zero_()
     out = pool(coords[None], channels_last=True)
     torch.cuda.synchronize()
+# ... and fused with the first correlation-encoder layer (kernel <pvo_half, true, true>): what the bench step launches
+w = db.corr_encoder_weights(torch.randn(128, 196, 1, 1, device=dev, generator=g) * 0.05, torch.half)
+bias = torch.randn(128, device=dev, generator=g)
+for _ in range(5):
+    flush.zero_()
+    out = pool.encoded(coords[None], w, bias)
+    torch.cuda.synchronize()
 print("done", out.shape)

@@ -16,7 +16,9 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         if r.get("Counter_Name") == C:
             per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for k, v in per.items():
-        if "corr_lookup" in k: res.setdefault("lookup_tiled" if "true>" in k else "lookup", {})[C] = v
+        if "corr_lookup" in k:
+            name = "lookup_enc" if "true, true>" in k else ("lookup_tiled" if "true, false>" in k else "lookup")
+            res.setdefault(name, {})[C] = v
         if "copy" in k.lower() and max(v) > 1e5: res.setdefault("copy", {})[C] = v
 print(json.dumps(res)[:2000])
 json.dump(res, open("$OUT/raw.json", "w"))
