@@ -155,6 +155,8 @@ int pvo_corr_lookup_encode_tiled(const void* const* volumes_host, const float* c
  *   pvo_bias_act     x[rows,C] <- act(x + bias[c]) in place (act = ReLU when relu != 0): the bias add and ReLU that
  *                    follow a bias-free MIOpen convolution, one pass instead of two
  *   pvo_segment_mean out[k] = mean of x[seg_idx[e]] over e in [seg_ptr[k], seg_ptr[k+1])  — GraphAgg's scatter_mean
+ *                    (in_bias != NULL: x is first mapped through relu(x + in_bias[c]), i.e. the bias + ReLU of the
+ *                    bias-free convolution that produced it, saving that pass)
  *                    over edges sharing a source frame (droid_net.py:83-87); x [E,HW,C], out [K,HW,C] */
 int pvo_gru_glo(const void* wn, const void* net, const float* w_bias, float* glo, int E, int HW, int C, int dtype,
                 void* stream);
@@ -185,7 +187,7 @@ int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const floa
 int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
                    int E, int H, int W, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
-int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, void* out,
+int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                      int K, int HW, int C, int dtype, void* stream);
 
 /* FactorGraph.update's arithmetic around the update operator (factor_graph.py:231-306, segm_filter off), two launches

@@ -34,7 +34,7 @@ SIGNATURES = {
     "pvo_gru_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),
     "pvo_heads_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_bias_act": (_i, [_vp, _vp, _c.c_longlong, _i, _i, _i, _vp]),
-    "pvo_segment_mean": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_segment_mean": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_out": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_graph_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

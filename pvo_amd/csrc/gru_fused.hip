@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256) void bias_act_kernel(uint16_t* __restrict__ x,
 // out[k, p, c] = mean over edges e in [ptr[k], ptr[k+1]) of x[idx[e], p, c]   (GraphAgg's scatter_mean, droid_net.py:87)
 template <typename T>
 __global__ __launch_bounds__(256) void seg_mean_kernel(const uint16_t* __restrict__ x, const int* __restrict__ ptr,
-                                                       const int* __restrict__ idx, uint16_t* __restrict__ out,
-                                                       int HW, int C) {
+                                                       const int* __restrict__ idx, const float* __restrict__ in_bias,
+                                                       uint16_t* __restrict__ out, int HW, int C) {
   const int k = blockIdx.y;
   const int e0 = ptr[k], e1 = ptr[k + 1];
   const int cpr = C >> 3;
@@ -233,9 +233,15 @@ __global__ __launch_bounds__(256) void seg_mean_kernel(const uint16_t* __restric
   const float inv = 1.0f / static_cast<float>(max(e1 - e0, 1));
   for (long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; id < per; id += static_cast<long long>(gridDim.x) * 256) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float bb[8];
+    if (in_bias) load8f(in_bias + static_cast<int>(id % cpr) * 8, bb);
     for (int o = e0; o < e1; ++o) {
       float f[8];
       H8<T>::unpack(*reinterpret_cast<const u32x4*>(x + (static_cast<long long>(idx[o]) * per + id) * 8), f);
+      if (in_bias) {      // x is a bias-free convolution output: relu(x + b), rounded to the storage type as a separate pass would
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = Elem<T>::to_f32(Elem<T>::from_f32(fmaxf(f[q] + bb[q], 0.0f)));
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += f[q];
     }
@@ -344,7 +350,7 @@ extern "C" int pvo_bias_act(void* x, const float* bias, long long rows, int C, i
   return PVO_OK;
 }
 
-extern "C" int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, void* out,
+extern "C" int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                                 int K, int HW, int C, int dtype, void* stream) {
   if (K < 0 || HW < 0 || C <= 0 || (C & 7)) return PVO_EINVAL;
   if (K == 0 || HW == 0) return PVO_OK;
@@ -353,8 +359,8 @@ extern "C" int pvo_segment_mean(const void* x, const int* seg_ptr, const int* se
   const long long per = static_cast<long long>(HW) * (C >> 3);
   dim3 grid(static_cast<unsigned>((per + 255) / 256 > 1024 ? 1024 : (per + 255) / 256), K);
   GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(seg_mean_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), seg_ptr, seg_idx, static_cast<uint16_t*>(out), HW, C),
-    hipLaunchKernelGGL(seg_mean_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), seg_ptr, seg_idx, static_cast<uint16_t*>(out), HW, C));
+    hipLaunchKernelGGL(seg_mean_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), seg_ptr, seg_idx, in_bias, static_cast<uint16_t*>(out), HW, C),
+    hipLaunchKernelGGL(seg_mean_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), seg_ptr, seg_idx, in_bias, static_cast<uint16_t*>(out), HW, C));
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }

@@ -450,6 +450,10 @@ def ba(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iteratio
 
 
 # --------------------------------------------------------------------------- edge-sharded BA pieces
+def ba_workspace_bytes(E, P, nframes, HW):
+    return int(_lib.load().pvo_ba_workspace_bytes(int(E), int(P), int(nframes), int(HW)))
+
+
 def ba_workspace(E, P, nframes, HW, device):
     """a private workspace tensor for the split BA entry points (one per rank / graph)"""
     n = _lib.load().pvo_ba_workspace_bytes(int(E), int(P), int(nframes), int(HW))
@@ -482,13 +486,16 @@ def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, mo
                                        _stream(dev)), "ba_local")
 
 
-def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None):
-    """damp + solve the (all-reduced) system, retract poses, back-substitute this rank's depths -> [dx, dz]"""
+def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None, outputs=True):
+    """damp + solve the (all-reduced) system, retract poses, back-substitute this rank's depths -> [dx, dz]
+    (outputs=False: poses / disps are updated in place and no dx / dz tensors are produced -> [None, None])"""
     dev = _dev(poses, disps, sys, ii, jj, workspace)
     F, ht, wd = disps.shape
     P = int(t1) - int(t0)
-    dx = torch.zeros(max(P, 0), 6, dtype=torch.float32, device=dev)
-    dz = torch.zeros(int(dz_rows), ht * wd, dtype=torch.float32, device=dev)
+    dx = torch.zeros(max(P, 0), 6, dtype=torch.float32, device=dev) if outputs else None
+    dz = torch.zeros(int(dz_rows), ht * wd, dtype=torch.float32, device=dev) if outputs else None
+    if not outputs:
+        dz_rows = 0
     with torch.cuda.device(dev):
         check(_lib.load().pvo_ba_finish(_ptr(poses), _ptr(disps), _ptr(sys), _ptr(ii), _ptr(jj), ii.shape[0], F, ht, wd,
                                         int(t0), int(t1), float(lm), float(ep), 1 if motion_only else 0,
@@ -626,8 +633,9 @@ def conv7x7_c8(x, w_taps, bias):
     return y
 
 
-def segment_mean(x, seg_ptr, seg_idx, K):
-    """out[k] = mean of x[seg_idx[e]] for e in [seg_ptr[k], seg_ptr[k+1]); x channels-last [E,C,H,W] -> [K,C,H,W]"""
+def segment_mean(x, seg_ptr, seg_idx, K, in_bias=None):
+    """out[k] = mean of x[seg_idx[e]] for e in [seg_ptr[k], seg_ptr[k+1]); x channels-last [E,C,H,W] -> [K,C,H,W].
+    in_bias (f32 [C]): average relu(x + in_bias) instead (x = a bias-free convolution output)."""
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype not in (torch.float16, torch.bfloat16):
         raise PvoHipError("segment_mean: x must be a channels-last 16-bit [E,C,H,W] tensor")
     dev = _dev(x, seg_ptr, seg_idx)
@@ -636,7 +644,7 @@ def segment_mean(x, seg_ptr, seg_idx, K):
     E, C, H, W = x.shape
     out = torch.empty(K, H, W, C, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_segment_mean(_ptr(x), _ptr(seg_ptr), _ptr(seg_idx), _ptr(out), K, H * W, C,
+        check(_lib.load().pvo_segment_mean(_ptr(x), _ptr(seg_ptr), _ptr(seg_idx), _bias(in_bias, C, "in_bias"), _ptr(out), K, H * W, C,
                                            _dtype_code(x, "x"), _stream(dev)), "segment_mean")
     return out
 

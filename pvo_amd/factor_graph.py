@@ -360,6 +360,31 @@ class FactorGraph:
         st["graph"].replay()
         self._age_h = [a + 1 for a in self._age_h]
 
+    def _ba_planned(self, target, weight, eta, ii, jj, t0, t1, itrs, motion_only, n_in):
+        """DepthVideo.ba through the split entry points: the plan (unique depth frames, per-frame edge lists - the
+        reference rebuilds these on the host in every iteration, droid_kernels.cu:1314-1322) depends only on the edge
+        set and the window, so it is built once per edge set instead of once per update; no dx / dz tensors."""
+        from . import droid_backends as db
+        v = self.video
+        F, ht, wd = v.disps.shape
+        P = t1 - t0
+        key = (self._version, t0, t1, n_in, bool(motion_only), int(ii.shape[0]), int(eta.shape[0]))
+        st = self.__dict__.get("_ba_state")
+        if st is None or st["key"] != key:
+            need = db.ba_workspace_bytes(int(ii.shape[0]), P, F, ht * wd)
+            ws = st["ws"] if st is not None and st["ws"].numel() >= need else \
+                torch.empty(need + (need >> 2), dtype=torch.uint8, device=self.device)
+            n6 = 6 * P
+            sysb = st["sys"] if st is not None and st["sys"].numel() >= n6 * n6 + n6 else \
+                torch.empty(max(n6 * n6 + n6, 1), dtype=torch.float64, device=self.device)
+            db.ba_plan(ii, jj, F, ht * wd, -1 if motion_only else int(eta.shape[0]), t0, t1, ws)
+            st = self.__dict__["_ba_state"] = {"key": key, "ws": ws, "sys": sysb, "ii": ii, "jj": jj}
+        ii, jj = st["ii"], st["jj"]             # the tensors the plan was built from
+        for _ in range(itrs):
+            db.ba_local(v.poses, v.disps, v.intrinsics[0], target, weight, eta, ii, jj, t0, t1, motion_only, st["sys"], st["ws"])
+            db.ba_finish(v.poses, v.disps, st["sys"], ii, jj, t0, t1, 1e-4, 0.1, motion_only, st["ws"], outputs=False)
+        v.disps.clamp_(min=0.001)
+
     @torch.no_grad()
     def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only, host_age=True):
         from . import droid_backends as db
@@ -393,7 +418,7 @@ class FactorGraph:
         if n_in:
             # integer indices from the host mirror: a boolean mask would synchronise to size its result
             m = self._cached(("inac_idx", t0), lambda: self._idx([k for k, v in enumerate(m_l) if v]))
-            ii, jj = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
+            ii, jj = self._cached(("ba_edges", t0), lambda: (torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])))
             target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)
             weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
             src2 = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
@@ -401,7 +426,7 @@ class FactorGraph:
         else:
             ii, jj = self.ii, self.jj
         eta = 0.2 * self.damping[src_t] + EP
-        self.video.ba(target_ba, weight_ba, eta, ii, jj, t0, t1, itrs=itrs, lm=1e-4, ep=0.1, motion_only=motion_only)
+        self._ba_planned(target_ba, weight_ba, eta, ii, jj, t0, t1, itrs, motion_only, n_in)
         self.age += 1
         if host_age:
             self._age_h = [a + 1 for a in self._age_h]
