@@ -204,6 +204,14 @@ int pvo_graph_post(const float* coords1, const void* heads, float* raw_mask, flo
                    float* weight, float* target_ba, float* weight_ba, float* full_flow,
                    int E, int H, int W, float dy_thresh, int dtype, void* stream);
 
+/* GraphAgg's eta head + FactorGraph's damping bookkeeping in one launch (droid_net.py:93-95, factor_graph.py:281-283):
+ *   e = 0.01 * softplus(raw[pos[r]] + bias[0]);  damping[frame[r]] = e      (pos[r] >= 0)
+ *   e = damping[frame[r]]                                                   (pos[r] <  0: frame with inactive edges only)
+ *   eta[r] = 0.2 * e + EP
+ * raw [K,HW] 16-bit (bias-free 128->1 convolution), frame int64 [R], pos int32 [R], damping f32 [buffer,HW], eta f32 [R,HW]. */
+int pvo_eta_finish(const void* raw, const float* bias, const int64_t* frame, const int* pos,
+                   float* damping, float* eta, int R, int HW, float EP, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Reprojection helpers                                                       */
 /* ------------------------------------------------------------------------- */

@@ -24,6 +24,7 @@ SIGNATURES = {
     "pvo_altcorr_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_altcorr_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pvo_eta_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_float, _i, _vp]),
     "pvo_gru_glo_chunks": (_i, [_i]),
     "pvo_gru_glo_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_conv7x7_c8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

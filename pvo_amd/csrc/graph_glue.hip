@@ -75,6 +75,31 @@ __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restric
   weight_ba[ob] = wt.x; weight_ba[ob + HW] = wt.y;
 }
 
+// eta / damping: GraphAgg's eta head (droid_net.py:93-95: 0.01 * softplus(conv(net))) and the damping bookkeeping of
+// FactorGraph.update (factor_graph.py:281-283: damping[unique(ii)] = eta; eta_ba = 0.2 * damping[frames] + EP), eight
+// tiny PyTorch launches, in one kernel.  raw [K,HW] = the bias-free 128->1 convolution output (16-bit); row r of the BA's
+// eta belongs to frame `frame[r]`; pos[r] is that frame's row in raw, or -1 for a frame that only carries inactive edges
+// (its stored damping is used, nothing is written).
+template <typename T>
+__global__ __launch_bounds__(256) void eta_finish_kernel(const uint16_t* __restrict__ raw, const float* __restrict__ bias,
+                                                         const long long* __restrict__ frame, const int* __restrict__ pos,
+                                                         float* __restrict__ damping, float* __restrict__ eta, int HW, float EP) {
+  const int r = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= HW) return;
+  const long long f = frame[r];
+  const int k = pos[r];
+  float e;
+  if (k >= 0) {
+    const float v = h2f_<T>(raw[static_cast<size_t>(k) * HW + x]) + bias[0];
+    const float sp = v > 20.0f ? v : log1pf(expf(v));            // torch softplus, beta = 1, threshold = 20
+    e = __fmul_rn(0.01f, sp);
+    damping[f * HW + x] = e;
+  } else {
+    e = damping[f * HW + x];
+  }
+  eta[static_cast<size_t>(r) * HW + x] = __fadd_rn(__fmul_rn(0.2f, e), EP);
+}
+
 }  // namespace
 
 extern "C" int pvo_graph_motion(const float* target, const float* coords1, const float* delta_dy, const float* raw_mask,
@@ -112,6 +137,24 @@ extern "C" int pvo_graph_post(const float* coords1, const void* heads, float* ra
     hipLaunchKernelGGL(graph_post_kernel<pvo_half>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh);
   else if (dtype == PVO_BF16)
     hipLaunchKernelGGL(graph_post_kernel<pvo_bf16>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_eta_finish(const void* raw, const float* bias, const int64_t* frame, const int* pos,
+                              float* damping, float* eta, int R, int HW, float EP, int dtype, void* stream) {
+  if (R < 0 || HW < 0) return PVO_EINVAL;
+  if (R == 0 || HW == 0) return PVO_OK;
+  if (!raw || !bias || !frame || !pos || !damping || !eta || R > 65535) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const dim3 grid((HW + 255) / 256, R);
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(eta_finish_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(raw), bias,
+                       reinterpret_cast<const long long*>(frame), pos, damping, eta, HW, EP);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(eta_finish_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(raw), bias,
+                       reinterpret_cast<const long long*>(frame), pos, damping, eta, HW, EP);
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;

@@ -678,6 +678,23 @@ def graph_motion(target, coords1, delta_dy, raw_mask, dtype):
     return motn.permute(0, 3, 1, 2)[None]
 
 
+def eta_finish(raw, bias, frame, pos, damping, EP):
+    """eta head + damping bookkeeping: raw [K,1,H,W] 16-bit (bias-free eta convolution), bias f32 [1], frame int64 [R],
+    pos int32 [R] (row of raw, or -1), damping f32 [buffer,H,W] (updated in place) -> eta f32 [R,H,W] for the BA"""
+    dev = _dev(raw, bias, frame, pos, damping)
+    K, _, H, W = raw.shape
+    R = frame.shape[0]
+    if raw.dtype not in (torch.float16, torch.bfloat16) or frame.dtype != torch.int64 or pos.dtype != torch.int32 \
+            or pos.shape[0] != R or damping.dtype != torch.float32 or tuple(damping.shape[1:]) != (H, W):
+        raise PvoHipError("eta_finish: raw 16-bit [K,1,H,W], frame int64 [R], pos int32 [R], damping f32 [*,H,W]")
+    _contig(damping, "damping")
+    eta = torch.empty(R, H, W, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_eta_finish(_ptr(raw.contiguous()), _bias(bias, 1, "bias"), _ptr(frame), _ptr(pos), _ptr(damping),
+                                         _ptr(eta), R, H * W, float(EP), _dtype_code(raw, "raw"), _stream(dev)), "eta_finish")
+    return eta
+
+
 def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5):
     """factor_graph.py:249-306 after the update operator.  heads [E,8,H,W] channels-last 16-bit (delta | delta_dy |
     weight | delta_mask); raw_mask [1,E,H,W,2] is updated IN PLACE; target_ba / weight_ba [E,2,H,W] f32 are filled.

@@ -414,18 +414,27 @@ class FactorGraph:
         self.raw_mask = self.raw_mask.contiguous()
         self.target_cam, self.delta_dy, self.weight, self.full_flow = db.graph_post(
             coords1, heads, self.raw_mask, target_ba[n_in:], weight_ba[n_in:], self.dy_thresh)
-        self.damping[src_t] = damping[0].float()
+        rows = src
         if n_in:
             # integer indices from the host mirror: a boolean mask would synchronise to size its result
             m = self._cached(("inac_idx", t0), lambda: self._idx([k for k, v in enumerate(m_l) if v]))
             ii, jj = self._cached(("ba_edges", t0), lambda: (torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])))
             target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)
             weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
-            src2 = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
-            src_t = self._cached(("src2", t0), lambda: self._idx(src2))
+            rows = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
         else:
             ii, jj = self.ii, self.jj
-        eta = 0.2 * self.damping[src_t] + EP
+        if isinstance(damping, tuple):           # raw eta head: softplus, scaling and the damping bookkeeping in one kernel
+            def _rows():
+                from .droid_backends import to_device_async
+                where = {f: k for k, f in enumerate(src)}
+                return self._idx(rows), to_device_async([where.get(f, -1) for f in rows], torch.int32, self.device)
+            frames_t, pos_t = self._cached(("eta_rows", t0 if n_in else None), _rows)
+            eta = db.eta_finish(damping[0], damping[1], frames_t, pos_t, self.damping, EP)
+        else:
+            self.damping[src_t] = damping[0].float()
+            rows_t = self._cached(("src2", t0), lambda: self._idx(rows)) if n_in else src_t
+            eta = 0.2 * self.damping[rows_t] + EP
         self._ba_planned(target_ba, weight_ba, eta, ii, jj, t0, t1, itrs, motion_only, n_in)
         self.age += 1
         if host_age:

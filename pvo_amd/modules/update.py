@@ -187,8 +187,10 @@ class GraphAgg(nn.Module):
         self.eta = nn.Sequential(nn.Conv2d(128, 1, 3, padding=1), GradientClip(), nn.Softplus())
         self.upmask_disp = nn.Sequential(nn.Conv2d(128, 8 * 8 * 9, 1, padding=0))
 
-    def forward(self, net, ii, segments=None):
-        """segments (optional): (seg_ptr int32 [K+1], seg_idx int32 [E], K) — the CSR of edges grouped by source
+    def forward(self, net, ii, segments=None, raw_eta=False):
+        """raw_eta (fast path only): return (bias-free eta convolution output [K,1,H,W] 16-bit, its bias f32 [1]) in
+        place of eta, for pvo_eta_finish (softplus, scaling and the damping bookkeeping in one kernel).
+        segments (optional): (seg_ptr int32 [K+1], seg_idx int32 [E], K) — the CSR of edges grouped by source
         frame in the order of sorted(unique(ii)).  With it the grouping needs no torch.unique (which synchronises
         with the host to size its output) and the mean is one HIP kernel instead of zeros + 2 index_add + divide."""
         batch, num, ch, ht, wd = net.shape
@@ -210,9 +212,12 @@ class GraphAgg(nn.Module):
             net = db.bias_act_(net.contiguous(memory_format=torch.channels_last), fb[1])
             # bias-free convolutions (MIOpen adds a bias in a separate pass): eta's bias joins the fp32 softplus input,
             # upmask's is added by the in-place bias kernel
-            eta = F.softplus(F.conv2d(net, _w16(self, self.eta[0], dt), None, padding=1).float().add_(fb[2]))
+            eta_raw = F.conv2d(net, _w16(self, self.eta[0], dt), None, padding=1)
             up = F.conv2d(net, _w16(self, self.upmask_disp[0], dt), None).contiguous(memory_format=torch.channels_last)
             upmask = db.bias_act_(up, fb[3], relu=False).view(batch, -1, 8 * 8 * 9, ht, wd)
+            if raw_eta:
+                return (eta_raw, fb[2]), upmask, None, None
+            eta = F.softplus(eta_raw.float().add_(fb[2]))
             return eta.view(batch, -1, ht, wd).mul_(0.01), upmask, None, None
         else:
             _, ix = torch.unique(ii, return_inverse=True)
@@ -377,7 +382,7 @@ class DynamicUpdateModule(nn.Module):
         if raw_heads:
             if self._last_heads is None or ii is None:
                 raise RuntimeError("raw_heads needs the fused 16-bit inference path and ii")
-            eta, upmask_disp, _, _ = self.agg(net.view(*out_dim), ii.to(net.device), agg_segments)
+            eta, upmask_disp, _, _ = self.agg(net.view(*out_dim), ii.to(net.device), agg_segments, raw_eta=agg_segments is not None)
             return net.view(*out_dim), self._last_heads, eta, {"disp": upmask_disp, "flow": None, "dy_mask": None}
         if use_aff_bri:
             aff = self.param_linear(self.global_avg_pool(net).view(batch * num, -1)).view(batch, num, -1)
