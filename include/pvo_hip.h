@@ -186,6 +186,11 @@ int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const floa
  * re-arranged to [52 taps (ky*7+kx; 49 real + 3 zero)][128 outputs][8 input channels] in `dtype`; bias f32 [128]. */
 int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
                    int E, int H, int W, int dtype, void* stream);
+/* y[E,H,W,Cout] = act(conv3x3(x[E,H,W,128], zero padding 1) + bias) on the matrix cores: the update operator's
+ * 128-input 3x3 convolutions (corr_encoder[2], flow_encoder[2], GraphAgg.conv1).  Cout in {64, 128, 256, 512};
+ * w_taps [9 taps (ky*3+kx)][Cout][128] in `dtype`; bias f32 [Cout] or NULL; relu != 0 applies ReLU. */
+int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void* y,
+                     int E, int H, int W, int Cout, int relu, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                      int K, int HW, int C, int dtype, void* stream);

@@ -172,6 +172,116 @@ __global__ __launch_bounds__(256) void gru_glo_mfma_kernel(const uint16_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------
+// pvo_conv3x3_c128: y = act(conv3x3(x, w) + bias), x [E,H,W,128] -> y [E,H,W,Cout], zero padding 1, Cout in {64,128,256,512}.
+//   The update operator's 128-input 3x3 convolutions (corr_encoder[2], flow_encoder[2], GraphAgg.conv1; droid_net.py:
+//   79-95,172-180) run at 0.3-0.5 PFLOP/s in MIOpen/CK at these shapes (67 us for 128 -> 128 over 36 x 48 x 64 pixels).
+//   Workgroup = 8x16 pixel tile x 128 output channels (64 when Cout = 64); the 10x18 halo (46 KB) is staged once in LDS
+//   with a 272-byte row stride; wave w owns NT 16-channel column tiles and, tap by tap, keeps that tap's 4*NT weight
+//   fragments in registers (the next tap's are in flight) while it sweeps the 8 tile rows: 8*4*NT v_mfma_f32_16x16x32 per
+//   tap on 8*NT independent accumulators, one 16-byte LDS read per NT MFMAs.  Results leave through an LDS slab as whole
+//   pixel rows.  Weights arrive as [9 taps][Cout][128 input channels] 16-bit.
+// ---------------------------------------------------------------------------
+constexpr int kC3Halo = (kTH + 2) * (kTW + 2), kC3Stride = 272;
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv3x3_c128_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                           int H, int W, int Cout, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c3s[];          // [180][272 B]; later the output slab
+  constexpr int kCoutWG = 64 * NT;                                            // output channels per workgroup
+  const int ntx = (W + kTW - 1) / kTW;
+  const int cg = blockIdx.x / ntx, tx_ = blockIdx.x - cg * ntx;                // output-channel group, tile column
+  const int e = blockIdx.z, y0 = blockIdx.y * kTH, x0 = tx_ * kTW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int co0 = cg * kCoutWG + wave * (16 * NT);                            // first output channel of this wave
+
+  // stage the halo tile
+  const uint16_t* xe = x + static_cast<size_t>(e) * H * W * 128;
+  {
+    const int ch = tid & 15;
+#pragma unroll
+    for (int it = 0; it < (kC3Halo * 16 + 255) / 256; ++it) {
+      const int pos = (tid >> 4) + 16 * it;
+      if (pos < kC3Halo) {
+        const int hy = y0 - 1 + pos / (kTW + 2), hx = x0 - 1 + pos % (kTW + 2);
+        cs_u32x4 v = {0u, 0u, 0u, 0u};
+        if (hy >= 0 && hy < H && hx >= 0 && hx < W) v = *reinterpret_cast<const cs_u32x4*>(xe + (static_cast<size_t>(hy) * W + hx) * 128 + ch * 8);
+        *reinterpret_cast<cs_u32x4*>(c3s + pos * kC3Stride + ch * 16) = v;
+      }
+    }
+  }
+  // weight fragments: B[k = cin][n = cout] of tap t; lane (li, lk) holds column li of tile nt, input channels kc*32 + lk*8 ..+8
+  const uint16_t* wl = wt + (static_cast<size_t>(co0 + li)) * 128 + lk * 8;
+  const size_t tap_stride = static_cast<size_t>(Cout) * 128;
+  cs_u32x4 bcur[4][NT], bnxt[4][NT];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bcur[kc][nt] = *reinterpret_cast<const cs_u32x4*>(wl + static_cast<size_t>(nt) * 16 * 128 + kc * 32);
+  cs_v4f acc[kTH][NT];
+#pragma unroll
+  for (int py = 0; py < kTH; ++py)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[py][nt] = cs_v4f{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {                              // (not unrolled: all 9 taps' fragments would be hoisted: 256 VGPRs)
+    if (t < 8) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bnxt[kc][nt] = *reinterpret_cast<const cs_u32x4*>(wl + (t + 1) * tap_stride + static_cast<size_t>(nt) * 16 * 128 + kc * 32);
+    }
+    const unsigned char* tp = c3s + ((t / 3) * (kTW + 2) + (t % 3) + li) * kC3Stride + lk * 16;
+#pragma unroll
+    for (int py = 0; py < kTH; ++py) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const cs_u32x4 a = *reinterpret_cast<const cs_u32x4*>(tp + py * (kTW + 2) * kC3Stride + kc * 64);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[py][nt] = cs_mfma<T>(a, bcur[kc][nt], acc[py][nt]);
+      }
+    }
+    if (t < 8) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bcur[kc][nt] = bnxt[kc][nt];
+    }
+  }
+  __syncthreads();                                           // the halo tile is consumed: its LDS becomes the output slab
+  // slab [8 rows][16 px][kCoutWG channels] with a (kCoutWG*2 + 16)-byte pixel stride
+  constexpr int kOutStride = kCoutWG * 2 + 16;
+  float bb[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bb[nt] = bias ? bias[co0 + nt * 16 + li] : 0.0f;
+#pragma unroll
+  for (int py = 0; py < kTH; ++py)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                           // D rows lk*4 + r = pixels, column li = channel
+        float v = acc[py][nt][r] + bb[nt];
+        if (relu) v = fmaxf(v, 0.0f);
+        *reinterpret_cast<uint16_t*>(c3s + (py * 16 + lk * 4 + r) * kOutStride + (wave * 16 * NT + nt * 16 + li) * 2) =
+            static_cast<uint16_t>(cs_bits<T>(v));
+      }
+  __syncthreads();
+  constexpr int kChunks = kCoutWG / 8;                        // 16-byte chunks per pixel
+  for (int id = tid; id < kTH * 16 * kChunks; id += 256) {
+    const int p = id / kChunks, c = id - p * kChunks;
+    const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+    if (gy < H && gx < W)
+      *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * Cout + cg * kCoutWG + c * 8) =
+          *reinterpret_cast<const cs_u32x4*>(c3s + p * kOutStride + c * 16);
+  }
+}
+
 }  // namespace
 
 extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
@@ -213,6 +323,34 @@ extern "C" int pvo_gru_glo_fused(const void* net, const void* w_weight, const fl
                        static_cast<const uint16_t*>(w_weight), w_bias, glo_part, HW, chunk);
   else
     return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void* y,
+                                int E, int H, int W, int Cout, int relu, int dtype, void* stream) {
+  if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
+  if (Cout != 64 && (Cout <= 0 || (Cout & 127))) return PVO_EUNSUPPORTED;
+  if (E == 0 || H == 0 || W == 0) return PVO_OK;
+  if (!x || !w_taps || !y || E > 65535) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_taps) | reinterpret_cast<uintptr_t>(y)) & 15) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const int ntx = (W + kTW - 1) / kTW;
+  const size_t lds = static_cast<size_t>(kC3Halo) * kC3Stride;      // 48960 B >= the output slab (128 px x 272 B)
+  const uint16_t* xp = static_cast<const uint16_t*>(x);
+  const uint16_t* wp = static_cast<const uint16_t*>(w_taps);
+  uint16_t* yp = static_cast<uint16_t*>(y);
+  if (Cout == 64) {
+    dim3 grid(ntx, (H + kTH - 1) / kTH, E);
+    if (dtype == PVO_F16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_half, 1>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
+    else if (dtype == PVO_BF16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_bf16, 1>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
+    else return PVO_EUNSUPPORTED;
+  } else {
+    dim3 grid(ntx * (Cout / 128), (H + kTH - 1) / kTH, E);
+    if (dtype == PVO_F16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_half, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
+    else if (dtype == PVO_BF16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_bf16, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
+    else return PVO_EUNSUPPORTED;
+  }
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }

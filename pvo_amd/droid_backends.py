@@ -633,6 +633,29 @@ def conv7x7_c8(x, w_taps, bias):
     return y
 
 
+def conv3x3_c128_weights(weight, dtype):
+    """[Cout,128,3,3] conv filter -> the [9,Cout,128] tap-major layout pvo_conv3x3_c128 reads"""
+    co, ci, kh, kw = weight.shape
+    if (ci, kh, kw) != (128, 3, 3) or (co != 64 and co % 128):
+        raise PvoHipError("conv3x3_c128: filter must be [Cout,128,3,3] with Cout in {64,128,256,512}")
+    return weight.detach().permute(2, 3, 0, 1).reshape(9, co, 128).to(dtype).contiguous()
+
+
+def conv3x3_c128(x, w_taps, bias=None, relu=False):
+    """act(conv3x3(x) + bias): x [E,128,H,W] channels-last 16-bit -> [E,Cout,H,W] channels-last"""
+    _cl(x, "x", 128)
+    dev = _dev(x, w_taps)
+    E, _, H, W = x.shape
+    if w_taps.dim() != 3 or w_taps.shape[0] != 9 or w_taps.shape[2] != 128 or w_taps.dtype != x.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("conv3x3_c128: w_taps must be the [9,Cout,128] tensor of conv3x3_c128_weights in x's dtype")
+    Cout = w_taps.shape[1]
+    y = torch.empty(E, H, W, Cout, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_conv3x3_c128(_ptr(x), _ptr(w_taps), _bias(bias, Cout, "bias"), _ptr(y), E, H, W, Cout,
+                                           1 if relu else 0, _dtype_code(x, "x"), _stream(dev)), "conv3x3_c128")
+    return y
+
+
 def segment_mean(x, seg_ptr, seg_idx, K, in_bias=None):
     """out[k] = mean of x[seg_idx[e]] for e in [seg_ptr[k], seg_ptr[k+1]); x channels-last [E,C,H,W] -> [K,C,H,W].
     in_bias (f32 [C]): average relu(x + in_bias) instead (x = a bias-free convolution output)."""

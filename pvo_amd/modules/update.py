@@ -59,6 +59,10 @@ def scatter_mean(src, index, dim, dim_size=None):
     return out / cnt.clamp(min=1).view(view)
 
 
+import os as _os
+_HIP_CONV3 = _os.environ.get("PVO_HIP_CONV3") == "1"
+
+
 def _w16(owner, conv, dt):
     """conv.weight in `dt`, channels-last, cached on `owner` (MIOpen's NHWC solvers want NHWC filters; without the
     cache PyTorch re-lays the filter out on every call - a 5 us copy kernel per convolution)."""
@@ -278,6 +282,15 @@ class DynamicUpdateModule(nn.Module):
                              "a1": f(self.agg.conv1.bias), "a2": f(self.agg.conv2.bias)}
         return b
 
+    def _taps3(self, conv, dt):
+        cache = self.__dict__.setdefault("_taps3_cache", {})
+        w = conv.weight
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] is not w or hit[1] != w._version or hit[2].dtype != dt or hit[2].device != w.device:
+            from .. import droid_backends as db
+            hit = cache[id(conv)] = (w, w._version, db.conv3x3_c128_weights(w, dt))
+        return hit[2]
+
     def _enc0_w(self, dt):
         w = self.corr_encoder[0].weight
         hit = self.__dict__.get("_enc0")
@@ -369,8 +382,12 @@ class DynamicUpdateModule(nn.Module):
             else:
                 c1 = db.bias_act_(cl_(conv(self.corr_encoder[0], cl_(corr))), b32["c0"])             # + bias, ReLU: one pass
             f1 = db.conv7x7_c8(cl_(flow), self._flow_taps(dt), b32["f0"])     # 7x7, 8 -> 128, + bias + ReLU: one MFMA kernel
-            cf = conv(self.corr_encoder[2], c1, padding=1)                  # their bias + ReLU happen in gru_assemble
-            ff = conv(self.flow_encoder[2], f1, padding=1)
+            if _HIP_CONV3:      # A/B switch: the hand-written 128-input 3x3 kernel instead of MIOpen (same speed)
+                cf = db.conv3x3_c128(c1, self._taps3(self.corr_encoder[2], dt))
+                ff = db.conv3x3_c128(f1, self._taps3(self.flow_encoder[2], dt))
+            else:
+                cf = conv(self.corr_encoder[2], c1, padding=1)              # their bias + ReLU happen in gru_assemble
+                ff = conv(self.flow_encoder[2], f1, padding=1)
             net = self.gru.fused_forward(cl_(net), cl_(inp), cl_(cf), cl_(ff), b32["c2"], b32["f2"])
         else:
             corr = self.corr_encoder(corr)

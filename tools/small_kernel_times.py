@@ -27,5 +27,13 @@ rows = [("conv7x7_c8 (28 MB out)", lambda: db.conv7x7_c8(motn, wt, b(128)) if Fa
         ("bias_act_ (28+28 MB)", lambda: db.bias_act_(big, B128)),
         ("copy 28 MB (reference point)", lambda: big.clone())]
 B128, B512, B8 = b(128), b(512), b(8)
+import torch.nn.functional as F
+torch.backends.cudnn.benchmark = True
+for co in (64, 128, 256, 512):
+    wc = (torch.randn(co, 128, 3, 3, device=dev) * 0.03).half()
+    wcl = wc.contiguous(memory_format=cl)
+    wt3 = db.conv3x3_c128_weights(wc, torch.half)
+    rows.append(("conv3x3_c128 -> %d (HIP)" % co, lambda wt3=wt3: db.conv3x3_c128(big, wt3)))
+    rows.append(("conv3x3 128 -> %d (MIOpen)" % co, lambda wcl=wcl: F.conv2d(big, wcl, None, padding=1)))
 for name, fn in rows:
     print(f"{name:32s} {t(fn):7.1f} us")
