@@ -65,6 +65,27 @@ class FactorGraph:
             return t
         return t[0].contiguous(memory_format=torch.channels_last)[None]
 
+    def _cat_cl(self, old, new):
+        """append edges to a channels-last [1,E,C,H,W] state tensor.  The concatenation runs on the physical [E,H,W,C]
+        views (a plain row append); torch.cat on the strided 5-D tensors falls into a generic element-wise copy kernel
+        that needs 49 us for 28 MB (four of them per keyframe in the profile)."""
+        new = self._cl5(new)
+        if old is None:
+            return new
+        if self.device.type == "cuda":
+            a, b = old[0].permute(0, 2, 3, 1), new[0].permute(0, 2, 3, 1)
+            if a.is_contiguous() and b.is_contiguous():
+                return torch.cat([a, b], 0).permute(0, 3, 1, 2)[None]
+        return self._cl5(torch.cat([old, new], 1))
+
+    def _take_cl(self, t, idx):
+        """t[:, idx] for a channels-last [1,E,C,H,W] state tensor, as a row gather on the physical layout"""
+        if self.device.type == "cuda" and t.shape[1] > 0:
+            a = t[0].permute(0, 2, 3, 1)
+            if a.is_contiguous():
+                return a.index_select(0, idx).permute(0, 3, 1, 2)[None]
+        return self._cl5(t[:, idx])
+
     def _cached(self, key, make):
         v = self._cache.get(key)
         if v is None:
@@ -112,14 +133,13 @@ class FactorGraph:
                 corr = CorrBlock(self.video.fmaps[ii][None], self.video.fmaps[jj][None], channels_last=True)
                 self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self.video.inps[ii][None]
-            self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
-            self.inp = self._cl5(self.inp)       # stored channels-last once, so no update re-lays it out
+            self.inp = self._cat_cl(self.inp, inp)   # stored channels-last once, so no update re-lays it out
         target, _ = self.video.reproject(ii, jj)
         zeros2 = torch.zeros_like(target)
         self.ii, self.jj = torch.cat([self.ii, ii]), torch.cat([self.jj, jj])
         self.age = torch.cat([self.age, torch.zeros_like(ii)])
         self._ii_h += ii_l; self._jj_h += jj_l; self._age_h += [0] * len(ii_l)
-        self.net = self._cl5(net if self.net is None else torch.cat([self.net, net], 1))
+        self.net = self._cat_cl(self.net, net)
         self.target_cam = torch.cat([self.target_cam, target], 1)
         self.weight = torch.cat([self.weight, zeros2], 1)
         self.raw_mask = torch.cat([self.raw_mask, zeros2[..., :self.mask_num]], 1)
@@ -162,9 +182,9 @@ class FactorGraph:
             else:
                 self.corr = self.corr[keep]
         if self.net is not None:
-            self.net = self._cl5(self.net[:, keep])
+            self.net = self._take_cl(self.net, keep)
         if self.inp is not None:
-            self.inp = self._cl5(self.inp[:, keep])
+            self.inp = self._take_cl(self.inp, keep)
         if self.segm is not None:
             self.segm = self.segm[:, keep]
         self.target_cam, self.weight = self.target_cam[:, keep], self.weight[:, keep]
