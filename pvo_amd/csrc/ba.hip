@@ -84,7 +84,7 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.w = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(Kmax) * HW));
   w.dx = reinterpret_cast<float*>(take(sizeof(float) * (n6 + 8)));
   w.sys = reinterpret_cast<double*>(take(sizeof(double) * (n6 * n6 + n6 + 8)));
-  w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + n6 + 21 * (n6 / 6) + 32 : 8)));
+  w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + n6 + 27 * (n6 / 6) + 32 : 8)));
   w.bytes = off;
   return w;
 }
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
 //                             no communication);  (b) one thread per remaining row solves its 1x6 panel in place;
 //                         barrier;  (c) rank-6 trailing update over a 16x16 thread grid;  barrier.
 // 2 barriers per 6 columns (the column-at-a-time version needed 6, and a serial fp64 sqrt/div in front of each).
-// Ld[kb][21] keeps the factored diagonal blocks (row-major lower) for the back substitution.
+// Ld[kb][27] keeps the factored diagonal blocks (row-major lower, 21) and their reciprocal diagonals (6) for the back substitution.
 // 1/sqrt(d) in fp64: hardware estimate (v_rsq_f64) + two Newton steps; the library sqrt and divide are ~30-instruction
 // software sequences each and sit on the serial critical path of the factorisation
 __device__ __forceinline__ double rsqrt_nr(double d) {
@@ -594,7 +594,9 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
     if (!ok) { if (tid == 0) *fail_flag = 1; __syncthreads(); return; }      // uniform: every thread saw the same block
     if (tid == 0) {
 #pragma unroll
-      for (int q = 0; q < 21; ++q) Ld[kb * 21 + q] = L[q];
+      for (int q = 0; q < 21; ++q) Ld[kb * 27 + q] = L[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Ld[kb * 27 + 21 + q] = rd[q];
     }
     // (b) panel rows j0+6 .. n (inclusive: the rhs row)
     for (int i = j0 + 6 + tid; i <= n; i += nt) {
@@ -625,38 +627,31 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
     }
     __syncthreads();
   }
-  // back substitution L^T x = y (y in row n), block rows from the bottom; x overwrites y
+  // back substitution L^T x = y (y in row n), block rows from the bottom; x overwrites y.  Right-looking: once the six
+  // unknowns of block kb are known, every earlier entry takes its update y[i] -= sum_c L[j0+c][i] x[c] independently, so
+  // a block step is one redundant 6x6 triangular solve per thread (registers, reciprocal diagonals, no division), one
+  // parallel update and ONE barrier.  (The left-looking form - dot products over the rows below, 36 wave shuffles of
+  // doubles, a serial thread-0 solve with six fp64 divisions, two barriers - cost 20 of the solve's 37 us at P = 7:
+  // measured with ablation builds.)
   double* y = A + static_cast<long long>(n) * n;
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   for (int kb = P - 1; kb >= 0; --kb) {
     const int j0 = 6 * kb;
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = j0 + 6 + tid; i < n; i += nt) {
-      const double xi = y[i];
+    const double* L = Ld + kb * 27;
+    double x[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) s[c] += A[i * n + j0 + c] * xi;
+    for (int c = 5; c >= 0; --c) {
+      double v = y[j0 + c];
+#pragma unroll
+      for (int k = c + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + c] * x[k];
+      x[c] = v * L[21 + c];                                  // reciprocal diagonal
     }
+    __syncthreads();                                         // everyone has read y[j0..j0+6) before it is overwritten
+    if (tid < 6) y[j0 + tid] = x[tid];
+    for (int i = tid; i < j0; i += nt) {
+      double v = y[i];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      double v = s[c];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) red[wave * 6 + c] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double x[6];
-      const double* L = Ld + kb * 21;
-#pragma unroll
-      for (int c = 5; c >= 0; --c) {
-        double v = y[j0 + c];
-        for (int w = 0; w < nw; ++w) v -= red[w * 6 + c];
-#pragma unroll
-        for (int k = c + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + c] * x[k];
-        x[c] = v / L[c * (c + 1) / 2 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) y[j0 + c] = x[c];
+      for (int c = 0; c < 6; ++c) v -= A[(j0 + c) * n + i] * x[c];
+      y[i] = v;
     }
     __syncthreads();
   }
@@ -671,8 +666,8 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   const int n = 6 * P;
   double* A = use_lds ? reinterpret_cast<double*>(smem + 16) : chol_global;     // (n+1) x n: system, then the rhs row
   double* b = A + static_cast<long long>(n) * n;
-  double* Ld = b + n;                                                            // [P][21] factored diagonal blocks
-  double* red = Ld + 21 * P;                                                     // [4][6] wave partials
+  double* Ld = b + n;                                                            // [P][21 + 6] factored diagonal blocks + reciprocal diagonals
+  double* red = Ld + 27 * P;                                                     // [4][6] wave partials
   if (threadIdx.x == 0) fail = 0;
   for (int idx = threadIdx.x; idx < n * n + n; idx += blockDim.x) {
     double v = sys[idx];
@@ -818,7 +813,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, const double* sys,
   hipStream_t st = pvo_stream(stream);
   const int n6 = 6 * P;
   const int use_lds = n6 <= kLdsCholMax;
-  const size_t lds = 16 + (use_lds ? sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 21 * P + 24) : 0);
+  const size_t lds = 16 + (use_lds ? sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : 0);
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024 - 64) != hipSuccess) return PVO_ELAUNCH;
