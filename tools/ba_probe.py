@@ -31,3 +31,12 @@ for name in sys.argv[1:]:
         run()
     torch.cuda.synchronize()
     print(os.path.basename(name), "P=%d" % (nf - 1), "%.1f us per BA iteration (plan + 5 kernels)" % ((time.perf_counter() - t0) / 100 * 1e6))
+    if hasattr(lib, "pvo_probe_ts"):
+        import numpy as np
+        ts = np.zeros(256, dtype=np.int64)
+        lib.pvo_probe_ts(ctypes.c_void_p(ts.ctypes.data))
+        P = nf - 1
+        print("clock64 ticks (100 MHz => 10 ns each?) entry->loaded %d, factor total %d, back+out %d" % (ts[200] - ts[210], ts[201] - ts[200], ts[211] - ts[201]))
+        for kb in range(P):
+            a = ts[0] if kb == 0 else ts[4 + (kb - 1) * 4]
+            print("  block %d: chol6 %d  panel %d  barrier %d  trailing+barrier %d" % (kb, ts[1 + kb * 4] - a, ts[2 + kb * 4] - ts[1 + kb * 4], ts[3 + kb * 4] - ts[2 + kb * 4], ts[4 + kb * 4] - ts[3 + kb * 4]))
