@@ -122,15 +122,22 @@ __device__ __forceinline__ void fetch_row8_16(const uint16_t* base, long long g,
 // ix..ix+7: they live in row (iy & 7) of tiles c0 = ix >> 3 and c0 + 1; two aligned 16-byte loads and a
 // funnel shift by (ix & 7) elements.  Elements outside [0, w2) hold don't-care bits (masked by the caller).
 typedef uint32_t lk_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void fetch_row8_tiled(const uint16_t* base, long long pbase, int tw, int iy, int ix,
-                                                bool rowok, uint32_t u[4]) {
-  const int c0 = ix >> 3, s = ix & 7;
-  lk_u32x4 A = {0u, 0u, 0u, 0u}, B = {0u, 0u, 0u, 0u};
-  if (rowok) {
-    const uint16_t* rowp = base + pbase + static_cast<long long>(iy >> 3) * tw * 64 + (iy & 7) * 8;
-    if (static_cast<unsigned>(c0) < static_cast<unsigned>(tw)) A = *reinterpret_cast<const lk_u32x4*>(rowp + c0 * 64);
-    if (static_cast<unsigned>(c0 + 1) < static_cast<unsigned>(tw)) B = *reinterpret_cast<const lk_u32x4*>(rowp + (c0 + 1) * 64);
-  }
+// The two halves are separate so that a lane can have the loads of all pyramid levels in flight before it consumes
+// the first one (with the fetch inside the level loop the compiler waits after every level: two loads in flight per
+// lane, the HBM latency exposed eight times per workgroup).  Addresses are clamped into the plane instead of
+// predicated: no exec-mask branches between the loads; whatever a clamped load returns is masked by the caller.
+__device__ __forceinline__ void tiled_issue(const uint16_t* base, long long pbase, int tw, int h2, int iy, int ix,
+                                            lk_u32x4& A, lk_u32x4& B) {
+  const int c0 = ix >> 3;
+  const int iyc = min(max(iy, 0), h2 - 1);
+  const int ca = min(max(c0, 0), tw - 1), cb = min(max(c0 + 1, 0), tw - 1);
+  const uint16_t* rowp = base + pbase + static_cast<long long>(iyc >> 3) * tw * 64 + (iyc & 7) * 8;
+  A = *reinterpret_cast<const lk_u32x4*>(rowp + ca * 64);
+  B = *reinterpret_cast<const lk_u32x4*>(rowp + cb * 64);
+}
+
+__device__ __forceinline__ void tiled_finish(lk_u32x4 A, lk_u32x4 B, int ix, uint32_t u[4]) {
+  const int s = ix & 7;
   // funnel shift of the 8 dwords (A:B) by s elements, written with scalars only (local arrays of the
   // selects end up in scratch memory: 64 B/lane and 5x the HBM write traffic, measured)
   const bool by2 = (s & 4) != 0, by1 = (s & 2) != 0;
@@ -142,6 +149,12 @@ __device__ __forceinline__ void fetch_row8_tiled(const uint16_t* base, long long
   u[1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
   u[2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
   u[3] = __builtin_amdgcn_alignbyte(q4, q3, sh);
+}
+
+// value of lane+1 within a 16-lane row (DPP row_shl:1; the last lane of a row reads 0): the next tap row of the same
+// pixel for the 8-lane groups used here, without the LDS crossbar a __shfl_down goes through
+__device__ __forceinline__ uint32_t next_lane(uint32_t x) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x101, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ void fetch_row8_32(const float* base, long long g, uint32_t mask, float v[8]) {
@@ -215,7 +228,19 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
         y0 = a.coords[(static_cast<long long>(n) * 2 + 1) * HW + pix];
       }
     }
-    const long long plane = static_cast<long long>(a.slots ? a.slots[n] : n) * HW + pix;
+    const long long plane = static_cast<long long>(a.slots ? a.slots[n] : n) * HW + (pix_ok ? pix : pix0);
+
+    lk_u32x4 RA[kMaxLevels], RB[kMaxLevels];
+    if constexpr (TILED && sizeof(S) == 2) {
+#pragma unroll
+      for (int l = 0; l < kMaxLevels; ++l) {
+        if (l < a.nlev) {
+          const LookupLevel L = a.lv[l];
+          const int ixp = pvo_floor_to_int(x0 * L.scale) - 3, iyp = pvo_floor_to_int(y0 * L.scale) - 3 + row;
+          tiled_issue(reinterpret_cast<const uint16_t*>(L.vol), plane * L.plane_elems, L.tw, L.h2, iyp, ixp, RA[l], RB[l]);
+        }
+      }
+    }
 
 #pragma unroll
     for (int l = 0; l < kMaxLevels; ++l) {
@@ -236,15 +261,15 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
 
       // own tap row, and the next one (y offset row+1) from lane+1 of this 8-lane group
       float v[8], vn[8];
-      const uint32_t maskn = __shfl_down(mask, 1, 64);
+      const uint32_t maskn = next_lane(mask);
       if constexpr (sizeof(S) == 2) {
         uint32_t u[4], un[4];
         if constexpr (TILED)
-          fetch_row8_tiled(reinterpret_cast<const uint16_t*>(L.vol), plane * L.plane_elems, L.tw, iy, ix, rowok, u);
+          tiled_finish(RA[l], RB[l], ix, u);
         else
           fetch_row8_16(reinterpret_cast<const uint16_t*>(L.vol), g, L.total, mask, u);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) un[k] = __shfl_down(u[k], 1, 64);
+        for (int k = 0; k < 4; ++k) un[k] = next_lane(u[k]);
         unpack8<T>(u, v);
         unpack8<T>(un, vn);
       } else {
