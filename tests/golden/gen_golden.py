@@ -342,6 +342,97 @@ def gen_droidnet():
     print("droidnet_forward: %d frames %dx%d, %d state tensors" % (N, H, W, len(net.state_dict())))
 
 
+LOWMEM_EDGES = ([0, 0, 1, 5, 8, 8, 9, 9], [1, 2, 0, 6, 9, 7, 8, 7])
+
+
+def lowmem_records(seed=6):
+    """recorded stand-in outputs for the update_lowmem fixture (shared by the generator and the test)"""
+    g = torch.Generator().manual_seed(seed)
+    E, ht, wd, F = 8, 5, 7, 10
+    return dict(
+        E=E, ht=ht, wd=wd, F=F,
+        coords1=[torch.randn(1, E, ht, wd, 2, generator=g) * 3 + 4 for _ in range(2)],
+        target_cam=torch.randn(1, E, ht, wd, 2, generator=g) * 3 + 4,
+        weight0=torch.rand(1, E, ht, wd, 2, generator=g),
+        raw_mask=torch.randn(1, E, ht, wd, 2, generator=g),
+        delta_dy=torch.randn(1, E, ht, wd, 2, generator=g) * 0.2,
+        net=torch.randn(1, E, 128, ht, wd, generator=g),
+        net_out=[torch.randn(1, E, 128, ht, wd, generator=g) for _ in range(2)],
+        delta=[torch.randn(1, E, ht, wd, 4, generator=g) * 0.5 for _ in range(2)],
+        weight_out=[torch.randn(1, E, ht, wd, 2, generator=g) for _ in range(2)],
+        damp_table=[torch.rand(F, ht, wd, generator=g) * 0.01 for _ in range(2)],
+        delta_m=[torch.randn(1, E, ht, wd, 2, generator=g) for _ in range(2)],
+        inps=torch.randn(F, 128, ht, wd, generator=g), fmaps=torch.randn(F, 128, ht, wd, generator=g),
+    )
+
+
+def gen_lowmem_glue():
+    """FactorGraph.update_lowmem (factor_graph.py:309-360), two steps over two source-frame chunks, with recorded
+    stand-ins for video.reproject, the alt-corr block, the update operator and video.ba: pins the chunking, the motion
+    features (built from target_cam - coords0, not the fresh reprojection), the raw-eta damping and the BA arguments
+    (t0 = 1, t1 = counter, lm = 1e-5, ep = 1e-2)."""
+    import factor_graph as ref_fg
+    rec = lowmem_records()
+    E, ht, wd, F = rec["E"], rec["ht"], rec["wd"], rec["F"]
+    ii, jj = torch.tensor(LOWMEM_EDGES[0]), torch.tensor(LOWMEM_EDGES[1])
+    cap = {"motn": [], "ba": [], "calls": []}
+    step = {"k": -1}
+
+    class Counter:
+        value = F
+
+    class Video:
+        pass
+    v = Video()
+    v.ht, v.wd, v.counter = ht * 8, wd * 8, Counter()
+    v.disps, v.dirty = torch.ones(F, ht, wd), torch.zeros(F, dtype=torch.bool)
+    v.segm_filter, v.thresh = False, 0.5
+    v.fmaps, v.inps = rec["fmaps"], rec["inps"]
+
+    def reproject(a, b):
+        step["k"] += 1
+        return rec["coords1"][step["k"]].clone(), torch.ones(1, E, ht, wd, 1)
+    v.reproject = reproject
+
+    def ba(target, weight, eta, ii_, jj_, t0, t1, itrs=2, lm=1e-4, ep=0.1, motion_only=False):
+        cap["ba"].append(dict(target=target.clone(), weight=weight.clone(), eta=eta.clone(), t0=t0, t1=t1, itrs=itrs, lm=lm, ep=ep,
+                              motion_only=motion_only))
+    v.ba = ba
+
+    class FakeAlt:
+        def __init__(self, fmaps, *a, **k):
+            pass
+
+        def __call__(self, coords, ii_, jj_):
+            return torch.zeros(1, ii_.shape[0], 196, ht, wd)
+    ref_fg.AltCorrBlock = FakeAlt
+
+    def update_op(net, inp, corr, motn, ii_, jj_, flag):
+        k = step["k"]
+        sel = torch.tensor([e for e in range(E) if (int(ii[e]) // 8) == (int(ii_[0]) // 8)])
+        cap["motn"].append(motn.clone()); cap["calls"].append(sel.clone())
+        frames = torch.unique(ii_)
+        return (rec["net_out"][k][:, sel], rec["delta"][k][:, sel], rec["weight_out"][k][:, sel],
+                rec["damp_table"][k][frames][None], {}, rec["delta_m"][k][:, sel])
+    fg = ref_fg.FactorGraph(v, update_op, device="cpu", corr_impl="alt")
+    fg.ii, fg.jj, fg.age = ii.clone(), jj.clone(), torch.zeros(E, dtype=torch.long)
+    fg.net = rec["net"].clone()
+    fg.target_cam, fg.weight = rec["target_cam"].clone(), rec["weight0"].clone()
+    fg.raw_mask, fg.delta_dy = rec["raw_mask"].clone(), rec["delta_dy"].clone()
+    fg.update_lowmem(steps=2)
+    out = dict(ii=ii.numpy(), jj=jj.numpy(), n_calls=np.int64(len(cap["calls"])),
+               out_target_cam=fg.target_cam.numpy(), out_weight=fg.weight.numpy(), out_raw_mask=fg.raw_mask.numpy(),
+               out_delta_dy=fg.delta_dy.numpy(), out_damping=fg.damping.numpy(), out_net=fg.net.numpy().astype(np.float16),
+               dirty=v.dirty.numpy())
+    for n, m in enumerate(cap["motn"]):
+        out["motn_%d" % n] = m.numpy(); out["call_edges_%d" % n] = cap["calls"][n].numpy()
+    for n, b in enumerate(cap["ba"]):
+        out["ba_target_%d" % n] = b["target"].numpy(); out["ba_weight_%d" % n] = b["weight"].numpy(); out["ba_eta_%d" % n] = b["eta"].numpy()
+        out["ba_args_%d" % n] = np.array([b["t0"], b["t1"], b["itrs"], b["lm"], b["ep"], float(b["motion_only"])])
+    np.savez_compressed(os.path.join(HERE, "lowmem_glue.npz"), **out)
+    print("lowmem_glue: %d operator calls, %d BA calls" % (len(cap["calls"]), len(cap["ba"])))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -353,3 +444,4 @@ if __name__ == "__main__":
     gen_graph()
     gen_factor_graph_glue()
     gen_droidnet()
+    gen_lowmem_glue()

@@ -96,3 +96,77 @@ def test_graph_replay_matches_eager_updates(cuda):
         else:
             assert d.max().item() < 5e-2, k
     assert torch.allclose(a["poses"], b["poses"], atol=1e-4)
+
+
+def test_update_lowmem_glue_matches_reference(monkeypatch):
+    """FactorGraph.update_lowmem against the reference's own update_lowmem run with the same recorded stand-ins
+    (tests/golden/gen_golden.py: gen_lowmem_glue): chunking by source frame, motion features, damping, BA arguments."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from gen_golden import LOWMEM_EDGES, lowmem_records
+    import pvo_amd.modules.corr as corr_mod
+    from pvo_amd.factor_graph import FactorGraph
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lowmem_glue.npz"))
+    rec = lowmem_records()
+    E, ht, wd, F = rec["E"], rec["ht"], rec["wd"], rec["F"]
+    ii_l, jj_l = LOWMEM_EDGES
+    cap = {"motn": [], "ba": [], "calls": []}
+    step = {"k": -1}
+
+    class Video:
+        pass
+    v = Video()
+    v.ht, v.wd, v.counter = ht * 8, wd * 8, F
+    v.disps, v.dirty = torch.ones(F, ht, wd), torch.zeros(F, dtype=torch.bool)
+    v.segm_filter, v.thresh = False, 0.5
+    v.fmaps, v.inps, v.nets = rec["fmaps"].permute(0, 2, 3, 1).contiguous(), rec["inps"], torch.zeros(F, 128, ht, wd)
+    v.segms = torch.zeros(F, 1, ht, wd, dtype=torch.int)
+
+    def reproject(a, b):
+        step["k"] += 1
+        return rec["coords1"][step["k"]].clone(), torch.ones(1, E, ht, wd, 1)
+    v.reproject = reproject
+    v.ba = lambda target, weight, eta, ii_, jj_, t0, t1, itrs=2, lm=1e-4, ep=0.1, motion_only=False: cap["ba"].append(
+        dict(target=target.clone(), weight=weight.clone(), eta=eta.clone(), args=[t0, t1, itrs, lm, ep, float(motion_only)]))
+
+    class FakeAlt:
+        def __init__(self, fmaps, *a, **k):
+            pass
+
+        def __call__(self, coords, ii_, jj_):
+            return torch.zeros(1, ii_.shape[0], 196, ht, wd)
+    monkeypatch.setattr(corr_mod, "AltCorrBlock", FakeAlt)
+
+    def update_op(net, inp, corr, motn, ii_, jj_, flag):
+        k = step["k"]
+        sel = torch.tensor([e for e in range(E) if (ii_l[e] // 8) == (int(ii_[0]) // 8)])
+        cap["motn"].append(motn.clone()); cap["calls"].append(sel.clone())
+        assert torch.equal(inp[0], rec["inps"][ii_])                   # context features of the source frames
+        frames = torch.unique(ii_)
+        return (rec["net_out"][k][:, sel], rec["delta"][k][:, sel], rec["weight_out"][k][:, sel],
+                rec["damp_table"][k][frames][None], {}, rec["delta_m"][k][:, sel])
+    fg = FactorGraph(v, update_op, device="cpu", corr_impl="alt")
+    fg.ii, fg.jj = torch.tensor(ii_l), torch.tensor(jj_l)
+    fg._ii_h, fg._jj_h, fg._age_h = list(ii_l), list(jj_l), [0] * E
+    fg.age = torch.zeros(E, dtype=torch.long)
+    fg.net = rec["net"].clone()
+    fg.target_cam, fg.weight = rec["target_cam"].clone(), rec["weight0"].clone()
+    fg.raw_mask, fg.delta_dy = rec["raw_mask"].clone(), rec["delta_dy"].clone()
+    fg.update_lowmem(steps=2)
+
+    assert len(cap["calls"]) == int(z["n_calls"]) and len(cap["ba"]) == 2
+    for n in range(len(cap["calls"])):
+        assert np.array_equal(cap["calls"][n].numpy(), z["call_edges_%d" % n])
+        assert np.allclose(cap["motn"][n].numpy(), z["motn_%d" % n], atol=1e-6)
+    for n, b in enumerate(cap["ba"]):
+        assert np.allclose(b["target"].numpy(), z["ba_target_%d" % n], atol=1e-6)
+        assert np.allclose(b["weight"].numpy(), z["ba_weight_%d" % n], atol=1e-6)
+        assert np.allclose(b["eta"].numpy(), z["ba_eta_%d" % n], atol=1e-9)
+        assert np.allclose(np.array(b["args"]), z["ba_args_%d" % n])
+    for name, t in (("out_target_cam", fg.target_cam), ("out_weight", fg.weight), ("out_raw_mask", fg.raw_mask),
+                    ("out_delta_dy", fg.delta_dy), ("out_damping", fg.damping)):
+        assert np.allclose(t.numpy(), z[name], atol=1e-6), name
+    assert np.allclose(fg.net.numpy(), z["out_net"].astype(np.float32), atol=2e-3)
+    assert np.array_equal(v.dirty.numpy(), z["dirty"])
