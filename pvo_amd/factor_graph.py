@@ -93,12 +93,10 @@ class FactorGraph:
         return v
 
     def _filter_repeated(self, ii, jj):
+        """drop requested edges that already exist as active or inactive edges (factor_graph.py:65-77).  As in the
+        reference, a pair that appears twice inside one request is NOT de-duplicated."""
         have = set(zip(self._ii_h, self._jj_h)) | set(zip(self._ii_inac_h, self._jj_inac_h))
-        keep = []
-        for k, e in enumerate(zip(ii, jj)):
-            if e not in have:
-                keep.append(k)
-                have.add(e)        # also de-duplicates inside the request
+        keep = [k for k, e in enumerate(zip(ii, jj)) if e not in have]
         return [ii[k] for k in keep], [jj[k] for k in keep]
 
     @staticmethod

@@ -433,6 +433,115 @@ def gen_lowmem_glue():
     print("lowmem_glue: %d operator calls, %d BA calls" % (len(cap["calls"]), len(cap["ba"])))
 
 
+def proximity_case(seed=8):
+    g = torch.Generator().manual_seed(seed)
+    t = 12
+    d = torch.rand(t, t, generator=g) * 40.0                       # pairwise "frame distances", some above the thresholds
+    d = 0.5 * (d + d.t())
+    have = ([0, 1, 1, 2, 5, 9, 9], [1, 0, 2, 1, 9, 5, 4])            # active edges, two of them long range
+    bad = ([7], [2])
+    inac = ([3, 8], [0, 3])
+    return t, d, have, bad, inac
+
+
+def gen_proximity():
+    """FactorGraph.add_proximity_factors (factor_graph.py:372-429) with a recorded distance matrix: pins the greedy
+    selection (radius edges, distance threshold, non-maximum suppression around existing / chosen edges) and the order
+    in which edges are handed to add_factors."""
+    import factor_graph as ref_fg
+    t, d, have, bad, inac = proximity_case()
+    out = dict(d=d.numpy())
+
+    class Counter:
+        value = t
+
+    class Video:
+        pass
+    v = Video()
+    v.ht, v.wd, v.counter = 64, 64, Counter()
+    v.disps = torch.ones(t, 8, 8)
+    v.segm_filter = False
+    v.distance = lambda ii, jj, beta=0.3: d[ii.long(), jj.long()].clone()
+    for n, kw in enumerate((dict(t0=0, t1=0, rad=2, nms=2, thresh=16.0), dict(t0=7, t1=0, rad=2, nms=1, thresh=12.0),
+                            dict(t0=2, t1=1, rad=1, nms=3, thresh=30.0))):
+        fg = ref_fg.FactorGraph(v, None, device="cpu")
+        fg.ii, fg.jj = torch.tensor(have[0]), torch.tensor(have[1])
+        fg.ii_bad, fg.jj_bad = torch.tensor(bad[0]), torch.tensor(bad[1])
+        fg.ii_inac, fg.jj_inac = torch.tensor(inac[0]), torch.tensor(inac[1])
+        got = {}
+        fg.add_factors = lambda ii, jj, remove=False: got.update(ii=ii.clone(), jj=jj.clone(), remove=remove)
+        fg.add_proximity_factors(beta=0.3, remove=bool(n), **kw)
+        out["ii_%d" % n], out["jj_%d" % n], out["remove_%d" % n] = got["ii"].numpy(), got["jj"].numpy(), np.int64(got["remove"])
+        out["args_%d" % n] = np.array([kw["t0"], kw["t1"], kw["rad"], kw["nms"], kw["thresh"]])
+    np.savez_compressed(os.path.join(HERE, "proximity_factors.npz"), **out)
+    print("proximity_factors: %s edges" % [int(out["ii_%d" % n].shape[0]) for n in range(3)])
+
+
+def bookkeeping_video(F=8, ht=2, wd=3):
+    """mock DepthVideo for the edge-bookkeeping fixture; every buffer row f carries the value f"""
+    class Video:
+        pass
+    v = Video()
+    v.ht, v.wd = ht * 8, wd * 8
+    col = torch.arange(F).float()
+    v.poses = col[:, None].repeat(1, 7).clone()
+    v.disps = col[:, None, None].repeat(1, ht, wd).clone()
+    v.intrinsics = col[:, None].repeat(1, 4).clone()
+    v.nets = col[:, None, None, None].repeat(1, 128, ht, wd).clone()
+    v.inps = v.nets.clone() + 100
+    v.fmaps = v.nets.clone() + 200
+    v.segms = torch.arange(F).int()[:, None, None, None].repeat(1, 1, ht, wd).clone()
+    v.segm_filter, v.thresh = True, 0.5
+
+    def reproject(ii, jj):
+        val = (torch.as_tensor(ii).float() * 10 + torch.as_tensor(jj).float())[None, :, None, None, None]
+        return val.repeat(1, 1, ht, wd, 2), torch.ones(1, len(ii), ht, wd, 1)
+    v.reproject = reproject
+    import contextlib
+    v.get_lock = contextlib.nullcontext                # the reference wraps rm_keyframe's buffer moves in the video lock
+    return v
+
+
+def bookkeeping_script(fg, set_age):
+    """the sequence of edge operations both implementations run; returns snapshots after every step"""
+    snaps = []
+
+    def snap():
+        snaps.append(dict(ii=fg.ii.clone(), jj=fg.jj.clone(), age=fg.age.clone(), ii_inac=fg.ii_inac.clone(), jj_inac=fg.jj_inac.clone(),
+                          target=fg.target_cam[0, :, 0, 0, 0].clone(), target_inac=fg.target_cam_inac[0, :, 0, 0, 0].clone(),
+                          net=fg.net[0, :, 0, 0, 0].float().clone(), segm=fg.segm[0, :, 0, 0, 0].clone(),
+                          weight=fg.weight[0, :, 0, 0, 0].clone()))
+    fg.add_neighborhood_factors(0, 5, r=2); snap()
+    set_age(fg, [3, 11, 7, 0, 13, 5, 9, 1, 12, 6, 2, 10, 4, 8])
+    fg.weight = fg.weight + torch.arange(fg.ii.shape[0]).float()[None, :, None, None, None]      # make per-edge state distinguishable
+    fg.corr = object()                                                 # a volume "exists": eviction is armed
+    fg.add_factors([5, 4, 5, 0, 5, 6], [4, 5, 3, 1, 4, 5], remove=True); snap()      # two duplicates, 4 new edges -> eviction + store
+    fg.rm_keyframe(2); snap()
+    fg.rm_factors(torch.tensor([k % 3 == 0 for k in range(fg.ii.shape[0])]), store=False); snap()
+    fg.add_factors(torch.tensor([1, 3]), torch.tensor([3, 1])); snap()
+    return snaps
+
+
+def gen_bookkeeping():
+    """FactorGraph edge bookkeeping (factor_graph.py:65-225): duplicate filtering, age-based eviction with storage of the
+    evicted edges, rm_keyframe's index shifts and buffer moves, rm_factors, on a mock video."""
+    import factor_graph as ref_fg
+    v = bookkeeping_video()
+    fg = ref_fg.FactorGraph(v, None, device="cpu", corr_impl="alt", max_factors=10)
+
+    def set_age(f, ages):
+        f.age = torch.tensor(ages)
+    snaps = bookkeeping_script(fg, set_age)
+    out = {}
+    for n, sn in enumerate(snaps):
+        for k, t in sn.items():
+            out["%s_%d" % (k, n)] = t.numpy()
+    out.update(poses=v.poses.numpy(), disps=v.disps.numpy(), nets=v.nets[:, 0, 0, 0].numpy(), fmaps=v.fmaps[:, 0, 0, 0].numpy(),
+               segms=v.segms[:, 0, 0, 0].numpy(), n_snaps=np.int64(len(snaps)))
+    np.savez_compressed(os.path.join(HERE, "edge_bookkeeping.npz"), **out)
+    print("edge_bookkeeping: edges per step %s" % [int(sn["ii"].shape[0]) for sn in snaps])
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -445,3 +554,5 @@ if __name__ == "__main__":
     gen_factor_graph_glue()
     gen_droidnet()
     gen_lowmem_glue()
+    gen_proximity()
+    gen_bookkeeping()

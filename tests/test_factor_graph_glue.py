@@ -170,3 +170,69 @@ def test_update_lowmem_glue_matches_reference(monkeypatch):
         assert np.allclose(t.numpy(), z[name], atol=1e-6), name
     assert np.allclose(fg.net.numpy(), z["out_net"].astype(np.float32), atol=2e-3)
     assert np.array_equal(v.dirty.numpy(), z["dirty"])
+
+
+def test_proximity_factor_selection_matches_reference():
+    """add_proximity_factors against the reference's own greedy selection on a recorded distance matrix
+    (tests/golden/gen_golden.py: gen_proximity): same edges, same order, same `remove` flag"""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from gen_golden import proximity_case
+    from pvo_amd.factor_graph import FactorGraph
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "proximity_factors.npz"))
+    t, d, have, bad, inac = proximity_case()
+    assert np.array_equal(d.numpy(), z["d"])
+
+    class Video:
+        pass
+    v = Video()
+    v.ht, v.wd, v.counter = 64, 64, t
+    v.disps = torch.ones(t, 8, 8)
+    v.segm_filter = False
+    v.distance = lambda ii, jj, beta=0.3: d[torch.as_tensor(ii).long(), torch.as_tensor(jj).long()].clone()
+    for n in range(3):
+        t0, t1, rad, nms, thresh = [float(x) for x in z["args_%d" % n]]
+        fg = FactorGraph(v, None, device="cpu")
+        fg._ii_h, fg._jj_h = list(have[0]), list(have[1])
+        fg.ii, fg.jj = torch.tensor(have[0]), torch.tensor(have[1])
+        fg.ii_bad, fg.jj_bad = torch.tensor(bad[0]), torch.tensor(bad[1])
+        fg._ii_inac_h, fg._jj_inac_h = list(inac[0]), list(inac[1])
+        got = {}
+        fg.add_factors = lambda ii, jj, remove=False: got.update(ii=list(ii), jj=list(jj), remove=remove)
+        fg.add_proximity_factors(int(t0), int(t1), rad=int(rad), nms=int(nms), beta=0.3, thresh=thresh, remove=bool(n))
+        assert got["ii"] == z["ii_%d" % n].tolist() and got["jj"] == z["jj_%d" % n].tolist(), n
+        assert int(got["remove"]) == int(z["remove_%d" % n])
+
+
+def test_edge_bookkeeping_matches_reference():
+    """add_neighborhood_factors / add_factors (duplicates, age-based eviction with storage) / rm_keyframe / rm_factors
+    against the reference's FactorGraph on a mock video (tests/golden/gen_golden.py: gen_bookkeeping), state compared after
+    every step - including the reference's position-indexed eviction mask and rm_keyframe's buffer moves"""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from gen_golden import bookkeeping_script, bookkeeping_video
+    from pvo_amd.factor_graph import FactorGraph
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "edge_bookkeeping.npz"))
+    v = bookkeeping_video()
+    v.fmaps = v.fmaps.permute(0, 2, 3, 1).contiguous()               # the build keeps feature maps channels-last
+    fg = FactorGraph(v, None, device="cpu", corr_impl="alt", max_factors=10)
+
+    def set_age(f, ages):
+        f.age = torch.tensor(ages)
+        f._age_h = list(ages)
+    snaps = bookkeeping_script(fg, set_age)
+    assert len(snaps) == int(z["n_snaps"])
+    for n, sn in enumerate(snaps):
+        for k, t in sn.items():
+            assert np.array_equal(t.numpy(), z["%s_%d" % (k, n)]), (k, n, t, z["%s_%d" % (k, n)])
+        # the host mirrors track the device lists
+        assert fg._ii_h == fg.ii.tolist() and fg._jj_h == fg.jj.tolist() and fg._age_h == fg.age.tolist() or n < len(snaps) - 1
+    assert fg._ii_h == fg.ii.tolist() and fg._jj_h == fg.jj.tolist() and fg._age_h == fg.age.tolist()
+    assert fg._ii_inac_h == fg.ii_inac.tolist() and fg._jj_inac_h == fg.jj_inac.tolist()
+    assert np.array_equal(v.poses.numpy(), z["poses"]) and np.array_equal(v.disps.numpy(), z["disps"])
+    assert np.array_equal(v.nets[:, 0, 0, 0].numpy(), z["nets"]) and np.array_equal(v.fmaps[:, 0, 0, 0].numpy(), z["fmaps"])
+    assert np.array_equal(v.segms[:, 0, 0, 0].numpy(), z["segms"])
