@@ -27,7 +27,7 @@ class DroidFrontend:
         """add edges, optimise, decide whether the previous frame stays a keyframe (droid_frontend.py:36-70)"""
         self.count += 1
         self.t1 += 1
-        if self.graph._ii_h:
+        if self.graph.corr is not None:                      # droid_frontend.py:42-43
             self.graph.rm_factors([a > self.max_age for a in self.graph._age_h], store=True)
         self.graph.add_proximity_factors(self.t1 - 5, max(self.t1 - self.frontend_window, 0), rad=self.frontend_radius,
                                          nms=self.frontend_nms, thresh=self.frontend_thresh, beta=self.beta, remove=True)

@@ -88,6 +88,7 @@ def test_closed_loop_ate_hip_equals_oracle_path(cuda):
     op2 = OracleFlowOperator(scene, ov, _oracle_reproject)
     fe2 = DroidFrontend(op2, ov, device="cpu", **kw)
     fe2.graph.corr_impl = "none"
+    fe2.graph.corr = type("NoVolumes", (), {"__call__": lambda self, coords, **kw: None})()   # "a volume exists" (droid_frontend.py:42)
     poses_cpu, frames_cpu = run_sequence(scene, ov, fe2, op2)
     assert frames_hip == frames_cpu and len(frames_hip) >= 10          # same keyframe decisions
     gt = camera_centres(scene.poses[frames_hip].numpy())
