@@ -61,6 +61,7 @@ def scatter_mean(src, index, dim, dim_size=None):
 
 import os as _os
 _HIP_CONV3 = _os.environ.get("PVO_HIP_CONV3") == "1"
+_AGG_HIP_CONV = _os.environ.get("PVO_AGG_HIP_CONV", "1") == "1"
 
 
 def _w16(owner, conv, dt):
@@ -212,8 +213,15 @@ class GraphAgg(nn.Module):
             x = F.conv2d(net.contiguous(memory_format=torch.channels_last), _w16(self, self.conv1, dt), None, padding=1)
             # conv1's bias + ReLU are applied by the mean kernel as it reads (one pass over the 28 MB tensor instead of two)
             x = db.segment_mean(x.contiguous(memory_format=torch.channels_last), segments[0], segments[1], segments[2], in_bias=fb[0])
-            net = F.conv2d(x, _w16(self, self.conv2, dt), None, padding=1)
-            net = db.bias_act_(net.contiguous(memory_format=torch.channels_last), fb[1])
+            if _AGG_HIP_CONV:   # K frames only: the hand-written 3x3 kernel (bias + ReLU inside) instead of MIOpen + a bias pass
+                hit = self.__dict__.get("_taps2")
+                w = self.conv2.weight
+                if hit is None or hit[0] is not w or hit[1] != w._version or hit[2].dtype != dt or hit[2].device != w.device:
+                    hit = self.__dict__["_taps2"] = (w, w._version, db.conv3x3_c128_weights(w, dt))
+                net = db.conv3x3_c128(x, hit[2], fb[1], relu=True)
+            else:
+                net = F.conv2d(x, _w16(self, self.conv2, dt), None, padding=1)
+                net = db.bias_act_(net.contiguous(memory_format=torch.channels_last), fb[1])
             # bias-free convolutions (MIOpen adds a bias in a separate pass): eta's bias joins the fp32 softplus input,
             # upmask's is added by the in-place bias kernel
             eta_raw = F.conv2d(net, _w16(self, self.eta[0], dt), None, padding=1)
