@@ -268,12 +268,12 @@ def main():
         launch = lambda: graph.corr.encoded(coords1, enc_w, enc_b)
     else:
         launch = lambda: graph.corr(coords1, channels_last=True)
-    flush = torch.empty(600 * 1024 * 1024, dtype=torch.uint8, device=device)
+    flush = torch.zeros(150 * 1024 * 1024, dtype=torch.float32, device=device)      # 600 MB
     for _ in range(3):
         launch()
     cold = []
     for _ in range(20):
-        flush.sum()             # a 600 MB READ evicts the cache with clean lines (a fill would leave 256 MB of dirty
+        flush.max()             # a 600 MB READ (one reduction kernel) evicts the cache with clean lines (a fill would leave 256 MB of dirty
         # lines whose write-back competes with the timed kernel: 71 us instead of the ~48 us rocprof sees in the steps)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); launch(); e1.record()
