@@ -197,6 +197,7 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # N host processes share the cores
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
