@@ -7,8 +7,8 @@
 //   bias+ReLU pass; here it is one kernel bound by its 28 MB output write.
 //   Mapping: 8 input channels in 16-bit = 16 bytes = exactly one lane's k-group of v_mfma_f32_16x16x32, so one MFMA
 //   consumes 4 taps (lane group lk = lane >> 4 selects the tap) of 16 pixels against 16 output channels.  49 taps = 13
-//   MFMAs (the last one padded with zero weights).  A workgroup owns an 8x16 pixel tile whose 14x22 halo (4.9 KB) sits
-//   in LDS; wave w owns output channels [32w, 32w+32) and keeps its 26 weight fragments in registers for all 8 tile rows.
+//   MFMAs (the last one padded with zero weights).  A workgroup owns a 16x16 pixel tile whose 22x22 halo (7.7 KB) sits
+//   in LDS; wave w owns output channels [32w, 32w+32) and keeps its 26 weight fragments in registers for all 16 tile rows.
 //   Weights arrive pre-arranged as [52 taps (49 + 3 zero)][128 outputs][8 channels] 16-bit.
 #include "common.h"
 
@@ -34,16 +34,18 @@ template <> __device__ __forceinline__ uint32_t cs_bits<pvo_half>(float x) {
 template <> __device__ __forceinline__ uint32_t cs_bits<pvo_bf16>(float x) { return pvo_f32_to_bf16(x); }
 
 constexpr int kTH = 8, kTW = 16, kR = 3;
-constexpr int kHW_ = kTW + 2 * kR, kHH_ = kTH + 2 * kR;       // 22 x 14 halo
+constexpr int kTH7 = 16;                                      // the 7x7 kernel's tile is 16 rows high: weight fragments are
+                                                              // fetched once per 256 pixels (they were 3x the output in L2 reads)
+constexpr int kHW_ = kTW + 2 * kR, kHH7 = kTH7 + 2 * kR;      // 22 x 22 halo
 constexpr int kTaps = 49, kSteps = 13;                        // 13 MFMAs x 4 taps
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                          const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                          int H, int W) {
-  __shared__ __attribute__((aligned(16))) unsigned char halo[kHH_ * kHW_ * 16];
+  __shared__ __attribute__((aligned(16))) unsigned char halo[kHH7 * kHW_ * 16];
   __shared__ __attribute__((aligned(16))) unsigned char slab[2][16 * 272];     // one tile row: 16 pixels x 128 channels (+16 B pad), double buffered
-  const int e = blockIdx.z, y0 = blockIdx.y * kTH, x0 = blockIdx.x * kTW;
+  const int e = blockIdx.z, y0 = blockIdx.y * kTH7, x0 = blockIdx.x * kTW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
       bf[s][nt] = *reinterpret_cast<const cs_u32x4*>(wt + (static_cast<size_t>(4 * s + lk) * 128 + wave * 32 + nt * 16 + li) * 8);
 
   const uint16_t* xe = x + static_cast<size_t>(e) * H * W * 8;
-  for (int pos = tid; pos < kHH_ * kHW_; pos += 256) {
+  for (int pos = tid; pos < kHH7 * kHW_; pos += 256) {
     const int hy = y0 - kR + pos / kHW_, hx = x0 - kR + pos % kHW_;
     cs_u32x4 v = {0u, 0u, 0u, 0u};
     if (hy >= 0 && hy < H && hx >= 0 && hx < W) v = *reinterpret_cast<const cs_u32x4*>(xe + (static_cast<size_t>(hy) * W + hx) * 8);
@@ -76,14 +78,19 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
   bb[1] = bias[wave * 32 + 16 + li];
   __syncthreads();
 
-  for (int py = 0; py < kTH; ++py) {
+  for (int py = 0; py < kTH7; ++py) {
+    if (y0 + py >= H) break;                                  // (uniform) rows below the image
     cs_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
     const unsigned char* rowp = halo + py * kHW_ * 16;
+    // (clock64 stamps: 5k cycles of set-up + 1364 cycles per row per workgroup, i.e. the kernel's ~19 us is one workgroup's
+    // latency - only 1.7 workgroups per CU exist at S-B - not a throughput limit; forcing the reads ahead changed nothing)
+    cs_u32x4 afr[kSteps];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) afr[s] = *reinterpret_cast<const cs_u32x4*>(rowp + toff[s]);
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
-      const cs_u32x4 a = *reinterpret_cast<const cs_u32x4*>(rowp + toff[s]);
-      d0 = cs_mfma<T>(a, bf[s][0], d0);
-      d1 = cs_mfma<T>(a, bf[s][1], d1);
+      d0 = cs_mfma<T>(afr[s], bf[s][0], d0);
+      d1 = cs_mfma<T>(afr[s], bf[s][1], d1);
     }
     // D: column li = channel, rows lk*4 + r = pixels.  bias + ReLU, then the four waves' 32-channel slices meet in a
     // workgroup slab so that every pixel leaves as one contiguous 256-byte row (a wave storing its own 64-byte slice
@@ -133,24 +140,39 @@ __global__ __launch_bounds__(256) void gru_glo_mfma_kernel(const uint16_t* __res
   float s0 = 0.0f, s1 = 0.0f;
   const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, HW);
   const uint16_t* ne = net + static_cast<size_t>(e) * HW * 128;
-  for (int p0 = p_begin; p0 < p_end; p0 += kGloTile) {
-    __syncthreads();
+  // software pipeline: the next tile's 16 KB are in flight (registers) while this tile is multiplied
+  cs_u32x4 pre[4];
+  auto fetch = [&](int p0) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {                      // 64 px x 16 chunks of 16 B
       const int id = tid + 256 * it, px = id >> 4, c = id & 15;
-      cs_u32x4 v = {0u, 0u, 0u, 0u};
-      if (p0 + px < p_end) v = *reinterpret_cast<const cs_u32x4*>(ne + static_cast<size_t>(p0 + px) * 128 + c * 8);
-      *reinterpret_cast<cs_u32x4*>(tile + px * kGloStride + c * 16) = v;
+      pre[it] = cs_u32x4{0u, 0u, 0u, 0u};
+      if (p0 + px < p_end) pre[it] = *reinterpret_cast<const cs_u32x4*>(ne + static_cast<size_t>(p0 + px) * 128 + c * 8);
+    }
+  };
+  fetch(p_begin);
+  for (int p0 = p_begin; p0 < p_end; p0 += kGloTile) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int id = tid + 256 * it, px = id >> 4, c = id & 15;
+      *reinterpret_cast<cs_u32x4*>(tile + px * kGloStride + c * 16) = pre[it];
     }
     __syncthreads();
+    if (p0 + kGloTile < p_end) fetch(p0 + kGloTile);
+    cs_u32x4 afr[4][4];                                    // the tile's 16 A fragments, requested up front
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc)
+        afr[g][kc] = *reinterpret_cast<const cs_u32x4*>(tile + (g * 16 + li) * kGloStride + kc * 64 + lk * 16);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       cs_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
-        const cs_u32x4 a = *reinterpret_cast<const cs_u32x4*>(tile + (g * 16 + li) * kGloStride + kc * 64 + lk * 16);
-        d0 = cs_mfma<T>(a, bf[kc][0], d0);
-        d1 = cs_mfma<T>(a, bf[kc][1], d1);
+        d0 = cs_mfma<T>(afr[g][kc], bf[kc][0], d0);
+        d1 = cs_mfma<T>(afr[g][kc], bf[kc][1], d1);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {                       // D rows lk*4 + r = pixels, column li = channel
@@ -291,7 +313,7 @@ extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bi
   if (!x || !w_taps || !bias || !y || E > 65535) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_taps) | reinterpret_cast<uintptr_t>(y)) & 15) return PVO_EINVAL;
   hipStream_t st = pvo_stream(stream);
-  dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, E);
+  dim3 grid((W + kTW - 1) / kTW, (H + kTH7 - 1) / kTH7, E);
   if (dtype == PVO_F16)
     hipLaunchKernelGGL(conv7x7_c8_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x),
                        static_cast<const uint16_t*>(w_taps), bias, static_cast<uint16_t*>(y), H, W);
