@@ -1,28 +1,38 @@
-"""DroidBackend - global bundle adjustment over all keyframes (VO_Module/droid_slam/droid_backend.py:9-41).
+"""Global bundle adjustment over every keyframe collected so far.
 
-A fresh factor graph with `corr_impl="alt"` (no stored volumes: features are correlated on the fly by the
-alt-corr HIP kernel), proximity edges over the whole video, `update_lowmem` for `steps` iterations.
+Role of the reference's `DroidBackend` (VO_Module/droid_slam/droid_backend.py:9-41), same constructor and call
+signature.  One pass = rescale the map to unit mean inverse depth, connect all keyframes by proximity (no stored
+correlation volumes: `corr_impl="alt"` correlates features on the fly with the alt-corr HIP kernel), iterate
+`FactorGraph.update_lowmem`, drop the edges again.
 """
 import torch
 
 from .factor_graph import FactorGraph
 
+_EDGE_BUDGET = 100000          # droid_backend.py:31: effectively unlimited
+
 
 class DroidBackend:
     def __init__(self, net, video, args):
-        self.video, self.update_op, self.device = video, net.update, args.device
+        self.video = video
+        self.update_op = net.update
+        self.device = args.device
         self.t0 = self.t1 = 0
-        self.beta = args.beta
-        self.backend_thresh, self.backend_radius, self.backend_nms = \
-            args.backend_thresh, args.backend_radius, args.backend_nms
+        # proximity-edge selection parameters (droid_backend.py:19-22)
+        self.edge_rule = dict(rad=args.backend_radius, nms=args.backend_nms, thresh=args.backend_thresh, beta=args.beta)
+        self.beta, self.backend_radius = args.beta, args.backend_radius
+        self.backend_nms, self.backend_thresh = args.backend_nms, args.backend_thresh
+
+    def _connect_all(self):
+        graph = FactorGraph(self.video, self.update_op, self.device, corr_impl="alt", max_factors=_EDGE_BUDGET)
+        graph.add_proximity_factors(**self.edge_rule)
+        return graph
 
     @torch.no_grad()
     def __call__(self, steps=12):
-        t = self.video.counter
+        n_keyframes = self.video.counter
         self.video.normalize()
-        graph = FactorGraph(self.video, self.update_op, self.device, corr_impl="alt", max_factors=100000)
-        graph.add_proximity_factors(rad=self.backend_radius, nms=self.backend_nms, thresh=self.backend_thresh,
-                                    beta=self.beta)
+        graph = self._connect_all()
         graph.update_lowmem(steps=steps)
         graph.clear_edges()
-        self.video.dirty[:t] = True
+        self.video.dirty[:n_keyframes] = True
