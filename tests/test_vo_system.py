@@ -138,3 +138,39 @@ def test_handoff_files_round_trip(tmp_path):
     rows = np.loadtxt(str(tmp_path / "traj.txt"))
     assert rows.shape == (2, 12) and np.allclose(rows[0], [1, 0, 0, 1, 0, 1, 0, 2, 0, 0, 1, 3])
     assert np.allclose(rows[1, [0, 1, 4, 5]], [np.cos(0.5), -np.sin(0.5), np.sin(0.5), np.cos(0.5)], atol=1e-9)
+
+
+def test_sequence_reader_and_pose_file_parser(tmp_path):
+    """tools/test_vo.py: VKITTI2 directory layout -> (t, BGR image, scaled intrinsics, 1/8 segment ids); extrinsic.txt
+    -> camera-to-world poses (every second row, inverted)"""
+    import importlib.util
+    import os
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("test_vo_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "test_vo.py"))
+    tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+    root = tmp_path / "Scene01"
+    (root / "15-deg-left" / "frames" / "rgb" / "Camera_0").mkdir(parents=True)
+    (root / "15-deg-left" / "panFPN_segm").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    for k in range(3):
+        Image.fromarray(rng.integers(0, 255, (60, 200, 3), dtype=np.uint8)).save(root / "15-deg-left" / "frames" / "rgb" / "Camera_0" / ("rgb_%05d.jpg" % k))
+        seg = np.zeros((60, 200, 3), dtype=np.uint8); seg[:, 100:, 0] = 7; seg[:, 100:, 1] = 1      # id 7 + 256
+        Image.fromarray(seg).save(root / "15-deg-left" / "panFPN_segm" / ("seg_%05d.png" % k))
+    frames = list(tool.image_stream(str(root), image_size=(30, 101), mode="val", segm_filter=True))
+    assert len(frames) == 3
+    t, image, intr, segm = frames[1]
+    assert t == 1 and image.shape == (3, 24, 96) and image.dtype == torch.int32 and segm.shape == (1, 1, 3, 12)
+    assert torch.allclose(intr, torch.tensor([725.0087 * 101 / 200, 725.0087 * 101 / 200, 620.5 * 30 / 60, 187.0 * 30 / 60]))
+    assert set(segm.unique().tolist()) <= {0, 263}
+    assert tool.rgb2id(np.array([[[1, 2, 3]]]))[0, 0] == 1 + 512 + 3 * 65536
+    # pose file: header + two cameras per frame
+    T = np.eye(4); T[:3, 3] = [1.0, 2.0, 3.0]
+    rows = ["frame cameraID r11 ..."]
+    for f in range(2):
+        for cam in range(2):
+            M = T.copy(); M[0, 3] += f + 10 * cam
+            rows.append("%d %d " % (f, cam) + " ".join("%.6f" % v for v in M.reshape(-1)))
+    (root / "15-deg-left" / "extrinsic.txt").write_text("\n".join(rows) + "\n")
+    poses = tool.read_vkitti2_poses(str(root / "15-deg-left" / "extrinsic.txt"))
+    assert poses.shape == (2, 4, 4) and np.allclose(poses[1][:3, 3], [-2.0, -2.0, -3.0])
+    assert tool.parse_args(["--datapath", "x"]).frontend_window == 25
