@@ -191,6 +191,11 @@ int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y
  * w_taps [9 taps (ky*3+kx)][Cout][128] in `dtype`; bias f32 [Cout] or NULL; relu != 0 applies ReLU. */
 int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void* y,
                      int E, int H, int W, int Cout, int relu, int dtype, void* stream);
+/* y[E,H,W,Cout] = act(conv3x3(x[E,H,W,Cin], zero padding 1) + bias) for wide layers on the matrix cores (implicit GEMM,
+ * 16x16 pixel tile x 128 outputs per workgroup): Cin % 32 == 0, Cout % 128 == 0; w_taps [9 taps][Cout][Cin] in `dtype`;
+ * bias f32 [Cout] or NULL; relu != 0 applies ReLU. */
+int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
+                int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                      int K, int HW, int C, int dtype, void* stream);

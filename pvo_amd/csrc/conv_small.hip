@@ -304,6 +304,197 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const uint16_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------
+// pvo_conv3x3: y = act(conv3x3(x, w) + bias) for wide layers, x [E,H,W,Cin] -> y [E,H,W,Cout], Cin % 32 == 0,
+// Cout % 128 == 0 - the GRU gate / candidate convolutions (320 -> 256, 320 -> 128) and the heads' first stage
+// (128 -> 512), which MIOpen/CK run at 0.69-0.74 PFLOP/s.
+//   Implicit GEMM on v_mfma_f32_32x32x16: workgroup = 16x16 pixel tile (M = 256) x 128 output channels, 4 waves as 2 x 2,
+//   each wave 128 pixels x 64 channels = 8 accumulator tiles (128 AGPRs).  K runs over (32-channel chunk, tap): the
+//   chunk's 18x18 halo (20.7 KB, 80-byte pixel stride) and the (chunk, tap) filter slab (128 x 32, 80-byte row stride) sit
+//   in LDS, both double buffered; the next slab (and, at the last tap, the next halo chunk) travels global -> registers
+//   while the current step's 16 MFMAs per wave run, then registers -> the idle LDS buffer, one barrier per step.
+//   Per step a wave reads 12 KB of fragments for 16 MFMAs: ~94 B/clk per CU at full matrix rate, under the LDS limit;
+//   every filter byte is fetched once per 256 pixels (the 8x16-tile kernel above re-fetched it per 128 and stalled there).
+//   Filters arrive as [9 taps][Cout][Cin] 16-bit.
+// ---------------------------------------------------------------------------
+typedef float cs_v16f __attribute__((ext_vector_type(16)));
+template <typename T> __device__ __forceinline__ cs_v16f cs_mfma32(cs_u32x4 a, cs_u32x4 b, cs_v16f c);
+template <> __device__ __forceinline__ cs_v16f cs_mfma32<pvo_half>(cs_u32x4 a, cs_u32x4 b, cs_v16f c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cs_v8h, a), __builtin_bit_cast(cs_v8h, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ cs_v16f cs_mfma32<pvo_bf16>(cs_u32x4 a, cs_u32x4 b, cs_v16f c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cs_v8b, a), __builtin_bit_cast(cs_v8b, b), c, 0, 0, 0);
+}
+
+constexpr int kBT = 16;                                   // 16 x 16 pixel tile
+constexpr int kBHalo = (kBT + 2) * (kBT + 2);             // 324 halo positions
+constexpr int kBStride = 80;                              // bytes per halo position / filter row of a 32-channel chunk
+constexpr int kBA = kBHalo * kBStride, kBB = 128 * kBStride;   // 25920 + 10240 bytes per buffer
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                          const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                          int H, int W, int Cin, int Cout, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bs[];      // A[2] | B[2]; later the output slab
+  unsigned char* As = bs;
+  unsigned char* Bs = bs + 2 * kBA;
+  const int ntx = (W + kBT - 1) / kBT;
+  const int cg = blockIdx.x / ntx, tx_ = blockIdx.x - cg * ntx;
+  const int e = blockIdx.z, y0 = blockIdx.y * kBT, x0 = tx_ * kBT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kg = lane >> 5;
+  const int nC = Cin >> 5;                                // 32-channel chunks
+  const uint16_t* xe = x + static_cast<size_t>(e) * H * W * Cin;
+  const uint16_t* wb = wt + static_cast<size_t>(cg) * 128 * Cin;
+  const size_t tap_stride = static_cast<size_t>(Cout) * Cin;
+
+  // global -> register staging: the halo chunk needed next (6 x 16 B per thread) and the filter slabs of the next TWO
+  // steps (2 x 2 x 16 B).  A slab is requested two steps before it is used and parked in LDS one step before: with a
+  // one-step distance the wave sat ~560 cycles per step in s_waitcnt vmcnt (clock64 stamps), L2 latency under load
+  // being longer than one step's 16 MFMAs.
+  cs_u32x4 ra[6], rb0[2], rb1[2];
+  int aoff[6];                                            // element offset of this thread's halo pieces inside the image, -1 = zero
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int id = tid + 256 * it;                        // piece = (position, 16-byte quarter of the 64-byte chunk row)
+    const int pos = id >> 2, q = id & 3;
+    aoff[it] = -1;
+    if (pos < kBHalo) {
+      const int hy = y0 - 1 + pos / (kBT + 2), hx = x0 - 1 + pos % (kBT + 2);
+      if (hy >= 0 && hy < H && hx >= 0 && hx < W) aoff[it] = (hy * W + hx) * Cin + q * 8;
+    }
+  }
+  auto fetch_a = [&](int cc) {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      ra[it] = cs_u32x4{0u, 0u, 0u, 0u};
+      if (aoff[it] >= 0) ra[it] = *reinterpret_cast<const cs_u32x4*>(xe + aoff[it] + cc * 32);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int id = tid + 256 * it;
+      if ((id >> 2) < kBHalo) *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = ra[it];
+    }
+  };
+  // filter slab of step s = (chunk cc, tap t): rows n = tid >> 2 (+64), quarter q = tid & 3
+  const uint16_t* wrow = wb + static_cast<size_t>(tid >> 2) * Cin + (tid & 3) * 8;
+  auto fetch_b = [&](cs_u32x4 (&r)[2], int cc, int t) {
+    const uint16_t* p = wrow + t * tap_stride + cc * 32;
+    r[0] = *reinterpret_cast<const cs_u32x4*>(p);
+    r[1] = *reinterpret_cast<const cs_u32x4*>(p + static_cast<size_t>(64) * Cin);
+  };
+  auto store_b = [&](const cs_u32x4 (&r)[2], int buf) {
+    unsigned char* d = Bs + buf * kBB + (tid >> 2) * kBStride + (tid & 3) * 16;
+    *reinterpret_cast<cs_u32x4*>(d) = r[0];
+    *reinterpret_cast<cs_u32x4*>(d + 64 * kBStride) = r[1];
+  };
+
+  cs_v16f acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+  // this lane's A rows: M-tile mt of wave-row wm covers tile rows 8*wm + 2*mt + (li >> 4), column li & 15
+  const int arow = 8 * wm + (li >> 4), acol = li & 15;
+  const int S = nC * 9;                                   // steps; S >= 9
+
+  // one step: fragments of (chunk cc, tap t) from A[cc & 1] / B[par]; `rload` receives the slab of step s + 2, `rstore`
+  // (the slab of step s + 1, requested one step ago) is parked in B[par ^ 1] before the barrier
+  auto step = [&](int s, int cc, int t, int par, cs_u32x4 (&rload)[2], const cs_u32x4 (&rstore)[2]) {
+    const unsigned char* Ab = As + (cc & 1) * kBA + (((arow + t / 3) * (kBT + 2)) + acol + t % 3) * kBStride + kg * 16;
+    const unsigned char* Bb = Bs + par * kBB + (wn * 64 + li) * kBStride + kg * 16;
+    cs_u32x4 af[4], bf2[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const cs_u32x4*>(Ab + mt * 2 * (kBT + 2) * kBStride);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bf2[nt] = *reinterpret_cast<const cs_u32x4*>(Bb + nt * 32 * kBStride);
+    // requests for later steps go out behind this step's first fragment reads
+    if (s + 2 < S) {
+      const int t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2;
+      fetch_b(rload, t + 2 >= 9 ? cc + 1 : cc, t2);
+    }
+    if (t == 7 && cc + 1 < nC) fetch_a(cc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      cs_u32x4 an[4], bn[2];
+      if (ks == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) an[mt] = *reinterpret_cast<const cs_u32x4*>(Ab + mt * 2 * (kBT + 2) * kBStride + 32);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bn[nt] = *reinterpret_cast<const cs_u32x4*>(Bb + nt * 32 * kBStride + 32);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(af[mt], bf2[nt], acc[mt][nt]);
+      if (ks == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = an[mt];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bf2[nt] = bn[nt];
+      }
+    }
+    if (s + 1 < S) store_b(rstore, par ^ 1);
+    if (t == 8 && cc + 1 < nC) store_a((cc + 1) & 1);
+    __syncthreads();
+  };
+
+  // prologue: halo chunk 0 and slab 0 in LDS, slab 1 in rb1 (parked by step 0), slab 2 requested by step 0 into rb0
+  fetch_a(0); fetch_b(rb0, 0, 0); fetch_b(rb1, 0, 1);
+  store_a(0); store_b(rb0, 0);
+  __syncthreads();
+  {
+    int cc = 0, t = 0;
+#pragma unroll 1
+    for (int s = 0; s < S; s += 2) {
+      step(s, cc, t, 0, rb0, rb1);                          // even step: reads B[0]; rb1 -> B[1]; slab s+2 -> rb0
+      if (++t == 9) { t = 0; ++cc; }
+      if (s + 1 < S) {
+        step(s + 1, cc, t, 1, rb1, rb0);                    // odd step: reads B[1]; rb0 -> B[0]; slab s+3 -> rb1
+        if (++t == 9) { t = 0; ++cc; }
+      }
+    }
+  }
+
+  // epilogue: two halves of 128 pixels through an LDS slab [128 px][128 ch] (272-byte pixel stride) -> whole-row stores
+  // D layout of a 32x32 tile: column li = channel, rows (r & 3) + 8 * (r >> 2) + 4 * kg = pixel inside the M-tile
+  float bb[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bb[nt] = bias ? bias[cg * 128 + wn * 64 + nt * 32 + li] : 0.0f;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;            // pixel inside this wave-row's 128
+            float v = acc[mt][nt][r] + bb[nt];
+            if (relu) v = fmaxf(v, 0.0f);
+            *reinterpret_cast<uint16_t*>(bs + m * 272 + (wn * 64 + nt * 32 + li) * 2) = static_cast<uint16_t>(cs_bits<T>(v));
+          }
+    }
+    __syncthreads();
+    for (int id = tid; id < 128 * 16; id += 256) {
+      const int m = id >> 4, c = id & 15;
+      const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
+      if (gy < H && gx < W)
+        *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * Cout + cg * 128 + c * 8) =
+            *reinterpret_cast<const cs_u32x4*>(bs + m * 272 + c * 16);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
@@ -372,6 +563,34 @@ extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* 
     if (dtype == PVO_F16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_half, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
     else if (dtype == PVO_BF16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_bf16, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
     else return PVO_EUNSUPPORTED;
+  }
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
+                           int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream) {
+  if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
+  if (Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 127)) return PVO_EUNSUPPORTED;
+  if (E == 0 || H == 0 || W == 0) return PVO_OK;
+  if (!x || !w_taps || !y || E > 65535) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_taps) | reinterpret_cast<uintptr_t>(y)) & 15) return PVO_EINVAL;
+  if (static_cast<long long>(H) * W * Cin > 0x7fffffffLL) return PVO_EUNSUPPORTED;
+  hipStream_t st = pvo_stream(stream);
+  const int ntx = (W + kBT - 1) / kBT;
+  const size_t lds = 2 * kBA + 2 * kBB;                    // 72320 B (>= the 34816-byte output slab)
+  dim3 grid(ntx * (Cout / 128), (H + kBT - 1) / kBT, E);
+  const uint16_t* xp = static_cast<const uint16_t*>(x);
+  const uint16_t* wp = static_cast<const uint16_t*>(w_taps);
+  uint16_t* yp = static_cast<uint16_t*>(y);
+  if (dtype == PVO_F16) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu);
+  } else if (dtype == PVO_BF16) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu);
+  } else {
+    return PVO_EUNSUPPORTED;
   }
   PVO_CHECK_LAUNCH();
   return PVO_OK;

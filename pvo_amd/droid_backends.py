@@ -633,6 +633,29 @@ def conv7x7_c8(x, w_taps, bias):
     return y
 
 
+def conv3x3_weights(weight, dtype):
+    """[Cout,Cin,3,3] conv filter -> the [9,Cout,Cin] tap-major layout pvo_conv3x3 reads"""
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or ci % 32 or co % 128:
+        raise PvoHipError("conv3x3: filter must be [Cout,Cin,3,3] with Cin % 32 == 0 and Cout % 128 == 0")
+    return weight.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(dtype).contiguous()
+
+
+def conv3x3(x, w_taps, bias=None, relu=False):
+    """act(conv3x3(x) + bias): x [E,Cin,H,W] channels-last 16-bit -> [E,Cout,H,W] channels-last (wide layers)"""
+    dev = _dev(x, w_taps)
+    E, Cin, H, W = x.shape
+    _cl(x, "x", Cin)
+    if w_taps.dim() != 3 or w_taps.shape[0] != 9 or w_taps.shape[2] != Cin or w_taps.dtype != x.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("conv3x3: w_taps must be the [9,Cout,Cin] tensor of conv3x3_weights in x's dtype")
+    Cout = w_taps.shape[1]
+    y = torch.empty(E, H, W, Cout, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_conv3x3(_ptr(x), _ptr(w_taps), _bias(bias, Cout, "bias"), _ptr(y), E, H, W, Cin, Cout,
+                                      1 if relu else 0, _dtype_code(x, "x"), _stream(dev)), "conv3x3")
+    return y
+
+
 def conv3x3_c128_weights(weight, dtype):
     """[Cout,128,3,3] conv filter -> the [9,Cout,128] tap-major layout pvo_conv3x3_c128 reads"""
     co, ci, kh, kw = weight.shape

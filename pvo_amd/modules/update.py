@@ -62,6 +62,17 @@ def scatter_mean(src, index, dim, dim_size=None):
 import os as _os
 _HIP_CONV3 = _os.environ.get("PVO_HIP_CONV3") == "1"
 _AGG_HIP_CONV = _os.environ.get("PVO_AGG_HIP_CONV", "1") == "1"
+_HIP_WIDE_CONV = _os.environ.get("PVO_HIP_WIDE_CONV", "1") == "1"     # GRU gate/candidate + heads' first stage on pvo_conv3x3
+
+
+def _taps_wide(owner, key, weight_fn, dt):
+    """[9,Cout,Cin] tap-major filter for pvo_conv3x3, cached on `owner` under `key`; weight_fn() returns [Cout,Cin,3,3]"""
+    cache = owner.__dict__.setdefault("_taps_wide_cache", {})
+    hit = cache.get(key)
+    if hit is None or hit.dtype != dt:
+        from .. import droid_backends as db
+        hit = cache[key] = db.conv3x3_weights(weight_fn(), dt)
+    return hit
 
 
 def _w16(owner, conv, dt):
@@ -93,6 +104,7 @@ class ConvGRU(nn.Module):
         self._fb = None
         self._ws = None
         self._P_key = None
+        self.__dict__.pop("_taps_wide_cache", None)
         return super().train(mode)
 
     def _fused_zr(self):
@@ -138,9 +150,10 @@ class ConvGRU(nn.Module):
         with torch.autocast("cuda", enabled=False):
             g = torch.addmm(fb["g"], part.view(E, K * c), fb["wg_t_tiled"])   # context of z | r | q (+ conv biases), fp32
         db.gru_assemble(net, None, corr_feat, flow_feat, X, corr_bias, flow_bias)   # X = [net | relu(cf) | relu(ff)]
-        zr = F.conv2d(X, ws["zr_dyn"], None, padding=1)
+        wide = _HIP_WIDE_CONV and X.shape[1] % 32 == 0
+        zr = db.conv3x3(X, _taps_wide(self, "zr", lambda: ws["zr_dyn"], dt)) if wide else F.conv2d(X, ws["zr_dyn"], None, padding=1)
         db.gru_gate(zr, g, net, Z, X, P_zr)                                 # X[:, :128] <- r * net
-        q = F.conv2d(X, ws["q_dyn"], None, padding=1)
+        q = db.conv3x3(X, _taps_wide(self, "q", lambda: ws["q_dyn"], dt)) if wide else F.conv2d(X, ws["q_dyn"], None, padding=1)
         return db.gru_out(q, g, Z, net, P_q)
 
     def _split_weights(self, dt):
@@ -272,11 +285,20 @@ class DynamicUpdateModule(nn.Module):
         self._b32 = None
         self._w2r = None
         self.fused_gru = True          # use pvo_amd/csrc/gru_fused.hip on the inference path
+        # derived inference tensors (re-laid-out filters, fp32 biases, ...) are dropped whenever weights are (re)loaded
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_derived())
+
+    def _drop_derived(self):
+        for m in self.modules():
+            for k in ("_taps_wide_cache", "_w16_cache", "_fb32", "_ftaps", "_enc0", "_taps3_cache", "_taps2"):
+                m.__dict__.pop(k, None)
+        self.train(self.training)
 
     def train(self, mode=True):
         self._fused_heads = None
         self._b32 = None
         self._w2r = None
+        self.__dict__.pop("_taps_wide_cache", None)
         return super().train(mode)
 
     def _bias32(self):
@@ -345,7 +367,10 @@ class DynamicUpdateModule(nn.Module):
             from .. import droid_backends as db
             # first stage 128 -> 4*128 as one bias-free MIOpen conv; bias, ReLU and the four 128 -> 2 second-stage
             # convolutions happen in ONE hand-written kernel (a 512 -> 8 conv has no efficient GEMM shape)
-            x = F.conv2d(net, f[0].to(net.dtype), None, padding=1).contiguous(memory_format=torch.channels_last)
+            if _HIP_WIDE_CONV:
+                x = db.conv3x3(net, _taps_wide(self, "heads1", lambda: f[0], net.dtype))
+            else:
+                x = F.conv2d(net, f[0].to(net.dtype), None, padding=1).contiguous(memory_format=torch.channels_last)
             b32 = self._bias32()
             y = db.heads_out(x, b32["h1"], self._heads_w2(net.dtype), b32["h2"])
             self._last_heads = y                       # [E,8,H,W] channels-last: delta | delta_dy | weight | delta_mask
