@@ -196,6 +196,18 @@ int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void*
  * bias f32 [Cout] or NULL; relu != 0 applies ReLU. */
 int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
                 int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream);
+/* The ConvGRU's two large convolutions with the gate arithmetic as their epilogue (modules/gru.py:26-31); the 256 gate
+ * pre-activations and the 128 candidate pre-activations never reach HBM.
+ *   pvo_gru_conv_gates:     Z  = sigmoid(conv3x3(X, w)[:, :128] + g[e, 0:128]   + P_zr[:, :128])
+ *                           RN = sigmoid(conv3x3(X, w)[:, 128:] + g[e, 128:256] + P_zr[:, 128:]) * net
+ *   pvo_gru_conv_candidate: net_out = (1 - Z) * net + Z * tanh(conv3x3([RN | X[:, 128:]], w) + g[e, 256:384] + P_q)
+ * X [E,H,W,Cin] (Cin = 320: [net | corr features | flow features]; the candidate reads its first 128 channels from RN
+ * instead), w_taps [9][256 or 128][Cin], g f32 [E,384], P_zr [E,H,W,256], P_q / net / Z / RN / net_out [E,H,W,128]. */
+int pvo_gru_conv_gates(const void* X, const void* w_taps, const float* g, const void* P_zr, const void* net,
+                       void* Z, void* RN, int E, int H, int W, int Cin, int dtype, void* stream);
+int pvo_gru_conv_candidate(const void* X, const void* RN, const void* w_taps, const float* g, const void* P_q,
+                           const void* Z, const void* net, void* net_out,
+                           int E, int H, int W, int Cin, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                      int K, int HW, int C, int dtype, void* stream);

@@ -33,6 +33,23 @@ template <> __device__ __forceinline__ uint32_t cs_bits<pvo_half>(float x) {
 }
 template <> __device__ __forceinline__ uint32_t cs_bits<pvo_bf16>(float x) { return pvo_f32_to_bf16(x); }
 
+template <typename T> __device__ __forceinline__ float cs_val(uint32_t b);
+template <> __device__ __forceinline__ float cs_val<pvo_half>(uint32_t b) {
+  union { uint16_t u; _Float16 h; } c; c.u = static_cast<uint16_t>(b); return static_cast<float>(c.h);
+}
+template <> __device__ __forceinline__ float cs_val<pvo_bf16>(uint32_t b) { return pvo_bf16_to_f32(static_cast<uint16_t>(b)); }
+template <typename T> __device__ __forceinline__ void cs_unpack8(cs_u32x4 v, float f[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[2 * k] = cs_val<T>(w[k] & 0xffffu); f[2 * k + 1] = cs_val<T>(w[k] >> 16); }
+}
+template <typename T> __device__ __forceinline__ cs_u32x4 cs_pack8(const float f[8]) {
+  cs_u32x4 v;
+  v.x = cs_bits<T>(f[0]) | (cs_bits<T>(f[1]) << 16); v.y = cs_bits<T>(f[2]) | (cs_bits<T>(f[3]) << 16);
+  v.z = cs_bits<T>(f[4]) | (cs_bits<T>(f[5]) << 16); v.w = cs_bits<T>(f[6]) | (cs_bits<T>(f[7]) << 16);
+  return v;
+}
+
 constexpr int kTH = 8, kTW = 16, kR = 3;
 constexpr int kTH7 = 16;                                      // the 7x7 kernel's tile is 16 rows high: weight fragments are
                                                               // fetched once per 256 pixels (they were 3x the output in L2 reads)
@@ -326,6 +343,22 @@ template <> __device__ __forceinline__ cs_v16f cs_mfma32<pvo_bf16>(cs_u32x4 a, c
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cs_v8b, a), __builtin_bit_cast(cs_v8b, b), c, 0, 0, 0);
 }
 
+// Optional fused ConvGRU epilogues (VO_Module/droid_slam/modules/gru.py:26-31) and a split input:
+//   mode 1 (gates, Cout = 256): channel group 0 -> y  = Z  = sigmoid(acc + g[e, c] + P[row, c])                [rows,128]
+//                               channel group 1 -> y2 = RN = sigmoid(acc + g[e,128+c] + P[row,128+c]) * net    [rows,128]
+//   mode 2 (candidate, Cout = 128):               y  = (1 - Z) * net + Z * tanh(acc + g[e,256+c] + P[row, c])  [rows,128]
+//   x2: the first x2_chunks 32-channel chunks of the input come from x2 (pixel stride x2_stride) instead of x - the
+//       candidate convolution reads [RN | X[:, 128:]] without RN ever being copied into X.
+struct BigEpi {
+  int mode;
+  const float* g;            // [E,384] f32: context of z | r | q (biases folded in)
+  const uint16_t* P;         // precomputed static-input term, [rows,256] (mode 1) or [rows,128] (mode 2)
+  const uint16_t* net;       // [rows,128]
+  const uint16_t* Z;         // [rows,128] (mode 2)
+  uint16_t* y2;              // [rows,128] (mode 1)
+  const uint16_t* x2; int x2_chunks; int x2_stride;
+};
+
 constexpr int kBT = 16;                                   // 16 x 16 pixel tile
 constexpr int kBHalo = (kBT + 2) * (kBT + 2);             // 324 halo positions
 constexpr int kBStride = 80;                              // bytes per halo position / filter row of a 32-channel chunk
@@ -334,7 +367,7 @@ constexpr int kBA = kBHalo * kBStride, kBB = 128 * kBStride;   // 25920 + 10240 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
-                                                          int H, int W, int Cin, int Cout, int relu) {
+                                                          int H, int W, int Cin, int Cout, int relu, BigEpi ep) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bs[];      // A[2] | B[2]; later the output slab
   unsigned char* As = bs;
   unsigned char* Bs = bs + 2 * kBA;
@@ -355,22 +388,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   // one-step distance the wave sat ~560 cycles per step in s_waitcnt vmcnt (clock64 stamps), L2 latency under load
   // being longer than one step's 16 MFMAs.
   cs_u32x4 ra[6], rb0[2], rb1[2];
-  int aoff[6];                                            // element offset of this thread's halo pieces inside the image, -1 = zero
+  int apix[6];                                            // pixel index of this thread's halo pieces inside the image, -1 = zero
 #pragma unroll
   for (int it = 0; it < 6; ++it) {
     const int id = tid + 256 * it;                        // piece = (position, 16-byte quarter of the 64-byte chunk row)
-    const int pos = id >> 2, q = id & 3;
-    aoff[it] = -1;
+    const int pos = id >> 2;
+    apix[it] = -1;
     if (pos < kBHalo) {
       const int hy = y0 - 1 + pos / (kBT + 2), hx = x0 - 1 + pos % (kBT + 2);
-      if (hy >= 0 && hy < H && hx >= 0 && hx < W) aoff[it] = (hy * W + hx) * Cin + q * 8;
+      if (hy >= 0 && hy < H && hx >= 0 && hx < W) apix[it] = hy * W + hx;
     }
   }
+  const uint16_t* x2e = ep.x2 ? ep.x2 + static_cast<size_t>(e) * H * W * ep.x2_stride : nullptr;
   auto fetch_a = [&](int cc) {
+    const bool from2 = x2e != nullptr && cc < ep.x2_chunks;                  // uniform
+    const uint16_t* src = from2 ? x2e : xe;
+    const int stride = from2 ? ep.x2_stride : Cin;
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
       ra[it] = cs_u32x4{0u, 0u, 0u, 0u};
-      if (aoff[it] >= 0) ra[it] = *reinterpret_cast<const cs_u32x4*>(xe + aoff[it] + cc * 32);
+      if (apix[it] >= 0) ra[it] = *reinterpret_cast<const cs_u32x4*>(src + static_cast<size_t>(apix[it]) * stride + cc * 32 + ((tid + 256 * it) & 3) * 8);
     }
   };
   auto store_a = [&](int buf) {
@@ -463,6 +500,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
   }
 
+  if (ep.mode != 0) {
+    // fused ConvGRU epilogue: pre-activations cross the workgroup through an fp32 slab [128 px][128 ch] (528-byte pixel
+    // stride, 67.6 KB of the 72 KB), then every thread finishes 8 channels of a pixel with coalesced 16-byte accesses
+    float* slab = reinterpret_cast<float*>(bs);
+    const uint16_t* gate_p = ep.P;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if (wm == half) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+              slab[m * 132 + wn * 64 + nt * 32 + li] = acc[mt][nt][r];
+            }
+      }
+      __syncthreads();
+      for (int id = tid; id < 128 * 16; id += 256) {
+        const int m = id >> 4, c = id & 15;
+        const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
+        if (gy < H && gx < W) {
+          const size_t row = (static_cast<size_t>(e) * H + gy) * W + gx;
+          float a[8], gg[8], pp[8], nn[8], o[8];
+          const float4 a0 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8), a1 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8 + 4);
+          a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+          const int goff = ep.mode == 1 ? cg * 128 : 256;
+          const float* gp = ep.g + static_cast<size_t>(e) * 384 + goff + c * 8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) gg[k] = gp[k];
+          const int pstride = ep.mode == 1 ? 256 : 128;
+          cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(gate_p + row * pstride + (ep.mode == 1 ? cg * 128 : 0) + c * 8), pp);
+          cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(ep.net + row * 128 + c * 8), nn);
+          if (ep.mode == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float sg = 1.0f / (1.0f + __expf(-(a[k] + gg[k] + pp[k])));
+              o[k] = cg == 0 ? sg : sg * nn[k];
+            }
+            uint16_t* dst = cg == 0 ? y : ep.y2;
+            *reinterpret_cast<cs_u32x4*>(dst + row * 128 + c * 8) = cs_pack8<T>(o);
+          } else {
+            float zz[8];
+            cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(ep.Z + row * 128 + c * 8), zz);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (1.0f - zz[k]) * nn[k] + zz[k] * tanhf(a[k] + gg[k] + pp[k]);
+            *reinterpret_cast<cs_u32x4*>(y + row * 128 + c * 8) = cs_pack8<T>(o);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   // epilogue: two halves of 128 pixels through an LDS slab [128 px][128 ch] (272-byte pixel stride) -> whole-row stores
   // D layout of a 32x32 tile: column li = channel, rows (r & 3) + 8 * (r >> 2) + 4 * kg = pixel inside the M-tile
   float bb[2];
@@ -568,8 +660,8 @@ extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* 
   return PVO_OK;
 }
 
-extern "C" int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
-                           int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream) {
+static int launch_big(const void* x, const void* w_taps, const float* bias, void* y,
+                      int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream, const BigEpi& ep) {
   if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
   if (Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 127)) return PVO_EUNSUPPORTED;
   if (E == 0 || H == 0 || W == 0) return PVO_OK;
@@ -578,20 +670,47 @@ extern "C" int pvo_conv3x3(const void* x, const void* w_taps, const float* bias,
   if (static_cast<long long>(H) * W * Cin > 0x7fffffffLL) return PVO_EUNSUPPORTED;
   hipStream_t st = pvo_stream(stream);
   const int ntx = (W + kBT - 1) / kBT;
-  const size_t lds = 2 * kBA + 2 * kBB;                    // 72320 B (>= the 34816-byte output slab)
+  const size_t lds = 2 * kBA + 2 * kBB;                    // 72320 B (>= the output slabs)
   dim3 grid(ntx * (Cout / 128), (H + kBT - 1) / kBT, E);
   const uint16_t* xp = static_cast<const uint16_t*>(x);
   const uint16_t* wp = static_cast<const uint16_t*>(w_taps);
   uint16_t* yp = static_cast<uint16_t*>(y);
   if (dtype == PVO_F16) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu);
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ep);
   } else if (dtype == PVO_BF16) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu);
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ep);
   } else {
     return PVO_EUNSUPPORTED;
   }
   PVO_CHECK_LAUNCH();
   return PVO_OK;
+}
+
+extern "C" int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
+                           int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream) {
+  return launch_big(x, w_taps, bias, y, E, H, W, Cin, Cout, relu, dtype, stream, BigEpi{});
+}
+
+extern "C" int pvo_gru_conv_gates(const void* X, const void* w_taps, const float* g, const void* P_zr, const void* net,
+                                  void* Z, void* RN, int E, int H, int W, int Cin, int dtype, void* stream) {
+  if (!g || !P_zr || !net || !RN) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(P_zr) | reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(RN)) & 15) return PVO_EINVAL;
+  BigEpi ep{};
+  ep.mode = 1; ep.g = g; ep.P = static_cast<const uint16_t*>(P_zr); ep.net = static_cast<const uint16_t*>(net);
+  ep.y2 = static_cast<uint16_t*>(RN);
+  return launch_big(X, w_taps, nullptr, Z, E, H, W, Cin, 256, 0, dtype, stream, ep);
+}
+
+extern "C" int pvo_gru_conv_candidate(const void* X, const void* RN, const void* w_taps, const float* g, const void* P_q,
+                                      const void* Z, const void* net, void* net_out,
+                                      int E, int H, int W, int Cin, int dtype, void* stream) {
+  if (!g || !P_q || !net || !Z || !RN) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(P_q) | reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(RN)) & 15) return PVO_EINVAL;
+  BigEpi ep{};
+  ep.mode = 2; ep.g = g; ep.P = static_cast<const uint16_t*>(P_q); ep.net = static_cast<const uint16_t*>(net);
+  ep.Z = static_cast<const uint16_t*>(Z);
+  ep.x2 = static_cast<const uint16_t*>(RN); ep.x2_chunks = 4; ep.x2_stride = 128;
+  return launch_big(X, w_taps, nullptr, net_out, E, H, W, Cin, 128, 0, dtype, stream, ep);
 }

@@ -656,6 +656,38 @@ def conv3x3(x, w_taps, bias=None, relu=False):
     return y
 
 
+def gru_conv_gates(X, w_taps, g, P_zr, net):
+    """gate convolution + sigmoid gates in one kernel -> (Z, RN), each [E,128,H,W] channels-last.
+    X [E,Cin,H,W] = [net | corr | flow], w_taps [9,256,Cin], g [E,384] f32, P_zr [E,256,H,W], net [E,128,H,W]."""
+    E, Cin, H, W = X.shape
+    _cl(X, "X", Cin); _cl(P_zr, "P_zr", 256); _cl(net, "net", 128)
+    dev = _dev(X, w_taps, g, P_zr, net)
+    _f32(g, "g"); _contig(g, "g")
+    if tuple(w_taps.shape) != (9, 256, Cin) or w_taps.dtype != X.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("gru_conv_gates: w_taps must be [9,256,Cin] in X's dtype")
+    Z = torch.empty(E, H, W, 128, dtype=X.dtype, device=dev).permute(0, 3, 1, 2)
+    RN = torch.empty(E, H, W, 128, dtype=X.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_conv_gates(_ptr(X), _ptr(w_taps), _ptr(g), _ptr(P_zr), _ptr(net), _ptr(Z), _ptr(RN),
+                                             E, H, W, Cin, _dtype_code(X, "X"), _stream(dev)), "gru_conv_gates")
+    return Z, RN
+
+
+def gru_conv_candidate(X, RN, w_taps, g, P_q, Z, net):
+    """candidate convolution over [RN | X[:, 128:]] + the GRU state update in one kernel -> new hidden state"""
+    E, Cin, H, W = X.shape
+    _cl(X, "X", Cin); _cl(RN, "RN", 128); _cl(P_q, "P_q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
+    dev = _dev(X, RN, w_taps, g, P_q, Z, net)
+    _f32(g, "g"); _contig(g, "g")
+    if tuple(w_taps.shape) != (9, 128, Cin) or w_taps.dtype != X.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("gru_conv_candidate: w_taps must be [9,128,Cin] in X's dtype")
+    out = torch.empty(E, H, W, 128, dtype=X.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_conv_candidate(_ptr(X), _ptr(RN), _ptr(w_taps), _ptr(g), _ptr(P_q), _ptr(Z), _ptr(net),
+                                                 _ptr(out), E, H, W, Cin, _dtype_code(X, "X"), _stream(dev)), "gru_conv_candidate")
+    return out
+
+
 def conv3x3_c128_weights(weight, dtype):
     """[Cout,128,3,3] conv filter -> the [9,Cout,128] tap-major layout pvo_conv3x3_c128 reads"""
     co, ci, kh, kw = weight.shape

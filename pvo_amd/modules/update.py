@@ -62,6 +62,7 @@ def scatter_mean(src, index, dim, dim_size=None):
 import os as _os
 _HIP_CONV3 = _os.environ.get("PVO_HIP_CONV3") == "1"
 _AGG_HIP_CONV = _os.environ.get("PVO_AGG_HIP_CONV", "1") == "1"
+_FUSED_GRU_EPILOGUE = _os.environ.get("PVO_FUSED_GRU_EPILOGUE", "1") == "1"
 _HIP_WIDE_CONV = _os.environ.get("PVO_HIP_WIDE_CONV", "1") == "1"     # GRU gate/candidate + heads' first stage on pvo_conv3x3
 
 
@@ -151,6 +152,11 @@ class ConvGRU(nn.Module):
             g = torch.addmm(fb["g"], part.view(E, K * c), fb["wg_t_tiled"])   # context of z | r | q (+ conv biases), fp32
         db.gru_assemble(net, None, corr_feat, flow_feat, X, corr_bias, flow_bias)   # X = [net | relu(cf) | relu(ff)]
         wide = _HIP_WIDE_CONV and X.shape[1] % 32 == 0
+        if wide and _FUSED_GRU_EPILOGUE:
+            # both large convolutions with the gate arithmetic as their epilogue: zr and q never reach HBM, r*net goes to
+            # its own tensor (the candidate kernel reads [r*net | X[:, 128:]]), two element-wise kernels disappear
+            Zg, RN = db.gru_conv_gates(X, _taps_wide(self, "zr", lambda: ws["zr_dyn"], dt), g, P_zr, net)
+            return db.gru_conv_candidate(X, RN, _taps_wide(self, "q", lambda: ws["q_dyn"], dt), g, P_q, Zg, net)
         zr = db.conv3x3(X, _taps_wide(self, "zr", lambda: ws["zr_dyn"], dt)) if wide else F.conv2d(X, ws["zr_dyn"], None, padding=1)
         db.gru_gate(zr, g, net, Z, X, P_zr)                                 # X[:, :128] <- r * net
         q = db.conv3x3(X, _taps_wide(self, "q", lambda: ws["q_dyn"], dt)) if wide else F.conv2d(X, ws["q_dyn"], None, padding=1)
