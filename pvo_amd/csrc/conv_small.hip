@@ -528,9 +528,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
           const float4 a0 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8), a1 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8 + 4);
           a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
           const int goff = ep.mode == 1 ? cg * 128 : 256;
-          const float* gp = ep.g + static_cast<size_t>(e) * 384 + goff + c * 8;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) gg[k] = gp[k];
+          const float* gp = ep.g + static_cast<size_t>(e) * 384 + goff + c * 8;      // 32-byte aligned
+          const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+          gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
           const int pstride = ep.mode == 1 ? 256 : 128;
           cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(gate_p + row * pstride + (ep.mode == 1 ? cg * 128 : 0) + c * 8), pp);
           cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(ep.net + row * 128 + c * 8), nn);
