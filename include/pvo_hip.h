@@ -208,6 +208,15 @@ int pvo_gru_conv_gates(const void* X, const void* w_taps, const float* g, const 
 int pvo_gru_conv_candidate(const void* X, const void* RN, const void* w_taps, const float* g, const void* P_q,
                            const void* Z, const void* net, void* net_out,
                            int E, int H, int W, int Cin, int dtype, void* stream);
+/* The same two kernels reading the GRU input as three tensors - net (or RN) [E,H,W,128], cf [E,H,W,128], ff [E,H,W,64],
+ * the latter two bias-free convolution outputs that are mapped through relu(v + bias) while they are staged - so that the
+ * concatenated [E,H,W,320] input is never assembled.  w_taps [9][256 | 128][320]. */
+int pvo_gru_gates(const void* net, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
+                  const void* w_taps, const float* g, const void* P_zr, void* Z, void* RN,
+                  int E, int H, int W, int dtype, void* stream);
+int pvo_gru_candidate(const void* RN, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
+                      const void* w_taps, const float* g, const void* P_q, const void* Z, const void* net,
+                      void* net_out, int E, int H, int W, int dtype, void* stream);
 int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                      int K, int HW, int C, int dtype, void* stream);

@@ -27,6 +27,8 @@ SIGNATURES = {
     "pvo_eta_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_float, _i, _vp]),
     "pvo_gru_glo_chunks": (_i, [_i]),
     "pvo_gru_glo_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "pvo_gru_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_gru_candidate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_conv_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pvo_gru_conv_candidate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -357,6 +357,11 @@ struct BigEpi {
   const uint16_t* Z;         // [rows,128] (mode 2)
   uint16_t* y2;              // [rows,128] (mode 1)
   const uint16_t* x2; int x2_chunks; int x2_stride;
+  // segmented input (nseg > 0 replaces x / x2): the input channels are the concatenation of up to three tensors, each
+  // with its own pixel stride; a segment with a bias is mapped through relu(v + bias[c]) while it is staged - so the
+  // ConvGRU reads [net | relu(cf + b) | relu(ff + b)] straight from the three tensors and no [E,H,W,320] copy is assembled
+  int nseg;
+  const uint16_t* seg_p[3]; int seg_stride[3]; int seg_chunks[3]; const float* seg_bias[3];
 };
 
 constexpr int kBT = 16;                                   // 16 x 16 pixel tile
@@ -400,21 +405,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
   }
   const uint16_t* x2e = ep.x2 ? ep.x2 + static_cast<size_t>(e) * H * W * ep.x2_stride : nullptr;
+  const size_t img = static_cast<size_t>(e) * H * W;
+  float4 sb0 = {0.f, 0.f, 0.f, 0.f}, sb1 = {0.f, 0.f, 0.f, 0.f};      // this thread's 8 bias values of the chunk in flight
+  bool a_bias = false;                                              // (uniform) the chunk in flight wants relu(v + bias)
   auto fetch_a = [&](int cc) {
-    const bool from2 = x2e != nullptr && cc < ep.x2_chunks;                  // uniform
-    const uint16_t* src = from2 ? x2e : xe;
-    const int stride = from2 ? ep.x2_stride : Cin;
+    const uint16_t* src; int stride; int coff = cc * 32;
+    a_bias = false;
+    if (ep.nseg > 0) {                                              // uniform walk over at most three segments
+      int sgi = 0, c0 = cc;
+      while (sgi + 1 < ep.nseg && c0 >= ep.seg_chunks[sgi]) { c0 -= ep.seg_chunks[sgi]; ++sgi; }
+      stride = ep.seg_stride[sgi];
+      src = ep.seg_p[sgi] + img * stride;
+      coff = c0 * 32;
+      if (ep.seg_bias[sgi]) {
+        a_bias = true;
+        const float* bp = ep.seg_bias[sgi] + coff + (tid & 3) * 8;
+        sb0 = *reinterpret_cast<const float4*>(bp); sb1 = *reinterpret_cast<const float4*>(bp + 4);
+      }
+    } else {
+      const bool from2 = x2e != nullptr && cc < ep.x2_chunks;       // uniform
+      src = from2 ? x2e : xe;
+      stride = from2 ? ep.x2_stride : Cin;
+    }
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
       ra[it] = cs_u32x4{0u, 0u, 0u, 0u};
-      if (apix[it] >= 0) ra[it] = *reinterpret_cast<const cs_u32x4*>(src + static_cast<size_t>(apix[it]) * stride + cc * 32 + ((tid + 256 * it) & 3) * 8);
+      if (apix[it] >= 0) ra[it] = *reinterpret_cast<const cs_u32x4*>(src + static_cast<size_t>(apix[it]) * stride + coff + (tid & 3) * 8);
     }
   };
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
       const int id = tid + 256 * it;
-      if ((id >> 2) < kBHalo) *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = ra[it];
+      if ((id >> 2) < kBHalo) {
+        cs_u32x4 v = ra[it];
+        if (a_bias && apix[it] >= 0) {                               // zero padding stays zero: it is applied after the ReLU
+          float f[8];
+          cs_unpack8<T>(v, f);
+          f[0] = fmaxf(f[0] + sb0.x, 0.f); f[1] = fmaxf(f[1] + sb0.y, 0.f); f[2] = fmaxf(f[2] + sb0.z, 0.f); f[3] = fmaxf(f[3] + sb0.w, 0.f);
+          f[4] = fmaxf(f[4] + sb1.x, 0.f); f[5] = fmaxf(f[5] + sb1.y, 0.f); f[6] = fmaxf(f[6] + sb1.z, 0.f); f[7] = fmaxf(f[7] + sb1.w, 0.f);
+          v = cs_pack8<T>(f);
+        }
+        *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = v;
+      }
     }
   };
   // filter slab of step s = (chunk cc, tap t): rows n = tid >> 2 (+64), quarter q = tid & 3
@@ -713,4 +746,41 @@ extern "C" int pvo_gru_conv_candidate(const void* X, const void* RN, const void*
   ep.Z = static_cast<const uint16_t*>(Z);
   ep.x2 = static_cast<const uint16_t*>(RN); ep.x2_chunks = 4; ep.x2_stride = 128;
   return launch_big(X, w_taps, nullptr, net_out, E, H, W, Cin, 128, 0, dtype, stream, ep);
+}
+
+static int seg_setup(BigEpi& ep, const void* a, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias) {
+  if (!a || !cf || !ff) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(cf) | reinterpret_cast<uintptr_t>(ff)) & 15) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(cf_bias) | reinterpret_cast<uintptr_t>(ff_bias)) & 15) return PVO_EINVAL;
+  ep.nseg = 3;
+  ep.seg_p[0] = static_cast<const uint16_t*>(a);  ep.seg_stride[0] = 128; ep.seg_chunks[0] = 4; ep.seg_bias[0] = nullptr;
+  ep.seg_p[1] = static_cast<const uint16_t*>(cf); ep.seg_stride[1] = 128; ep.seg_chunks[1] = 4; ep.seg_bias[1] = cf_bias;
+  ep.seg_p[2] = static_cast<const uint16_t*>(ff); ep.seg_stride[2] = 64;  ep.seg_chunks[2] = 2; ep.seg_bias[2] = ff_bias;
+  return PVO_OK;
+}
+
+extern "C" int pvo_gru_gates(const void* net, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
+                             const void* w_taps, const float* g, const void* P_zr, void* Z, void* RN,
+                             int E, int H, int W, int dtype, void* stream) {
+  if (!g || !P_zr || !RN) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(P_zr) | reinterpret_cast<uintptr_t>(RN)) & 15) return PVO_EINVAL;
+  BigEpi ep{};
+  const int rc = seg_setup(ep, net, cf, ff, cf_bias, ff_bias);
+  if (rc != PVO_OK) return rc;
+  ep.mode = 1; ep.g = g; ep.P = static_cast<const uint16_t*>(P_zr); ep.net = static_cast<const uint16_t*>(net);
+  ep.y2 = static_cast<uint16_t*>(RN);
+  return launch_big(net, w_taps, nullptr, Z, E, H, W, 320, 256, 0, dtype, stream, ep);
+}
+
+extern "C" int pvo_gru_candidate(const void* RN, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
+                                 const void* w_taps, const float* g, const void* P_q, const void* Z, const void* net,
+                                 void* net_out, int E, int H, int W, int dtype, void* stream) {
+  if (!g || !P_q || !net || !Z) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(P_q) | reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(Z)) & 15) return PVO_EINVAL;
+  BigEpi ep{};
+  const int rc = seg_setup(ep, RN, cf, ff, cf_bias, ff_bias);
+  if (rc != PVO_OK) return rc;
+  ep.mode = 2; ep.g = g; ep.P = static_cast<const uint16_t*>(P_q); ep.net = static_cast<const uint16_t*>(net);
+  ep.Z = static_cast<const uint16_t*>(Z);
+  return launch_big(RN, w_taps, nullptr, net_out, E, H, W, 320, 128, 0, dtype, stream, ep);
 }

@@ -688,6 +688,39 @@ def gru_conv_candidate(X, RN, w_taps, g, P_q, Z, net):
     return out
 
 
+def gru_gates(net, cf, ff, cf_bias, ff_bias, w_taps, g, P_zr):
+    """gate convolution over [net | relu(cf + b) | relu(ff + b)] read from the three tensors + sigmoid gates -> (Z, RN)"""
+    _cl(net, "net", 128); _cl(cf, "cf", 128); _cl(ff, "ff", 64); _cl(P_zr, "P_zr", 256)
+    dev = _dev(net, cf, ff, w_taps, g, P_zr)
+    _f32(g, "g"); _contig(g, "g")
+    E, _, H, W = net.shape
+    if tuple(w_taps.shape) != (9, 256, 320) or w_taps.dtype != net.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("gru_gates: w_taps must be [9,256,320] in net's dtype")
+    Z = torch.empty(E, H, W, 128, dtype=net.dtype, device=dev).permute(0, 3, 1, 2)
+    RN = torch.empty(E, H, W, 128, dtype=net.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_gates(_ptr(net), _ptr(cf), _ptr(ff), _bias(cf_bias, 128, "cf_bias"), _bias(ff_bias, 64, "ff_bias"),
+                                        _ptr(w_taps), _ptr(g), _ptr(P_zr), _ptr(Z), _ptr(RN), E, H, W,
+                                        _dtype_code(net, "net"), _stream(dev)), "gru_gates")
+    return Z, RN
+
+
+def gru_candidate(RN, cf, ff, cf_bias, ff_bias, w_taps, g, P_q, Z, net):
+    """candidate convolution over [RN | relu(cf + b) | relu(ff + b)] + the GRU state update -> new hidden state"""
+    _cl(RN, "RN", 128); _cl(cf, "cf", 128); _cl(ff, "ff", 64); _cl(P_q, "P_q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
+    dev = _dev(RN, cf, ff, w_taps, g, P_q, Z, net)
+    _f32(g, "g"); _contig(g, "g")
+    E, _, H, W = net.shape
+    if tuple(w_taps.shape) != (9, 128, 320) or w_taps.dtype != net.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("gru_candidate: w_taps must be [9,128,320] in net's dtype")
+    out = torch.empty(E, H, W, 128, dtype=net.dtype, device=dev).permute(0, 3, 1, 2)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_candidate(_ptr(RN), _ptr(cf), _ptr(ff), _bias(cf_bias, 128, "cf_bias"), _bias(ff_bias, 64, "ff_bias"),
+                                            _ptr(w_taps), _ptr(g), _ptr(P_q), _ptr(Z), _ptr(net), _ptr(out), E, H, W,
+                                            _dtype_code(net, "net"), _stream(dev)), "gru_candidate")
+    return out
+
+
 def conv3x3_c128_weights(weight, dtype):
     """[Cout,128,3,3] conv filter -> the [9,Cout,128] tap-major layout pvo_conv3x3_c128 reads"""
     co, ci, kh, kw = weight.shape

@@ -63,6 +63,7 @@ import os as _os
 _HIP_CONV3 = _os.environ.get("PVO_HIP_CONV3") == "1"
 _AGG_HIP_CONV = _os.environ.get("PVO_AGG_HIP_CONV", "1") == "1"
 _FUSED_GRU_EPILOGUE = _os.environ.get("PVO_FUSED_GRU_EPILOGUE", "1") == "1"
+_GRU_NO_ASSEMBLE = _os.environ.get("PVO_GRU_NO_ASSEMBLE", "0") == "1"   # measured: 125 vs 129 keyframe updates/s with the assembled input
 _HIP_WIDE_CONV = _os.environ.get("PVO_HIP_WIDE_CONV", "1") == "1"     # GRU gate/candidate + heads' first stage on pvo_conv3x3
 
 
@@ -150,6 +151,13 @@ class ConvGRU(nn.Module):
             fb["wg_t_tiled"], fb["K"] = fb["wg_t"].repeat(K, 1).contiguous(), K
         with torch.autocast("cuda", enabled=False):
             g = torch.addmm(fb["g"], part.view(E, K * c), fb["wg_t_tiled"])   # context of z | r | q (+ conv biases), fp32
+        if _HIP_WIDE_CONV and _FUSED_GRU_EPILOGUE and _GRU_NO_ASSEMBLE and corr_bias is not None and flow_bias is not None:
+            # the two wide convolutions read net / corr features / flow features from their own tensors (bias + ReLU of the
+            # features applied while the halo is staged) and carry the gate arithmetic: no concatenated X, no zr, no q
+            Zg, RN = db.gru_gates(net, corr_feat, flow_feat, corr_bias, flow_bias,
+                                  _taps_wide(self, "zr", lambda: ws["zr_dyn"], dt), g, P_zr)
+            return db.gru_candidate(RN, corr_feat, flow_feat, corr_bias, flow_bias,
+                                    _taps_wide(self, "q", lambda: ws["q_dyn"], dt), g, P_q, Zg, net)
         db.gru_assemble(net, None, corr_feat, flow_feat, X, corr_bias, flow_bias)   # X = [net | relu(cf) | relu(ff)]
         wide = _HIP_WIDE_CONV and X.shape[1] % 32 == 0
         if wide and _FUSED_GRU_EPILOGUE:
