@@ -179,6 +179,28 @@ def cpu_baseline():
                       "parts: build %.2fs/edge lookup %.2fs upd %.2fs ba %.2fs" % (nthreads, t_build, t_lookup, t_upd, t_ba)}
 
 
+def synthetic_ate(device):
+    """The ATE half of BASELINE.json's metric, on the only sequence available here: a synthetic plane scene tracked by
+    the frontend + HIP BA with ground-truth correspondences (+ fixed noise) standing in for the learned operator (no
+    checkpoint or dataset exists in this environment).  Sim(3)-aligned translation RMSE, as test_vo.py:162-163 computes."""
+    import numpy as np
+    from pvo_amd import droid_backends as db
+    from pvo_amd.depth_video import DepthVideo
+    from pvo_amd.frontend import DroidFrontend
+    from pvo_amd.synthetic import OracleFlowOperator, PlaneScene, run_sequence
+    from pvo_amd.trajectory import ate_rmse, camera_centres
+    scene = PlaneScene(ht=24, wd=32, n_frames=14, seed=0)
+    video = DepthVideo(image_size=(scene.ht * 8, scene.wd * 8), buffer=32, device=device)
+    op = OracleFlowOperator(scene, video, lambda p, d, k, i, j: db.reproject(p, d, k, i, j)[0])
+    fe = DroidFrontend(op, video, device=device, warmup=8, keyframe_thresh=0.5, frontend_thresh=16.0, frontend_window=20,
+                       frontend_radius=2, frontend_nms=1)
+    poses, frames = run_sequence(scene, video, fe, op)
+    gt = camera_centres(scene.poses[frames].numpy())
+    return {"value": float(ate_rmse(camera_centres(poses.numpy()), gt)), "unit": "scene units",
+            "trajectory_length": float(np.linalg.norm(gt[-1] - gt[0])), "keyframes": len(frames),
+            "sequence": "synthetic plane scene, 24x32 maps, 14 frames, ground-truth correspondences + 0.05 px noise in place of the learned operator"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,6 +345,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["ate_rmse"] = synthetic_ate(device)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -22,4 +22,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(10):
     graph.update(None, None, use_inactive=True)
 pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(30)
