@@ -542,6 +542,72 @@ def gen_bookkeeping():
     print("edge_bookkeeping: edges per step %s" % [int(sn["ii"].shape[0]) for sn in snaps])
 
 
+def filler_case(seed=9):
+    """keyframe time stamps / poses and the non-keyframe stamps to fill (shared by generator and test)"""
+    from pvo_amd.geom.se3 import SE3
+    g = torch.Generator().manual_seed(seed)
+    ts = torch.tensor([0.0, 3.0, 4.0, 8.0, 9.0])
+    xi = torch.randn(5, 6, generator=g) * torch.tensor([0.3, 0.3, 0.3, 0.05, 0.05, 0.05])
+    poses = SE3.exp(torch.cumsum(xi, 0)).data
+    stamps = [0, 1, 2, 3, 5, 6.5, 8, 9, 11]                       # on keyframes, between them, after the last one
+    return ts, poses, stamps
+
+
+def gen_filler():
+    """PoseTrajectoryFiller.__fill (trajectory_filler.py:35-77) with a recording stand-in for FactorGraph and a zero
+    feature encoder: pins the keyframe bracketing, the constant-twist interpolation on se(3), the edges that connect each
+    frame to its bracketing keyframes and the six motion-only updates over [N, N+M)."""
+    import trajectory_filler as ref_tf
+    from pvo_amd.geom.se3 import SE3
+    ts, poses, stamps = filler_case()
+    N, M, ht, wd = ts.shape[0], len(stamps), 16, 24
+    rec = {"calls": []}
+
+    class Counter:
+        value = N
+
+    class Video:
+        def __setitem__(self, index, item):
+            rec["set_index"] = (index.start, index.stop)
+            rec["set_tstamp"], rec["set_poses"], rec["set_disp"], rec["set_intr"] = item[0].clone(), item[2].clone(), item[3], item[4].clone()
+            self.poses[index] = item[2]
+    v = Video()
+    v.counter = Counter()
+    v.tstamp = torch.cat([ts, torch.zeros(16)])
+    v.poses = torch.cat([poses, torch.zeros(16, 7)])
+
+    class Graph:
+        def __init__(self, video, update_op, *a, **k):
+            pass
+
+        def add_factors(self, ii, jj):
+            rec["calls"].append(("add", ii.clone(), jj.clone()))
+
+        def update(self, t0, t1, motion_only=False):
+            rec["calls"].append(("update", t0, t1, motion_only, v.counter.value))
+    ref_tf.FactorGraph = Graph
+
+    class Net:
+        cnet = None
+        update = None
+
+        @staticmethod
+        def fnet(x):
+            return torch.zeros(x.shape[0], x.shape[1], 128, ht // 8, wd // 8)
+    filler = ref_tf.PoseTrajectoryFiller(Net, v, device="cpu")
+    images = [torch.zeros(3, ht, wd) for _ in stamps]
+    intr = [torch.tensor([10.0, 10.0, 12.0, 8.0]) for _ in stamps]
+    out = filler._PoseTrajectoryFiller__fill(stamps, images, intr)
+    adds = [c for c in rec["calls"] if c[0] == "add"]
+    ups = [c for c in rec["calls"] if c[0] == "update"]
+    res = dict(init_poses=rec["set_poses"].numpy(), set_index=np.array(rec["set_index"]), set_tstamp=rec["set_tstamp"].numpy(),
+               set_intr=rec["set_intr"].numpy(), set_disp=np.float64(rec["set_disp"]), returned=out[0].data.numpy(),
+               add0_ii=adds[0][1].numpy(), add0_jj=adds[0][2].numpy(), add1_ii=adds[1][1].numpy(), add1_jj=adds[1][2].numpy(),
+               updates=np.array([[u[1], u[2], int(u[3]), u[4]] for u in ups]), counter_after=np.int64(v.counter.value))
+    np.savez_compressed(os.path.join(HERE, "trajectory_filler.npz"), **res)
+    print("trajectory_filler: %d frames, %d update calls" % (M, len(ups)))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -556,3 +622,4 @@ if __name__ == "__main__":
     gen_lowmem_glue()
     gen_proximity()
     gen_bookkeeping()
+    gen_filler()

@@ -174,3 +174,58 @@ def test_sequence_reader_and_pose_file_parser(tmp_path):
     poses = tool.read_vkitti2_poses(str(root / "15-deg-left" / "extrinsic.txt"))
     assert poses.shape == (2, 4, 4) and np.allclose(poses[1][:3, 3], [-2.0, -2.0, -3.0])
     assert tool.parse_args(["--datapath", "x"]).frontend_window == 25
+
+
+def test_trajectory_filler_matches_reference(monkeypatch):
+    """PoseTrajectoryFiller._fill against the reference's own __fill (tests/golden/gen_golden.py: gen_filler): bracketing
+    keyframes, se(3) interpolation, edges to both bracketing keyframes, six motion-only updates over the temporary slots"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from gen_golden import filler_case
+    import pvo_amd.trajectory_filler as tf
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "trajectory_filler.npz"))
+    ts, poses, stamps = filler_case()
+    N, M, ht, wd = ts.shape[0], len(stamps), 16, 24
+    rec = {"calls": []}
+
+    class Video:
+        def __setitem__(self, index, item):
+            rec["set_index"] = (index.start, index.stop)
+            rec["set_tstamp"], rec["set_poses"], rec["set_disp"], rec["set_intr"] = item[0].clone(), item[2].clone(), item[3], item[4].clone()
+            self.poses[index] = item[2]
+    v = Video()
+    v.counter = N
+    v.tstamp = torch.cat([ts, torch.zeros(16)])
+    v.poses = torch.cat([poses, torch.zeros(16, 7)])
+
+    class Graph:
+        def __init__(self, video, update_op, *a, **k):
+            pass
+
+        def add_factors(self, ii, jj):
+            rec["calls"].append(("add", torch.as_tensor(ii).clone(), torch.as_tensor(jj).clone()))
+
+        def update(self, t0, t1, motion_only=False):
+            rec["calls"].append(("update", t0, t1, motion_only, v.counter))
+    monkeypatch.setattr(tf, "FactorGraph", Graph)
+
+    class Net:
+        cnet = None
+        update = None
+
+        @staticmethod
+        def fnet(x):
+            return torch.zeros(x.shape[0], x.shape[1], 128, ht // 8, wd // 8)
+    filler = tf.PoseTrajectoryFiller(Net, v, device="cpu")
+    out = filler._fill(stamps, [torch.zeros(3, ht, wd) for _ in stamps], [torch.tensor([10.0, 10.0, 12.0, 8.0]) for _ in stamps])
+    assert np.allclose(rec["set_poses"].numpy(), z["init_poses"], atol=1e-5)
+    assert list(rec["set_index"]) == z["set_index"].tolist() and np.allclose(rec["set_tstamp"].numpy(), z["set_tstamp"])
+    assert np.allclose(rec["set_intr"].numpy(), z["set_intr"]) and float(rec["set_disp"]) == float(z["set_disp"])
+    adds = [c for c in rec["calls"] if c[0] == "add"]
+    ups = [c for c in rec["calls"] if c[0] == "update"]
+    assert adds[0][1].tolist() == z["add0_ii"].tolist() and adds[0][2].tolist() == z["add0_jj"].tolist()
+    assert adds[1][1].tolist() == z["add1_ii"].tolist() and adds[1][2].tolist() == z["add1_jj"].tolist()
+    assert [[u[1], u[2], int(u[3]), u[4]] for u in ups] == z["updates"].tolist()
+    assert v.counter == int(z["counter_after"]) == N
+    assert np.allclose(out[0].data.numpy(), z["returned"], atol=1e-5)
