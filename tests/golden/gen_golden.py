@@ -608,6 +608,92 @@ def gen_filler():
     print("trajectory_filler: %d frames, %d update calls" % (M, len(ups)))
 
 
+class RecordingGraph:
+    """stand-in for FactorGraph in the frontend fixture: records every call (shared by the generator and the test)"""
+    log = None
+    script = None
+
+    def __init__(self, video, update_op, device="cpu", max_factors=-1, **kw):
+        self.video = video
+        RecordingGraph.log.append(("init", max_factors))
+        self.corr = None
+        self.ii = torch.zeros(0, dtype=torch.long); self.age = torch.zeros(0, dtype=torch.long)
+        self._ii_h, self._age_h = [], []
+
+    def _set(self, ii, age):
+        self.ii, self.age = torch.tensor(ii), torch.tensor(age)
+        self._ii_h, self._age_h = list(ii), list(age)
+
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        RecordingGraph.log.append(("neigh", t0, t1, r)); self.corr = object(); self._set([0, 1, 2], [0, 0, 0])
+
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
+        RecordingGraph.log.append(("prox", t0, t1, rad, nms, round(float(beta), 6), float(thresh), bool(remove)))
+        self._set([max(t0, 0), max(t0, 0) + 1, 30], [3, 26, 1])
+
+    def rm_factors(self, mask, store=False):
+        m = [bool(x) for x in (mask.tolist() if isinstance(mask, torch.Tensor) else mask)]
+        RecordingGraph.log.append(("rm", m, bool(store)))
+
+    def rm_keyframe(self, ix):
+        RecordingGraph.log.append(("rm_keyframe", int(ix)))
+
+    def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
+        RecordingGraph.log.append(("update", t0, t1, bool(use_inactive)))
+
+
+def frontend_video(buf=16, ht=4, wd=6):
+    class Video:
+        pass
+    v = Video()
+    v.poses = torch.arange(buf).float()[:, None].repeat(1, 7).clone()
+    v.disps = torch.arange(buf).float()[:, None, None].repeat(1, ht, wd).clone() + torch.arange(wd).float() * 0.01
+    v.dirty = torch.zeros(buf, dtype=torch.bool)
+    v.tstamp = torch.arange(buf).float()
+    return v
+
+
+FRONTEND_DISTANCES = [1.0, 5.0, 0.3, 9.0]           # keyframe test outcomes of four successive updates (thresh 2.25)
+
+
+def gen_frontend():
+    """DroidFrontend.__call__ (droid_frontend.py:36-112) over an initialisation and four updates (two of which drop the
+    previous keyframe) with a recording stand-in for FactorGraph: pins the call sequence and arguments, the pose / depth
+    guesses for the next frame, the counter and dirty bookkeeping."""
+    import contextlib
+    import droid_frontend as ref_fe
+    from argparse import Namespace
+
+    class Counter:
+        value = 0
+
+    class Ready:
+        value = 0
+    v = frontend_video()
+    v.counter, v.ready, v.get_lock = Counter(), Ready(), contextlib.nullcontext
+    dist = list(FRONTEND_DISTANCES)
+    RecordingGraph.log = []
+    v.distance = lambda ii, jj, beta=0.3, bidirectional=True: (RecordingGraph.log.append(("dist", list(ii), list(jj), round(float(beta), 6), bidirectional)), torch.tensor([dist.pop(0)]))[1]
+    ref_fe.FactorGraph = RecordingGraph
+    net = Namespace(update=None)
+    args = Namespace(device="cpu", warmup=5, beta=0.6, frontend_nms=1, keyframe_thresh=2.25, frontend_window=25,
+                     frontend_thresh=12.0, frontend_radius=2)
+    fe = ref_fe.DroidFrontend(net, v, args)
+    snaps = []
+    for step in range(10):
+        if v.counter.value < 5 or fe.is_initialized:
+            v.counter.value += 1                                  # the motion filter appended a keyframe
+        fe()
+        snaps.append((v.counter.value, fe.t1, int(fe.is_initialized), v.poses[:, 0].clone(), v.disps[:, 0, 0].clone(), v.dirty.clone()))
+        if not dist and fe.is_initialized and step > 6:
+            break
+    out = dict(log=np.array([repr(x) for x in RecordingGraph.log]), counter=np.array([s_[0] for s_ in snaps]), t1=np.array([s_[1] for s_ in snaps]),
+               init=np.array([s_[2] for s_ in snaps]), poses=torch.stack([s_[3] for s_ in snaps]).numpy(),
+               disps=torch.stack([s_[4] for s_ in snaps]).numpy(), dirty=torch.stack([s_[5] for s_ in snaps]).numpy())
+    np.savez_compressed(os.path.join(HERE, "frontend_calls.npz"), **out)
+    print("frontend_calls: %d graph calls over %d frontend invocations" % (len(RecordingGraph.log), len(snaps)))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -623,3 +709,4 @@ if __name__ == "__main__":
     gen_proximity()
     gen_bookkeeping()
     gen_filler()
+    gen_frontend()

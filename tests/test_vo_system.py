@@ -229,3 +229,35 @@ def test_trajectory_filler_matches_reference(monkeypatch):
     assert [[u[1], u[2], int(u[3]), u[4]] for u in ups] == z["updates"].tolist()
     assert v.counter == int(z["counter_after"]) == N
     assert np.allclose(out[0].data.numpy(), z["returned"], atol=1e-5)
+
+
+def test_frontend_call_sequence_matches_reference(monkeypatch):
+    """DroidFrontend against the reference's own frontend driving the same recording stand-in for FactorGraph
+    (tests/golden/gen_golden.py: gen_frontend): the initialisation and four updates, two of which drop a keyframe"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import gen_golden as G
+    import pvo_amd.frontend as fe_mod
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_calls.npz"))
+    v = G.frontend_video()
+    v.counter = 0
+    dist = list(G.FRONTEND_DISTANCES)
+    G.RecordingGraph.log = []
+    v.distance = lambda ii, jj, beta=0.3, bidirectional=True: (G.RecordingGraph.log.append(("dist", list(ii), list(jj), round(float(beta), 6), bidirectional)), torch.tensor([dist.pop(0)]))[1]
+    monkeypatch.setattr(fe_mod, "FactorGraph", G.RecordingGraph)
+    fe = fe_mod.DroidFrontend(None, v, device="cpu", warmup=5, beta=0.6, frontend_nms=1, keyframe_thresh=2.25,
+                              frontend_window=25, frontend_thresh=12.0, frontend_radius=2, max_factors=48)
+    snaps = []
+    for step in range(10):
+        if v.counter < 5 or fe.is_initialized:
+            v.counter += 1
+        fe()
+        snaps.append((v.counter, fe.t1, int(fe.is_initialized), v.poses[:, 0].clone(), v.disps[:, 0, 0].clone(), v.dirty.clone()))
+        if not dist and fe.is_initialized and step > 6:
+            break
+    assert [repr(x) for x in G.RecordingGraph.log] == z["log"].tolist()
+    assert [s[0] for s in snaps] == z["counter"].tolist() and [s[1] for s in snaps] == z["t1"].tolist()
+    assert [s[2] for s in snaps] == z["init"].tolist()
+    assert np.allclose(torch.stack([s[3] for s in snaps]).numpy(), z["poses"]) and np.allclose(torch.stack([s[4] for s in snaps]).numpy(), z["disps"])
+    assert np.array_equal(torch.stack([s[5] for s in snaps]).numpy(), z["dirty"])
