@@ -694,6 +694,75 @@ def gen_frontend():
     print("frontend_calls: %d graph calls over %d frontend invocations" % (len(RecordingGraph.log), len(snaps)))
 
 
+MOTION_SCRIPT = [3.0, 0.5, 1.0, 2.0, 0.2]          # mean flow magnitude the (mock) update operator reports per frame after the first
+
+
+class MotionNet:
+    """mock network for the motion-filter fixture: deterministic features, an update operator with scripted flow"""
+
+    def __init__(self, ht, wd):
+        self.h, self.w = ht // 8, wd // 8
+        self.calls = []
+        self.script = list(MOTION_SCRIPT)
+
+    def fnet(self, x):
+        return x.mean(dim=2, keepdim=True).mean(dim=(3, 4), keepdim=True).expand(1, x.shape[1], 128, self.h, self.w) + 0.0
+
+    def cnet(self, x):
+        return x.mean(dim=2, keepdim=True).mean(dim=(3, 4), keepdim=True).expand(1, x.shape[1], 256, self.h, self.w) * 2.0
+
+    def update(self, net, inp, corr, **kw):
+        self.calls.append((tuple(net.shape), tuple(inp.shape), float(net.float().mean()), float(inp.float().mean())))
+        mag = self.script.pop(0)
+        delta = torch.zeros(1, 1, self.h, self.w, 4)
+        delta[..., 0] = mag                                      # |delta[..., 0:2]| = mag everywhere
+        return net, delta, torch.zeros(1, 1, self.h, self.w, 2), torch.zeros(1, 1, self.h, self.w, 2)
+
+
+def motion_frames(n=6, ht=32, wd=48):
+    g = torch.Generator().manual_seed(10)
+    return [(float(t), torch.randint(0, 256, (3, ht, wd), generator=g).int(), torch.tensor([40.0, 40.0, 24.0, 16.0]) * (1 + 0.01 * t), None)
+            for t in range(n)]
+
+
+def gen_motion_filter():
+    """MotionFilter.track (motion_filter.py:46-87) with a mock network: which frames become keyframes (mean one-step flow
+    above `thresh`), and what is appended to the video for them (identity pose and unit depth only for the first)."""
+    import motion_filter as ref_mf
+    ht, wd = 32, 48
+    appended = []
+
+    class Counter:
+        value = 0
+
+    class Video:
+        counter = Counter()
+
+        def append(self, *item):
+            appended.append(item); Video.counter.value += 1
+
+    class FakeCorr:
+        def __init__(self, f1, f2, *a, **k):
+            pass
+
+        def __call__(self, coords):
+            return torch.zeros(1, 1, 196, ht // 8, wd // 8)
+    ref_mf.CorrBlock = FakeCorr
+    net = MotionNet(ht, wd)
+    mf = ref_mf.MotionFilter(net, Video(), thresh=1.75, device="cpu")
+    counts = []
+    for t, image, intr, segm in motion_frames():
+        mf.track(t, image, None, intr, segm)
+        counts.append(mf.count)
+    out = dict(n_appended=np.int64(len(appended)), counts=np.array(counts), tstamps=np.array([a[0] for a in appended]),
+               has_pose=np.array([a[2] is not None for a in appended]), has_disp=np.array([a[3] is not None for a in appended]),
+               intr=torch.stack([a[4] for a in appended]).numpy(), fmap_mean=np.array([float(a[5].float().mean()) for a in appended]),
+               net_mean=np.array([float(a[6].float().mean()) for a in appended]), inp_mean=np.array([float(a[7].float().mean()) for a in appended]),
+               op_calls=np.array([[c[2], c[3]] for c in net.calls]))
+    np.savez_compressed(os.path.join(HERE, "motion_filter.npz"), **out)
+    print("motion_filter: %d of %d frames became keyframes" % (len(appended), len(counts)))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -710,3 +779,4 @@ if __name__ == "__main__":
     gen_bookkeeping()
     gen_filler()
     gen_frontend()
+    gen_motion_filter()

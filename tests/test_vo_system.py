@@ -261,3 +261,44 @@ def test_frontend_call_sequence_matches_reference(monkeypatch):
     assert [s[2] for s in snaps] == z["init"].tolist()
     assert np.allclose(torch.stack([s[3] for s in snaps]).numpy(), z["poses"]) and np.allclose(torch.stack([s[4] for s in snaps]).numpy(), z["disps"])
     assert np.array_equal(torch.stack([s[5] for s in snaps]).numpy(), z["dirty"])
+
+
+def test_motion_filter_decisions_match_reference(monkeypatch):
+    """MotionFilter.track against the reference's own filter on a mock network (tests/golden/gen_golden.py:
+    gen_motion_filter): same frames promoted to keyframes, same pose / depth / intrinsics / features stored for them"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import gen_golden as G
+    import pvo_amd.motion_filter as mf_mod
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "motion_filter.npz"))
+    ht, wd = 32, 48
+    appended = []
+
+    class Video:
+        counter = 0
+
+        def append(self, tstamp, pose, disp, intrinsics, fmap, net, inp, segm=None, image=None):
+            appended.append((tstamp, pose, disp, intrinsics, fmap, net, inp)); Video.counter += 1
+
+    class FakeCorr:
+        def __init__(self, f1, f2, *a, **k):
+            pass
+
+        def __call__(self, coords):
+            return torch.zeros(1, 1, 196, ht // 8, wd // 8)
+    monkeypatch.setattr(mf_mod, "CorrBlock", FakeCorr)
+    net = G.MotionNet(ht, wd)
+    mf = mf_mod.MotionFilter(net, Video(), thresh=1.75, device="cpu")
+    counts = []
+    for t, image, intr, segm in G.motion_frames():
+        mf.track(t, image, None, intr, segm)
+        counts.append(mf.count)
+    assert len(appended) == int(z["n_appended"]) and counts == z["counts"].tolist()
+    assert [a[0] for a in appended] == z["tstamps"].tolist()
+    assert [a[1] is not None for a in appended] == z["has_pose"].tolist() and [a[2] is not None for a in appended] == z["has_disp"].tolist()
+    assert torch.equal(appended[0][1].cpu(), torch.tensor([0, 0, 0, 0, 0, 0, 1.0])) and appended[0][2] == 1.0
+    assert np.allclose(torch.stack([a[3] for a in appended]).numpy(), z["intr"])
+    for k, name in ((4, "fmap_mean"), (5, "net_mean"), (6, "inp_mean")):
+        assert np.allclose([float(a[k].float().mean()) for a in appended], z[name], atol=1e-5), name
+    assert np.allclose(np.array([[c[2], c[3]] for c in net.calls]), z["op_calls"], atol=1e-5)
