@@ -763,6 +763,60 @@ def gen_motion_filter():
     print("motion_filter: %d of %d frames became keyframes" % (len(appended), len(counts)))
 
 
+def video_script(v, set_counter, log):
+    """the DepthVideo calls both implementations answer (native calls are recorded by `log`)"""
+    g = torch.Generator().manual_seed(21)
+    F = 6
+    v.poses[:F] = torch.randn(F, 7, generator=g)
+    v.disps[:F] = torch.rand(F, v.disps.shape[1], v.disps.shape[2], generator=g) + 0.5
+    v.intrinsics[:F] = torch.tensor([20.0, 21.0, 12.0, 8.0])
+    set_counter(v, F)
+    res = {}
+    res["d_pairs"] = v.distance([0, 2, 5], [1, 4, 3], beta=0.4, bidirectional=True)
+    res["d_one_way"] = v.distance(torch.tensor([1, 3]), torch.tensor([0, 2]), beta=0.7, bidirectional=False)
+    res["d_matrix"] = v.distance(beta=0.3)
+    ii, jj = torch.tensor([0, 1, 3, 4]), torch.tensor([1, 0, 4, 2])
+    ht, wd = v.disps.shape[1:]
+    tg, wt = torch.randn(4, 2, ht, wd, generator=g), torch.rand(4, 2, ht, wd, generator=g)
+    eta = torch.rand(4, ht, wd, generator=g)
+    v.ba(tg, wt, eta, ii, jj, t0=1, t1=5, itrs=3, lm=1e-3, ep=0.2, motion_only=False)
+    v.ba(tg, wt, None, ii, jj)                                       # defaults: t1 from the edges, unit-row eta of 1e-7
+    v.normalize()
+    res["poses"], res["disps"], res["dirty"] = v.poses[:F].clone(), v.disps[:F].clone(), v.dirty[:F + 1].clone()
+    return res
+
+
+def make_native_recorder(log):
+    def frame_distance(poses, disps, intr, ii, jj, beta):
+        log.append(("frame_distance", tuple(poses.shape), tuple(intr.tolist()), ii.tolist(), jj.tolist(), round(float(beta), 6)))
+        return (ii * 10 + jj).float() + float(poses[0, 0])
+
+    def ba(poses, disps, intr, target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only, *a, **k):
+        log.append(("ba", tuple(intr.tolist()), tuple(eta.shape), float(eta.flatten()[0]), ii.tolist(), jj.tolist(), int(t0), int(t1), int(itrs),
+                    round(float(lm), 9), round(float(ep), 9), bool(motion_only), float(target.sum()), float(weight.sum())))
+        disps[1, 0, :3] = torch.tensor([-1.0, 0.0005, 0.3])           # the caller clamps at 0.001
+        return [None, None]
+    return frame_distance, ba
+
+
+def gen_depth_video():
+    """DepthVideo.distance / ba / normalize (depth_video.py:145-214) with recording stand-ins for the two native calls:
+    pins argument order and defaults (shared intrinsics[0], bidirectional averaging, t1 and eta defaults, the 0.001 clamp)."""
+    import depth_video as ref_dv
+    log = []
+    fd, ba = make_native_recorder(log)
+    ref_dv.droid_backends.frame_distance, ref_dv.droid_backends.ba = fd, ba
+    v = ref_dv.DepthVideo(image_size=[32, 48], buffer=8, device="cpu")
+
+    def set_counter(video, n):
+        video.counter.value = n
+    res = video_script(v, set_counter, log)
+    out = {k: t.numpy() for k, t in res.items()}
+    out["log"] = np.array([repr(x) for x in log])
+    np.savez_compressed(os.path.join(HERE, "depth_video_calls.npz"), **out)
+    print("depth_video_calls: %d native calls" % len(log))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -780,3 +834,4 @@ if __name__ == "__main__":
     gen_filler()
     gen_frontend()
     gen_motion_filter()
+    gen_depth_video()

@@ -302,3 +302,26 @@ def test_motion_filter_decisions_match_reference(monkeypatch):
     for k, name in ((4, "fmap_mean"), (5, "net_mean"), (6, "inp_mean")):
         assert np.allclose([float(a[k].float().mean()) for a in appended], z[name], atol=1e-5), name
     assert np.allclose(np.array([[c[2], c[3]] for c in net.calls]), z["op_calls"], atol=1e-5)
+
+
+def test_depth_video_native_calls_match_reference(monkeypatch):
+    """DepthVideo.distance / ba / normalize against the reference's DepthVideo with recording stand-ins for the native
+    calls (tests/golden/gen_golden.py: gen_depth_video): argument order, defaults, averaging, clamping"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import gen_golden as G
+    import pvo_amd.depth_video as dv
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "depth_video_calls.npz"))
+    log = []
+    fd, ba = G.make_native_recorder(log)
+    monkeypatch.setattr(dv.db, "frame_distance", fd)
+    monkeypatch.setattr(dv.db, "ba", ba)
+    v = dv.DepthVideo(image_size=(32, 48), buffer=8, device="cpu")
+
+    def set_counter(video, n):
+        video.counter = n
+    res = G.video_script(v, set_counter, log)
+    assert [repr(x) for x in log] == z["log"].tolist()
+    for k, t in res.items():
+        assert np.allclose(t.numpy(), z[k], atol=1e-6), k
