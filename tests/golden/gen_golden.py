@@ -117,6 +117,11 @@ def gen_ba():
         # one reprojection with Jacobians (pins coords/valid and, through BA, the Jacobians)
         coords, valid = pops.projective_transform(SE3(s["poses"][None]), s["disps"][None], intr_all, s["ii"], s["jj"])
         out["reproj_coords"] = coords[0].numpy(); out["reproj_valid"] = valid[0].numpy()
+        # back-projection of every pixel through its frame's pose (what droid_backends.iproj computes: pose.act((X,Y,1,d)) / w),
+        # written with the reference's pops.iproj
+        X0, _ = pops.iproj(s["disps"][None], intr_all)
+        Xw = SE3(s["poses"][None])[:, :, None, None] * X0
+        out["iproj_points"] = (Xw[0, ..., :3] / Xw[0, ..., 3:]).numpy()
         Gs, disps = SE3(s["poses"][None].clone()), s["disps"][None].clone()
         for it in range(2):
             # the reference adds 1e-7 to C on top of eta (ba.py:91); the native path does not

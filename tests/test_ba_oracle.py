@@ -99,3 +99,16 @@ def test_frame_distance_properties():
     assert O.frame_distance(far, d["disps"], d["intr"], np.array([0]), np.array([1]), 0.3)[0] == 1000.0
     a = O.frame_distance(d["poses"], d["disps"], d["intr"], np.array([0, 0]), np.array([1, 2]), 0.3)
     assert 0 < a[0] < a[1]
+
+
+@pytest.mark.parametrize("fx", ["ba_python_a.npz", "ba_python_b.npz"])
+def test_iproj_and_projmap_restatements_match_reference_python(fx):
+    """oracle_iproj / oracle_projmap (restated from droid_kernels.cu:758-830, 405-493) against the reference's Python
+    geometry on scenes where the two coincide (all depths > 0.25): pose.act((X,Y,1,d)) / w from pops.iproj, and the
+    reprojected coordinates of pops.projective_transform with every pixel valid."""
+    d = _load(fx)
+    P = d["poses"].shape[0]
+    pts = O.iproj(d["poses"], d["disps"], d["intr"])
+    assert pts.shape == d["iproj_points"].shape and np.allclose(pts, d["iproj_points"], rtol=1e-5, atol=1e-5)
+    coords, valid = O.projmap(d["poses"], d["disps"], d["intr"], d["ii"], d["jj"])
+    assert np.allclose(coords[..., :2], d["reproj_coords"], atol=1e-4) and np.all(valid == 1.0)
