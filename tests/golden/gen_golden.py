@@ -122,6 +122,9 @@ def gen_ba():
         X0, _ = pops.iproj(s["disps"][None], intr_all)
         Xw = SE3(s["poses"][None])[:, :, None, None] * X0
         out["iproj_points"] = (Xw[0, ..., :3] / Xw[0, ..., 3:]).numpy()
+        # mean magnitude of the flow induced by camera motion, per edge: frame_distance's beta = 1 term
+        flow, _ = pops.induced_flow(SE3(s["poses"][None]), s["disps"][None], intr_all, s["ii"], s["jj"])
+        out["induced_flow_mean"] = flow[0].norm(dim=-1).mean(dim=(1, 2)).numpy()
         Gs, disps = SE3(s["poses"][None].clone()), s["disps"][None].clone()
         for it in range(2):
             # the reference adds 1e-7 to C on top of eta (ba.py:91); the native path does not

@@ -112,3 +112,12 @@ def test_iproj_and_projmap_restatements_match_reference_python(fx):
     assert pts.shape == d["iproj_points"].shape and np.allclose(pts, d["iproj_points"], rtol=1e-5, atol=1e-5)
     coords, valid = O.projmap(d["poses"], d["disps"], d["intr"], d["ii"], d["jj"])
     assert np.allclose(coords[..., :2], d["reproj_coords"], atol=1e-4) and np.all(valid == 1.0)
+
+
+@pytest.mark.parametrize("fx", ["ba_python_a.npz", "ba_python_b.npz"])
+def test_frame_distance_reprojection_term_matches_reference_python(fx):
+    """beta = 1 leaves only the mean reprojection-flow magnitude in frame_distance (droid_kernels.cu:497-636); with every
+    depth above 0.25 that is the mean norm of the reference's pops.induced_flow"""
+    d = _load(fx)
+    dist = O.frame_distance(d["poses"], d["disps"], d["intr"], d["ii"], d["jj"], 1.0)
+    assert np.allclose(dist, d["induced_flow_mean"], rtol=1e-5, atol=1e-5)
