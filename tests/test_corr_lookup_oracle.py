@@ -104,3 +104,47 @@ def test_half_conversion_is_ieee_rne():
     with np.errstate(over="ignore"):
         ref = x.astype(np.float16).view(np.uint16)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_16bit_lookup_equals_c10_half_arithmetic_op_by_op(dtype):
+    """The oracle's software 16-bit arithmetic against c10::Half / c10::BFloat16 themselves: the reference kernel's statement
+    sequence (correlation_kernels.cu:44-66) written with torch scalar-type tensors on the CPU, where every `*` and `+=` is
+    ATen's half operator (convert to float, operate, round) - the same operators the CUDA kernel instantiates for scalar_t.
+    Bit-exact, including the accumulation order into each output cell and the skipped out-of-range taps."""
+    g = torch.Generator().manual_seed(4)
+    N, h1, w1, h2, w2, r = 1, 3, 4, 6, 7, 3
+    vol = torch.randn(N, h1, w1, h2, w2, generator=g).to(dtype)
+    coords = torch.rand(N, 2, h1, w1, generator=g) * torch.tensor([w2 + 4.0, h2 + 4.0]).view(1, 2, 1, 1) - 2.0
+    rd = 2 * r + 1
+    out = torch.zeros(N, rd, rd, h1, w1, dtype=dtype)
+    one = torch.tensor(1.0)
+    for n in range(N):
+        for y in range(h1):
+            for x in range(w1):
+                x0, y0 = coords[n, 0, y, x], coords[n, 1, y, x]
+                dx, dy = x0 - torch.floor(x0), y0 - torch.floor(y0)
+                w = {(0, 0): ((one - dx) * (one - dy)).to(dtype), (0, 1): ((one - dx) * dy).to(dtype),
+                     (1, 0): (dx * (one - dy)).to(dtype), (1, 1): (dx * dy).to(dtype)}
+                for i in range(rd + 1):
+                    for j in range(rd + 1):
+                        x1, y1 = int(torch.floor(x0)) - r + i, int(torch.floor(y0)) - r + j
+                        if not (0 <= x1 < w2 and 0 <= y1 < h2):
+                            continue
+                        s = vol[n, y, x, y1, x1]
+                        # the four statements of correlation_kernels.cu:56-65, in that order
+                        if i > 0 and j > 0:
+                            out[n, i - 1, j - 1, y, x] += s * w[(1, 1)]
+                        if i > 0 and j < rd:
+                            out[n, i - 1, j, y, x] += s * w[(1, 0)]
+                        if i < rd and j > 0:
+                            out[n, i, j - 1, y, x] += s * w[(0, 1)]
+                        if i < rd and j < rd:
+                            out[n, i, j, y, x] += s * w[(0, 0)]
+    bf16 = dtype == torch.bfloat16
+    if bf16:
+        got = O.corr_index_forward(O.f32_to_bf16_bits(vol.float().numpy()), coords.numpy(), r, bf16=True)
+        assert np.array_equal(got, O.f32_to_bf16_bits(out.float().numpy()))
+    else:
+        got = O.corr_index_forward(vol.numpy(), coords.numpy(), r)
+        assert np.array_equal(got.view(np.uint16), out.numpy().view(np.uint16))
