@@ -33,6 +33,21 @@ class DroidBackend:
         n_keyframes = self.video.counter
         self.video.normalize()
         graph = self._connect_all()
-        graph.update_lowmem(steps=steps)
+        sharded, before = None, None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # one process per GPU, every rank holds the same video: each keeps the edges whose source frame it owns
+            # (the selection above is deterministic, so all ranks agree on the partition) and the BA's reduced pose
+            # system is all-reduced once per Gauss-Newton step (pvo_amd/parallel.py)
+            from .parallel import ShardedBA, partition_by_source
+            owner, _ = partition_by_source(graph._ii_h, torch.distributed.get_world_size())
+            rank = torch.distributed.get_rank()
+            graph.rm_factors([o != rank for o in owner])
+            sharded, before = ShardedBA(), self.video.disps.clone()
+        if graph._ii_h:
+            graph.update_lowmem(steps=steps, sharded=sharded)
+        elif sharded is not None:
+            raise RuntimeError("rank %d owns no edges: fewer source frames than ranks" % rank)
+        if sharded is not None:
+            sharded.sync_disps(self.video.disps, before)                 # every rank ends with all depth maps
         graph.clear_edges()
         self.video.dirty[:n_keyframes] = True

@@ -207,22 +207,34 @@ class FactorGraph:
         self.rm_factors(m, store=False)
 
     @torch.no_grad()
-    def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8):
-        """global-BA update without correlation volumes (factor_graph.py:309-360): features are correlated on the
-        fly by the alt-corr kernel, the update operator runs over source-frame chunks of 8, then ONE dense BA over
-        all keyframes [1, t) with lm=1e-5, ep=1e-2.  As in the reference the motion features are built from
-        `target_cam - coords0` (not the fresh reprojection) and the damping is the raw eta (no 0.2 factor)."""
+    def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8, sharded=None):
+        """global-BA update without correlation volumes (factor_graph.py:309-360): features are correlated on the fly
+        by the alt-corr kernel, the update operator runs over source-frame chunks of 8, then ONE dense BA over all
+        keyframes [1, t) with lm=1e-5, ep=1e-2.  As in the reference the motion features are built from
+        `target_cam - coords0` (not the fresh reprojection) and the damping is the raw eta (no 0.2 factor).
+
+        sharded (a `pvo_amd.parallel.ShardedBA`): this graph holds only the edges whose SOURCE frame this rank owns
+        (`parallel.partition_by_source`).  Lookup, update operator, GraphAgg's per-source mean and the depth update are
+        then rank-local; the BA's reduced pose system is all-reduced once per Gauss-Newton step, every rank takes the
+        identical pose step, and depth maps of frames a rank does not own stay untouched on that rank
+        (`ShardedBA.sync_disps` merges them when something needs all of them)."""
         from .modules.corr import AltCorrBlock
         t = self.video.counter
         ht, wd = self.ht, self.wd
         corr_op = AltCorrBlock(self.video.fmaps[None, :t], channels_last=True)
-        jmax = max(self._jj_h)
+        jmax = max(self._jj_h + self._ii_h) if sharded is not None else max(self._jj_h)
         chunks = []
         for i in range(0, jmax + 1, 8):
             sel = [k for k, a in enumerate(self._ii_h) if i <= a < i + 8]
             if sel:
                 chunks.append((torch.tensor(sel, device=self.device), sorted({self._ii_h[k] for k in sel})))
-        src = torch.tensor(sorted(set(self._ii_h)), device=self.device)
+        src_l = sorted(set(self._ii_h))
+        src = torch.tensor(src_l, device=self.device)
+        if sharded is not None:
+            # the BA optimises every depth map of the window; eta needs a row for each of them, in the order of
+            # unique([1, t) U local sources); frames without a local edge get a neutral row (their update is 0)
+            rows_l = sorted(set(range(1, t)) | set(src_l))
+            row_of_src = torch.tensor([rows_l.index(f) for f in src_l], device=self.device)
         for _ in range(steps):
             coords1, _ = self.video.reproject(self.ii, self.jj)
             cam = self.target_cam - self.coords0
@@ -245,7 +257,14 @@ class FactorGraph:
             eta = self.damping[src].contiguous() + EP
             target = self.target_cam.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
             weight = self.weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
-            self.video.ba(target, weight, eta, self.ii, self.jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
+            if sharded is None:
+                self.video.ba(target, weight, eta, self.ii, self.jj, 1, t, itrs=itrs, lm=1e-5, ep=1e-2, motion_only=False)
+            else:
+                eta_rows = torch.ones(len(rows_l), ht, wd, dtype=eta.dtype, device=self.device)
+                eta_rows[row_of_src] = eta
+                sharded.ba(self.video.poses, self.video.disps, self.video.intrinsics[0], target, weight, eta_rows,
+                           self.ii.contiguous(), self.jj.contiguous(), 1, t, itrs=itrs, lm=1e-5, ep=1e-2)
+                self.video.disps.clamp_(min=0.001)                   # DepthVideo.ba's clamp (depth_video.py:214)
             self.video.dirty[:t] = True
 
     def add_neighborhood_factors(self, t0, t1, r=3):

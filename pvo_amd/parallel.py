@@ -86,3 +86,11 @@ class ShardedBA:
             dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
         disps.copy_(disps_before + delta)
         return disps
+
+
+def shard_edges(ii, jj, world_size, rank):
+    """this rank's share of a factor graph under the source-frame partition: (ii_local, jj_local, edge indices)"""
+    owner, _ = partition_by_source(ii, world_size)
+    keep = [k for k, o in enumerate(owner) if o == rank]
+    ii, jj = [int(v) for v in ii], [int(v) for v in jj]
+    return [ii[k] for k in keep], [jj[k] for k in keep], keep

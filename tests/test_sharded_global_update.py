@@ -1,0 +1,127 @@
+"""Edge-sharded GLOBAL update (BASELINE config 4: factor-graph edges sharded across GPUs with one pose all-reduce per
+Gauss-Newton step).  Two gloo ranks each run FactorGraph.update_lowmem(sharded=ShardedBA) on the edges whose source frame
+they own - operator calls, damping and depth updates rank-local, the reduced pose system all-reduced - and must reproduce
+the single-process update of the whole graph.  Native steps are answered by the CPU oracle (tests/test_sharded_ba.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(__file__))
+from oracle import oracle as O
+from pvo_amd.parallel import ShardedBA, shard_edges
+from test_sharded_ba import OracleBackend
+
+
+def _scene():
+    from test_geom_ba_gpu import _scene
+    return _scene(33, 7, 8, 10, 3, 1)
+
+
+class _Video:
+    def __init__(self, s):
+        F, ht, wd = s["disps"].shape
+        self.ht, self.wd, self.counter = ht * 8, wd * 8, F
+        self.poses, self.disps = s["poses"].clone(), s["disps"].clone()
+        self.intrinsics = s["intr"][None].repeat(F, 1).contiguous()
+        self.dirty = torch.zeros(F, dtype=torch.bool)
+        self.fmaps = torch.zeros(F, ht, wd, 128)
+        self.inps = torch.zeros(F, 128, ht, wd)
+        self.nets = torch.zeros(F, 128, ht, wd)
+        self.segms = torch.zeros(F, 1, ht, wd, dtype=torch.int)
+        self.segm_filter, self.thresh = False, 0.5
+
+    def reproject(self, ii, jj):
+        c, v = O.reproject(self.poses.numpy(), self.disps.numpy(), self.intrinsics.numpy(), np.asarray(ii), np.asarray(jj))
+        return torch.from_numpy(c)[None], torch.from_numpy(v)[None]
+
+    def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1, motion_only=False):
+        r = O.ba(self.poses.numpy(), self.disps.numpy(), self.intrinsics[0].numpy(), target.numpy(), weight.numpy(), eta.numpy(),
+                 ii.numpy(), jj.numpy(), t0, t1, itrs, lm, ep, motion_only=motion_only)
+        self.poses.copy_(torch.from_numpy(r["poses"])); self.disps.copy_(torch.from_numpy(r["disps"]).clamp(min=0.001))
+
+
+class _Operator:
+    """per-edge outputs from tables keyed by the edge (i, j) / the source frame, so that a rank holding a subset of the
+    edges sees exactly the values the whole-graph run sees for them"""
+
+    def __init__(self, s):
+        g = torch.Generator().manual_seed(7)
+        F, ht, wd = s["disps"].shape
+        self.key = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(s["ii"], s["jj"]))}
+        E = len(self.key)
+        self.delta = torch.randn(2, E, ht, wd, 4, generator=g) * 0.3
+        self.weight = torch.randn(2, E, ht, wd, 2, generator=g)
+        self.delta_m = torch.randn(2, E, ht, wd, 2, generator=g)
+        self.damp = torch.rand(2, F, ht, wd, generator=g) * 0.05 + 0.01
+        self.step = -1
+
+    def parameters(self):
+        return iter(())
+
+    def __call__(self, net, inp, corr, motn, ii, jj, flag=False, **kw):
+        idx = torch.tensor([self.key[(int(i), int(j))] for i, j in zip(ii, jj)])
+        k = self.step
+        return net, self.delta[k][idx][None], self.weight[k][idx][None], self.damp[k][torch.unique(ii)][None], {}, self.delta_m[k][idx][None]
+
+
+def _run(s, ii, jj, sharded, steps=2):
+    import pvo_amd.modules.corr as corr_mod
+    from pvo_amd.factor_graph import FactorGraph
+    F, ht, wd = s["disps"].shape
+
+    class FakeAlt:
+        def __init__(self, fmaps, *a, **k):
+            pass
+
+        def __call__(self, coords, ii_, jj_):
+            return torch.zeros(1, ii_.shape[0], 196, ht, wd)
+    corr_mod.AltCorrBlock = FakeAlt
+    v, op = _Video(s), _Operator(s)
+    # count reprojections to know which global step the operator is in (one reproject per step)
+    real_reproject = v.reproject
+
+    def reproject(a, b):
+        op.step += 1
+        return real_reproject(a, b)
+    v.reproject = reproject
+    fg = FactorGraph(v, op, device="cpu", corr_impl="alt")
+    op.step = -2                                               # add_factors reprojects once
+    fg.add_factors(list(ii), list(jj))
+    op.step = -1
+    fg.update_lowmem(steps=steps, sharded=sharded)
+    return v
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = _scene()
+    ii, jj, _ = shard_edges(s["ii"].tolist(), s["jj"].tolist(), world, rank)
+    sb = ShardedBA(backend=OracleBackend())
+    before = s["disps"].clone()
+    v = _run(s, ii, jj, sb)
+    sb.sync_disps(v.disps, before)
+    out[rank] = (v.poses.numpy().copy(), v.disps.numpy().copy(), len(ii))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_global_update_equals_single_process():
+    s = _scene()
+    whole = _run(s, s["ii"].tolist(), s["jj"].tolist(), None)                          # DepthVideo.ba on the whole graph
+    one = _run(s, s["ii"].tolist(), s["jj"].tolist(), ShardedBA(backend=OracleBackend()))   # sharded code path, one rank
+    assert np.abs(one.poses.numpy() - whole.poses.numpy()).max() < 2e-5
+    assert np.abs(one.disps.numpy() - whole.disps.numpy()).max() < 2e-5
+    assert np.abs(whole.poses.numpy() - s["poses"].numpy()).max() > 1e-4               # the update did move the poses
+    world = 2
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, 29531, out), nprocs=world, join=True)
+    assert out[0][2] + out[1][2] == s["ii"].shape[0] and min(out[0][2], out[1][2]) > 0
+    for r in range(world):
+        assert np.abs(out[r][0] - whole.poses.numpy()).max() < 5e-5
+        assert np.abs(out[r][1] - whole.disps.numpy()).max() < 5e-5
+    assert np.array_equal(out[0][0], out[1][0])                                        # pose replicas bit-identical
