@@ -228,12 +228,14 @@ int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, cons
  *   pvo_graph_post    heads [E,H,W,8] (`dtype`) = delta | delta_dy | weight logits | delta_mask as pvo_heads_out writes them:
  *                     raw_mask += delta_mask (in place); bin = sigmoid(raw_mask) >= dy_thresh; target = coords1 + delta;
  *                     delta_dy = delta_dy_raw (1-bin); weight = sigmoid(logits + 10 (1-bin)); full_flow = coords1 + delta_dy - coords0;
- *                     target_ba / weight_ba [E,2,H,W] are the layouts pvo_ba reads                (:249-306) */
+ *                     target_ba / weight_ba [E,2,H,W] are the layouts pvo_ba reads                (:249-306)
+ *                     force_dyn (optional, uint8 [E,H,W]): pixels whose bin is forced to 0 ("dynamic") on both channels -
+ *                     the outcome of the panoptic segment vote (:256-276), computed by the caller from the updated mask */
 int pvo_graph_motion(const float* target, const float* coords1, const float* delta_dy, const float* raw_mask,
                      void* motn, int E, int H, int W, int dtype, void* stream);
 int pvo_graph_post(const float* coords1, const void* heads, float* raw_mask, float* target, float* delta_dy,
                    float* weight, float* target_ba, float* weight_ba, float* full_flow,
-                   int E, int H, int W, float dy_thresh, int dtype, void* stream);
+                   int E, int H, int W, float dy_thresh, const unsigned char* force_dyn, int dtype, void* stream);
 
 /* GraphAgg's eta head + FactorGraph's damping bookkeeping in one launch (droid_net.py:93-95, factor_graph.py:281-283):
  *   e = 0.01 * softplus(raw[pos[r]] + bias[0]);  damping[frame[r]] = e      (pos[r] >= 0)

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restric
                                                          float2* __restrict__ raw_mask, float2* __restrict__ target,
                                                          float2* __restrict__ delta_dy, float2* __restrict__ weight,
                                                          float* __restrict__ target_ba, float* __restrict__ weight_ba,
-                                                         float2* __restrict__ full_flow, int E, int HW, int W, float dy_thresh) {
+                                                         float2* __restrict__ full_flow, int E, int HW, int W, float dy_thresh,
+                                                         const uint8_t* __restrict__ force_dyn) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= E * HW) return;
   const int e = idx / HW, pix = idx - e * HW;
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restric
   float2 rm = raw_mask[idx];
   rm.x += m0; rm.y += m1;
   raw_mask[idx] = rm;
-  const float b0 = (1.0f / (1.0f + expf(-rm.x)) >= dy_thresh) ? 1.0f : 0.0f;    // 1: static, 0: dynamic
-  const float b1 = (1.0f / (1.0f + expf(-rm.y)) >= dy_thresh) ? 1.0f : 0.0f;
+  float b0 = (1.0f / (1.0f + expf(-rm.x)) >= dy_thresh) ? 1.0f : 0.0f;    // 1: static, 0: dynamic
+  float b1 = (1.0f / (1.0f + expf(-rm.y)) >= dy_thresh) ? 1.0f : 0.0f;
+  if (force_dyn && force_dyn[idx]) { b0 = 0.0f; b1 = 0.0f; }     // panoptic vote: the pixel's segment is dynamic on this edge
   const float2 tg = {c1.x + d0, c1.y + d1};
   const float2 dd = {g0 * (1.0f - b0), g1 * (1.0f - b1)};
   const float2 wt = {1.0f / (1.0f + expf(-(w0 + (1.0f - b0) * 10.0f))), 1.0f / (1.0f + expf(-(w1 + (1.0f - b1) * 10.0f)))};
@@ -124,7 +126,7 @@ extern "C" int pvo_graph_motion(const float* target, const float* coords1, const
 
 extern "C" int pvo_graph_post(const float* coords1, const void* heads, float* raw_mask, float* target, float* delta_dy,
                               float* weight, float* target_ba, float* weight_ba, float* full_flow,
-                              int E, int H, int W, float dy_thresh, int dtype, void* stream) {
+                              int E, int H, int W, float dy_thresh, const unsigned char* force_dyn, int dtype, void* stream) {
   if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
   const long long n = static_cast<long long>(E) * H * W;
   if (n == 0) return PVO_OK;
@@ -134,9 +136,9 @@ extern "C" int pvo_graph_post(const float* coords1, const void* heads, float* ra
   const dim3 grid(static_cast<unsigned>((n + 255) / 256));
   auto f2 = [](float* p) { return reinterpret_cast<float2*>(p); };
   if (dtype == PVO_F16)
-    hipLaunchKernelGGL(graph_post_kernel<pvo_half>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh);
+    hipLaunchKernelGGL(graph_post_kernel<pvo_half>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, force_dyn);
   else if (dtype == PVO_BF16)
-    hipLaunchKernelGGL(graph_post_kernel<pvo_bf16>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh);
+    hipLaunchKernelGGL(graph_post_kernel<pvo_bf16>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, force_dyn);
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;

@@ -806,7 +806,7 @@ def eta_finish(raw, bias, frame, pos, damping, EP):
     return eta
 
 
-def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5):
+def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5, force_dyn=None):
     """factor_graph.py:249-306 after the update operator.  heads [E,8,H,W] channels-last 16-bit (delta | delta_dy |
     weight | delta_mask); raw_mask [1,E,H,W,2] is updated IN PLACE; target_ba / weight_ba [E,2,H,W] f32 are filled.
     Returns (target_cam, delta_dy, weight, full_flow), each [1,E,H,W,2] f32."""
@@ -817,7 +817,9 @@ def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5):
     new = lambda: torch.empty(1, E, H, W, 2, dtype=torch.float32, device=dev)
     target, delta_dy, weight, full_flow = new(), new(), new(), new()
     with torch.cuda.device(dev):
+        if force_dyn is not None and (force_dyn.dtype != torch.uint8 or tuple(force_dyn.shape) != (E, H, W) or not force_dyn.is_contiguous()):
+            raise PvoHipError("graph_post: force_dyn must be a contiguous uint8 [E,H,W] tensor")
         check(_lib.load().pvo_graph_post(_ptr(coords1), _ptr(heads), _ptr(raw_mask), _ptr(target), _ptr(delta_dy), _ptr(weight),
-                                         _ptr(target_ba), _ptr(weight_ba), _ptr(full_flow), E, H, W, float(dy_thresh),
+                                         _ptr(target_ba), _ptr(weight_ba), _ptr(full_flow), E, H, W, float(dy_thresh), _ptr(force_dyn),
                                          _dtype_code(heads, "heads"), _stream(dev)), "graph_post")
     return target, delta_dy, weight, full_flow

@@ -351,8 +351,8 @@ class FactorGraph:
         return bin_mask & keep.unsqueeze(-1)
 
     def _fused_ok(self):
-        """the two-kernel glue path: HIP device, no panoptic vote, an update operator that exposes raw_heads in 16 bit"""
-        if self.device.type != "cuda" or self.video.segm_filter or self.corr is None:
+        """the two-kernel glue path: HIP device, an update operator that exposes raw_heads in 16 bit"""
+        if self.device.type != "cuda" or self.corr is None:
             return False
         op = self.update_op
         if not hasattr(op, "_heads_w2") or getattr(op, "training", True) or not getattr(op, "fused_gru", False):
@@ -449,8 +449,15 @@ class FactorGraph:
         target_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
         weight_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
         self.raw_mask = self.raw_mask.contiguous()
+        force = None
+        if self.video.segm_filter:
+            # panoptic vote (factor_graph.py:256-276) on the updated mask: segments that are mostly dynamic on an edge are
+            # forced dynamic; the kernel below redoes the mask update itself and takes the vote's outcome as a byte per pixel
+            raw_new = self.raw_mask + heads[:, 6:8].permute(0, 2, 3, 1).float()[None]
+            bin_mask = torch.sigmoid(raw_new) >= self.dy_thresh
+            force = (self._segment_vote(bin_mask) != bin_mask).any(-1)[0].to(torch.uint8).contiguous()
         self.target_cam, self.delta_dy, self.weight, self.full_flow = db.graph_post(
-            coords1, heads, self.raw_mask, target_ba[n_in:], weight_ba[n_in:], self.dy_thresh)
+            coords1, heads, self.raw_mask, target_ba[n_in:], weight_ba[n_in:], self.dy_thresh, force_dyn=force)
         rows = src
         if n_in:
             # integer indices from the host mirror: a boolean mask would synchronise to size its result
