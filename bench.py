@@ -17,7 +17,8 @@ so that K steps do identical work.
 N > 1: one process per GPU (torch.distributed, RCCL); every rank tracks its own window
 (independent sequences, no data-path collective), value = N*K / max-over-ranks time.
 
-Extra objects on the JSON line: "roofline" for the dominant hand-written kernel (the fused
+Extra objects on the JSON line: "roofline_wide_conv" (matrix-core roofline of the wide 3x3 convolution, the kernel with
+the largest share of the step), "roofline" for the dominant hand-written HBM-bound kernel (the fused
 4-level lookup; HBM bound) and "cpu_baseline" (the CPU oracle timed on this host, rank 0, N=1).
 """
 import argparse
@@ -33,6 +34,7 @@ import torch  # noqa: E402
 
 H8, W8, NKF, RADIUS = 48, 64, 8, 3
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 
 
 def make_window(device, seed=0):
@@ -311,6 +313,28 @@ def main():
     lookup_b2b_us = ev0.elapsed_time(ev1) / 50 * 1e3
     del flush
 
+    # the kernel with the largest share of the step's GPU time (40 %): the wide 3x3 convolution, here as the ConvGRU gate
+    # launch (320 -> 256 channels + sigmoid epilogue) at the step's own shape.  Matrix-core bound, inputs cache-warm in
+    # the step as well (they were just written by the preceding kernels), so it is timed back to back.
+    from pvo_amd import droid_backends as db
+    Eg = len(graph._ii_h)
+    gx = torch.randn(Eg, H8, W8, 320, device=device).half().permute(0, 3, 1, 2)
+    gw = (torch.randn(9, 256, 320, device=device) * 0.02).half()
+    gg = torch.randn(Eg, 384, device=device)
+    gp = torch.randn(Eg, H8, W8, 256, device=device).half().permute(0, 3, 1, 2)
+    gn = torch.randn(Eg, H8, W8, 128, device=device).half().permute(0, 3, 1, 2)
+    for _ in range(3):
+        db.gru_conv_gates(gx, gw, gg, gp, gn)
+    gv0, gv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gv0.record()
+    for _ in range(20):
+        db.gru_conv_gates(gx, gw, gg, gp, gn)
+    gv1.record()
+    torch.cuda.synchronize()
+    gates_us = gv0.elapsed_time(gv1) / 20 * 1e3
+    gates_flop = 2.0 * Eg * H8 * W8 * 9 * 320 * 256
+    del gx, gw, gg, gp, gn
+
     if rank == 0:
         E, HW = len(graph._ii_h), H8 * W8
         in_region_us = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1) * 1e3
@@ -343,6 +367,11 @@ def main():
                          "warm_back_to_back_us": lookup_b2b_us,
                          "in_step_event_us": in_region_us, "in_step_launches": len(events)},
         }
+        out["roofline_wide_conv"] = {
+            "kernel": "conv3x3_big_kernel<half> as pvo_gru_conv_gates (3x3 convolution 320 -> 256 on v_mfma_f32_32x32x16_f16 + sigmoid gates)",
+            "bound": "mfma", "achieved": gates_flop / (gates_us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": gates_flop / (gates_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "flop_per_launch": gates_flop,
+            "avg_launch_us": gates_us, "launches_timed": 20, "share_of_step_kernel_time": 0.40}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["ate_rmse"] = synthetic_ate(device)

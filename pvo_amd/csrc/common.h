@@ -23,11 +23,10 @@ struct pvo_bf16 { uint16_t v; };
 __device__ __forceinline__ float pvo_bf16_to_f32(uint16_t h) {
   return __uint_as_float(static_cast<uint32_t>(h) << 16);
 }
+// round to nearest even, NaN stays a (quiet) NaN: one v_cvt_pk_bf16_f32 on gfx950.  Same values as the integer
+// formulation in oracle/oracle_corr.c (f2b) for everything but the NaN payload.
 __device__ __forceinline__ uint16_t pvo_f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x0040u);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return static_cast<uint16_t>(u >> 16);
+  return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
 }
 
 template <typename T> struct Elem;

@@ -364,6 +364,19 @@ struct BigEpi {
   const uint16_t* seg_p[3]; int seg_stride[3]; int seg_chunks[3]; const float* seg_bias[3];
 };
 
+#ifdef PVO_PROBE_BIG
+// diagnostic build only (tools/big_probe.py): per workgroup {start, main loop end, end} shader-clock stamps and the
+// hardware id of the CU it ran on, to see how many workgroups a CU really holds and what a step costs under contention
+__device__ unsigned long long big_probe[8 * 4096];
+#define BIG_STAMP(slot)                                                                                   \
+  if (tid == 0) {                                                                                         \
+    const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                        \
+    if (wg_ < 4096) big_probe[wg_ * 8 + (slot)] = __builtin_amdgcn_s_memtime();                            \
+  }
+#else
+#define BIG_STAMP(slot)
+#endif
+
 constexpr int kBT = 16;                                   // 16 x 16 pixel tile
 constexpr int kBHalo = (kBT + 2) * (kBT + 2);             // 324 halo positions
 constexpr int kBStride = 80;                              // bytes per halo position / filter row of a 32-channel chunk
@@ -384,6 +397,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kg = lane >> 5;
   const int nC = Cin >> 5;                                // 32-channel chunks
+#ifdef PVO_PROBE_BIG
+  if (tid == 0) {
+    const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wg_ < 4096) {
+      big_probe[wg_ * 8 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+      big_probe[wg_ * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+    }
+  }
+#endif
+  BIG_STAMP(0)
   const uint16_t* xe = x + static_cast<size_t>(e) * H * W * Cin;
   const uint16_t* wb = wt + static_cast<size_t>(cg) * 128 * Cin;
   const size_t tap_stride = static_cast<size_t>(Cout) * Cin;
@@ -533,13 +556,71 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
   }
 
+  BIG_STAMP(1)
   if (ep.mode != 0) {
     // fused ConvGRU epilogue: pre-activations cross the workgroup through an fp32 slab [128 px][128 ch] (528-byte pixel
     // stride, 67.6 KB of the 72 KB), then every thread finishes 8 channels of a pixel with coalesced 16-byte accesses
     float* slab = reinterpret_cast<float*>(bs);
-    const uint16_t* gate_p = ep.P;
+    // every thread finishes channels 8c .. 8c+7 of pixels m = (tid >> 4) + 16 k, k = 0..7, of each half; the per-pixel
+    // operands (P, net, Z) are requested four pixels at a time, the first four BEFORE the accumulators cross the slab:
+    // the probe build showed 32.7k cycles (19 % of a workgroup's life) in this epilogue
+    // when each pixel's loads were waited for one after the other
+    const int c = tid & 15, m0 = tid >> 4;
+    const int pstride = ep.mode == 1 ? 256 : 128;
+    const uint16_t* gate_p = ep.P + (ep.mode == 1 ? cg * 128 : 0) + c * 8;
+    float gg[8];
+    {
+      const float* gp = ep.g + static_cast<size_t>(e) * 384 + (ep.mode == 1 ? cg * 128 : 256) + c * 8;      // 32-byte aligned
+      const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+      gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+    }
+    uint16_t* const dst = (ep.mode == 1 && cg != 0) ? ep.y2 : y;
+    cs_u32x4 pv[4], nv[4], zv[4];
+    auto request = [&](int half, int b) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = m0 + 16 * (4 * b + k);
+        const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
+        const bool in = gy < H && gx < W;
+        const size_t rr = in ? (static_cast<size_t>(e) * H + gy) * W + gx : 0;      // a valid address either way; the value is dropped
+        pv[k] = *reinterpret_cast<const cs_u32x4*>(gate_p + rr * pstride);
+        nv[k] = *reinterpret_cast<const cs_u32x4*>(ep.net + rr * 128 + c * 8);
+        if (ep.mode == 2) zv[k] = *reinterpret_cast<const cs_u32x4*>(ep.Z + rr * 128 + c * 8);
+      }
+    };
+    auto finish = [&](int half, int b) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = m0 + 16 * (4 * b + k);
+        const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
+        float a[8], pp[8], nn[8], o[8];
+        const float4 a0 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8), a1 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8 + 4);
+        a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+        cs_unpack8<T>(pv[k], pp);
+        cs_unpack8<T>(nv[k], nn);
+        if (ep.mode == 1) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(a[q] + gg[q] + pp[q])));      // v_rcp_f32: 1 ulp
+            o[q] = cg == 0 ? sg : sg * nn[q];
+          }
+        } else {
+          float zz[8];
+          cs_unpack8<T>(zv[k], zz);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            // tanh(x) = 1 - 2 / (1 + exp(2x)): exact limits at both ends (exp -> inf gives 1, exp -> 0 gives -1), ~1e-6
+            // absolute error in between - the result is rounded to 16 bits
+            const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * (a[q] + gg[q] + pp[q])));
+            o[q] = (1.0f - zz[q]) * nn[q] + zz[q] * th;
+          }
+        }
+        if (gy < H && gx < W) *reinterpret_cast<cs_u32x4*>(dst + ((static_cast<size_t>(e) * H + gy) * W + gx) * 128 + c * 8) = cs_pack8<T>(o);
+      }
+    };
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
+      request(half, 0);
       if (wm == half) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -552,40 +633,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
             }
       }
       __syncthreads();
-      for (int id = tid; id < 128 * 16; id += 256) {
-        const int m = id >> 4, c = id & 15;
-        const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
-        if (gy < H && gx < W) {
-          const size_t row = (static_cast<size_t>(e) * H + gy) * W + gx;
-          float a[8], gg[8], pp[8], nn[8], o[8];
-          const float4 a0 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8), a1 = *reinterpret_cast<const float4*>(slab + m * 132 + c * 8 + 4);
-          a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-          const int goff = ep.mode == 1 ? cg * 128 : 256;
-          const float* gp = ep.g + static_cast<size_t>(e) * 384 + goff + c * 8;      // 32-byte aligned
-          const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
-          gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-          const int pstride = ep.mode == 1 ? 256 : 128;
-          cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(gate_p + row * pstride + (ep.mode == 1 ? cg * 128 : 0) + c * 8), pp);
-          cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(ep.net + row * 128 + c * 8), nn);
-          if (ep.mode == 1) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float sg = 1.0f / (1.0f + __expf(-(a[k] + gg[k] + pp[k])));
-              o[k] = cg == 0 ? sg : sg * nn[k];
-            }
-            uint16_t* dst = cg == 0 ? y : ep.y2;
-            *reinterpret_cast<cs_u32x4*>(dst + row * 128 + c * 8) = cs_pack8<T>(o);
-          } else {
-            float zz[8];
-            cs_unpack8<T>(*reinterpret_cast<const cs_u32x4*>(ep.Z + row * 128 + c * 8), zz);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (1.0f - zz[k]) * nn[k] + zz[k] * tanhf(a[k] + gg[k] + pp[k]);
-            *reinterpret_cast<cs_u32x4*>(y + row * 128 + c * 8) = cs_pack8<T>(o);
-          }
-        }
-      }
+      finish(half, 0);
+      request(half, 1);
+      finish(half, 1);
       __syncthreads();
     }
+    BIG_STAMP(2)
     return;
   }
   // epilogue: two halves of 128 pixels through an LDS slab [128 px][128 ch] (272-byte pixel stride) -> whole-row stores
@@ -618,9 +671,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
     __syncthreads();
   }
+  BIG_STAMP(2)
 }
 
 }  // namespace
+
+#ifdef PVO_PROBE_BIG
+extern "C" int pvo_big_probe_read(void* dst, int n) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(big_probe), static_cast<size_t>(n) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
                               int E, int H, int W, int dtype, void* stream) {
