@@ -65,6 +65,18 @@ _AGG_HIP_CONV = _os.environ.get("PVO_AGG_HIP_CONV", "1") == "1"
 _FUSED_GRU_EPILOGUE = _os.environ.get("PVO_FUSED_GRU_EPILOGUE", "1") == "1"
 _GRU_NO_ASSEMBLE = _os.environ.get("PVO_GRU_NO_ASSEMBLE", "0") == "1"   # measured: 125 vs 129 keyframe updates/s with the assembled input
 _HIP_WIDE_CONV = _os.environ.get("PVO_HIP_WIDE_CONV", "1") == "1"     # GRU gate/candidate + heads' first stage on pvo_conv3x3
+# The aggregation branch (conv1 over the edges, mean per source frame, then four small kernels over the K keyframes that
+# leave most of the chip idle) runs on a second HIP stream beside the heads, which only share its input.  "0": one stream.
+_AGG_SIDE_STREAM = _os.environ.get("PVO_AGG_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
 
 
 def _taps_wide(owner, key, weight_fn, dt):
@@ -442,12 +454,27 @@ class DynamicUpdateModule(nn.Module):
             net = self.gru(net, inp, corr, flow)
 
         self._last_heads = None
-        delta, delta_dy, weight, delta_m = self._heads(net)
         if raw_heads:
-            if self._last_heads is None or ii is None:
-                raise RuntimeError("raw_heads needs the fused 16-bit inference path and ii")
-            eta, upmask_disp, _, _ = self.agg(net.view(*out_dim), ii.to(net.device), agg_segments, raw_eta=agg_segments is not None)
+            if ii is None:
+                raise RuntimeError("raw_heads needs ii")
+            run_agg = lambda: self.agg(net.view(*out_dim), ii.to(net.device), agg_segments, raw_eta=agg_segments is not None)
+            if _AGG_SIDE_STREAM and net.is_cuda and not torch.cuda.is_current_stream_capturing():
+                # fork / join around the two branches.  Everything the side stream allocates is either freed inside the
+                # block or handed to the main stream after the join, and the next fork waits for the main stream again,
+                # so the caching allocator never hands a block to one stream while the other can still touch it
+                main, side = torch.cuda.current_stream(net.device), _side_stream(net.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    eta, upmask_disp, _, _ = run_agg()
+                self._heads(net)
+                main.wait_stream(side)
+            else:
+                self._heads(net)
+                eta, upmask_disp, _, _ = run_agg()
+            if self._last_heads is None:
+                raise RuntimeError("raw_heads needs the fused 16-bit inference path")
             return net.view(*out_dim), self._last_heads, eta, {"disp": upmask_disp, "flow": None, "dy_mask": None}
+        delta, delta_dy, weight, delta_m = self._heads(net)
         if use_aff_bri:
             aff = self.param_linear(self.global_avg_pool(net).view(batch * num, -1)).view(batch, num, -1)
 
