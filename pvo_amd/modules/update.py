@@ -247,8 +247,7 @@ class GraphAgg(nn.Module):
             fb = self.__dict__.get("_fb32")
             if fb is None or fb[0].device != net.device:
                 f32 = lambda t: t.detach().float().contiguous()
-                fb = self.__dict__["_fb32"] = (f32(self.conv1.bias), f32(self.conv2.bias), f32(self.eta[0].bias),
-                                               f32(self.upmask_disp[0].bias))
+                fb = self.__dict__["_fb32"] = (f32(self.conv1.bias), f32(self.conv2.bias), f32(self.eta[0].bias))
             x = F.conv2d(net.contiguous(memory_format=torch.channels_last), _w16(self, self.conv1, dt), None, padding=1)
             # conv1's bias + ReLU are applied by the mean kernel as it reads (one pass over the 28 MB tensor instead of two)
             x = db.segment_mean(x.contiguous(memory_format=torch.channels_last), segments[0], segments[1], segments[2], in_bias=fb[0])
@@ -261,11 +260,19 @@ class GraphAgg(nn.Module):
             else:
                 net = F.conv2d(x, _w16(self, self.conv2, dt), None, padding=1)
                 net = db.bias_act_(net.contiguous(memory_format=torch.channels_last), fb[1])
-            # bias-free convolutions (MIOpen adds a bias in a separate pass): eta's bias joins the fp32 softplus input,
-            # upmask's is added by the in-place bias kernel
+            # bias-free convolution (MIOpen adds a bias in a separate pass): eta's bias joins the fp32 softplus input
             eta_raw = F.conv2d(net, _w16(self, self.eta[0], dt), None, padding=1)
-            up = F.conv2d(net, _w16(self, self.upmask_disp[0], dt), None).contiguous(memory_format=torch.channels_last)
-            upmask = db.bias_act_(up, fb[3], relu=False).view(batch, -1, 8 * 8 * 9, ht, wd)
+            # the 1x1 upsampling-mask layer over K frames as ONE GEMM with its bias ([K h w, 128] x [128, 576], hipBLASLt):
+            # the grouped-convolution kernel MIOpen picks for this small batch takes 36 us and leaves the bias to a second pass
+            up_w = self.__dict__.get("_up_gemm")
+            w = self.upmask_disp[0].weight
+            if up_w is None or up_w[0] is not w or up_w[1] != w._version or up_w[2].dtype != dt or up_w[2].device != w.device:
+                up_w = self.__dict__["_up_gemm"] = (w, w._version, w.detach().reshape(w.shape[0], -1).t().to(dt).contiguous(),
+                                                    self.upmask_disp[0].bias.detach().to(dt).contiguous())
+            K = net.shape[0]
+            x2 = net.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(K * ht * wd, net.shape[1])
+            up = torch.addmm(up_w[3], x2, up_w[2]).view(K, ht, wd, -1).permute(0, 3, 1, 2)       # [K,576,h,w] channels-last
+            upmask = up.view(batch, -1, 8 * 8 * 9, ht, wd)
             if raw_eta:
                 return (eta_raw, fb[2]), upmask, None, None
             eta = F.softplus(eta_raw.float().add_(fb[2]))
@@ -316,7 +323,7 @@ class DynamicUpdateModule(nn.Module):
 
     def _drop_derived(self):
         for m in self.modules():
-            for k in ("_taps_wide_cache", "_w16_cache", "_fb32", "_ftaps", "_enc0", "_taps3_cache", "_taps2"):
+            for k in ("_taps_wide_cache", "_w16_cache", "_fb32", "_ftaps", "_enc0", "_taps3_cache", "_taps2", "_up_gemm"):
                 m.__dict__.pop(k, None)
         self.train(self.training)
 
