@@ -8,8 +8,8 @@ maps, 36 edges |i-j|<=3), following droid_frontend.py:36-70 of the reference:
     re-create the newest keyframe's edges  (volume + pyramid build for 6 edges, reproject)
     frame distances over the window         (proximity search input, 2 x 56 pairs)
     4 graph updates, keyframe-distance test, 2 more graph updates
-where one graph update = reproject -> 4-level correlation lookup -> update operator (fp16
-autocast, MIOpen) -> mask/weight glue -> dense BA x2 (factor_graph.py:227-307).
+where one graph update = reproject -> 4-level correlation lookup -> update operator (fp16) ->
+mask/weight glue -> dense BA x2 (factor_graph.py:227-307), issued as ONE native call (pvo_graph_update).
 Inputs are synthetic (seeded), resident in HBM before the timed region; the update operator has
 random-init weights of the reference architecture.  State is restored at the start of every step
 so that K steps do identical work.
@@ -84,7 +84,7 @@ class Snapshot:
         self.g.damping.copy_(self.damping)
 
 
-def keyframe_update(video, graph, snap, lookup_events=None):
+def keyframe_update(video, graph, snap):
     """droid_frontend.py:36-70 on a full window"""
     snap.restore()
     newest = NKF - 1
@@ -94,10 +94,10 @@ def keyframe_update(video, graph, snap, lookup_events=None):
     snap_edges_fix(graph, snap)
     d = video.distance(beta=0.3, bidirectional=True)          # NKF x NKF proximity matrix
     for _ in range(4):
-        graph.update(None, None, use_inactive=True) if lookup_events is None else timed_update(graph, lookup_events)
+        graph.update(None, None, use_inactive=True)
     dk = video.distance([newest - 2], [newest - 1], beta=0.3, bidirectional=True)
     for _ in range(2):
-        graph.update(None, None, use_inactive=True) if lookup_events is None else timed_update(graph, lookup_events)
+        graph.update(None, None, use_inactive=True)
     return d, dk
 
 
@@ -111,74 +111,104 @@ def snap_edges_fix(graph, snap):
     graph.raw_mask = snap.raw_mask[:, p]; graph.delta_dy = snap.delta_dy[:, p]
 
 
-def timed_update(graph, events):
-    """graph.update with HIP events around the correlation lookup (same stream as the kernel)"""
-    corr = graph.corr
-
-    class _Timed:
-        def __call__(self, coords, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = corr(coords, **kw)
-            e.record()
-            events.append((s, e))
-            return out
-
-        def encoded(self, coords, w, b):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = corr.encoded(coords, w, b)
-            e.record()
-            events.append((s, e))
-            return out
-
-        def __getattr__(self, k):
-            return getattr(corr, k)
-    graph.corr = _Timed()
+def _host_cpu():
+    """(model name, physical cores, logical cpus) of this host"""
+    import subprocess
+    model, sockets, cps = "unknown", 1, None
     try:
-        graph.update(None, None, use_inactive=True)
-    finally:
-        graph.corr = corr
+        for line in subprocess.run(["lscpu"], stdout=subprocess.PIPE, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                model = v
+            elif k == "Socket(s)":
+                sockets = int(v)
+            elif k == "Core(s) per socket":
+                cps = int(v)
+    except Exception:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (sockets * cps if cps else logical), logical
+
+
+def _median_time(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def cpu_baseline():
-    """The CPU oracle (port of the reference algorithm) on this host: ONE graph update's worth of
-    lookup + update operator + BA, plus one edge of volume build, scaled to a keyframe update."""
+    """The same keyframe update on this host's CPU cores, from the formulations the reference itself would run with its
+    CUDA extension disabled (BASELINE.json configs[0]) where it has one:
+      volume build   torch.matmul + 3 x avg_pool2d (modules/corr.py:24-38,63-71; pvo_amd.modules.corr.CorrBlock.corr)
+      BA             the PyTorch BA (geom/ba.py:31-106; pvo_amd.geom.ba.BA, pinned equal to it), 2 iterations
+      update operator the module in fp32 (droid_net.py:256-314)
+      lookup         the reference has NO CPU lookup (modules/corr.py:4 imports the CUDA extension unconditionally): the C
+                     oracle (a single-threaded port of correlation_kernels.cu:19-70) stands in
+    torch threads = physical cores; warm-ups, then the median.  A bounded sample: one graph update's parts, scaled to the
+    6 updates + 6 new edges of a keyframe update."""
     import numpy as np
+    import torch.nn.functional as F
     from oracle import oracle as O
+    from pvo_amd.geom import ba as tba
+    from pvo_amd.geom.se3 import SE3
+    from pvo_amd.modules.corr import CorrBlock
     from pvo_amd.modules.update import DynamicUpdateModule
-    g = np.random.default_rng(0)
-    E = 36
-    nthreads = os.cpu_count() or 1
-    torch.set_num_threads(nthreads)
-    # build: 1 edge, fp16 features (scaled x6 edges per keyframe)
-    f1 = g.standard_normal((1, 128, H8, W8)).astype(np.float16); f2 = g.standard_normal((1, 128, H8, W8)).astype(np.float16)
-    t = time.perf_counter(); pyr1 = O.corr_build(f1, f2, 4); t_build = time.perf_counter() - t
-    # lookup: 6 edges (scaled x6 to 36)
-    pyr = [np.repeat(p, 6, 0) for p in pyr1]
-    coords = (np.stack(np.meshgrid(np.arange(W8), np.arange(H8)), -1)[None].astype(np.float32)
-              + g.normal(0, 4, (6, H8, W8, 2)).astype(np.float32))
-    t = time.perf_counter(); O.corr_pyramid_lookup(pyr, coords, 3); t_lookup = (time.perf_counter() - t) * 6
-    # update operator: torch CPU fp32, all cores
-    torch.manual_seed(0)
-    upd = DynamicUpdateModule().eval()
+    model, cores, logical = _host_cpu()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    E, HW = 36, H8 * W8
     with torch.no_grad():
-        a = (torch.randn(1, E, 128, H8, W8), torch.randn(1, E, 128, H8, W8), torch.randn(1, E, 196, H8, W8), torch.randn(1, E, 8, H8, W8))
-        ii = torch.arange(NKF).repeat_interleave(6)[:E]
-        t = time.perf_counter(); upd(*a, ii, None); t_upd = time.perf_counter() - t
-    # BA: 2 iterations on the S-B graph
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_geom_ba_gpu import _scene
-    s = _scene(0, NKF, H8, W8, RADIUS, 1)
-    t = time.perf_counter()
-    O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
-         s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, NKF, 2, 1e-4, 0.1)
-    t_ba = time.perf_counter() - t
-    per_kf = 6 * (t_lookup + t_upd + t_ba) + 6 * t_build
-    return {"value": 1.0 / per_kf, "unit": "keyframe updates/s", "cores": nthreads, "kind": "port",
-            "sample": "1 of 6 graph updates (lookup 6 of 36 edges x6, update operator fp32 on %d torch threads, "
-                      "BA 2 iters single thread) + volume build of 1 of 6 edges; scaled to one keyframe update; "
-                      "parts: build %.2fs/edge lookup %.2fs upd %.2fs ba %.2fs" % (nthreads, t_build, t_lookup, t_upd, t_ba)}
+        # volume build + pyramid for the 6 edges a keyframe adds (fp32 on the CPU, as configs[0] runs it)
+        f1, f2 = torch.randn(1, 6, 128, H8, W8, generator=g), torch.randn(1, 6, 128, H8, W8, generator=g)
+
+        def build():
+            c = CorrBlock.corr(f1, f2).reshape(6 * HW, 1, H8, W8)
+            pyr = [c]
+            for _ in range(3):
+                pyr.append(F.avg_pool2d(pyr[-1], 2, stride=2))
+            return pyr
+        t_build = _median_time(build, 3, 10)
+        pyr = [p.view(6, H8, W8, p.shape[-2], p.shape[-1]).numpy() for p in build()]
+        # lookup: C oracle, 6 of the 36 edges, scaled
+        coords = (np.stack(np.meshgrid(np.arange(W8), np.arange(H8)), -1)[None].astype(np.float32)
+                  + np.random.default_rng(0).normal(0, 4, (6, H8, W8, 2)).astype(np.float32))
+        t_lookup = _median_time(lambda: O.corr_pyramid_lookup(pyr, coords, 3), 1, 3) * 6
+        # update operator, fp32, all 36 edges
+        torch.manual_seed(0)
+        upd = DynamicUpdateModule().eval()
+        a = (torch.randn(1, E, 128, H8, W8, generator=g), torch.randn(1, E, 128, H8, W8, generator=g),
+             torch.randn(1, E, 196, H8, W8, generator=g), torch.randn(1, E, 8, H8, W8, generator=g))
+        ii = torch.tensor([i for i in range(NKF) for j in range(NKF) if i != j and abs(i - j) <= RADIUS])
+        jj = torch.tensor([j for i in range(NKF) for j in range(NKF) if i != j and abs(i - j) <= RADIUS])
+        t_upd = _median_time(lambda: upd(*a, ii, None), 1, 3)
+        # PyTorch BA, 2 iterations (what FactorGraph.update runs per update), fixedp = 1
+        xi = torch.tensor([0.05, 0.0, 0.02, 0.0, 0.01, 0.0])
+        poses = SE3(torch.stack([SE3.exp(max(k - 1, 0) * xi).data for k in range(NKF)])[None])
+        disps = torch.ones(1, NKF, H8, W8)
+        intr = torch.tensor([40.0, 40.0, 32.0, 24.0]).view(1, 1, 4).repeat(1, NKF, 1)
+        target = torch.randn(1, E, H8, W8, 2, generator=g) * 2 + torch.stack(torch.meshgrid(
+            torch.arange(W8).float(), torch.arange(H8).float(), indexing="xy"), -1)[None, None]
+        weight = torch.rand(1, E, H8, W8, 2, generator=g)
+        eta = torch.full((1, NKF, H8, W8), 1e-4)
+
+        def ba2():
+            p, d = poses, disps
+            for _ in range(2):
+                p, d = tba.BA(target, weight, eta, p, d, intr, ii, jj, fixedp=1)
+        t_ba = _median_time(ba2, 3, 10)
+    per_kf = 6 * (t_lookup + t_upd + t_ba) + t_build
+    return {"value": 1.0 / per_kf, "unit": "keyframe updates/s", "cores": cores, "kind": "port",
+            "host": "%s, %d physical cores / %d logical" % (model, cores, logical),
+            "sample": "one graph update's parts, medians after warm-up, scaled to a keyframe update (6 updates + 6 new edges): "
+                      "volume build of 6 edges torch.matmul + avg_pool2d fp32 on %d threads %.3fs (median of 10); lookup C oracle "
+                      "single thread %.2fs for 36 edges (6 measured, median of 3); update operator torch fp32 on %d threads %.2fs "
+                      "(median of 3); PyTorch BA x2 on %d threads %.3fs (median of 10)" % (cores, t_build, t_lookup, cores, t_upd, cores, t_ba),
+            "parts_s": {"build_6_edges": t_build, "lookup_36_edges": t_lookup, "update_operator": t_upd, "ba_2_iters": t_ba}}
 
 
 def synthetic_ate(device):
@@ -209,7 +239,6 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graphs", action="store_true", help="replay repeated updates from a captured HIP graph (slower here, see main())")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -226,41 +255,40 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from pvo_amd import _lib
+    from pvo_amd import droid_backends as db
     _lib.load()                                         # fail loudly if the HIP library is missing
-    torch.backends.cudnn.benchmark = True               # MIOpen find mode: pick the fastest conv solvers during warm-up
     video, graph = make_window(device, seed=rank)
+    if not graph._fused_ok():
+        raise SystemExit("the native update path is not active")
     snap = Snapshot(video, graph)
     snap.edge_list = list(zip(graph._ii_h, graph._jj_h))
-    # opt-in: replay repeated updates of an unchanged edge set from a HIP graph.  Measured here it LOSES (79 vs 97
-    # keyframe updates/s): the edge set changes every keyframe, and capture + hipGraphInstantiate of ~70 nodes costs
-    # more than the five replays save.  It pays only when one edge set is iterated many times (initialisation).
-    graph.use_graphs = args.graphs
-    if os.environ.get("PVO_FUSED_ENCODER") == "0":      # A/B switch for the fused lookup + encoder kernel
-        graph.fused_encoder = False
 
-    # one-time library initialisation, before the counted warm-up: MIOpen's solver search (find mode) and its on-disk
-    # kernel cache are cold on a fresh machine and otherwise leak into the first timed steps (75 vs 89 steps/s measured)
-    # ... and so are the GPU's clocks and the host's caches: keep priming (bounded: 3 s) until a block of 8 steps is no
-    # faster than the block before it.  None of this is timed or counted; the timed region below is exactly K steps.
-    prev, t_prime = None, time.perf_counter()
-    while True:
+    # Untimed priming until the step time has converged (clocks, caches, allocator): blocks of 8 steps until two
+    # consecutive blocks are within 3 % of the best seen, at most 40 blocks.  (No library needs a solver search any
+    # more: every kernel of the step is in libpvo_hip.)
+    best, calm, blocks = None, 0, 0
+    while calm < 2 and blocks < 40:
         torch.cuda.synchronize(); tb = time.perf_counter()
         for _ in range(8):
             keyframe_update(video, graph, snap)
         torch.cuda.synchronize(); blk = time.perf_counter() - tb
-        if (prev is not None and blk > 0.97 * prev) or time.perf_counter() - t_prime > 3.0:
-            break
-        prev = blk
+        calm = calm + 1 if (best is not None and blk < 1.03 * best) else 0
+        best = blk if best is None else min(best, blk)
+        blocks += 1
     for _ in range(args.warmup):
         keyframe_update(video, graph, snap)
-    events = []
+    updates_per_step = 6
+    db.probe_arm("lookup", args.steps * updates_per_step)      # HIP events around the lookup kernel, on its stream, in the timed steps
+    host_issue = []
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        keyframe_update(video, graph, snap, None if graph.use_graphs else events)
+        th = time.perf_counter()
+        keyframe_update(video, graph, snap)
+        host_issue.append(time.perf_counter() - th)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -270,36 +298,32 @@ def main():
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    in_step_lookup = db.probe_read(args.steps * updates_per_step)
 
-    if graph.use_graphs:
-        # events cannot bracket a kernel inside a replayed graph: the in-step lookup time is sampled on two
-        # extra, untimed eager steps
-        graph.use_graphs = False
+    # per-stage durations inside the step, from a few extra untimed steps (one probe at a time)
+    stage_us = {}
+    for stage in ("gates", "candidate", "ba", "update"):
+        db.probe_arm(stage, 2 * updates_per_step)
         for _ in range(2):
-            keyframe_update(video, graph, snap, events)
-        torch.cuda.synchronize()
-        graph.use_graphs = True
+            keyframe_update(video, graph, snap)
+        v = db.probe_read(2 * updates_per_step)
+        stage_us[stage] = 1e3 * sum(v) / max(len(v), 1)
 
-    # the dominant hand-written kernel on the bench's own inputs, as the step launches it (lookup fused with the first
-    # encoder layer when the pool is tiled).  COLD: the 0.9 GB volume pool never fits the 256 MB Infinity Cache inside
-    # a step, but 50 identical back-to-back launches would be served from it (175 MB of traffic per launch), so the
-    # cache is evicted (by a 600 MB read) before every timed launch and each launch gets its own pair of HIP events on the launch stream.
+    # the dominant HBM-bound kernel on the bench's own inputs, as the step launches it (lookup fused with the first
+    # encoder layer).  COLD: the 0.9 GB volume pool never fits the 256 MB Infinity Cache inside a step, but identical
+    # back-to-back launches would be served from it, so the cache is evicted (by a 600 MB read) before every timed launch
+    # and each launch gets its own pair of HIP events on the launch stream.
     coords1, _ = video.reproject(graph.ii, graph.jj)
-    fused_enc = bool(getattr(graph.corr, "tiled", False) and graph.fused_encoder)
-    if fused_enc:
-        op = graph.update_op
-        dt16 = next(op.parameters()).dtype
-        enc_w, enc_b = op._enc0_w(dt16), op._bias32()["c0"]
-        launch = lambda: graph.corr.encoded(coords1, enc_w, enc_b)
-    else:
-        launch = lambda: graph.corr(coords1, channels_last=True)
+    pw = graph.update_op.packed_weights(torch.float16)
+    c1 = coords1[0].contiguous()
+    launch = lambda: db.corr_lookup_encode_tiled(graph.corr.levels, c1, pw.tensors["enc0_w"], pw.tensors["enc0_b"],
+                                                 slots=graph.corr.slots_tensor())
     flush = torch.zeros(150 * 1024 * 1024, dtype=torch.float32, device=device)      # 600 MB
     for _ in range(3):
         launch()
     cold = []
     for _ in range(20):
-        flush.max()             # a 600 MB READ (one reduction kernel) evicts the cache with clean lines (a fill would leave 256 MB of dirty
-        # lines whose write-back competes with the timed kernel: 71 us instead of the ~48 us rocprof sees in the steps)
+        flush.max()             # a 600 MB READ evicts the cache with clean lines (a fill would leave dirty lines to write back)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); launch(); e1.record()
         cold.append((e0, e1))
@@ -313,40 +337,40 @@ def main():
     lookup_b2b_us = ev0.elapsed_time(ev1) / 50 * 1e3
     del flush
 
-    # the kernel with the largest share of the step's GPU time (40 %): the wide 3x3 convolution, here as the ConvGRU gate
-    # launch (320 -> 256 channels + sigmoid epilogue) at the step's own shape.  Matrix-core bound, inputs cache-warm in
-    # the step as well (they were just written by the preceding kernels), so it is timed back to back.
-    from pvo_amd import droid_backends as db
+    # the kernel with the largest share of the step's GPU time: the wide 3x3 convolution, here as the ConvGRU gate launch
+    # (320 -> 256 channels + sigmoid epilogue) at the step's own shape, back to back (its inputs are cache-warm in the step too)
     Eg = len(graph._ii_h)
-    gx = torch.randn(Eg, H8, W8, 320, device=device).half().permute(0, 3, 1, 2)
+    gn = torch.tanh(torch.randn(Eg, H8, W8, 128, device=device)).half().permute(0, 3, 1, 2)
+    gc = torch.relu(torch.randn(Eg, H8, W8, 192, device=device)).half().permute(0, 3, 1, 2)
     gw = (torch.randn(9, 256, 320, device=device) * 0.02).half()
     gg = torch.randn(Eg, 384, device=device)
     gp = torch.randn(Eg, H8, W8, 256, device=device).half().permute(0, 3, 1, 2)
-    gn = torch.randn(Eg, H8, W8, 128, device=device).half().permute(0, 3, 1, 2)
     for _ in range(3):
-        db.gru_conv_gates(gx, gw, gg, gp, gn)
+        db.gru_conv_gates(gn, gc, gw, gg, gp)
     gv0, gv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gv0.record()
     for _ in range(20):
-        db.gru_conv_gates(gx, gw, gg, gp, gn)
+        db.gru_conv_gates(gn, gc, gw, gg, gp)
     gv1.record()
     torch.cuda.synchronize()
     gates_us = gv0.elapsed_time(gv1) / 20 * 1e3
     gates_flop = 2.0 * Eg * H8 * W8 * 9 * 320 * 256
-    del gx, gw, gg, gp, gn
+    del gn, gc, gw, gg, gp
 
     if rank == 0:
         E, HW = len(graph._ii_h), H8 * W8
-        in_region_us = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1) * 1e3
-        lookup_us = lookup_cold_us
-        out_ch = 128 if fused_enc else 196
-        alg_bytes = E * HW * (4 * 64 * 2 + 8 + out_ch * 2)      # taps + coords + output, fp16 (912*HW per edge unfused)
+        in_us = sorted(1e3 * v for v in in_step_lookup)
+        lookup_us = sum(in_us) / max(len(in_us), 1)          # the roofline is priced on the kernel as the timed steps ran it
+        alg_bytes = E * HW * (4 * 64 * 2 + 8 + 128 * 2)      # taps + coords + (encoded) output, fp16
         achieved = alg_bytes / (lookup_us * 1e-6) / 1e9 if lookup_us > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_lookup_pmc.json")
-        if os.path.exists(pmc):
-            j = json.load(open(pmc))
-            traffic = (j.get("fused_encoder", {}) if fused_enc else j).get("hbm_bytes_per_launch")
+        for name in ("r02_lookup_pmc.json", "r01_lookup_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                j = json.load(open(pmc))
+                traffic = j.get("fused_encoder", j).get("hbm_bytes_per_launch")
+                break
+        hi = sorted(host_issue)
         out = {
             "metric": "VO keyframe updates/sec (8-keyframe window, 512x384, 36 edges; 6 graph updates + edge rebuild per keyframe)",
             "value": world * args.steps / elapsed, "unit": "keyframe updates/s",
@@ -355,23 +379,27 @@ def main():
             "vs_baseline": None, "dtype": "f16 (volume, lookup, update operator) / f32 (BA assembly) / f64 (pose solve)",
             "data": "synthetic",
             "config": {"workload": "S-B: BASELINE.json configs[1] window (8 keyframes, 48x64 maps, E=36, itrs=2), synthetic",
-                       "edges": E, "graph_updates_per_step": 6, "parallelism": "independent window per GPU",
-                       "hip_graph_replay": bool(graph.use_graphs)},
-            "graph_updates_per_s": world * args.steps * 6 / elapsed,
-            "roofline": {"kernel": ("corr_lookup_r3_kernel<half, tiled, enc> (4-level lookup + 196->128 encoder layer, 8x8-tiled resident volumes)"
-                                    if fused_enc else "corr_lookup_r3_kernel<half, tiled> (fused 4-level lookup, 8x8-tiled resident volumes)"),
-                         "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "edges": E, "graph_updates_per_step": updates_per_step, "parallelism": "independent window per GPU",
+                       "update_path": "pvo_graph_update: one native call per graph update, no MIOpen / hipBLASLt"},
+            "graph_updates_per_s": world * args.steps * updates_per_step / elapsed,
+            "host": {"issue_ms_per_step_median": 1e3 * hi[len(hi) // 2], "issue_ms_per_step_max": 1e3 * hi[-1],
+                     "priming_blocks_of_8_steps": blocks},
+            "roofline": {"kernel": "corr_lookup_r3_kernel<half, tiled, enc> (4-level lookup + 196->128 encoder layer, 8x8-tiled resident volumes)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": lookup_us, "launches_timed": 20, "cache": "Infinity Cache evicted by a 600 MB read before every timed launch",
-                         "warm_back_to_back_us": lookup_b2b_us,
-                         "in_step_event_us": in_region_us, "in_step_launches": len(events)},
+                         "avg_launch_us": lookup_us, "launches_timed": len(in_us),
+                         "timing": "HIP events around the kernel on its launch stream, inside the %d timed steps" % args.steps,
+                         "in_step_us_min_median_max": [in_us[0], in_us[len(in_us) // 2], in_us[-1]] if in_us else None,
+                         "isolated_cold_us": lookup_cold_us, "isolated_cold": "Infinity Cache evicted by a 600 MB read before each of 20 launches",
+                         "warm_back_to_back_us": lookup_b2b_us},
+            "roofline_wide_conv": {
+                "kernel": "conv3x3_big_kernel<half> as pvo_gru_conv_gates (3x3 convolution 320 -> 256 on v_mfma_f32_32x32x16_f16 + sigmoid gates)",
+                "bound": "mfma", "achieved": gates_flop / (gates_us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": gates_flop / (gates_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "flop_per_launch": gates_flop,
+                "avg_launch_us": gates_us, "launches_timed": 20, "in_step_us": stage_us["gates"],
+                "share_of_update_time": stage_us["gates"] / stage_us["update"] if stage_us["update"] else None},
+            "stage_us_in_step": dict(stage_us, lookup=lookup_us),
         }
-        out["roofline_wide_conv"] = {
-            "kernel": "conv3x3_big_kernel<half> as pvo_gru_conv_gates (3x3 convolution 320 -> 256 on v_mfma_f32_32x32x16_f16 + sigmoid gates)",
-            "bound": "mfma", "achieved": gates_flop / (gates_us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": gates_flop / (gates_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "flop_per_launch": gates_flop,
-            "avg_launch_us": gates_us, "launches_timed": 20, "share_of_step_kernel_time": 0.40}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["ate_rmse"] = synthetic_ate(device)

@@ -115,7 +115,8 @@ int pvo_corr_build(const void* fmap1, const void* fmap2, void* const* levels_hos
  * pool is [slots, h1*w1 planes, ceil(Hl/8), ceil(Wl/8), 8, 8] elements (Hl = H >> l): one tile of 16-bit
  * elements is one 128-byte line, so an 8x8 tap window touches <= 4 lines instead of 8 (measured: -27 % HBM
  * traffic for the lookup).  Values are identical to the row-major pyramid.  Requirements: fp16/bf16, 4 levels,
- * radius 3, channels-last features, C in {16,32,64,128}, W % 64 == 0, H % 8 == 0, 16-byte aligned pointers;
+ * radius 3, channels-last features, C in {16,32,64,128}, H, W >= 8 (any map size: VKITTI2's 30x101 included),
+ * 16-byte aligned pointers;
  * anything else returns PVO_EUNSUPPORTED (use the row-major entry points). */
 int pvo_corr_build_tiled(const void* fmap1, const void* fmap2, void* const* levels_host,
                          int N, int C, int H, int W, int dtype, const int* out_slots, void* stream);
@@ -134,47 +135,55 @@ int pvo_corr_lookup_encode_tiled(const void* const* volumes_host, const float* c
                                  const int* slots, int num_slots, void* stream);
 
 /* ------------------------------------------------------------------------- */
-/* Update operator: fused element-wise half of the ConvGRU                    */
+/* Update operator (DynamicUpdateModule, droid_net.py:166-314) on the 16-bit     */
+/* inference path: every layer is a hand-written kernel, no MIOpen / hipBLASLt   */
 /* ------------------------------------------------------------------------- */
 
-/* The reference's ConvGRU.forward (modules/gru.py:19-32) around its three 3x3 convolutions.
- * All feature tensors are channels-last rows [E*HW, C] of fp16/bf16 (`dtype`), 16-byte aligned.
- *   pvo_gru_glo      glo[E,128] f32 = mean_p( sigmoid(wn) * net )        wn = w(net)      (gru.py:23-24)
- *   pvo_gru_assemble X[rows,448]   = [net | inp | relu(corr_feat[128]) | relu(flow_feat[64])]
- *                    (torch.cat of gru.py:20-21 plus the encoders' trailing ReLUs, droid_net.py:176,182)
- *   pvo_gru_gate     Z = sigmoid(zr[:, :128] + g[e, 0:128]);  X[:, :128] = sigmoid(zr[:,128:] + g[e,128:256]) * net
- *                    (gru.py:26-28; zr = conv([convz;convr])(X), g[E,384] f32 = context 1x1 convs of glo)
- *   pvo_gru_out      net_out = (1-Z)*net + Z*tanh(q + g[e,256:384])      q = convq(X)      (gru.py:28-31)
- * Static-input split: `inp` does not change between updates of an edge, and convolution is linear in its input
- * channels, so conv(W, [net|inp|corr|flow]) = conv(W[:, dyn], [net|corr|flow]) + conv(W[:, inp], inp).  With
- * with_inp = 0 / x_channels = 320, X holds only the 320 changing channels and P_zr [rows,256] / P_q [rows,128]
- * carry the precomputed inp terms (added before the gates' non-linearities).  That removes 128 of the 448 input
- * channels (29 %) from the two largest convolutions of every update.
- * Convolution biases are folded in: w_bias into pvo_gru_glo (sigmoid(wn + b)), corr_bias/flow_bias into
- * pvo_gru_assemble (relu(x + b)), the z/r/q biases into g; all bias pointers are f32 [C] and may be NULL.
- *   pvo_bias_act     x[rows,C] <- act(x + bias[c]) in place (act = ReLU when relu != 0): the bias add and ReLU that
- *                    follow a bias-free MIOpen convolution, one pass instead of two
- *   pvo_segment_mean out[k] = mean of x[seg_idx[e]] over e in [seg_ptr[k], seg_ptr[k+1])  — GraphAgg's scatter_mean
- *                    (in_bias != NULL: x is first mapped through relu(x + in_bias[c]), i.e. the bias + ReLU of the
- *                    bias-free convolution that produced it, saving that pass)
- *                    over edges sharing a source frame (droid_net.py:83-87); x [E,HW,C], out [K,HW,C] */
-int pvo_gru_glo(const void* wn, const void* net, const float* w_bias, float* glo, int E, int HW, int C, int dtype,
-                void* stream);
-/* pvo_gru_glo with the 1x1 convolution `w` folded in, as per-chunk partial means:
- *   glo_part[e, k, c] = (1/HW) * sum over pixels of chunk k (256 pixels) of sigmoid((W net)[c] + b[c]) * net[c]
- * so glo[e,c] = sum_k glo_part[e,k,c]; K = pvo_gru_glo_chunks(HW).  No zero fill and no atomics: the consumer's GEMM
- * against row-tiled weights sums the chunks.  net [E,HW,128] 16-bit, w_weight [128 out][128 in] in `dtype`,
+/* All feature tensors are channels-last rows [E*H*W, C] of fp16/bf16 (`dtype`), 16-byte aligned.  Convolution filters
+ * arrive re-arranged once by the host ("taps": [9 taps (ky*3+kx)][Cout][Cin]); biases are f32.
+ *
+ * ConvGRU (modules/gru.py:19-32), as issued here:
+ *   static-input split   conv(W,[net|inp|corr|flow]) = conv(W[:,dyn],[net|corr|flow]) + conv(W[:,inp], inp); `inp` is
+ *                        constant over an edge's life, so P_zr [rows,256] / P_q [rows,128] = conv(W[:,inp], inp) are
+ *                        computed once per edge (pvo_conv3x3) and added inside the gate epilogues
+ *   pvo_gru_glo_fused    per-chunk partial means of sigmoid(w(net) + b) * net  (gru.py:22-24, 1x1 conv inside)
+ *   pvo_gate_context     g[E,384] = [convz_glo | convr_glo | convq_glo](glo) + their biases + the z/r/q conv biases
+ *   pvo_gru_conv_gates / pvo_gru_conv_candidate   the two wide 3x3 convolutions with the gate arithmetic as epilogue */
+
+/* glo_part[e, k, c] = (1/HW) * sum over pixels of chunk k (256 pixels) of sigmoid((W net)[c] + b[c]) * net[c], so
+ * glo[e,c] = sum_k glo_part[e,k,c]; K = pvo_gru_glo_chunks(HW).  net [E,HW,128], w_weight [128 out][128 in] in `dtype`,
  * w_bias f32 [128] or NULL, glo_part f32 [E,K,128]. */
 int pvo_gru_glo_chunks(int HW);
 int pvo_gru_glo_fused(const void* net, const void* w_weight, const float* w_bias, float* glo_part,
                       int E, int HW, int dtype, void* stream);
-int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
-                     const float* corr_bias, const float* flow_bias,
-                     void* X, long long rows, int with_inp, int dtype, void* stream);
-int pvo_gru_gate(const void* zr, const float* g, const void* net, void* Z, void* X,
-                 const void* P_zr, int x_channels, int E, int HW, int dtype, void* stream);
-int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, void* net_out,
-                const void* P_q, int E, int HW, int dtype, void* stream);
+/* g[e, j] = g_bias[j] + sum_c (sum_k glo_part[e,k,c]) * wg_t[c, j];  wg_t f32 [128][384], g_bias f32 [384], g f32 [E,384] */
+int pvo_gate_context(const float* glo_part, const float* wg_t, const float* g_bias, float* g,
+                     int E, int chunks, void* stream);
+/* y[E,H,W,ystride (channels yoff .. yoff+Cout)] = act(conv3x3(x[E,H,W,128], zero padding 1) + bias) on the matrix cores:
+ * the 128-input 3x3 convolutions (corr_encoder[2], flow_encoder[2], GraphAgg.conv1/conv2; droid_net.py:79-95,172-180).
+ * Cout in {64, 128, 256, 512}; w_taps [9][Cout][128]; bias f32 [Cout] or NULL; relu != 0 applies ReLU.
+ * ystride = 0 means a dense output (ystride = Cout, yoff = 0); otherwise the result lands in a channel slice of a wider
+ * tensor (the encoders write [corr features | flow features] side by side for the ConvGRU). */
+int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void* y,
+                     int E, int H, int W, int Cout, int relu, int ystride, int yoff, int dtype, void* stream);
+/* the same for wide layers (implicit GEMM, 16x16 pixel tile x 128 outputs per workgroup): Cin % 32 == 0, Cout % 128 == 0;
+ * w_taps [9][Cout][Cin]. */
+int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
+                int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream);
+/* The ConvGRU's two large convolutions with the gate arithmetic as their epilogue (modules/gru.py:26-31); the 256 gate
+ * pre-activations and the 128 candidate pre-activations never reach HBM.  The input channels are read from two tensors,
+ * [net | cf] resp. [RN | cf] (cf [E,H,W,cf_channels], cf_channels % 32 == 0: the encoders' outputs side by side), so no
+ * concatenated input is assembled (the torch.cat's of gru.py:20-21,28).
+ *   pvo_gru_conv_gates:     Z  = sigmoid(conv3x3([net|cf], w)[:, :128] + g[e, 0:128]   + P_zr[:, :128])
+ *                           RN = sigmoid(conv3x3([net|cf], w)[:, 128:] + g[e, 128:256] + P_zr[:, 128:]) * net
+ *   pvo_gru_conv_candidate: net_out = (1 - Z) * net + Z * tanh(conv3x3([RN|cf], w) + g[e, 256:384] + P_q)
+ * w_taps [9][256 or 128][128 + cf_channels], g f32 [E,384], P_zr [E,H,W,256], P_q / net / Z / RN / net_out [E,H,W,128];
+ * net_out may alias net. */
+int pvo_gru_conv_gates(const void* net, const void* cf, int cf_channels, const void* w_taps, const float* g,
+                       const void* P_zr, void* Z, void* RN, int E, int H, int W, int dtype, void* stream);
+int pvo_gru_conv_candidate(const void* RN, const void* cf, int cf_channels, const void* w_taps, const float* g,
+                           const void* P_q, const void* Z, const void* net, void* net_out,
+                           int E, int H, int W, int dtype, void* stream);
 /* Second stage of the four output heads (droid_net.py:184-210) in one launch: y[E,H,W,8] =
  * Conv3x3(128->2) per head applied to relu(h1[..., head*128:(head+1)*128] + bias1), zero padding.
  * h1 [E,H,W,512] is the bias-free output of the four first-stage convolutions; w2 is
@@ -186,64 +195,133 @@ int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const floa
  * re-arranged to [52 taps (ky*7+kx; 49 real + 3 zero)][128 outputs][8 input channels] in `dtype`; bias f32 [128]. */
 int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
                    int E, int H, int W, int dtype, void* stream);
-/* y[E,H,W,Cout] = act(conv3x3(x[E,H,W,128], zero padding 1) + bias) on the matrix cores: the update operator's
- * 128-input 3x3 convolutions (corr_encoder[2], flow_encoder[2], GraphAgg.conv1).  Cout in {64, 128, 256, 512};
- * w_taps [9 taps (ky*3+kx)][Cout][128] in `dtype`; bias f32 [Cout] or NULL; relu != 0 applies ReLU. */
-int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void* y,
-                     int E, int H, int W, int Cout, int relu, int dtype, void* stream);
-/* y[E,H,W,Cout] = act(conv3x3(x[E,H,W,Cin], zero padding 1) + bias) for wide layers on the matrix cores (implicit GEMM,
- * 16x16 pixel tile x 128 outputs per workgroup): Cin % 32 == 0, Cout % 128 == 0; w_taps [9 taps][Cout][Cin] in `dtype`;
- * bias f32 [Cout] or NULL; relu != 0 applies ReLU. */
-int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
-                int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream);
-/* The ConvGRU's two large convolutions with the gate arithmetic as their epilogue (modules/gru.py:26-31); the 256 gate
- * pre-activations and the 128 candidate pre-activations never reach HBM.
- *   pvo_gru_conv_gates:     Z  = sigmoid(conv3x3(X, w)[:, :128] + g[e, 0:128]   + P_zr[:, :128])
- *                           RN = sigmoid(conv3x3(X, w)[:, 128:] + g[e, 128:256] + P_zr[:, 128:]) * net
- *   pvo_gru_conv_candidate: net_out = (1 - Z) * net + Z * tanh(conv3x3([RN | X[:, 128:]], w) + g[e, 256:384] + P_q)
- * X [E,H,W,Cin] (Cin = 320: [net | corr features | flow features]; the candidate reads its first 128 channels from RN
- * instead), w_taps [9][256 or 128][Cin], g f32 [E,384], P_zr [E,H,W,256], P_q / net / Z / RN / net_out [E,H,W,128]. */
-int pvo_gru_conv_gates(const void* X, const void* w_taps, const float* g, const void* P_zr, const void* net,
-                       void* Z, void* RN, int E, int H, int W, int Cin, int dtype, void* stream);
-int pvo_gru_conv_candidate(const void* X, const void* RN, const void* w_taps, const float* g, const void* P_q,
-                           const void* Z, const void* net, void* net_out,
-                           int E, int H, int W, int Cin, int dtype, void* stream);
-/* The same two kernels reading the GRU input as three tensors - net (or RN) [E,H,W,128], cf [E,H,W,128], ff [E,H,W,64],
- * the latter two bias-free convolution outputs that are mapped through relu(v + bias) while they are staged - so that the
- * concatenated [E,H,W,320] input is never assembled.  w_taps [9][256 | 128][320]. */
-int pvo_gru_gates(const void* net, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
-                  const void* w_taps, const float* g, const void* P_zr, void* Z, void* RN,
-                  int E, int H, int W, int dtype, void* stream);
-int pvo_gru_candidate(const void* RN, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
-                      const void* w_taps, const float* g, const void* P_q, const void* Z, const void* net,
-                      void* net_out, int E, int H, int W, int dtype, void* stream);
-int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream);
+/* y[rows,128] = relu(W corr + b) for an already sampled correlation tensor corr [rows,196] (channels-last, 8-byte aligned):
+ * corr_encoder[0:2] = Conv2d(196,128,1) + ReLU (droid_net.py:172-175) for callers without a resident volume pool (motion
+ * filter, global BA with alt-corr).  enc_weight as in pvo_corr_lookup_encode_tiled: [128][224], zero padded. */
+int pvo_corr_encode(const void* corr, const void* enc_weight, const float* enc_bias, void* y, long long rows,
+                    int dtype, void* stream);
+/* out[k] = mean over e in [seg_ptr[k], seg_ptr[k+1]) of x[seg_idx[e]] — GraphAgg's scatter_mean over the edges sharing a
+ * source frame (droid_net.py:83-87); in_bias != NULL: x is first mapped through relu(x + in_bias[c]) (the bias + ReLU of
+ * the bias-free convolution that produced it).  x [E,HW,C], out [K,HW,C]. */
 int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                      int K, int HW, int C, int dtype, void* stream);
+/* GraphAgg's eta head (droid_net.py:72-74,93-95): e = 0.01 * softplus(conv3x3(x, w)[1 channel] + bias), x [K,H,W,128],
+ * w_taps [9][128] in `dtype`, bias f32 [1].
+ *   frame == NULL: eta[k] = e for the K = R images (what GraphAgg returns).
+ *   frame != NULL: FactorGraph's damping bookkeeping as well (factor_graph.py:281-297): row r of eta belongs to frame
+ *     frame[r] (int64 [R]) and takes image pos[r] of x (int32 [R]; -1: the frame only carries inactive edges and keeps
+ *     its stored damping):  damping[frame[r]] = e (pos[r] >= 0);  eta[r] = 0.2 * damping[frame[r]] + EP.
+ * damping f32 [buffer,H,W] (updated in place), eta f32 [R,H,W]. */
+int pvo_eta_head(const void* x, const void* w_taps, const float* bias, const int64_t* frame, const int* pos,
+                 float* damping, float* eta, int R, int H, int W, float EP, int dtype, void* stream);
+/* y[rows,Cout] = act(x[rows,128] W^T + b), W [Cout][128] in `dtype`, Cout % 192 == 0: GraphAgg.upmask_disp =
+ * Conv2d(128, 576, 1) (droid_net.py:76-77). */
+int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, long long rows, int Cout, int relu,
+                     int dtype, void* stream);
 
-/* FactorGraph.update's arithmetic around the update operator (factor_graph.py:231-306, segm_filter off), two launches
- * instead of ~25 element-wise PyTorch launches.  All [E,H,W,2] tensors are f32.
+/* FactorGraph.update's arithmetic around the update operator (factor_graph.py:231-306).  All [E,H,W,2] tensors are f32.
  *   pvo_graph_motion  motn [E,H,W,8] (`dtype`, channels-last) = clamp([target-coords0 | target-coords0+delta_dy |
  *                     target-coords1 | raw_mask], +-64)                                   (:233-237)
+ *   pvo_segment_hist  panoptic vote, counting half (:256-261): tot[e,s] = pixels of segment s on edge e, dyn[e,s] = those
+ *                     whose UPDATED mask (raw_mask + delta_mask, read from heads) is dynamic on either channel;
+ *                     segm int32 [E,H,W] dense segment labels in [0, max_segments), 0 = no segment; tot/dyn int32
+ *                     [E,max_segments] (zeroed here)
  *   pvo_graph_post    heads [E,H,W,8] (`dtype`) = delta | delta_dy | weight logits | delta_mask as pvo_heads_out writes them:
- *                     raw_mask += delta_mask (in place); bin = sigmoid(raw_mask) >= dy_thresh; target = coords1 + delta;
- *                     delta_dy = delta_dy_raw (1-bin); weight = sigmoid(logits + 10 (1-bin)); full_flow = coords1 + delta_dy - coords0;
- *                     target_ba / weight_ba [E,2,H,W] are the layouts pvo_ba reads                (:249-306)
- *                     force_dyn (optional, uint8 [E,H,W]): pixels whose bin is forced to 0 ("dynamic") on both channels -
- *                     the outcome of the panoptic segment vote (:256-276), computed by the caller from the updated mask */
+ *                     raw_mask += delta_mask (in place); bin = sigmoid(raw_mask) >= dy_thresh; with segm != NULL, bin = 0
+ *                     on both channels where the pixel's segment s != 0 has dyn[e,s] / max(tot[e,s],1) > vote_thresh
+ *                     (:262-276); target = coords1 + delta; delta_dy = delta_dy_raw (1-bin); weight = sigmoid(logits +
+ *                     10 (1-bin)); full_flow = coords1 + delta_dy - coords0; target_ba / weight_ba [E,2,H,W] are the
+ *                     layouts pvo_ba reads                                                (:249-306)
+ * target / delta_dy may alias the tensors pvo_graph_motion read. */
 int pvo_graph_motion(const float* target, const float* coords1, const float* delta_dy, const float* raw_mask,
                      void* motn, int E, int H, int W, int dtype, void* stream);
+int pvo_segment_hist(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
+                     int E, int HW, int max_segments, float dy_thresh, int dtype, void* stream);
 int pvo_graph_post(const float* coords1, const void* heads, float* raw_mask, float* target, float* delta_dy,
                    float* weight, float* target_ba, float* weight_ba, float* full_flow,
-                   int E, int H, int W, float dy_thresh, const unsigned char* force_dyn, int dtype, void* stream);
+                   int E, int H, int W, float dy_thresh, const int* segm, const int* vote_tot, const int* vote_dyn,
+                   int max_segments, float vote_thresh, int dtype, void* stream);
 
-/* GraphAgg's eta head + FactorGraph's damping bookkeeping in one launch (droid_net.py:93-95, factor_graph.py:281-283):
- *   e = 0.01 * softplus(raw[pos[r]] + bias[0]);  damping[frame[r]] = e      (pos[r] >= 0)
- *   e = damping[frame[r]]                                                   (pos[r] <  0: frame with inactive edges only)
- *   eta[r] = 0.2 * e + EP
- * raw [K,HW] 16-bit (bias-free 128->1 convolution), frame int64 [R], pos int32 [R], damping f32 [buffer,HW], eta f32 [R,HW]. */
-int pvo_eta_finish(const void* raw, const float* bias, const int64_t* frame, const int* pos,
-                   float* damping, float* eta, int R, int HW, float EP, int dtype, void* stream);
+/* ---- the operator and the whole graph update as single calls (update_exec.hip) ------------------------------------ */
+
+enum {
+  PVO_OP_CONV128_WIDE = 1,   /* corr_encoder[2] / GraphAgg.conv1 on pvo_conv3x3 instead of pvo_conv3x3_c128 */
+  PVO_OP_SINGLE_STREAM = 2   /* no second stream for the aggregation branch */
+};
+
+/* Device pointers to the update operator's parameters, re-arranged once by the host (pvo_amd/modules/update.py
+ * `packed_weights`); parameter names are the reference's (droid_net.py:172-225, gru.py:9-17). */
+typedef struct pvo_update_weights {
+  int dtype;                                     /* PVO_F16 or PVO_BF16: every 16-bit tensor below and all activations */
+  int flags;                                     /* PVO_OP_* */
+  const void* enc0_w;   const float* enc0_b;     /* corr_encoder.0: [128][224] zero padded, [128] */
+  const void* cenc2_w;  const float* cenc2_b;    /* corr_encoder.2: taps [9][128][128], [128] */
+  const void* fenc0_w;  const float* fenc0_b;    /* flow_encoder.0: [52][128][8], [128] */
+  const void* fenc2_w;  const float* fenc2_b;    /* flow_encoder.2: taps [9][64][128], [64] */
+  const void* glo_w;    const float* glo_b;      /* gru.w: [128][128], [128] */
+  const float* gate_wt; const float* gate_b;     /* gru.conv{z,r,q}_glo: f32 [128][384] (transposed), f32 [384] (+ conv{z,r,q} biases) */
+  const void* zr_w;     const void* q_w;         /* gru.convz|convr, gru.convq over [net|corr|flow]: taps [9][256][320], [9][128][320] */
+  const void* zr_inp_w; const void* q_inp_w;     /* the same filters' `inp` input channels: taps [9][256][128], [9][128][128] */
+  const void* heads1_w; const float* heads1_b;   /* delta|delta_dy|weight|delta_mask .0: taps [9][512][128], [512] */
+  const void* heads2_w; const float* heads2_b;   /* ... .2: [4][2][9][128], [8] */
+  const void* agg1_w;   const float* agg1_b;     /* agg.conv1: taps [9][128][128], [128] */
+  const void* agg2_w;   const float* agg2_b;     /* agg.conv2 */
+  const void* eta_w;    const float* eta_b;      /* agg.eta.0: [9][128], [1] */
+  const void* up_w;     const float* up_b;       /* agg.upmask_disp.0: [576][128], [576] */
+} pvo_update_weights;
+
+/* One call of DynamicUpdateModule.forward(net, inp, corr, flow, ii) (droid_net.py:256-314). */
+typedef struct pvo_operator_args {
+  int E, H, W;
+  /* correlation features: the factor graph's tiled volume pool + coordinates (lookup fused with corr_encoder.0) ... */
+  const void* levels[4]; const int* slots; int num_slots;
+  const float* coords;        /* [E,H,W,2] f32 */
+  const void* corr;           /* ... or, when levels[0] == NULL, a sampled tensor [E,H,W,196] */
+  const void* motion;         /* [E,H,W,8] */
+  const void* net;            /* [E,H,W,128] hidden state */
+  void* net_out;              /* [E,H,W,128] new hidden state (may alias net) */
+  const void* inp;            /* [E,H,W,128] context features; read only when P_zr / P_q are NULL */
+  const void* P_zr; const void* P_q;   /* cached static-input terms [E,H,W,256], [E,H,W,128], or NULL */
+  const int* seg_ptr; const int* seg_idx; int K;   /* GraphAgg groups: CSR of edges by source frame (K = 0: no aggregation) */
+  void* heads;                /* [E,H,W,8] out: delta | delta_dy | weight logits | delta_mask */
+  const int64_t* eta_frame; const int* eta_pos; int R; float* damping; float EP;   /* see pvo_eta_head */
+  float* eta;                 /* [R or K,H,W] f32 out, or NULL */
+  void* upmask;               /* [K,H,W,576] out, or NULL */
+} pvo_operator_args;
+
+size_t pvo_operator_workspace_bytes(int E, int K, int H, int W);
+int pvo_update_operator(const pvo_update_weights* weights, const pvo_operator_args* args,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* One call of FactorGraph.update (factor_graph.py:227-307) on a resident tiled volume pool. */
+typedef struct pvo_graph_update_args {
+  pvo_operator_args op;       /* coords / corr / motion / heads / eta are supplied from the workspace */
+  int nframes;
+  float* poses; float* disps; const float* intrinsics;      /* [nframes,7], [nframes,H,W], [nframes,4]; poses / disps updated in place */
+  const int64_t* ii; const int64_t* jj;                      /* active edges [E] */
+  float* target; float* delta_dy; float* raw_mask;           /* [E,H,W,2] f32 state, updated in place */
+  float* weight; float* full_flow;                           /* [E,H,W,2] f32 out */
+  const int* segm; int max_segments; float vote_thresh;      /* panoptic vote (segm == NULL: off) */
+  float dy_thresh;
+  int n_in;                                                  /* inactive edges that take part in the BA (use_inactive) */
+  float* target_ba; float* weight_ba;                        /* [n_in + E,2,H,W] f32: rows [0,n_in) filled by the caller, the rest here */
+  const int64_t* ii_ba; const int64_t* jj_ba;                /* [n_in + E] */
+  int t0, t1, itrs, motion_only; float lm, ep;
+  double* sys; void* ba_ws; size_t ba_ws_bytes;              /* planned with pvo_ba_plan(ii_ba, jj_ba, ..., K_eta = op.R) */
+  int clamp_frames; float disp_min;                          /* disps[:clamp_frames].clamp_(min=disp_min) (depth_video.py:214) */
+  int want_upmask;                                           /* compute agg.upmask_disp although FactorGraph.update discards it */
+} pvo_graph_update_args;
+
+size_t pvo_graph_update_workspace_bytes(int E, int K, int R, int H, int W, int max_segments);
+/* Measurement hook: HIP events recorded on the launch stream around one stage of the following pvo_graph_update /
+ * pvo_update_operator calls (at most `capacity` occurrences), so a benchmark can read a kernel's duration inside its timed
+ * steps.  pvo_probe_read waits for the recorded events, writes their elapsed times in milliseconds to HOST memory,
+ * disarms the probe and returns the number of samples (or -1). */
+enum { PVO_STAGE_LOOKUP = 0, PVO_STAGE_GATES = 1, PVO_STAGE_CANDIDATE = 2, PVO_STAGE_BA = 3, PVO_STAGE_UPDATE = 4 };
+int pvo_probe_arm(int stage, int capacity);
+int pvo_probe_read(float* ms_host, int max_n);
+int pvo_graph_update(const pvo_update_weights* weights, const pvo_graph_update_args* args,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Reprojection helpers                                                       */

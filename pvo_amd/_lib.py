@@ -24,28 +24,31 @@ SIGNATURES = {
     "pvo_altcorr_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_altcorr_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_build": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "pvo_eta_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_float, _i, _vp]),
     "pvo_gru_glo_chunks": (_i, [_i]),
     "pvo_gru_glo_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "pvo_gru_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_candidate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_conv_gates": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "pvo_gru_conv_candidate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "pvo_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "pvo_conv3x3_c128": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "pvo_gate_context": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "pvo_gru_conv_gates": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_gru_conv_candidate": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pvo_conv3x3_c128": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv7x7_c8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_corr_encode": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _vp]),
+    "pvo_eta_head": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "pvo_conv1x1_c128": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _i, _vp]),
     "pvo_corr_build_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "pvo_corr_lookup_encode_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "pvo_corr_pyramid_lookup_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
-    "pvo_gru_glo": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_assemble": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),
     "pvo_heads_out": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_bias_act": (_i, [_vp, _vp, _c.c_longlong, _i, _i, _i, _vp]),
     "pvo_segment_mean": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_gate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_out": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_graph_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_graph_post": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
+    "pvo_segment_hist": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "pvo_graph_post": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _f, _i, _vp]),
+    "pvo_operator_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "pvo_update_operator": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "pvo_graph_update_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "pvo_graph_update": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "pvo_probe_arm": (_i, [_i, _i]),
+    "pvo_probe_read": (_i, [_vp, _i]),
     "pvo_frame_distance": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "pvo_projmap": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_iproj": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -60,6 +63,38 @@ SIGNATURES = {
     "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i,
                            _vp, _vp, _i, _vp, _vp, _sz, _vp]),
 }
+
+
+
+class UpdateWeights(_c.Structure):
+    """pvo_update_weights (include/pvo_hip.h)"""
+    _fields_ = [("dtype", _i), ("flags", _i)] + [(n, _vp) for n in (
+        "enc0_w", "enc0_b", "cenc2_w", "cenc2_b", "fenc0_w", "fenc0_b", "fenc2_w", "fenc2_b", "glo_w", "glo_b",
+        "gate_wt", "gate_b", "zr_w", "q_w", "zr_inp_w", "q_inp_w", "heads1_w", "heads1_b", "heads2_w", "heads2_b",
+        "agg1_w", "agg1_b", "agg2_w", "agg2_b", "eta_w", "eta_b", "up_w", "up_b")]
+
+
+class OperatorArgs(_c.Structure):
+    """pvo_operator_args"""
+    _fields_ = [("E", _i), ("H", _i), ("W", _i), ("levels", _vp * 4), ("slots", _vp), ("num_slots", _i),
+                ("coords", _vp), ("corr", _vp), ("motion", _vp), ("net", _vp), ("net_out", _vp), ("inp", _vp),
+                ("P_zr", _vp), ("P_q", _vp), ("seg_ptr", _vp), ("seg_idx", _vp), ("K", _i), ("heads", _vp),
+                ("eta_frame", _vp), ("eta_pos", _vp), ("R", _i), ("damping", _vp), ("EP", _f), ("eta", _vp),
+                ("upmask", _vp)]
+
+
+class GraphUpdateArgs(_c.Structure):
+    """pvo_graph_update_args"""
+    _fields_ = [("op", OperatorArgs), ("nframes", _i), ("poses", _vp), ("disps", _vp), ("intrinsics", _vp),
+                ("ii", _vp), ("jj", _vp), ("target", _vp), ("delta_dy", _vp), ("raw_mask", _vp), ("weight", _vp),
+                ("full_flow", _vp), ("segm", _vp), ("max_segments", _i), ("vote_thresh", _f), ("dy_thresh", _f),
+                ("n_in", _i), ("target_ba", _vp), ("weight_ba", _vp), ("ii_ba", _vp), ("jj_ba", _vp),
+                ("t0", _i), ("t1", _i), ("itrs", _i), ("motion_only", _i), ("lm", _f), ("ep", _f),
+                ("sys", _vp), ("ba_ws", _vp), ("ba_ws_bytes", _sz), ("clamp_frames", _i), ("disp_min", _f),
+                ("want_upmask", _i)]
+
+
+PVO_OP_CONV128_WIDE, PVO_OP_SINGLE_STREAM = 1, 2
 
 _lib = None
 

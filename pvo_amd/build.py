@@ -24,6 +24,8 @@ HIP_SOURCES = [
     "gru_fused.hip",
     "graph_glue.hip",
     "conv_small.hip",
+    "operator_small.hip",
+    "update_exec.hip",
     "ba.hip",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -226,7 +226,7 @@ constexpr int kC3Halo = (kTH + 2) * (kTW + 2), kC3Stride = 272;
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                            const float* __restrict__ bias, uint16_t* __restrict__ y,
-                                                           int H, int W, int Cout, int relu) {
+                                                           int H, int W, int Cout, int relu, int ystride, int yoff) {
   extern __shared__ __attribute__((aligned(16))) unsigned char c3s[];          // [180][272 B]; later the output slab
   constexpr int kCoutWG = 64 * NT;                                            // output channels per workgroup
   const int ntx = (W + kTW - 1) / kTW;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const uint16_t* __res
     const int p = id / kChunks, c = id - p * kChunks;
     const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
     if (gy < H && gx < W)
-      *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * Cout + cg * kCoutWG + c * 8) =
+      *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * ystride + yoff + cg * kCoutWG + c * 8) =
           *reinterpret_cast<const cs_u32x4*>(c3s + p * kOutStride + c * 16);
   }
 }
@@ -347,8 +347,9 @@ template <> __device__ __forceinline__ cs_v16f cs_mfma32<pvo_bf16>(cs_u32x4 a, c
 //   mode 1 (gates, Cout = 256): channel group 0 -> y  = Z  = sigmoid(acc + g[e, c] + P[row, c])                [rows,128]
 //                               channel group 1 -> y2 = RN = sigmoid(acc + g[e,128+c] + P[row,128+c]) * net    [rows,128]
 //   mode 2 (candidate, Cout = 128):               y  = (1 - Z) * net + Z * tanh(acc + g[e,256+c] + P[row, c])  [rows,128]
-//   x2: the first x2_chunks 32-channel chunks of the input come from x2 (pixel stride x2_stride) instead of x - the
-//       candidate convolution reads [RN | X[:, 128:]] without RN ever being copied into X.
+//   segmented input (nseg > 0 replaces x): the input channels are the concatenation of up to three tensors, each with its
+//       own pixel stride - the ConvGRU reads [net | encoder features] (gates) and [r * net | encoder features]
+//       (candidate) straight from the tensors their producers wrote; no concatenated copy is assembled.
 struct BigEpi {
   int mode;
   const float* g;            // [E,384] f32: context of z | r | q (biases folded in)
@@ -356,12 +357,8 @@ struct BigEpi {
   const uint16_t* net;       // [rows,128]
   const uint16_t* Z;         // [rows,128] (mode 2)
   uint16_t* y2;              // [rows,128] (mode 1)
-  const uint16_t* x2; int x2_chunks; int x2_stride;
-  // segmented input (nseg > 0 replaces x / x2): the input channels are the concatenation of up to three tensors, each
-  // with its own pixel stride; a segment with a bias is mapped through relu(v + bias[c]) while it is staged - so the
-  // ConvGRU reads [net | relu(cf + b) | relu(ff + b)] straight from the three tensors and no [E,H,W,320] copy is assembled
   int nseg;
-  const uint16_t* seg_p[3]; int seg_stride[3]; int seg_chunks[3]; const float* seg_bias[3];
+  const uint16_t* seg_p[3]; int seg_stride[3]; int seg_chunks[3];
 };
 
 #ifdef PVO_PROBE_BIG
@@ -385,7 +382,7 @@ constexpr int kBA = kBHalo * kBStride, kBB = 128 * kBStride;   // 25920 + 10240 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
-                                                          int H, int W, int Cin, int Cout, int relu, BigEpi ep) {
+                                                          int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, BigEpi ep) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bs[];      // A[2] | B[2]; later the output slab
   unsigned char* As = bs;
   unsigned char* Bs = bs + 2 * kBA;
@@ -427,28 +424,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       if (hy >= 0 && hy < H && hx >= 0 && hx < W) apix[it] = hy * W + hx;
     }
   }
-  const uint16_t* x2e = ep.x2 ? ep.x2 + static_cast<size_t>(e) * H * W * ep.x2_stride : nullptr;
   const size_t img = static_cast<size_t>(e) * H * W;
-  float4 sb0 = {0.f, 0.f, 0.f, 0.f}, sb1 = {0.f, 0.f, 0.f, 0.f};      // this thread's 8 bias values of the chunk in flight
-  bool a_bias = false;                                              // (uniform) the chunk in flight wants relu(v + bias)
   auto fetch_a = [&](int cc) {
-    const uint16_t* src; int stride; int coff = cc * 32;
-    a_bias = false;
+    const uint16_t* src = xe; int stride = Cin; int coff = cc * 32;
     if (ep.nseg > 0) {                                              // uniform walk over at most three segments
       int sgi = 0, c0 = cc;
       while (sgi + 1 < ep.nseg && c0 >= ep.seg_chunks[sgi]) { c0 -= ep.seg_chunks[sgi]; ++sgi; }
       stride = ep.seg_stride[sgi];
       src = ep.seg_p[sgi] + img * stride;
       coff = c0 * 32;
-      if (ep.seg_bias[sgi]) {
-        a_bias = true;
-        const float* bp = ep.seg_bias[sgi] + coff + (tid & 3) * 8;
-        sb0 = *reinterpret_cast<const float4*>(bp); sb1 = *reinterpret_cast<const float4*>(bp + 4);
-      }
-    } else {
-      const bool from2 = x2e != nullptr && cc < ep.x2_chunks;       // uniform
-      src = from2 ? x2e : xe;
-      stride = from2 ? ep.x2_stride : Cin;
     }
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
@@ -460,17 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
       const int id = tid + 256 * it;
-      if ((id >> 2) < kBHalo) {
-        cs_u32x4 v = ra[it];
-        if (a_bias && apix[it] >= 0) {                               // zero padding stays zero: it is applied after the ReLU
-          float f[8];
-          cs_unpack8<T>(v, f);
-          f[0] = fmaxf(f[0] + sb0.x, 0.f); f[1] = fmaxf(f[1] + sb0.y, 0.f); f[2] = fmaxf(f[2] + sb0.z, 0.f); f[3] = fmaxf(f[3] + sb0.w, 0.f);
-          f[4] = fmaxf(f[4] + sb1.x, 0.f); f[5] = fmaxf(f[5] + sb1.y, 0.f); f[6] = fmaxf(f[6] + sb1.z, 0.f); f[7] = fmaxf(f[7] + sb1.w, 0.f);
-          v = cs_pack8<T>(f);
-        }
-        *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = v;
-      }
+      if ((id >> 2) < kBHalo) *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = ra[it];
     }
   };
   // filter slab of step s = (chunk cc, tap t): rows n = tid >> 2 (+64), quarter q = tid & 3
@@ -666,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       const int m = id >> 4, c = id & 15;
       const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
       if (gy < H && gx < W)
-        *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * Cout + cg * 128 + c * 8) =
+        *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * ystride + yoff + cg * 128 + c * 8) =
             *reinterpret_cast<const cs_u32x4*>(bs + m * 272 + c * 16);
     }
     __syncthreads();
@@ -726,9 +700,11 @@ extern "C" int pvo_gru_glo_fused(const void* net, const void* w_weight, const fl
 }
 
 extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void* y,
-                                int E, int H, int W, int Cout, int relu, int dtype, void* stream) {
+                                int E, int H, int W, int Cout, int relu, int ystride, int yoff, int dtype, void* stream) {
   if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
   if (Cout != 64 && (Cout <= 0 || (Cout & 127))) return PVO_EUNSUPPORTED;
+  if (ystride == 0) ystride = Cout;
+  if (ystride < yoff + Cout || yoff < 0 || (ystride & 7) || (yoff & 7)) return PVO_EINVAL;
   if (E == 0 || H == 0 || W == 0) return PVO_OK;
   if (!x || !w_taps || !y || E > 65535) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_taps) | reinterpret_cast<uintptr_t>(y)) & 15) return PVO_EINVAL;
@@ -740,13 +716,13 @@ extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* 
   uint16_t* yp = static_cast<uint16_t*>(y);
   if (Cout == 64) {
     dim3 grid(ntx, (H + kTH - 1) / kTH, E);
-    if (dtype == PVO_F16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_half, 1>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
-    else if (dtype == PVO_BF16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_bf16, 1>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
+    if (dtype == PVO_F16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_half, 1>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu, ystride, yoff);
+    else if (dtype == PVO_BF16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_bf16, 1>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu, ystride, yoff);
     else return PVO_EUNSUPPORTED;
   } else {
     dim3 grid(ntx * (Cout / 128), (H + kTH - 1) / kTH, E);
-    if (dtype == PVO_F16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_half, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
-    else if (dtype == PVO_BF16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_bf16, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu);
+    if (dtype == PVO_F16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_half, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu, ystride, yoff);
+    else if (dtype == PVO_BF16) hipLaunchKernelGGL((conv3x3_c128_kernel<pvo_bf16, 2>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cout, relu, ystride, yoff);
     else return PVO_EUNSUPPORTED;
   }
   PVO_CHECK_LAUNCH();
@@ -754,9 +730,12 @@ extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* 
 }
 
 static int launch_big(const void* x, const void* w_taps, const float* bias, void* y,
-                      int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream, const BigEpi& ep) {
+                      int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream,
+                      const BigEpi& ep) {
   if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
   if (Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 127)) return PVO_EUNSUPPORTED;
+  if (ystride == 0) ystride = Cout;
+  if (ystride < yoff + Cout || yoff < 0 || (ystride & 7) || (yoff & 7)) return PVO_EINVAL;
   if (E == 0 || H == 0 || W == 0) return PVO_OK;
   if (!x || !w_taps || !y || E > 65535) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_taps) | reinterpret_cast<uintptr_t>(y)) & 15) return PVO_EINVAL;
@@ -768,12 +747,19 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
   const uint16_t* xp = static_cast<const uint16_t*>(x);
   const uint16_t* wp = static_cast<const uint16_t*>(w_taps);
   uint16_t* yp = static_cast<uint16_t*>(y);
+  static bool attr_set[2] = {false, false};                // hipFuncSetAttribute once per process, not per launch
   if (dtype == PVO_F16) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ep);
+    if (!attr_set[0]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      attr_set[0] = true;
+    }
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
   } else if (dtype == PVO_BF16) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ep);
+    if (!attr_set[1]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      attr_set[1] = true;
+    }
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
   } else {
     return PVO_EUNSUPPORTED;
   }
@@ -782,65 +768,43 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
 }
 
 extern "C" int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
-                           int E, int H, int W, int Cin, int Cout, int relu, int dtype, void* stream) {
-  return launch_big(x, w_taps, bias, y, E, H, W, Cin, Cout, relu, dtype, stream, BigEpi{});
+                           int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream) {
+  return launch_big(x, w_taps, bias, y, E, H, W, Cin, Cout, relu, ystride, yoff, dtype, stream, BigEpi{});
 }
 
-extern "C" int pvo_gru_conv_gates(const void* X, const void* w_taps, const float* g, const void* P_zr, const void* net,
-                                  void* Z, void* RN, int E, int H, int W, int Cin, int dtype, void* stream) {
-  if (!g || !P_zr || !net || !RN) return PVO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(P_zr) | reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(RN)) & 15) return PVO_EINVAL;
-  BigEpi ep{};
-  ep.mode = 1; ep.g = g; ep.P = static_cast<const uint16_t*>(P_zr); ep.net = static_cast<const uint16_t*>(net);
-  ep.y2 = static_cast<uint16_t*>(RN);
-  return launch_big(X, w_taps, nullptr, Z, E, H, W, Cin, 256, 0, dtype, stream, ep);
-}
-
-extern "C" int pvo_gru_conv_candidate(const void* X, const void* RN, const void* w_taps, const float* g, const void* P_q,
-                                      const void* Z, const void* net, void* net_out,
-                                      int E, int H, int W, int Cin, int dtype, void* stream) {
-  if (!g || !P_q || !net || !Z || !RN) return PVO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(P_q) | reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(RN)) & 15) return PVO_EINVAL;
-  BigEpi ep{};
-  ep.mode = 2; ep.g = g; ep.P = static_cast<const uint16_t*>(P_q); ep.net = static_cast<const uint16_t*>(net);
-  ep.Z = static_cast<const uint16_t*>(Z);
-  ep.x2 = static_cast<const uint16_t*>(RN); ep.x2_chunks = 4; ep.x2_stride = 128;
-  return launch_big(X, w_taps, nullptr, net_out, E, H, W, Cin, 128, 0, dtype, stream, ep);
-}
-
-static int seg_setup(BigEpi& ep, const void* a, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias) {
-  if (!a || !cf || !ff) return PVO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(cf) | reinterpret_cast<uintptr_t>(ff)) & 15) return PVO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(cf_bias) | reinterpret_cast<uintptr_t>(ff_bias)) & 15) return PVO_EINVAL;
-  ep.nseg = 3;
-  ep.seg_p[0] = static_cast<const uint16_t*>(a);  ep.seg_stride[0] = 128; ep.seg_chunks[0] = 4; ep.seg_bias[0] = nullptr;
-  ep.seg_p[1] = static_cast<const uint16_t*>(cf); ep.seg_stride[1] = 128; ep.seg_chunks[1] = 4; ep.seg_bias[1] = cf_bias;
-  ep.seg_p[2] = static_cast<const uint16_t*>(ff); ep.seg_stride[2] = 64;  ep.seg_chunks[2] = 2; ep.seg_bias[2] = ff_bias;
+// the ConvGRU input [first(128) | cf(cf_channels)] as two segments: `first` = net (gates) or r*net (candidate), `cf` = the
+// encoders' output written side by side (relu(corr features) | relu(flow features)) by their own convolutions
+static int seg_setup(BigEpi& ep, const void* first, const void* cf, int cf_channels) {
+  if (!first || !cf) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(first) | reinterpret_cast<uintptr_t>(cf)) & 15) return PVO_EINVAL;
+  if (cf_channels <= 0 || (cf_channels & 31)) return PVO_EUNSUPPORTED;
+  ep.nseg = 2;
+  ep.seg_p[0] = static_cast<const uint16_t*>(first); ep.seg_stride[0] = 128; ep.seg_chunks[0] = 4;
+  ep.seg_p[1] = static_cast<const uint16_t*>(cf); ep.seg_stride[1] = cf_channels; ep.seg_chunks[1] = cf_channels >> 5;
   return PVO_OK;
 }
 
-extern "C" int pvo_gru_gates(const void* net, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
-                             const void* w_taps, const float* g, const void* P_zr, void* Z, void* RN,
-                             int E, int H, int W, int dtype, void* stream) {
+extern "C" int pvo_gru_conv_gates(const void* net, const void* cf, int cf_channels, const void* w_taps, const float* g,
+                                  const void* P_zr, void* Z, void* RN, int E, int H, int W, int dtype, void* stream) {
   if (!g || !P_zr || !RN) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(P_zr) | reinterpret_cast<uintptr_t>(RN)) & 15) return PVO_EINVAL;
   BigEpi ep{};
-  const int rc = seg_setup(ep, net, cf, ff, cf_bias, ff_bias);
+  const int rc = seg_setup(ep, net, cf, cf_channels);
   if (rc != PVO_OK) return rc;
   ep.mode = 1; ep.g = g; ep.P = static_cast<const uint16_t*>(P_zr); ep.net = static_cast<const uint16_t*>(net);
   ep.y2 = static_cast<uint16_t*>(RN);
-  return launch_big(net, w_taps, nullptr, Z, E, H, W, 320, 256, 0, dtype, stream, ep);
+  return launch_big(net, w_taps, nullptr, Z, E, H, W, 128 + cf_channels, 256, 0, 0, 0, dtype, stream, ep);
 }
 
-extern "C" int pvo_gru_candidate(const void* RN, const void* cf, const void* ff, const float* cf_bias, const float* ff_bias,
-                                 const void* w_taps, const float* g, const void* P_q, const void* Z, const void* net,
-                                 void* net_out, int E, int H, int W, int dtype, void* stream) {
+extern "C" int pvo_gru_conv_candidate(const void* RN, const void* cf, int cf_channels, const void* w_taps, const float* g,
+                                      const void* P_q, const void* Z, const void* net, void* net_out,
+                                      int E, int H, int W, int dtype, void* stream) {
   if (!g || !P_q || !net || !Z) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(P_q) | reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(Z)) & 15) return PVO_EINVAL;
   BigEpi ep{};
-  const int rc = seg_setup(ep, RN, cf, ff, cf_bias, ff_bias);
+  const int rc = seg_setup(ep, RN, cf, cf_channels);
   if (rc != PVO_OK) return rc;
   ep.mode = 2; ep.g = g; ep.P = static_cast<const uint16_t*>(P_q); ep.net = static_cast<const uint16_t*>(net);
   ep.Z = static_cast<const uint16_t*>(Z);
-  return launch_big(RN, w_taps, nullptr, net_out, E, H, W, 320, 128, 0, dtype, stream, ep);
+  return launch_big(RN, w_taps, nullptr, net_out, E, H, W, 128 + cf_channels, 128, 0, 0, 0, dtype, stream, ep);
 }

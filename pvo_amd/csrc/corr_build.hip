@@ -193,18 +193,21 @@ __global__ __launch_bounds__(256) void corr_build_mfma_kernel(BuildArgs a) {
   const bool aligned = ((W & 63) == 0) && ((H & 7) == 0) &&
       (((reinterpret_cast<uintptr_t>(a.lv[0]) | reinterpret_cast<uintptr_t>(a.lv[1]) |
          reinterpret_cast<uintptr_t>(a.lv[2]) | reinterpret_cast<uintptr_t>(a.lv[3])) & 15) == 0 || a.nlev < 4);
-  if (aligned && a.nlev == 4 && a.tiled) {
-    // 8x8-tiled planes: the patch is one tile row high, so its level-0 part is 4 whole tiles = 512 contiguous
-    // bytes per source pixel; the coarser levels fill half / quarter tiles
-    const int tw0 = W >> 3, tw1 = (W + 15) >> 4, tw2 = (W + 31) >> 5, tw3 = (W + 63) >> 6;
-    const long long pe0 = static_cast<long long>(H >> 3) * tw0 * 64, pe1 = static_cast<long long>((H + 15) >> 4) * tw1 * 64,
-                    pe2 = static_cast<long long>((H + 31) >> 5) * tw2 * 64, pe3 = static_cast<long long>((H + 63) >> 6) * tw3 * 64;
+  if (a.nlev == 4 && a.tiled) {
+    // 8x8-tiled planes, any map size: level l is [ceil(Hl/8)][ceil(Wl/8)] tiles of 8x8 (Hl = H >> l).  The patch is one
+    // tile row high and 8-aligned, so its level-0 part is 4 whole tiles = 512 contiguous bytes per source pixel, and the
+    // coarser levels fill half / quarter tiles.  Whole tile rows are written wherever the TILE exists; elements of a tile
+    // beyond (Hl, Wl) - zero-padded target pixels, partial pooling windows - are padding no reader treats as valid.
+    const int tw0 = (W + 7) >> 3, tw1 = ((W >> 1) + 7) >> 3, tw2 = ((W >> 2) + 7) >> 3, tw3 = ((W >> 3) + 7) >> 3;
+    const int th1 = ((H >> 1) + 7) >> 3, th2 = ((H >> 2) + 7) >> 3, th3 = ((H >> 3) + 7) >> 3;
+    const long long pe0 = static_cast<long long>((H + 7) >> 3) * tw0 * 64, pe1 = static_cast<long long>(th1) * tw1 * 64,
+                    pe2 = static_cast<long long>(th2) * tw2 * 64, pe3 = static_cast<long long>(th3) * tw3 * 64;
     uint16_t* L0 = reinterpret_cast<uint16_t*>(a.lv[0]);
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {                   // level 0: 32 rows x 4 tiles x 8 tile rows
       const int id = lane + 64 * i;
       const int mrow = id >> 5, c = (id >> 3) & 3, t = id & 7;
-      if (mrow < rows_ok) {
+      if (mrow < rows_ok && (x2_0 >> 3) + c < tw0) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab0 + mrow * RS0 + (t * 32 + c * 8) * 2);
         *reinterpret_cast<u32x4*>(L0 + (plane0 + mrow) * pe0 + (static_cast<long long>(y2_0 >> 3) * tw0 + (x2_0 >> 3) + c) * 64 + t * 8) = v;
       }
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void corr_build_mfma_kernel(BuildArgs a) {
     for (int i = 0; i < 4; ++i) {                    // level 1: 32 rows x 2 tiles x 4 tile rows
       const int id = lane + 64 * i;
       const int mrow = id >> 3, c = (id >> 2) & 1, q = id & 3;
-      if (mrow < rows_ok) {
+      if (mrow < rows_ok && (x2_0 >> 4) + c < tw1 && (y2_0 >> 4) < th1) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab1 + mrow * RS1 + (q * 16 + c * 8) * 2);
         *reinterpret_cast<u32x4*>(L1 + (plane0 + mrow) * pe1 + (static_cast<long long>(y2_0 >> 4) * tw1 + (x2_0 >> 4) + c) * 64 +
                                   (((y2_0 >> 1) & 7) + q) * 8) = v;
@@ -223,14 +226,14 @@ __global__ __launch_bounds__(256) void corr_build_mfma_kernel(BuildArgs a) {
     uint16_t* L2 = reinterpret_cast<uint16_t*>(a.lv[2]);
     {                                                // level 2: 32 rows x 2 tile rows of one tile
       const int mrow = lane >> 1, q = lane & 1;
-      if (mrow < rows_ok) {
+      if (mrow < rows_ok && (x2_0 >> 5) < tw2 && (y2_0 >> 5) < th2) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab2 + mrow * RS2 + q * 16);
         *reinterpret_cast<u32x4*>(L2 + (plane0 + mrow) * pe2 + (static_cast<long long>(y2_0 >> 5) * tw2 + (x2_0 >> 5)) * 64 +
                                   (((y2_0 >> 2) & 7) + q) * 8) = v;
       }
     }
     uint16_t* L3 = reinterpret_cast<uint16_t*>(a.lv[3]);
-    if (lane < 32 && lane < rows_ok) {               // level 3: 4 values = half a tile row
+    if (lane < 32 && lane < rows_ok && (x2_0 >> 6) < tw3 && (y2_0 >> 6) < th3) {      // level 3: 4 values = half a tile row
       const uint2 v = *reinterpret_cast<const uint2*>(slab3 + lane * RS3);
       *reinterpret_cast<uint2*>(L3 + (plane0 + lane) * pe3 + (static_cast<long long>(y2_0 >> 6) * tw3 + (x2_0 >> 6)) * 64 +
                                 ((y2_0 >> 3) & 7) * 8 + ((x2_0 >> 3) & 7)) = v;
@@ -431,7 +434,7 @@ extern "C" int pvo_corr_build_tiled(const void* fmap1, const void* fmap2, void* 
     al |= reinterpret_cast<uintptr_t>(levels_host[l]);
   }
   // the tiled writer is the matrix-core kernel's aligned epilogue
-  if ((dtype != PVO_F16 && dtype != PVO_BF16) || C < 16 || C > kMaxC || (C & (C - 1)) || (W & 63) || (H & 7) || (al & 15))
+  if ((dtype != PVO_F16 && dtype != PVO_BF16) || C < 16 || C > kMaxC || (C & (C - 1)) || W < 8 || H < 8 || (al & 15))
     return PVO_EUNSUPPORTED;
   BuildArgs a{};
   a.f1 = fmap1; a.f2 = fmap2; a.N = N; a.C = C; a.H = H; a.W = W; a.nlev = 4; a.out_slots = out_slots; a.tiled = 1;

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restric
                                                          float2* __restrict__ delta_dy, float2* __restrict__ weight,
                                                          float* __restrict__ target_ba, float* __restrict__ weight_ba,
                                                          float2* __restrict__ full_flow, int E, int HW, int W, float dy_thresh,
-                                                         const uint8_t* __restrict__ force_dyn) {
+                                                         const int* __restrict__ segm, const int* __restrict__ vote_tot,
+                                                         const int* __restrict__ vote_dyn, int S, float vote_thresh) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= E * HW) return;
   const int e = idx / HW, pix = idx - e * HW;
@@ -66,7 +67,14 @@ __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restric
   raw_mask[idx] = rm;
   float b0 = (1.0f / (1.0f + expf(-rm.x)) >= dy_thresh) ? 1.0f : 0.0f;    // 1: static, 0: dynamic
   float b1 = (1.0f / (1.0f + expf(-rm.y)) >= dy_thresh) ? 1.0f : 0.0f;
-  if (force_dyn && force_dyn[idx]) { b0 = 0.0f; b1 = 0.0f; }     // panoptic vote: the pixel's segment is dynamic on this edge
+  if (segm) {      // panoptic vote (factor_graph.py:256-276): a segment (id != 0) whose dynamic fraction on this edge exceeds the threshold is forced dynamic
+    int sg = segm[idx];
+    sg = sg < 0 ? 0 : (sg >= S ? S - 1 : sg);
+    if (sg != 0) {
+      const float tot = static_cast<float>(vote_tot[static_cast<size_t>(e) * S + sg]), dyn = static_cast<float>(vote_dyn[static_cast<size_t>(e) * S + sg]);
+      if (dyn / fmaxf(tot, 1.0f) > vote_thresh) { b0 = 0.0f; b1 = 0.0f; }
+    }
+  }
   const float2 tg = {c1.x + d0, c1.y + d1};
   const float2 dd = {g0 * (1.0f - b0), g1 * (1.0f - b1)};
   const float2 wt = {1.0f / (1.0f + expf(-(w0 + (1.0f - b0) * 10.0f))), 1.0f / (1.0f + expf(-(w1 + (1.0f - b1) * 10.0f)))};
@@ -75,31 +83,6 @@ __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restric
   const size_t ob = static_cast<size_t>(e) * 2 * HW + pix;
   target_ba[ob] = tg.x; target_ba[ob + HW] = tg.y;
   weight_ba[ob] = wt.x; weight_ba[ob + HW] = wt.y;
-}
-
-// eta / damping: GraphAgg's eta head (droid_net.py:93-95: 0.01 * softplus(conv(net))) and the damping bookkeeping of
-// FactorGraph.update (factor_graph.py:281-283: damping[unique(ii)] = eta; eta_ba = 0.2 * damping[frames] + EP), eight
-// tiny PyTorch launches, in one kernel.  raw [K,HW] = the bias-free 128->1 convolution output (16-bit); row r of the BA's
-// eta belongs to frame `frame[r]`; pos[r] is that frame's row in raw, or -1 for a frame that only carries inactive edges
-// (its stored damping is used, nothing is written).
-template <typename T>
-__global__ __launch_bounds__(256) void eta_finish_kernel(const uint16_t* __restrict__ raw, const float* __restrict__ bias,
-                                                         const long long* __restrict__ frame, const int* __restrict__ pos,
-                                                         float* __restrict__ damping, float* __restrict__ eta, int HW, float EP) {
-  const int r = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-  if (x >= HW) return;
-  const long long f = frame[r];
-  const int k = pos[r];
-  float e;
-  if (k >= 0) {
-    const float v = h2f_<T>(raw[static_cast<size_t>(k) * HW + x]) + bias[0];
-    const float sp = v > 20.0f ? v : log1pf(expf(v));            // torch softplus, beta = 1, threshold = 20
-    e = __fmul_rn(0.01f, sp);
-    damping[f * HW + x] = e;
-  } else {
-    e = damping[f * HW + x];
-  }
-  eta[static_cast<size_t>(r) * HW + x] = __fadd_rn(__fmul_rn(0.2f, e), EP);
 }
 
 }  // namespace
@@ -126,37 +109,21 @@ extern "C" int pvo_graph_motion(const float* target, const float* coords1, const
 
 extern "C" int pvo_graph_post(const float* coords1, const void* heads, float* raw_mask, float* target, float* delta_dy,
                               float* weight, float* target_ba, float* weight_ba, float* full_flow,
-                              int E, int H, int W, float dy_thresh, const unsigned char* force_dyn, int dtype, void* stream) {
+                              int E, int H, int W, float dy_thresh, const int* segm, const int* vote_tot, const int* vote_dyn,
+                              int max_segments, float vote_thresh, int dtype, void* stream) {
   if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
   const long long n = static_cast<long long>(E) * H * W;
   if (n == 0) return PVO_OK;
   if (!coords1 || !heads || !raw_mask || !target || !delta_dy || !weight || !target_ba || !weight_ba || !full_flow || n >= (1LL << 31)) return PVO_EINVAL;
   if (reinterpret_cast<uintptr_t>(heads) & 15) return PVO_EINVAL;
+  if (segm && (!vote_tot || !vote_dyn || max_segments <= 0)) return PVO_EINVAL;
   hipStream_t st = pvo_stream(stream);
   const dim3 grid(static_cast<unsigned>((n + 255) / 256));
   auto f2 = [](float* p) { return reinterpret_cast<float2*>(p); };
   if (dtype == PVO_F16)
-    hipLaunchKernelGGL(graph_post_kernel<pvo_half>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, force_dyn);
+    hipLaunchKernelGGL(graph_post_kernel<pvo_half>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, segm, vote_tot, vote_dyn, max_segments, vote_thresh);
   else if (dtype == PVO_BF16)
-    hipLaunchKernelGGL(graph_post_kernel<pvo_bf16>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, force_dyn);
-  else return PVO_EUNSUPPORTED;
-  PVO_CHECK_LAUNCH();
-  return PVO_OK;
-}
-
-extern "C" int pvo_eta_finish(const void* raw, const float* bias, const int64_t* frame, const int* pos,
-                              float* damping, float* eta, int R, int HW, float EP, int dtype, void* stream) {
-  if (R < 0 || HW < 0) return PVO_EINVAL;
-  if (R == 0 || HW == 0) return PVO_OK;
-  if (!raw || !bias || !frame || !pos || !damping || !eta || R > 65535) return PVO_EINVAL;
-  hipStream_t st = pvo_stream(stream);
-  const dim3 grid((HW + 255) / 256, R);
-  if (dtype == PVO_F16)
-    hipLaunchKernelGGL(eta_finish_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(raw), bias,
-                       reinterpret_cast<const long long*>(frame), pos, damping, eta, HW, EP);
-  else if (dtype == PVO_BF16)
-    hipLaunchKernelGGL(eta_finish_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(raw), bias,
-                       reinterpret_cast<const long long*>(frame), pos, damping, eta, HW, EP);
+    hipLaunchKernelGGL(graph_post_kernel<pvo_bf16>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, segm, vote_tot, vote_dyn, max_segments, vote_thresh);
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;

@@ -1,21 +1,9 @@
-// gru_fused.hip — the element-wise half of the ConvGRU update operator, fused for gfx950.
+// gru_fused.hip — two layers of the update operator that are neither a plain convolution nor plain element-wise work.
 //
-// The reference's ConvGRU.forward (VO_Module/droid_slam/modules/gru.py:19-32) is, around its
-// three 3x3 convolutions, a chain of ~14 element-wise / concat launches over 28-100 MB tensors
-// (cat, cat, sigmoid, mul, mean, add, sigmoid, mul, cat, add, tanh, mul, mul, add) — 45 % of the
-// GPU time of a graph update once the convolutions run on MIOpen's MFMA kernels.  These four
-// kernels replace that chain; the convolutions stay in MIOpen:
-//
-//   gru_glo      glo[e,c]   = mean_p( sigmoid(wn[e,p,c]) * net[e,p,c] )              gru.py:23-24
-//   gru_assemble X[e,p,:]   = [ net | inp | relu(corr_feat) | relu(flow_feat) ]     gru.py:20-21 + encoder ReLUs
-//   gru_gate     z = sigmoid(zr[..,:128] + gz);  X[e,p,:128] = sigmoid(zr[..,128:] + gr) * net   gru.py:26-28
-//   gru_out      net = (1-z)*net + z*tanh(q + gq)                                    gru.py:28-31
-//
-// X is ONE persistent 448-channel channels-last buffer: the z/r convolution reads it, gru_gate
-// then overwrites its first 128 channels with r*net, and the q convolution reads the same buffer,
-// so neither torch.cat of gru.py:20-21,28 is materialised twice.
-// Layout: channels-last fp16/bf16 rows ([E, H*W, C]); 8 channels (16 B) per thread per access.
-// Arithmetic in fp32, one rounding to the storage type per output.
+//   seg_mean    GraphAgg's scatter_mean over the edges sharing a source frame (VO_Module/droid_slam/droid_net.py:83-87),
+//               with conv1's bias + ReLU applied as the input is read
+//   heads_out   the second stage of the four output heads, 4 x (ReLU + Conv3x3(128 -> 2)) (droid_net.py:184-210)
+// Layout: channels-last fp16/bf16 rows ([E, H*W, C]); 8 channels (16 B) per thread per access; arithmetic in fp32.
 #include "common.h"
 
 namespace {
@@ -60,165 +48,6 @@ __device__ __forceinline__ void load8f(const float* __restrict__ p, float f[8]) 
   }
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-}
-
-// glo[e,c] += (1/HW) * sum over this block's pixel chunk; glo zeroed by the host wrapper
-template <typename T>
-__global__ __launch_bounds__(256) void gru_glo_kernel(const uint16_t* __restrict__ wn, const uint16_t* __restrict__ net,
-                                                      const float* __restrict__ bias, float* __restrict__ glo, int HW, int C, int chunk) {
-  __shared__ float red[16][129];
-  const int e = blockIdx.y;
-  const int cg = threadIdx.x & 15, pl = threadIdx.x >> 4;      // C == 128: 16 groups of 8 channels
-  const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float bw[8];
-  load8f(bias ? bias + cg * 8 : nullptr, bw);
-  for (int p = p0 + pl; p < p1; p += 16) {
-    const long long o = (static_cast<long long>(e) * HW + p) * C + cg * 8;
-    float a[8], b[8];
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(wn + o), a);
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + o), b);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += sigmoidf_(a[k] + bw[k]) * b[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) red[pl][cg * 8 + k] = acc[k];
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
-    atomicAdd(glo + static_cast<long long>(e) * C + threadIdx.x, s / static_cast<float>(HW));
-  }
-}
-
-// X [E*HW, 448] <- [net(128) | inp(128) | relu(cf)(128) | relu(ff)(64)]
-template <typename T>
-__global__ __launch_bounds__(256) void gru_assemble_kernel(const uint16_t* __restrict__ net, const uint16_t* __restrict__ inp,
-                                                           const uint16_t* __restrict__ cf, const uint16_t* __restrict__ ff,
-                                                           const float* __restrict__ bc, const float* __restrict__ bf,
-                                                           uint16_t* __restrict__ X, long long rows, int with_inp) {
-  // with_inp == 0: X has 320 channels [net | relu(cf) | relu(ff)] (the inp block's convolution is precomputed)
-  const unsigned cpr = with_inp ? 56u : 40u;                  // 16-byte chunks per row of X
-  const unsigned total = static_cast<unsigned>(rows) * cpr;
-  for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
-    const unsigned row = id / cpr;
-    const int chx = static_cast<int>(id - row * cpr);          // chunk inside X
-    const int ch = (with_inp || chx < 16) ? chx : chx + 16;    // chunk in the 448-channel numbering
-    u32x4 v;
-    if (ch < 16) v = *reinterpret_cast<const u32x4*>(net + static_cast<size_t>(row) * 128 + ch * 8);
-    else if (ch < 32) v = *reinterpret_cast<const u32x4*>(inp + static_cast<size_t>(row) * 128 + (ch - 16) * 8);
-    else {
-      v = (ch < 48) ? *reinterpret_cast<const u32x4*>(cf + static_cast<size_t>(row) * 128 + (ch - 32) * 8)
-                    : *reinterpret_cast<const u32x4*>(ff + static_cast<size_t>(row) * 64 + (ch - 48) * 8);
-      float f[8];
-      H8<T>::unpack(v, f);
-      float bb[8];
-      load8f((ch < 48) ? (bc ? bc + (ch - 32) * 8 : nullptr) : (bf ? bf + (ch - 48) * 8 : nullptr), bb);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k] + bb[k], 0.0f);
-      v = H8<T>::pack(f);
-    }
-    *reinterpret_cast<u32x4*>(X + static_cast<size_t>(row) * (cpr * 8) + chx * 8) = v;
-  }
-}
-
-// zr [E*HW, 256], g [E, 384] fp32 (z | r | q context), net [E*HW,128]; writes Z [E*HW,128] and X[:, :128] = r*net
-template <typename T>
-__global__ __launch_bounds__(256) void gru_gate_kernel(const uint16_t* __restrict__ zr, const float* __restrict__ g,
-                                                       const uint16_t* __restrict__ net, uint16_t* __restrict__ Z,
-                                                       uint16_t* __restrict__ X, long long rows, int HW,
-                                                       const uint16_t* __restrict__ P, int xc) {
-  const unsigned total = static_cast<unsigned>(rows) * 16u;
-  for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
-    const size_t row = id >> 4;
-    const int ch = static_cast<int>(id & 15u);
-    const int e = static_cast<int>((id >> 4) / static_cast<unsigned>(HW));
-    float a[8], b[8], n[8], z[8], rn[8];
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(zr + row * 256 + ch * 8), a);
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(zr + row * 256 + 128 + ch * 8), b);
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + row * 128 + ch * 8), n);
-    float gz[8], gr[8];
-    load8f(g + static_cast<long long>(e) * 384 + ch * 8, gz);
-    load8f(g + static_cast<long long>(e) * 384 + 128 + ch * 8, gr);
-    if (P) {   // precomputed convolution of the (static) inp block, [rows, 256]
-      float pz[8], pr[8];
-      H8<T>::unpack(*reinterpret_cast<const u32x4*>(P + row * 256 + ch * 8), pz);
-      H8<T>::unpack(*reinterpret_cast<const u32x4*>(P + row * 256 + 128 + ch * 8), pr);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { gz[k] += pz[k]; gr[k] += pr[k]; }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      z[k] = sigmoidf_(a[k] + gz[k]);
-      rn[k] = sigmoidf_(b[k] + gr[k]) * n[k];
-    }
-    *reinterpret_cast<u32x4*>(Z + row * 128 + ch * 8) = H8<T>::pack(z);
-    *reinterpret_cast<u32x4*>(X + row * xc + ch * 8) = H8<T>::pack(rn);
-  }
-}
-
-// net_out = (1-z)*net + z*tanh(q + gq)
-template <typename T>
-__global__ __launch_bounds__(256) void gru_out_kernel(const uint16_t* __restrict__ q, const float* __restrict__ g,
-                                                      const uint16_t* __restrict__ Z, const uint16_t* __restrict__ net,
-                                                      uint16_t* __restrict__ out, long long rows, int HW,
-                                                      const uint16_t* __restrict__ P) {
-  const unsigned total = static_cast<unsigned>(rows) * 16u;
-  for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
-    const size_t row = id >> 4;
-    const int ch = static_cast<int>(id & 15u);
-    const int e = static_cast<int>((id >> 4) / static_cast<unsigned>(HW));
-    float a[8], z[8], n[8], o[8];
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(q + row * 128 + ch * 8), a);
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(Z + row * 128 + ch * 8), z);
-    H8<T>::unpack(*reinterpret_cast<const u32x4*>(net + row * 128 + ch * 8), n);
-    float gq[8];
-    load8f(g + static_cast<long long>(e) * 384 + 256 + ch * 8, gq);
-    if (P) {
-      float pq[8];
-      H8<T>::unpack(*reinterpret_cast<const u32x4*>(P + row * 128 + ch * 8), pq);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) gq[k] += pq[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (1.0f - z[k]) * n[k] + z[k] * tanhf(a[k] + gq[k]);
-    *reinterpret_cast<u32x4*>(out + row * 128 + ch * 8) = H8<T>::pack(o);
-  }
-}
-
-// x[row, c] = act(x[row, c] + bias[c]) in place; C % 8 == 0.  Four independent 16-byte chunks per thread,
-// all loads issued before the first store (in-place, so the compiler may not reorder them itself).
-template <typename T>
-__global__ __launch_bounds__(256) void bias_act_kernel(uint16_t* __restrict__ x, const float* __restrict__ bias,
-                                                       long long rows, int C, int relu) {
-  const unsigned cpr = static_cast<unsigned>(C) >> 3;
-  const unsigned total = static_cast<unsigned>(rows) * cpr;
-  const unsigned stride = gridDim.x * 256u;
-  for (unsigned base = blockIdx.x * 256u + threadIdx.x; base < total; base += 4u * stride) {
-    u32x4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned id = base + u * stride;
-      if (id < total) v[u] = *reinterpret_cast<const u32x4*>(x + static_cast<size_t>(id) * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned id = base + u * stride;
-      if (id < total) {
-        const int ch = static_cast<int>(id % cpr);
-        float f[8], bb[8];
-        H8<T>::unpack(v[u], f);
-        load8f(bias ? bias + ch * 8 : nullptr, bb);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          f[k] += bb[k];
-          if (relu) f[k] = fmaxf(f[k], 0.0f);
-        }
-        *reinterpret_cast<u32x4*>(x + static_cast<size_t>(id) * 8) = H8<T>::pack(f);
-      }
-    }
-  }
 }
 
 // out[k, p, c] = mean over edges e in [ptr[k], ptr[k+1]) of x[idx[e], p, c]   (GraphAgg's scatter_mean, droid_net.py:87)
@@ -266,89 +95,6 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
     else if ((dtype) == PVO_BF16) { CALL_B; }      \
     else return PVO_EUNSUPPORTED;                  \
   } while (0)
-
-extern "C" int pvo_gru_glo(const void* wn, const void* net, const float* w_bias, float* glo, int E, int HW, int C, int dtype,
-                           void* stream) {
-  if (E < 0 || HW < 0 || C != 128) return PVO_EINVAL;
-  if (E == 0 || HW == 0) return PVO_OK;
-  if (!wn || !net || !glo || !aligned16(wn) || !aligned16(net) || E > 65535) return PVO_EINVAL;
-  hipStream_t st = pvo_stream(stream);
-  if (hipMemsetAsync(glo, 0, sizeof(float) * static_cast<size_t>(E) * C, st) != hipSuccess) return PVO_ELAUNCH;
-  const int chunk = 512;
-  dim3 grid((HW + chunk - 1) / chunk, E);
-  GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_glo_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), w_bias, glo, HW, C, chunk),
-    hipLaunchKernelGGL(gru_glo_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(wn), static_cast<const uint16_t*>(net), w_bias, glo, HW, C, chunk));
-  PVO_CHECK_LAUNCH();
-  return PVO_OK;
-}
-
-extern "C" int pvo_gru_assemble(const void* net, const void* inp, const void* corr_feat, const void* flow_feat,
-                                const float* corr_bias, const float* flow_bias,
-                                void* X, long long rows, int with_inp, int dtype, void* stream) {
-  if (rows < 0) return PVO_EINVAL;
-  if (rows == 0) return PVO_OK;
-  if (!net || (with_inp && !inp) || !corr_feat || !flow_feat || !X) return PVO_EINVAL;
-  if (!inp) inp = net;   // unused when with_inp == 0
-  if (rows * 56 >= (1LL << 31)) return PVO_EUNSUPPORTED;
-  if (!aligned16(net) || !aligned16(inp) || !aligned16(corr_feat) || !aligned16(flow_feat) || !aligned16(X)) return PVO_EINVAL;
-  hipStream_t st = pvo_stream(stream);
-  const unsigned gsz = grid_for(rows * 56);
-  GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_assemble_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows, with_inp),
-    hipLaunchKernelGGL(gru_assemble_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(net), static_cast<const uint16_t*>(inp), static_cast<const uint16_t*>(corr_feat), static_cast<const uint16_t*>(flow_feat), corr_bias, flow_bias, static_cast<uint16_t*>(X), rows, with_inp));
-  PVO_CHECK_LAUNCH();
-  return PVO_OK;
-}
-
-extern "C" int pvo_gru_gate(const void* zr, const float* g, const void* net, void* Z, void* X,
-                            const void* P_zr, int x_channels, int E, int HW, int dtype, void* stream) {
-  if (x_channels != 448 && x_channels != 320) return PVO_EINVAL;
-  if (P_zr && !aligned16(P_zr)) return PVO_EINVAL;
-  if (E < 0 || HW < 0) return PVO_EINVAL;
-  const long long rows = static_cast<long long>(E) * HW;
-  if (rows == 0) return PVO_OK;
-  if (rows * 16 >= (1LL << 31)) return PVO_EUNSUPPORTED;
-  if (!zr || !g || !net || !Z || !X || !aligned16(zr) || !aligned16(net) || !aligned16(Z) || !aligned16(X)) return PVO_EINVAL;
-  hipStream_t st = pvo_stream(stream);
-  const unsigned gsz = grid_for(rows * 16);
-  GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_gate_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW, static_cast<const uint16_t*>(P_zr), x_channels),
-    hipLaunchKernelGGL(gru_gate_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(zr), g, static_cast<const uint16_t*>(net), static_cast<uint16_t*>(Z), static_cast<uint16_t*>(X), rows, HW, static_cast<const uint16_t*>(P_zr), x_channels));
-  PVO_CHECK_LAUNCH();
-  return PVO_OK;
-}
-
-extern "C" int pvo_gru_out(const void* q, const float* g, const void* Z, const void* net, void* net_out,
-                           const void* P_q, int E, int HW, int dtype, void* stream) {
-  if (P_q && !aligned16(P_q)) return PVO_EINVAL;
-  if (E < 0 || HW < 0) return PVO_EINVAL;
-  const long long rows = static_cast<long long>(E) * HW;
-  if (rows == 0) return PVO_OK;
-  if (rows * 16 >= (1LL << 31)) return PVO_EUNSUPPORTED;
-  if (!q || !g || !Z || !net || !net_out || !aligned16(q) || !aligned16(Z) || !aligned16(net) || !aligned16(net_out)) return PVO_EINVAL;
-  hipStream_t st = pvo_stream(stream);
-  const unsigned gsz = grid_for(rows * 16);
-  GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(gru_out_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW, static_cast<const uint16_t*>(P_q)),
-    hipLaunchKernelGGL(gru_out_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<const uint16_t*>(q), g, static_cast<const uint16_t*>(Z), static_cast<const uint16_t*>(net), static_cast<uint16_t*>(net_out), rows, HW, static_cast<const uint16_t*>(P_q)));
-  PVO_CHECK_LAUNCH();
-  return PVO_OK;
-}
-
-extern "C" int pvo_bias_act(void* x, const float* bias, long long rows, int C, int relu, int dtype, void* stream) {
-  if (rows < 0 || C <= 0 || (C & 7)) return PVO_EINVAL;
-  if (rows == 0) return PVO_OK;
-  if (!x || !aligned16(x)) return PVO_EINVAL;
-  if (rows * (C >> 3) >= (1LL << 31)) return PVO_EUNSUPPORTED;
-  hipStream_t st = pvo_stream(stream);
-  const unsigned gsz = grid_for((rows * (C >> 3) + 3) / 4);
-  GRU_DISPATCH(dtype,
-    hipLaunchKernelGGL(bias_act_kernel<pvo_half>, dim3(gsz), dim3(256), 0, st, static_cast<uint16_t*>(x), bias, rows, C, relu),
-    hipLaunchKernelGGL(bias_act_kernel<pvo_bf16>, dim3(gsz), dim3(256), 0, st, static_cast<uint16_t*>(x), bias, rows, C, relu));
-  PVO_CHECK_LAUNCH();
-  return PVO_OK;
-}
 
 extern "C" int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, const float* in_bias, void* out,
                                 int K, int HW, int C, int dtype, void* stream) {

@@ -1,0 +1,351 @@
+// operator_small.hip — the small layers of the update operator that used to go to MIOpen / hipBLASLt.
+//
+//   pvo_gate_context   g[e, 0:384] = Wg glo[e] + bg, glo[e] = sum of the per-chunk partial means pvo_gru_glo_fused wrote:
+//                      the three 1x1 "global context" convolutions of the ConvGRU (convz_glo | convr_glo | convq_glo,
+//                      VO_Module/droid_slam/modules/gru.py:13-15,26-30) as one tiny fp32 GEMV per edge
+//   pvo_eta_head       GraphAgg's eta head, Conv2d(128,1,3,padding=1) + Softplus, x0.01 (droid_net.py:72-74,93-95), and
+//                      optionally FactorGraph's damping bookkeeping (factor_graph.py:281-297) in the same launch
+//   pvo_conv1x1_c128   y = x W^T + b for a 128-channel channels-last tensor: GraphAgg.upmask_disp, Conv2d(128,576,1)
+//                      (droid_net.py:76-77,93)
+//   pvo_corr_encode    relu(W corr + b) for an already sampled 196-channel correlation tensor: corr_encoder[0:2],
+//                      Conv2d(196,128,1) + ReLU (droid_net.py:172-175).  The factor graph's resident volume pool goes
+//                      through pvo_corr_lookup_encode_tiled instead, where the 196 channels never reach HBM.
+//   pvo_segment_hist   per (edge, panoptic segment) pixel counts for the dynamic-segment vote (factor_graph.py:256-276)
+#include "common.h"
+
+namespace {
+
+typedef uint32_t os_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t os_u32x2 __attribute__((ext_vector_type(2)));
+typedef float os_v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 os_v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 os_v8b __attribute__((ext_vector_type(8)));
+
+template <typename T> __device__ __forceinline__ os_v4f os_mfma(os_u32x4 a, os_u32x4 b, os_v4f c);
+template <> __device__ __forceinline__ os_v4f os_mfma<pvo_half>(os_u32x4 a, os_u32x4 b, os_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(os_v8h, a), __builtin_bit_cast(os_v8h, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ os_v4f os_mfma<pvo_bf16>(os_u32x4 a, os_u32x4 b, os_v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(os_v8b, a), __builtin_bit_cast(os_v8b, b), c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ float os_val(uint32_t b);
+template <> __device__ __forceinline__ float os_val<pvo_half>(uint32_t b) {
+  union { uint16_t u; _Float16 h; } c; c.u = static_cast<uint16_t>(b); return static_cast<float>(c.h);
+}
+template <> __device__ __forceinline__ float os_val<pvo_bf16>(uint32_t b) { return pvo_bf16_to_f32(static_cast<uint16_t>(b)); }
+template <typename T> __device__ __forceinline__ uint32_t os_bits(float x);
+template <> __device__ __forceinline__ uint32_t os_bits<pvo_half>(float x) {
+  union { _Float16 h; uint16_t u; } c; c.h = static_cast<_Float16>(x); return c.u;
+}
+template <> __device__ __forceinline__ uint32_t os_bits<pvo_bf16>(float x) { return pvo_f32_to_bf16(x); }
+template <typename T> __device__ __forceinline__ void os_unpack8(os_u32x4 v, float f[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[2 * k] = os_val<T>(w[k] & 0xffffu); f[2 * k + 1] = os_val<T>(w[k] >> 16); }
+}
+
+// ---------------------------------------------------------------------------
+// gate context: one workgroup (128 threads) per edge
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void gate_context_kernel(const float* __restrict__ part, const float* __restrict__ wg_t,
+                                                           const float* __restrict__ gb, float* __restrict__ g, int chunks) {
+  __shared__ float glo[128];
+  const int e = blockIdx.x, t = threadIdx.x;
+  float s = 0.0f;
+  for (int k = 0; k < chunks; ++k) s += part[(static_cast<size_t>(e) * chunks + k) * 128 + t];
+  glo[t] = s;
+  __syncthreads();
+  float a0 = gb[t], a1 = gb[128 + t], a2 = gb[256 + t];
+#pragma unroll 8
+  for (int c = 0; c < 128; ++c) {
+    const float v = glo[c];
+    const float* w = wg_t + static_cast<size_t>(c) * 384 + t;
+    a0 = fmaf(v, w[0], a0); a1 = fmaf(v, w[128], a1); a2 = fmaf(v, w[256], a2);
+  }
+  float* o = g + static_cast<size_t>(e) * 384 + t;
+  o[0] = a0; o[128] = a1; o[256] = a2;
+}
+
+// ---------------------------------------------------------------------------
+// eta head: 16 lanes per pixel (8 channels each), 9 taps from global (the K-frame tensor is L2 resident), row reduction by
+// DPP.  Row r of the output belongs to frame frame[r] and reads image pos[r] of x (pos[r] < 0: no image - the frame only
+// carries inactive edges and keeps its stored damping).  frame == nullptr: plain head, eta[r] = 0.01 softplus(conv(x[r]) + b).
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float os_dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+  return v + __int_as_float(moved);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void eta_head_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                       const float* __restrict__ bias, const long long* __restrict__ frame,
+                                                       const int* __restrict__ pos, float* __restrict__ damping,
+                                                       float* __restrict__ eta, int H, int W, float EP) {
+  const int r = blockIdx.y;
+  const int HW = H * W;
+  const int pix = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const int k = frame ? pos[r] : r;
+  if (pix >= HW) return;
+  float e;
+  if (k >= 0) {
+    const int py = pix / W, px = pix - py * W;
+    const uint16_t* xe = x + static_cast<size_t>(k) * HW * 128 + l * 8;
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        float a[8], w[8];
+        os_unpack8<T>(*reinterpret_cast<const os_u32x4*>(xe + (static_cast<size_t>(yy) * W + xx) * 128), a);
+        os_unpack8<T>(*reinterpret_cast<const os_u32x4*>(wt + t * 128 + l * 8), w);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fmaf(a[q], w[q], acc);
+      }
+    }
+    acc = os_dpp_add<0xB1>(acc);     // 16-lane row sum: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+    acc = os_dpp_add<0x4E>(acc);
+    acc = os_dpp_add<0x141>(acc);
+    acc = os_dpp_add<0x140>(acc);
+    const float v = acc + bias[0];
+    const float sp = v > 20.0f ? v : log1pf(expf(v));            // torch softplus, beta = 1, threshold = 20
+    e = __fmul_rn(0.01f, sp);
+  } else {
+    e = damping[frame[r] * HW + pix];
+  }
+  if (l != 0) return;
+  if (frame) {
+    if (k >= 0) damping[frame[r] * HW + pix] = e;
+    eta[static_cast<size_t>(r) * HW + pix] = __fadd_rn(__fmul_rn(0.2f, e), EP);
+  } else {
+    eta[static_cast<size_t>(r) * HW + pix] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 1x1 convolution of a 128-channel tensor: workgroup = 64 rows x 192 output channels; the 64 x 128 input tile sits in LDS
+// (272-byte row stride), wave w owns 48 output channels (3 column tiles) with its 12 weight fragments in registers.
+// ---------------------------------------------------------------------------
+constexpr int kOsStride = 272;
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_c128_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                           long long rows, int Cout, int relu) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 400];     // input tile (64 x 272 B), later the output slab (64 x 400 B)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const long long r0 = static_cast<long long>(blockIdx.x) * 64;
+  const int c0 = blockIdx.y * 192 + wave * 48;
+  os_u32x4 bf[4][3];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+      bf[kc][nt] = *reinterpret_cast<const os_u32x4*>(wt + static_cast<size_t>(c0 + nt * 16 + li) * 128 + kc * 32 + lk * 8);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int id = tid + 256 * it, px = id >> 4, c = id & 15;
+    os_u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + px < rows) v = *reinterpret_cast<const os_u32x4*>(x + static_cast<size_t>(r0 + px) * 128 + c * 8);
+    *reinterpret_cast<os_u32x4*>(tile + px * kOsStride + c * 16) = v;
+  }
+  __syncthreads();
+  os_v4f d[4][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) d[g][nt] = os_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const os_u32x4 a = *reinterpret_cast<const os_u32x4*>(tile + (g * 16 + li) * kOsStride + kc * 64 + lk * 16);
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) d[g][nt] = os_mfma<T>(a, bf[kc][nt], d[g][nt]);
+    }
+  __syncthreads();
+  float bb[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) bb[nt] = bias ? bias[c0 + nt * 16 + li] : 0.0f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                        // D rows lk*4 + r = pixels, column li = channel
+        float v = d[g][nt][r] + bb[nt];
+        if (relu) v = fmaxf(v, 0.0f);
+        *reinterpret_cast<uint16_t*>(tile + (g * 16 + lk * 4 + r) * 400 + (wave * 48 + nt * 16 + li) * 2) = static_cast<uint16_t>(os_bits<T>(v));
+      }
+  __syncthreads();
+  for (int id = tid; id < 64 * 24; id += 256) {             // 24 chunks of 16 B per row
+    const int px = id / 24, c = id - px * 24;
+    if (r0 + px < rows)
+      *reinterpret_cast<os_u32x4*>(y + static_cast<size_t>(r0 + px) * Cout + blockIdx.y * 192 + c * 8) =
+          *reinterpret_cast<const os_u32x4*>(tile + px * 400 + c * 16);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// correlation encoder on a sampled tensor: rows of 196 16-bit channels (392 bytes: 8-byte aligned) are staged into LDS
+// rows of 224 channels (zero padded; 464-byte stride), then 64 rows x 128 outputs on the matrix cores (K = 224: 7 chunks)
+// against the same zero-padded [128][224] weight matrix pvo_corr_lookup_encode_tiled reads.
+// ---------------------------------------------------------------------------
+constexpr int kCeStride = 464;
+
+template <typename T>
+__global__ __launch_bounds__(256) void corr_encode_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                          const float* __restrict__ bias, uint16_t* __restrict__ y, long long rows) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[64 * kCeStride];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const long long r0 = static_cast<long long>(blockIdx.x) * 64;
+  for (int id = tid; id < 64 * 56; id += 256) {             // 56 pieces of 8 bytes per padded row
+    const int px = id / 56, c = id - px * 56;
+    os_u32x2 v = {0u, 0u};
+    if (c < 49 && r0 + px < rows) v = *reinterpret_cast<const os_u32x2*>(x + static_cast<size_t>(r0 + px) * 196 + c * 4);
+    *reinterpret_cast<os_u32x2*>(tile + px * kCeStride + c * 8) = v;
+  }
+  os_v4f d[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { d[g][0] = os_v4f{0.f, 0.f, 0.f, 0.f}; d[g][1] = os_v4f{0.f, 0.f, 0.f, 0.f}; }
+  __syncthreads();
+#pragma unroll 1
+  for (int kc = 0; kc < 7; ++kc) {
+    os_u32x4 b0 = *reinterpret_cast<const os_u32x4*>(wt + static_cast<size_t>(wave * 32 + li) * 224 + kc * 32 + lk * 8);
+    os_u32x4 b1 = *reinterpret_cast<const os_u32x4*>(wt + static_cast<size_t>(wave * 32 + 16 + li) * 224 + kc * 32 + lk * 8);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const os_u32x4 a = *reinterpret_cast<const os_u32x4*>(tile + (g * 16 + li) * kCeStride + kc * 64 + lk * 16);
+      d[g][0] = os_mfma<T>(a, b0, d[g][0]);
+      d[g][1] = os_mfma<T>(a, b1, d[g][1]);
+    }
+  }
+  __syncthreads();
+  const float bb0 = bias ? bias[wave * 32 + li] : 0.0f, bb1 = bias ? bias[wave * 32 + 16 + li] : 0.0f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      unsigned char* row = tile + (g * 16 + lk * 4 + r) * kOsStride;
+      *reinterpret_cast<uint16_t*>(row + (wave * 32 + li) * 2) = static_cast<uint16_t>(os_bits<T>(fmaxf(d[g][0][r] + bb0, 0.0f)));
+      *reinterpret_cast<uint16_t*>(row + (wave * 32 + 16 + li) * 2) = static_cast<uint16_t>(os_bits<T>(fmaxf(d[g][1][r] + bb1, 0.0f)));
+    }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int id = tid + 256 * it, px = id >> 4, c = id & 15;
+    if (r0 + px < rows)
+      *reinterpret_cast<os_u32x4*>(y + static_cast<size_t>(r0 + px) * 128 + c * 8) = *reinterpret_cast<const os_u32x4*>(tile + px * kOsStride + c * 16);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// segment histogram for the panoptic vote: tot[e, s] = pixels of segment s on edge e, dyn[e, s] = those whose UPDATED
+// mask (raw_mask + delta_mask) is dynamic on either channel (factor_graph.py:252-261)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void segment_hist_kernel(const int* __restrict__ segm, const float2* __restrict__ raw_mask,
+                                                           const uint16_t* __restrict__ heads, int* __restrict__ tot,
+                                                           int* __restrict__ dyn, int E, int HW, int S, float dy_thresh) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= E * HW) return;
+  const int e = idx / HW;
+  int s = segm[idx];
+  s = s < 0 ? 0 : (s >= S ? S - 1 : s);
+  const uint32_t q = *reinterpret_cast<const uint32_t*>(heads + static_cast<size_t>(idx) * 8 + 6);
+  const float2 rm = raw_mask[idx];
+  const float m0 = rm.x + os_val<T>(q & 0xffffu), m1 = rm.y + os_val<T>(q >> 16);
+  const bool d = !(1.0f / (1.0f + expf(-m0)) >= dy_thresh) || !(1.0f / (1.0f + expf(-m1)) >= dy_thresh);
+  atomicAdd(tot + static_cast<size_t>(e) * S + s, 1);
+  if (d) atomicAdd(dyn + static_cast<size_t>(e) * S + s, 1);
+}
+
+}  // namespace
+
+extern "C" int pvo_gate_context(const float* glo_part, const float* wg_t, const float* g_bias, float* g,
+                                int E, int chunks, void* stream) {
+  if (E < 0 || chunks <= 0) return PVO_EINVAL;
+  if (E == 0) return PVO_OK;
+  if (!glo_part || !wg_t || !g_bias || !g) return PVO_EINVAL;
+  hipLaunchKernelGGL(gate_context_kernel, dim3(E), dim3(128), 0, pvo_stream(stream), glo_part, wg_t, g_bias, g, chunks);
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_eta_head(const void* x, const void* w_taps, const float* bias, const int64_t* frame, const int* pos,
+                            float* damping, float* eta, int R, int H, int W, float EP, int dtype, void* stream) {
+  if (R < 0 || H < 0 || W < 0) return PVO_EINVAL;
+  if (R == 0 || H == 0 || W == 0) return PVO_OK;
+  if (!x || !w_taps || !bias || !eta || R > 65535) return PVO_EINVAL;
+  if (frame && (!pos || !damping)) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_taps)) & 15) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const dim3 grid((H * W + 15) / 16, R);
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(eta_head_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w_taps),
+                       bias, reinterpret_cast<const long long*>(frame), pos, damping, eta, H, W, EP);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(eta_head_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w_taps),
+                       bias, reinterpret_cast<const long long*>(frame), pos, damping, eta, H, W, EP);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, long long rows, int Cout, int relu,
+                                int dtype, void* stream) {
+  if (rows < 0) return PVO_EINVAL;
+  if (Cout <= 0 || Cout % 192) return PVO_EUNSUPPORTED;
+  if (rows == 0) return PVO_OK;
+  if (!x || !w || !y || rows > (1LL << 31) - 64) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y)) & 15) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const dim3 grid(static_cast<unsigned>((rows + 63) / 64), Cout / 192);
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(conv1x1_c128_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w), bias, static_cast<uint16_t*>(y), rows, Cout, relu);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(conv1x1_c128_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w), bias, static_cast<uint16_t*>(y), rows, Cout, relu);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_corr_encode(const void* corr, const void* enc_weight, const float* enc_bias, void* y, long long rows,
+                               int dtype, void* stream) {
+  if (rows < 0) return PVO_EINVAL;
+  if (rows == 0) return PVO_OK;
+  if (!corr || !enc_weight || !y || rows > (1LL << 31) - 64) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(corr) & 7) || ((reinterpret_cast<uintptr_t>(enc_weight) | reinterpret_cast<uintptr_t>(y)) & 15)) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const dim3 grid(static_cast<unsigned>((rows + 63) / 64));
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(corr_encode_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(corr), static_cast<const uint16_t*>(enc_weight), enc_bias, static_cast<uint16_t*>(y), rows);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(corr_encode_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(corr), static_cast<const uint16_t*>(enc_weight), enc_bias, static_cast<uint16_t*>(y), rows);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_segment_hist(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
+                                int E, int HW, int S, float dy_thresh, int dtype, void* stream) {
+  if (E < 0 || HW < 0 || S <= 0) return PVO_EINVAL;
+  const long long n = static_cast<long long>(E) * HW;
+  if (n == 0) return PVO_OK;
+  if (!segm || !raw_mask || !heads || !tot || !dyn || n >= (1LL << 31)) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  if (hipMemsetAsync(tot, 0, sizeof(int) * static_cast<size_t>(E) * S, st) != hipSuccess) return PVO_ELAUNCH;
+  if (hipMemsetAsync(dyn, 0, sizeof(int) * static_cast<size_t>(E) * S, st) != hipSuccess) return PVO_ELAUNCH;
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256));
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(segment_hist_kernel<pvo_half>, grid, dim3(256), 0, st, segm, reinterpret_cast<const float2*>(raw_mask), static_cast<const uint16_t*>(heads), tot, dyn, E, HW, S, dy_thresh);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(segment_hist_kernel<pvo_bf16>, grid, dim3(256), 0, st, segm, reinterpret_cast<const float2*>(raw_mask), static_cast<const uint16_t*>(heads), tot, dyn, E, HW, S, dy_thresh);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}

@@ -1,0 +1,316 @@
+// update_exec.hip — native executor of one factor-graph update.
+//
+// The reference issues one graph update (VO_Module/droid_slam/factor_graph.py:227-307) as ~150 PyTorch / cuDNN launches
+// from Python: reproject (lietorch chain), 4 lookups + cat, ~25 convolutions with their element-wise glue
+// (droid_net.py:256-314, modules/gru.py:19-32), the mask / weight arithmetic, and droid_backends.ba with its host round
+// trips.  Here the whole update is ONE C call that enqueues ~33 hand-written kernels on the caller's stream (the
+// aggregation branch on a second stream, forked and joined with events): no Python, no MIOpen / hipBLASLt, no allocation,
+// no host synchronisation.  Because every launch comes from this one function with caller-owned buffers, the call can
+// also be captured into a HIP graph by the caller.
+//
+//   pvo_update_operator   DynamicUpdateModule.forward (droid_net.py:256-314) on the 16-bit inference path
+//   pvo_graph_update      FactorGraph.update (factor_graph.py:227-307): reproject -> motion features -> operator ->
+//                         (panoptic vote) -> mask / weight glue -> eta / damping -> dense BA x itrs -> depth clamp
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct SideCtx { hipStream_t side; hipEvent_t fork, join; bool ok; };
+
+// one side stream + two events per device, created on first use (streams and events are host objects: the library still
+// allocates no device memory)
+SideCtx* side_ctx() {
+  static SideCtx ctx[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideCtx& c = ctx[dev];
+  if (!c.ok) {
+    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    c.ok = true;
+  }
+  return &c;
+}
+
+size_t al(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+// Measurement hook (bench.py): HIP events around one stage of the update, recorded on the launch stream itself, so that a
+// kernel's duration INSIDE the timed steps can be read without a profiler.  Disarmed (stage -1) it costs one compare.
+struct Probe { int stage; int cap; int n; hipEvent_t* ev; };
+Probe g_probe = {-1, 0, 0, nullptr};
+
+inline void probe_mark(int stage, int which, void* stream) {
+  if (g_probe.stage != stage || g_probe.n >= g_probe.cap) return;
+  (void)hipEventRecord(g_probe.ev[2 * g_probe.n + which], pvo_stream(stream));
+  if (which == 1) ++g_probe.n;
+}
+
+struct OpWs {
+  char *c1, *f1, *CF, *Z, *RN, *h1, *a1, *am, *a2, *P_zr, *P_q;
+  float *part, *g;
+  size_t bytes;
+};
+
+OpWs carve_op(void* base, int E, int K, int H, int W, int chunks) {
+  OpWs w{};
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += al(bytes); return r; };
+  const size_t px = static_cast<size_t>(E) * H * W, kpx = static_cast<size_t>(K) * H * W;
+  w.c1 = take(px * 128 * 2); w.f1 = take(px * 128 * 2); w.CF = take(px * 192 * 2);
+  w.Z = take(px * 128 * 2); w.RN = take(px * 128 * 2); w.h1 = take(px * 512 * 2);
+  w.a1 = take(px * 128 * 2); w.am = take(kpx * 128 * 2); w.a2 = take(kpx * 128 * 2);
+  w.P_zr = take(px * 256 * 2); w.P_q = take(px * 128 * 2);
+  w.part = reinterpret_cast<float*>(take(static_cast<size_t>(E) * chunks * 128 * 4));
+  w.g = reinterpret_cast<float*>(take(static_cast<size_t>(E) * 384 * 4));
+  w.bytes = off;
+  return w;
+}
+
+struct UpWs {
+  float *coords, *valid, *eta;
+  char *motion, *heads, *upmask;
+  int *vote_tot, *vote_dyn;
+  void* op;
+  size_t bytes;
+};
+
+UpWs carve_up(void* base, int E, int K, int R, int H, int W, int S, size_t op_bytes) {
+  UpWs w{};
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += al(bytes); return r; };
+  const size_t px = static_cast<size_t>(E) * H * W;
+  w.coords = reinterpret_cast<float*>(take(px * 2 * 4));
+  w.valid = reinterpret_cast<float*>(take(px * 4));
+  w.eta = reinterpret_cast<float*>(take(static_cast<size_t>(R > 0 ? R : 1) * H * W * 4));
+  w.motion = take(px * 8 * 2);
+  w.heads = take(px * 8 * 2);
+  w.upmask = take(static_cast<size_t>(K) * H * W * 576 * 2);
+  w.vote_tot = reinterpret_cast<int*>(take(static_cast<size_t>(E) * (S > 0 ? S : 0) * 4 + 4));
+  w.vote_dyn = reinterpret_cast<int*>(take(static_cast<size_t>(E) * (S > 0 ? S : 0) * 4 + 4));
+  w.op = take(op_bytes);
+  w.bytes = off;
+  return w;
+}
+
+void* ws_base(void* workspace) {
+  return reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+}
+
+#define RUN(call)                    \
+  do {                               \
+    const int rc_ = (call);          \
+    if (rc_ != PVO_OK) return rc_;   \
+  } while (0)
+
+// everything of the operator up to the new hidden state; the two branches that read it follow in `branches`
+int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, const void** P_zr, const void** P_q) {
+  const int E = a->E, H = a->H, W = a->W, dt = w->dtype;
+  const long long rows = static_cast<long long>(E) * H * W;
+  if (a->levels[0]) {
+    probe_mark(PVO_STAGE_LOOKUP, 0, stream);
+    RUN(pvo_corr_lookup_encode_tiled(a->levels, a->coords, w->enc0_w, w->enc0_b, b.c1, E, H, W, dt, a->slots, a->num_slots, stream));
+    probe_mark(PVO_STAGE_LOOKUP, 1, stream);
+  } else {
+    if (!a->corr) return PVO_EINVAL;
+    RUN(pvo_corr_encode(a->corr, w->enc0_w, w->enc0_b, b.c1, rows, dt, stream));
+  }
+  RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, stream));
+  // the encoders' second layers write relu(features + bias) side by side: CF = [corr features (128) | flow features (64)]
+  if (w->flags & PVO_OP_CONV128_WIDE)
+    RUN(pvo_conv3x3(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 128, 1, 192, 0, dt, stream));
+  else
+    RUN(pvo_conv3x3_c128(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 1, 192, 0, dt, stream));
+  RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, stream));
+  *P_zr = a->P_zr; *P_q = a->P_q;
+  if (!a->P_zr || !a->P_q) {       // static-input term not cached by the caller: conv(W[:, inp], inp) for this call
+    if (!a->inp) return PVO_EINVAL;
+    RUN(pvo_conv3x3(a->inp, w->zr_inp_w, nullptr, b.P_zr, E, H, W, 128, 256, 0, 0, 0, dt, stream));
+    RUN(pvo_conv3x3(a->inp, w->q_inp_w, nullptr, b.P_q, E, H, W, 128, 128, 0, 0, 0, dt, stream));
+    *P_zr = b.P_zr; *P_q = b.P_q;
+  }
+  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, stream));
+  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), stream));
+  probe_mark(PVO_STAGE_GATES, 0, stream);
+  RUN(pvo_gru_conv_gates(a->net, b.CF, 192, w->zr_w, b.g, *P_zr, b.Z, b.RN, E, H, W, dt, stream));
+  probe_mark(PVO_STAGE_GATES, 1, stream);
+  probe_mark(PVO_STAGE_CANDIDATE, 0, stream);
+  RUN(pvo_gru_conv_candidate(b.RN, b.CF, 192, w->q_w, b.g, *P_q, b.Z, a->net, a->net_out, E, H, W, dt, stream));
+  probe_mark(PVO_STAGE_CANDIDATE, 1, stream);
+  return PVO_OK;
+}
+
+int run_heads(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream) {
+  const int E = a->E, H = a->H, W = a->W, dt = w->dtype;
+  RUN(pvo_conv3x3(a->net_out, w->heads1_w, nullptr, b.h1, E, H, W, 128, 512, 0, 0, 0, dt, stream));
+  RUN(pvo_heads_out(b.h1, w->heads1_b, w->heads2_w, w->heads2_b, a->heads, E, H, W, dt, stream));
+  return PVO_OK;
+}
+
+int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream) {
+  const int E = a->E, H = a->H, W = a->W, K = a->K, dt = w->dtype;
+  if (K <= 0) return PVO_OK;
+  if (w->flags & PVO_OP_CONV128_WIDE)
+    RUN(pvo_conv3x3(a->net_out, w->agg1_w, nullptr, b.a1, E, H, W, 128, 128, 0, 0, 0, dt, stream));
+  else
+    RUN(pvo_conv3x3_c128(a->net_out, w->agg1_w, nullptr, b.a1, E, H, W, 128, 0, 0, 0, dt, stream));
+  // conv1's bias + ReLU are applied by the mean kernel as it reads
+  RUN(pvo_segment_mean(b.a1, a->seg_ptr, a->seg_idx, w->agg1_b, b.am, K, H * W, 128, dt, stream));
+  RUN(pvo_conv3x3_c128(b.am, w->agg2_w, w->agg2_b, b.a2, K, H, W, 128, 1, 0, 0, dt, stream));
+  if (a->eta)
+    RUN(pvo_eta_head(b.a2, w->eta_w, w->eta_b, a->eta_frame, a->eta_pos, a->damping, a->eta, a->eta_frame ? a->R : K, H, W, a->EP, dt, stream));
+  if (a->upmask)
+    RUN(pvo_conv1x1_c128(b.a2, w->up_w, w->up_b, a->upmask, static_cast<long long>(K) * H * W, 576, 0, dt, stream));
+  return PVO_OK;
+}
+
+int check_op(const pvo_update_weights* w, const pvo_operator_args* a) {
+  if (!w || !a) return PVO_EINVAL;
+  if (w->dtype != PVO_F16 && w->dtype != PVO_BF16) return PVO_EUNSUPPORTED;
+  if (a->E < 0 || a->H <= 0 || a->W <= 0 || a->K < 0) return PVO_EINVAL;
+  if (a->E > 0 && (!a->net || !a->net_out || !a->heads)) return PVO_EINVAL;
+  if (a->K > 0 && (!a->seg_ptr || !a->seg_idx)) return PVO_EINVAL;
+  return PVO_OK;
+}
+
+// trunk on `stream`, then the aggregation branch on the side stream beside the heads on `stream`.  join_now = false
+// leaves the join to the caller (pvo_graph_update joins only in front of the BA, so the K-frame kernels of the
+// aggregation branch, which occupy a fraction of the chip, also overlap the mask / weight glue).
+int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx** pending) {
+  const void *P_zr, *P_q;
+  RUN(run_trunk(w, a, b, stream, &P_zr, &P_q));
+  hipStream_t st = pvo_stream(stream);
+  SideCtx* sc = (a->K > 0 && !(w->flags & PVO_OP_SINGLE_STREAM)) ? side_ctx() : nullptr;
+  if (sc) {
+    if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
+    if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
+    RUN(run_agg(w, a, b, sc->side));
+    if (hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
+    RUN(run_heads(w, a, b, stream));
+    *pending = sc;
+  } else {
+    RUN(run_heads(w, a, b, stream));
+    RUN(run_agg(w, a, b, stream));
+    *pending = nullptr;
+  }
+  return PVO_OK;
+}
+
+int join(SideCtx* sc, void* stream) {
+  if (sc && hipStreamWaitEvent(pvo_stream(stream), sc->join, 0) != hipSuccess) return PVO_ELAUNCH;
+  return PVO_OK;
+}
+
+__global__ __launch_bounds__(256) void clamp_min_kernel(float* __restrict__ x, long long n, float lo) {
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) { const float v = x[i]; x[i] = (v < lo) ? lo : v; }      // NaN stays NaN, as in torch.clamp
+}
+
+}  // namespace
+
+extern "C" size_t pvo_operator_workspace_bytes(int E, int K, int H, int W) {
+  if (E < 0 || K < 0 || H <= 0 || W <= 0) return 0;
+  return carve_op(nullptr, E, K, H, W, pvo_gru_glo_chunks(H * W)).bytes + 256;
+}
+
+extern "C" int pvo_update_operator(const pvo_update_weights* w, const pvo_operator_args* a,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  RUN(check_op(w, a));
+  if (a->E == 0) return PVO_OK;
+  if (!workspace || workspace_bytes < pvo_operator_workspace_bytes(a->E, a->K, a->H, a->W)) return PVO_EWORKSPACE;
+  if (!a->motion) return PVO_EINVAL;
+  OpWs b = carve_op(ws_base(workspace), a->E, a->K, a->H, a->W, pvo_gru_glo_chunks(a->H * a->W));
+  SideCtx* pending = nullptr;
+  RUN(run_operator(w, a, b, stream, &pending));
+  return join(pending, stream);
+}
+
+extern "C" size_t pvo_graph_update_workspace_bytes(int E, int K, int R, int H, int W, int max_segments) {
+  if (E < 0 || K < 0 || R < 0 || H <= 0 || W <= 0 || max_segments < 0) return 0;
+  return carve_up(nullptr, E, K, R, H, W, max_segments, pvo_operator_workspace_bytes(E, K, H, W)).bytes + 256;
+}
+
+extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_update_args* u,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!w || !u) return PVO_EINVAL;
+  pvo_operator_args a = u->op;
+  a.net_out = a.net_out ? a.net_out : const_cast<void*>(a.net);
+  a.heads = reinterpret_cast<void*>(1);        // supplied from the workspace below
+  RUN(check_op(w, &a));
+  const int E = a.E, H = a.H, W = a.W, K = a.K, R = a.R, dt = w->dtype, HW = H * W;
+  if (E == 0) return PVO_OK;
+  if (!a.levels[0]) return PVO_EUNSUPPORTED;           // the factor graph's volumes live in the tiled pool
+  if (!u->poses || !u->disps || !u->intrinsics || !u->ii || !u->jj || !u->target || !u->delta_dy || !u->raw_mask ||
+      !u->weight || !u->full_flow || !u->target_ba || !u->weight_ba || !u->ii_ba || !u->jj_ba || !u->sys || !u->ba_ws)
+    return PVO_EINVAL;
+  if (K <= 0 || R <= 0 || !a.eta_frame || !a.eta_pos || !a.damping || u->n_in < 0) return PVO_EINVAL;
+  const int S = u->segm ? u->max_segments : 0;
+  if (u->segm && S <= 0) return PVO_EINVAL;
+  if (!workspace || workspace_bytes < pvo_graph_update_workspace_bytes(E, K, R, H, W, S)) return PVO_EWORKSPACE;
+  const size_t op_bytes = pvo_operator_workspace_bytes(E, K, H, W);
+  UpWs s = carve_up(ws_base(workspace), E, K, R, H, W, S, op_bytes);
+  OpWs b = carve_op(ws_base(s.op), E, K, H, W, pvo_gru_glo_chunks(HW));
+  hipStream_t st = pvo_stream(stream);
+
+  probe_mark(PVO_STAGE_UPDATE, 0, stream);
+  // factor_graph.py:231-237: reprojection and motion features
+  RUN(pvo_reproject(u->poses, u->disps, u->intrinsics, u->ii, u->jj, s.coords, s.valid, E, H, W, stream));
+  RUN(pvo_graph_motion(u->target, s.coords, u->delta_dy, u->raw_mask, s.motion, E, H, W, dt, stream));
+  a.coords = s.coords; a.corr = nullptr; a.motion = s.motion; a.heads = s.heads;
+  a.eta = s.eta;
+  if (u->want_upmask && !a.upmask) a.upmask = s.upmask;
+  SideCtx* pending = nullptr;
+  RUN(run_operator(w, &a, b, stream, &pending));
+  // :249-306: mask update, (panoptic vote), weights, targets in the BA's layout, full flow
+  if (u->segm)
+    RUN(pvo_segment_hist(u->segm, u->raw_mask, s.heads, s.vote_tot, s.vote_dyn, E, HW, S, u->dy_thresh, dt, stream));
+  RUN(pvo_graph_post(s.coords, s.heads, u->raw_mask, u->target, u->delta_dy, u->weight,
+                     u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW, u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW,
+                     u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
+                     S, u->vote_thresh, dt, stream));
+  RUN(join(pending, stream));
+  // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
+  const int Eb = u->n_in + E;
+  probe_mark(PVO_STAGE_BA, 0, stream);
+  for (int it = 0; it < u->itrs; ++it) {
+    RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, s.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
+                     H, W, R, u->t0, u->t1, u->motion_only, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
+    RUN(pvo_ba_finish(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
+                      u->motion_only, nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, stream));
+  }
+  probe_mark(PVO_STAGE_BA, 1, stream);
+  if (u->clamp_frames > 0) {               // depth_video.py:214 disps.clamp_(min=0.001)
+    const long long n = static_cast<long long>(u->clamp_frames) * HW;
+    hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, u->disps, n, u->disp_min);
+    PVO_CHECK_LAUNCH();
+  }
+  probe_mark(PVO_STAGE_UPDATE, 1, stream);
+  return PVO_OK;
+}
+
+extern "C" int pvo_probe_arm(int stage, int capacity) {
+  if (capacity < 0) return PVO_EINVAL;
+  if (capacity > g_probe.cap) {
+    hipEvent_t* ev = static_cast<hipEvent_t*>(realloc(g_probe.ev, sizeof(hipEvent_t) * 2 * capacity));
+    if (!ev) return PVO_EINVAL;
+    for (int i = 2 * g_probe.cap; i < 2 * capacity; ++i)
+      if (hipEventCreate(&ev[i]) != hipSuccess) return PVO_ELAUNCH;
+    g_probe.ev = ev; g_probe.cap = capacity;
+  }
+  g_probe.n = 0;
+  g_probe.stage = capacity > 0 ? stage : -1;
+  return PVO_OK;
+}
+
+extern "C" int pvo_probe_read(float* ms_host, int max_n) {
+  const int n = g_probe.n < max_n ? g_probe.n : max_n;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_probe.ev[2 * i + 1]) != hipSuccess) return -1;
+    if (hipEventElapsedTime(&ms_host[i], g_probe.ev[2 * i], g_probe.ev[2 * i + 1]) != hipSuccess) return -1;
+  }
+  g_probe.stage = -1;
+  return n;
+}

@@ -38,8 +38,36 @@ class DepthVideo:
         self.max_segments = 1024
 
     # ------------------------------------------------------------------ bookkeeping
-    def append(self, tstamp, pose, disp, intrinsics, fmap, net, inp, segm=None, image=None):
-        """store one keyframe; fmap may be [128,h,w] (reference layout) or [h,w,128]"""
+    def _fmap_cl(self, f, channels_last):
+        """feature map -> the stored channels-last layout.  The layout is taken from the shape wherever that is
+        unambiguous ([..,128,h,w] vs [..,h,w,128] with h,w of THIS video); for maps that are 128 wide or high pass
+        channels_last explicitly (MotionFilter / the trajectory filler produce the reference's [128,h,w])."""
+        h8, w8 = self.ht // 8, self.wd // 8
+        if channels_last is None:
+            is_cl = tuple(f.shape[-3:]) == (h8, w8, 128)
+            is_cf = tuple(f.shape[-3:]) == (128, h8, w8)
+            if is_cl == is_cf:
+                if is_cl:
+                    raise ValueError("feature map layout is ambiguous for a %dx%d map: pass channels_last=True/False" % (h8, w8))
+                raise ValueError("feature map of shape %s fits neither [128,%d,%d] nor [%d,%d,128]" % (tuple(f.shape), h8, w8, h8, w8))
+            channels_last = is_cl
+        return f if channels_last else f.movedim(-3, -1)
+
+    def _dense_segments(self, segm):
+        """panoptic ids -> dense per-frame labels in [0, max_segments) with 0 kept as 'no segment'.  The reference keys the
+        vote by lay * 1e6 + id (factor_graph.py:259), i.e. by the raw id; raw ids (R + 256 G + 65536 B, category * 1000 +
+        instance, ...) do not fit a histogram, and only the grouping inside one frame matters to the vote."""
+        seg = torch.as_tensor(segm, device=self.device).to(torch.int64)
+        u, inv = torch.unique(seg, return_inverse=True)
+        if u.numel() and int(u[0]) != 0:
+            inv = inv + 1
+        n = int(u.numel()) + (1 if u.numel() and int(u[0]) != 0 else 0)
+        if n > self.max_segments:
+            raise ValueError("frame has %d panoptic segments, more than max_segments = %d" % (n, self.max_segments))
+        return inv.to(torch.int32).reshape(seg.shape)
+
+    def append(self, tstamp, pose, disp, intrinsics, fmap, net, inp, segm=None, image=None, channels_last=None):
+        """store one keyframe; fmap may be [128,h,w] (reference layout) or [h,w,128] (see _fmap_cl)"""
         k = self.counter
         self.tstamp[k] = tstamp
         if pose is not None:
@@ -47,11 +75,11 @@ class DepthVideo:
         if disp is not None:
             self.disps[k] = disp
         self.intrinsics[k] = intrinsics
-        self.fmaps[k] = fmap.permute(1, 2, 0) if fmap.shape[0] == 128 and fmap.shape[-1] != 128 else fmap
+        self.fmaps[k] = self._fmap_cl(fmap, channels_last)
         self.nets[k] = net
         self.inps[k] = inp
         if segm is not None:
-            self.segms[k] = segm
+            self.segms[k] = self._dense_segments(segm).reshape(self.segms[k].shape)
         if image is not None and self.images is not None:
             self.images[k] = image
         self.counter = k + 1
@@ -68,14 +96,17 @@ class DepthVideo:
             if val is not None:
                 buf[index] = val
         if len(item) > 5 and item[5] is not None:
-            f = item[5]
-            self.fmaps[index] = f.movedim(-3, -1) if f.shape[-1] != 128 else f
+            self.fmaps[index] = self._fmap_cl(item[5], None)
         if len(item) > 6:
             self.nets[index] = item[6]
         if len(item) > 7:
             self.inps[index] = item[7]
         if self.segm_filter and len(item) > 8 and item[8] is not None:
-            self.segms[index] = item[8]
+            seg = torch.as_tensor(item[8], device=self.device)
+            if isinstance(index, int) or seg.dim() <= 3:
+                self.segms[index] = self._dense_segments(seg).reshape(self.segms[index].shape)
+            else:                                           # several frames at once: labels are per frame
+                self.segms[index] = torch.stack([self._dense_segments(x) for x in seg]).reshape(self.segms[index].shape)
 
     def __getitem__(self, index):
         """(pose, disp, intrinsics, fmap, net, inp) of a keyframe; negative ints count from the end (:103-121)"""
@@ -121,6 +152,11 @@ class DepthVideo:
         if return_matrix:
             N = self.counter
             ii, jj = torch.meshgrid(torch.arange(N), torch.arange(N), indexing="ij")
+        if not (isinstance(ii, torch.Tensor) and ii.is_cuda):      # host index lists: staged through the pinned ring, no stream drain
+            ii_h = torch.as_tensor(ii, dtype=torch.long).reshape(-1)
+            jj_h = torch.as_tensor(jj, dtype=torch.long).reshape(-1)
+            both = db.to_device_async(torch.cat([ii_h, jj_h]), torch.long, self.device)
+            ii, jj = both[:ii_h.numel()], both[ii_h.numel():]
         ii, jj = self.format_indicies(ii, jj, self.device)
         if bidirectional:
             poses = self.poses[:self.counter].clone()

@@ -43,13 +43,60 @@ def _dev(*ts):
     return dev
 
 
+class _PinnedRing:
+    """One persistent page-locked staging buffer per process.  `tensor.pin_memory()` per call is a fresh page-locked
+    allocation whenever the caching host allocator cannot recycle a block (its blocks are only recycled once the copy
+    that used them has completed, and the host runs ahead of the GPU), i.e. a hipHostMalloc - milliseconds, and a
+    device-wide lock - in the middle of the update loop.  Small index lists are copied into this ring instead; a quarter
+    of the ring is reused only after the copies issued from it have completed (an event per quarter)."""
+
+    def __init__(self, nbytes=1 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.nbytes, self.quarter = nbytes, nbytes // 4
+        self.off = 0
+        self.events = [None] * 4
+
+    def take(self, n, device):
+        n = (n + 15) & ~15
+        if n > self.quarter:
+            return None
+        q0 = self.off // self.quarter
+        if self.off + n > (q0 + 1) * self.quarter:            # does not fit in the current quarter: move on
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            self.events[q0] = ev
+            q0 = (q0 + 1) % 4
+            self.off = q0 * self.quarter
+            if self.events[q0] is not None:                   # copies issued from this quarter one lap ago
+                self.events[q0].synchronize()
+                self.events[q0] = None
+        seg = self.buf[self.off:self.off + n]
+        self.off += n
+        return seg
+
+
+_ring = None
+
+
 def to_device_async(values, dtype, device):
-    """host sequence -> device tensor through a pinned staging buffer and an asynchronous copy: unlike
-    torch.tensor(values, device=...) this does not drain the stream"""
-    t = torch.tensor(values, dtype=dtype)
-    if torch.device(device).type != "cuda":
-        return t
-    return t.pin_memory().to(device, non_blocking=True)
+    """host sequence -> device tensor through the pinned staging ring and an asynchronous copy: unlike
+    torch.tensor(values, device=...) this neither drains the stream nor allocates page-locked memory"""
+    global _ring
+    t = values.to(dtype) if isinstance(values, torch.Tensor) else torch.tensor(values, dtype=dtype)
+    device = torch.device(device)
+    if device.type != "cuda" or t.numel() == 0:
+        return t.to(device)
+    if _ring is None:
+        _ring = _PinnedRing()
+    nbytes = t.numel() * t.element_size()
+    seg = _ring.take(nbytes, device)
+    if seg is None:                                           # larger than a quarter of the ring: rare, one-off
+        return t.pin_memory().to(device, non_blocking=True)
+    stage = seg[:nbytes].view(dtype).view(t.shape)
+    stage.copy_(t)
+    out = torch.empty(t.shape, dtype=dtype, device=device)
+    out.copy_(stage, non_blocking=True)
+    return out
 
 
 def _stream(dev):
@@ -165,7 +212,7 @@ def tiled_level_shape(ht, wd, level):
 
 
 def tiled_supported(ht, wd, dtype):
-    return dtype in (torch.float16, torch.bfloat16) and wd % 64 == 0 and ht % 8 == 0
+    return dtype in (torch.float16, torch.bfloat16) and wd >= 8 and ht >= 8
 
 
 def corr_build_tiled(fmap1, fmap2, out, out_slots):
@@ -506,7 +553,7 @@ def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace,
     return [dx, dz]
 
 
-# --------------------------------------------------------------------------- fused ConvGRU element-wise ops
+# --------------------------------------------------------------------------- update operator layers
 def _cl(t, name, C):
     """a [E,C,H,W] tensor stored channels-last (physically [E,H,W,C]), 16-bit"""
     if t.dim() != 4 or t.shape[1] != C or not t.is_contiguous(memory_format=torch.channels_last):
@@ -523,72 +570,8 @@ def _bias(b, C, what):
     return _ptr(b)
 
 
-def gru_glo(wn, net, w_bias=None):
-    """mean over pixels of sigmoid(wn + w_bias)*net (gru.py:23-24) -> [E,128] float32"""
-    _cl(wn, "wn", 128); _cl(net, "net", 128)
-    dev = _dev(wn, net)
-    E, C, H, W = net.shape
-    glo = torch.empty(E, C, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_glo(_ptr(wn), _ptr(net), _bias(w_bias, 128, "w_bias"), _ptr(glo), E, H * W, C, _dtype_code(net, "net"), _stream(dev)), "gru_glo")
-    return glo
-
-
-def gru_assemble(net, inp, corr_feat, flow_feat, X, corr_bias=None, flow_bias=None):
-    """X [E,448,H,W] (channels-last) <- [net | inp | relu(corr_feat + corr_bias) | relu(flow_feat + flow_bias)];
-    with inp=None, X is [E,320,H,W] without the inp block (its convolution is precomputed, see gru_gate)."""
-    _cl(net, "net", 128); _cl(corr_feat, "corr_feat", 128); _cl(flow_feat, "flow_feat", 64)
-    if inp is not None:
-        _cl(inp, "inp", 128)
-    _cl(X, "X", 448 if inp is not None else 320)
-    dev = _dev(net, inp, corr_feat, flow_feat, X)
-    E, _, H, W = net.shape
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_assemble(_ptr(net), _ptr(inp), _ptr(corr_feat), _ptr(flow_feat),
-                                           _bias(corr_bias, 128, "corr_bias"), _bias(flow_bias, 64, "flow_bias"), _ptr(X), E * H * W,
-                                           1 if inp is not None else 0,
-                                           _dtype_code(net, "net"), _stream(dev)), "gru_assemble")
-
-
-def gru_gate(zr, g, net, Z, X, P_zr=None):
-    """Z <- sigmoid(zr[:, :128] + P_zr[:, :128] + g_z);  X[:, :128] <- sigmoid(zr[:, 128:] + P_zr[:, 128:] + g_r) * net
-    (gru.py:26-28); X has 448 or 320 channels"""
-    _cl(zr, "zr", 256); _cl(net, "net", 128); _cl(Z, "Z", 128); _cl(X, "X", X.shape[1])
-    if P_zr is not None:
-        _cl(P_zr, "P_zr", 256)
-    dev = _dev(zr, g, net, Z, X, P_zr)
-    _f32(g, "g"); _contig(g, "g")
-    E, _, H, W = net.shape
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_gate(_ptr(zr), _ptr(g), _ptr(net), _ptr(Z), _ptr(X), _ptr(P_zr), X.shape[1], E, H * W,
-                                       _dtype_code(net, "net"), _stream(dev)), "gru_gate")
-
-
-def gru_out(q, g, Z, net, P_q=None):
-    """(1-Z)*net + Z*tanh(q + P_q + g_q)   (gru.py:28-31) -> new hidden state, channels-last [E,128,H,W]"""
-    _cl(q, "q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
-    if P_q is not None:
-        _cl(P_q, "P_q", 128)
-    dev = _dev(q, g, Z, net, P_q)
-    _f32(g, "g"); _contig(g, "g")
-    E, _, H, W = net.shape
-    out = torch.empty_like(net, memory_format=torch.channels_last)
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_out(_ptr(q), _ptr(g), _ptr(Z), _ptr(net), _ptr(out), _ptr(P_q), E, H * W,
-                                      _dtype_code(net, "net"), _stream(dev)), "gru_out")
-    return out
-
-
-def bias_act_(x, bias, relu=True):
-    """in place x <- act(x + bias[c]) on a channels-last 16-bit [N,C,H,W] tensor; returns x"""
-    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype not in (torch.float16, torch.bfloat16):
-        raise PvoHipError("bias_act_: x must be a channels-last 16-bit [N,C,H,W] tensor")
-    dev = _dev(x)
-    N, C, H, W = x.shape
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_bias_act(_ptr(x), _bias(bias, C, "bias"), N * H * W, C, 1 if relu else 0,
-                                       _dtype_code(x, "x"), _stream(dev)), "bias_act")
-    return x
+def _new_cl(E, C, H, W, dtype, dev):
+    return torch.empty(E, H, W, C, dtype=dtype, device=dev).permute(0, 3, 1, 2)
 
 
 def gru_glo_fused(net, w_weight, w_bias=None):
@@ -609,6 +592,21 @@ def gru_glo_fused(net, w_weight, w_bias=None):
     return part
 
 
+def gate_context(glo_part, wg_t, g_bias):
+    """g [E,384] f32 = (sum over chunks of glo_part [E,K,128]) @ wg_t [128,384] + g_bias [384]: the ConvGRU's three
+    global-context 1x1 convolutions (gru.py:13-15) with every per-channel bias of the gates folded in"""
+    dev = _dev(glo_part, wg_t, g_bias)
+    E, K, C = glo_part.shape
+    for t, n in ((glo_part, "glo_part"), (wg_t, "wg_t"), (g_bias, "g_bias")):
+        _f32(t, n); _contig(t, n)
+    if C != 128 or tuple(wg_t.shape) != (128, 384) or g_bias.numel() != 384:
+        raise PvoHipError("gate_context: glo_part [E,K,128], wg_t [128,384], g_bias [384]")
+    g = torch.empty(E, 384, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gate_context(_ptr(glo_part), _ptr(wg_t), _ptr(g_bias), _ptr(g), E, K, _stream(dev)), "gate_context")
+    return g
+
+
 def conv7x7_c8_weights(weight, dtype):
     """[128,8,7,7] conv filter -> the [52,128,8] tap-major layout pvo_conv7x7_c8 reads (3 zero taps of padding)"""
     co, ci, kh, kw = weight.shape
@@ -626,7 +624,7 @@ def conv7x7_c8(x, w_taps, bias):
     E, _, H, W = x.shape
     if w_taps.dtype != x.dtype or tuple(w_taps.shape) != (52, 128, 8) or not w_taps.is_contiguous():
         raise PvoHipError("conv7x7_c8: w_taps must be the [52,128,8] tensor of conv7x7_c8_weights in x's dtype")
-    y = torch.empty(E, H, W, 128, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    y = _new_cl(E, 128, H, W, x.dtype, dev)
     with torch.cuda.device(dev):
         check(_lib.load().pvo_conv7x7_c8(_ptr(x), _ptr(w_taps), _bias(bias, 128, "bias"), _ptr(y), E, H, W,
                                          _dtype_code(x, "x"), _stream(dev)), "conv7x7_c8")
@@ -634,113 +632,102 @@ def conv7x7_c8(x, w_taps, bias):
 
 
 def conv3x3_weights(weight, dtype):
-    """[Cout,Cin,3,3] conv filter -> the [9,Cout,Cin] tap-major layout pvo_conv3x3 reads"""
+    """[Cout,Cin,3,3] conv filter -> the [9,Cout,Cin] tap-major layout pvo_conv3x3 / pvo_conv3x3_c128 read"""
     co, ci, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or ci % 32 or co % 128:
-        raise PvoHipError("conv3x3: filter must be [Cout,Cin,3,3] with Cin % 32 == 0 and Cout % 128 == 0")
+    if (kh, kw) != (3, 3):
+        raise PvoHipError("conv3x3: filter must be [Cout,Cin,3,3]")
     return weight.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(dtype).contiguous()
 
 
-def conv3x3(x, w_taps, bias=None, relu=False):
-    """act(conv3x3(x) + bias): x [E,Cin,H,W] channels-last 16-bit -> [E,Cout,H,W] channels-last (wide layers)"""
-    dev = _dev(x, w_taps)
+conv3x3_c128_weights = conv3x3_weights
+
+
+def _out_slice(out, out_offset, E, Cout, H, W, dtype, dev):
+    """(tensor to return, pointer tensor, ystride, yoff): a fresh dense output, or a channel slice of `out`"""
+    if out is None:
+        y = _new_cl(E, Cout, H, W, dtype, dev)
+        return y, y, 0, 0
+    if out.dim() != 4 or out.shape[0] != E or tuple(out.shape[2:]) != (H, W) or out.dtype != dtype or \
+            not out.is_contiguous(memory_format=torch.channels_last) or out_offset < 0 or out_offset + Cout > out.shape[1]:
+        raise PvoHipError("out must be a channels-last [E,C>=offset+Cout,H,W] tensor of the input dtype")
+    return out[:, out_offset:out_offset + Cout], out, out.shape[1], out_offset
+
+
+def conv3x3(x, w_taps, bias=None, relu=False, out=None, out_offset=0):
+    """act(conv3x3(x) + bias): x [E,Cin,H,W] channels-last 16-bit -> [E,Cout,H,W] channels-last (wide layers: Cin % 32
+    == 0, Cout % 128 == 0).  out / out_offset: write into channels [out_offset, out_offset + Cout) of `out`."""
+    dev = _dev(x, w_taps, out)
     E, Cin, H, W = x.shape
     _cl(x, "x", Cin)
     if w_taps.dim() != 3 or w_taps.shape[0] != 9 or w_taps.shape[2] != Cin or w_taps.dtype != x.dtype or not w_taps.is_contiguous():
         raise PvoHipError("conv3x3: w_taps must be the [9,Cout,Cin] tensor of conv3x3_weights in x's dtype")
     Cout = w_taps.shape[1]
-    y = torch.empty(E, H, W, Cout, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    ret, y, ys, yo = _out_slice(out, out_offset, E, Cout, H, W, x.dtype, dev)
     with torch.cuda.device(dev):
         check(_lib.load().pvo_conv3x3(_ptr(x), _ptr(w_taps), _bias(bias, Cout, "bias"), _ptr(y), E, H, W, Cin, Cout,
-                                      1 if relu else 0, _dtype_code(x, "x"), _stream(dev)), "conv3x3")
-    return y
+                                      1 if relu else 0, ys, yo, _dtype_code(x, "x"), _stream(dev)), "conv3x3")
+    return ret
 
 
-def gru_conv_gates(X, w_taps, g, P_zr, net):
-    """gate convolution + sigmoid gates in one kernel -> (Z, RN), each [E,128,H,W] channels-last.
-    X [E,Cin,H,W] = [net | corr | flow], w_taps [9,256,Cin], g [E,384] f32, P_zr [E,256,H,W], net [E,128,H,W]."""
-    E, Cin, H, W = X.shape
-    _cl(X, "X", Cin); _cl(P_zr, "P_zr", 256); _cl(net, "net", 128)
-    dev = _dev(X, w_taps, g, P_zr, net)
-    _f32(g, "g"); _contig(g, "g")
-    if tuple(w_taps.shape) != (9, 256, Cin) or w_taps.dtype != X.dtype or not w_taps.is_contiguous():
-        raise PvoHipError("gru_conv_gates: w_taps must be [9,256,Cin] in X's dtype")
-    Z = torch.empty(E, H, W, 128, dtype=X.dtype, device=dev).permute(0, 3, 1, 2)
-    RN = torch.empty(E, H, W, 128, dtype=X.dtype, device=dev).permute(0, 3, 1, 2)
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_conv_gates(_ptr(X), _ptr(w_taps), _ptr(g), _ptr(P_zr), _ptr(net), _ptr(Z), _ptr(RN),
-                                             E, H, W, Cin, _dtype_code(X, "X"), _stream(dev)), "gru_conv_gates")
-    return Z, RN
-
-
-def gru_conv_candidate(X, RN, w_taps, g, P_q, Z, net):
-    """candidate convolution over [RN | X[:, 128:]] + the GRU state update in one kernel -> new hidden state"""
-    E, Cin, H, W = X.shape
-    _cl(X, "X", Cin); _cl(RN, "RN", 128); _cl(P_q, "P_q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
-    dev = _dev(X, RN, w_taps, g, P_q, Z, net)
-    _f32(g, "g"); _contig(g, "g")
-    if tuple(w_taps.shape) != (9, 128, Cin) or w_taps.dtype != X.dtype or not w_taps.is_contiguous():
-        raise PvoHipError("gru_conv_candidate: w_taps must be [9,128,Cin] in X's dtype")
-    out = torch.empty(E, H, W, 128, dtype=X.dtype, device=dev).permute(0, 3, 1, 2)
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_conv_candidate(_ptr(X), _ptr(RN), _ptr(w_taps), _ptr(g), _ptr(P_q), _ptr(Z), _ptr(net),
-                                                 _ptr(out), E, H, W, Cin, _dtype_code(X, "X"), _stream(dev)), "gru_conv_candidate")
-    return out
-
-
-def gru_gates(net, cf, ff, cf_bias, ff_bias, w_taps, g, P_zr):
-    """gate convolution over [net | relu(cf + b) | relu(ff + b)] read from the three tensors + sigmoid gates -> (Z, RN)"""
-    _cl(net, "net", 128); _cl(cf, "cf", 128); _cl(ff, "ff", 64); _cl(P_zr, "P_zr", 256)
-    dev = _dev(net, cf, ff, w_taps, g, P_zr)
-    _f32(g, "g"); _contig(g, "g")
-    E, _, H, W = net.shape
-    if tuple(w_taps.shape) != (9, 256, 320) or w_taps.dtype != net.dtype or not w_taps.is_contiguous():
-        raise PvoHipError("gru_gates: w_taps must be [9,256,320] in net's dtype")
-    Z = torch.empty(E, H, W, 128, dtype=net.dtype, device=dev).permute(0, 3, 1, 2)
-    RN = torch.empty(E, H, W, 128, dtype=net.dtype, device=dev).permute(0, 3, 1, 2)
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_gates(_ptr(net), _ptr(cf), _ptr(ff), _bias(cf_bias, 128, "cf_bias"), _bias(ff_bias, 64, "ff_bias"),
-                                        _ptr(w_taps), _ptr(g), _ptr(P_zr), _ptr(Z), _ptr(RN), E, H, W,
-                                        _dtype_code(net, "net"), _stream(dev)), "gru_gates")
-    return Z, RN
-
-
-def gru_candidate(RN, cf, ff, cf_bias, ff_bias, w_taps, g, P_q, Z, net):
-    """candidate convolution over [RN | relu(cf + b) | relu(ff + b)] + the GRU state update -> new hidden state"""
-    _cl(RN, "RN", 128); _cl(cf, "cf", 128); _cl(ff, "ff", 64); _cl(P_q, "P_q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
-    dev = _dev(RN, cf, ff, w_taps, g, P_q, Z, net)
-    _f32(g, "g"); _contig(g, "g")
-    E, _, H, W = net.shape
-    if tuple(w_taps.shape) != (9, 128, 320) or w_taps.dtype != net.dtype or not w_taps.is_contiguous():
-        raise PvoHipError("gru_candidate: w_taps must be [9,128,320] in net's dtype")
-    out = torch.empty(E, H, W, 128, dtype=net.dtype, device=dev).permute(0, 3, 1, 2)
-    with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_candidate(_ptr(RN), _ptr(cf), _ptr(ff), _bias(cf_bias, 128, "cf_bias"), _bias(ff_bias, 64, "ff_bias"),
-                                            _ptr(w_taps), _ptr(g), _ptr(P_q), _ptr(Z), _ptr(net), _ptr(out), E, H, W,
-                                            _dtype_code(net, "net"), _stream(dev)), "gru_candidate")
-    return out
-
-
-def conv3x3_c128_weights(weight, dtype):
-    """[Cout,128,3,3] conv filter -> the [9,Cout,128] tap-major layout pvo_conv3x3_c128 reads"""
-    co, ci, kh, kw = weight.shape
-    if (ci, kh, kw) != (128, 3, 3) or (co != 64 and co % 128):
-        raise PvoHipError("conv3x3_c128: filter must be [Cout,128,3,3] with Cout in {64,128,256,512}")
-    return weight.detach().permute(2, 3, 0, 1).reshape(9, co, 128).to(dtype).contiguous()
-
-
-def conv3x3_c128(x, w_taps, bias=None, relu=False):
-    """act(conv3x3(x) + bias): x [E,128,H,W] channels-last 16-bit -> [E,Cout,H,W] channels-last"""
+def conv3x3_c128(x, w_taps, bias=None, relu=False, out=None, out_offset=0):
+    """act(conv3x3(x) + bias): x [E,128,H,W] channels-last 16-bit -> [E,Cout,H,W] channels-last, Cout in {64,128,256,512}"""
     _cl(x, "x", 128)
-    dev = _dev(x, w_taps)
+    dev = _dev(x, w_taps, out)
     E, _, H, W = x.shape
     if w_taps.dim() != 3 or w_taps.shape[0] != 9 or w_taps.shape[2] != 128 or w_taps.dtype != x.dtype or not w_taps.is_contiguous():
-        raise PvoHipError("conv3x3_c128: w_taps must be the [9,Cout,128] tensor of conv3x3_c128_weights in x's dtype")
+        raise PvoHipError("conv3x3_c128: w_taps must be the [9,Cout,128] tensor of conv3x3_weights in x's dtype")
     Cout = w_taps.shape[1]
-    y = torch.empty(E, H, W, Cout, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    ret, y, ys, yo = _out_slice(out, out_offset, E, Cout, H, W, x.dtype, dev)
     with torch.cuda.device(dev):
         check(_lib.load().pvo_conv3x3_c128(_ptr(x), _ptr(w_taps), _bias(bias, Cout, "bias"), _ptr(y), E, H, W, Cout,
-                                           1 if relu else 0, _dtype_code(x, "x"), _stream(dev)), "conv3x3_c128")
+                                           1 if relu else 0, ys, yo, _dtype_code(x, "x"), _stream(dev)), "conv3x3_c128")
+    return ret
+
+
+def gru_conv_gates(net, cf, w_taps, g, P_zr):
+    """gate convolution over [net | cf] + sigmoid gates in one kernel -> (Z, RN), each [E,128,H,W] channels-last.
+    cf [E,C,H,W] (C % 32 == 0), w_taps [9,256,128+C], g [E,384] f32, P_zr [E,256,H,W]."""
+    E, _, H, W = net.shape
+    C = cf.shape[1]
+    _cl(net, "net", 128); _cl(cf, "cf", C); _cl(P_zr, "P_zr", 256)
+    dev = _dev(net, cf, w_taps, g, P_zr)
+    _f32(g, "g"); _contig(g, "g")
+    if tuple(w_taps.shape) != (9, 256, 128 + C) or w_taps.dtype != net.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("gru_conv_gates: w_taps must be [9,256,128+C] in net's dtype")
+    Z, RN = _new_cl(E, 128, H, W, net.dtype, dev), _new_cl(E, 128, H, W, net.dtype, dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_conv_gates(_ptr(net), _ptr(cf), C, _ptr(w_taps), _ptr(g), _ptr(P_zr), _ptr(Z), _ptr(RN),
+                                             E, H, W, _dtype_code(net, "net"), _stream(dev)), "gru_conv_gates")
+    return Z, RN
+
+
+def gru_conv_candidate(RN, cf, w_taps, g, P_q, Z, net):
+    """candidate convolution over [RN | cf] + the GRU state update in one kernel -> new hidden state"""
+    E, _, H, W = net.shape
+    C = cf.shape[1]
+    _cl(RN, "RN", 128); _cl(cf, "cf", C); _cl(P_q, "P_q", 128); _cl(Z, "Z", 128); _cl(net, "net", 128)
+    dev = _dev(RN, cf, w_taps, g, P_q, Z, net)
+    _f32(g, "g"); _contig(g, "g")
+    if tuple(w_taps.shape) != (9, 128, 128 + C) or w_taps.dtype != net.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("gru_conv_candidate: w_taps must be [9,128,128+C] in net's dtype")
+    out = _new_cl(E, 128, H, W, net.dtype, dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_gru_conv_candidate(_ptr(RN), _ptr(cf), C, _ptr(w_taps), _ptr(g), _ptr(P_q), _ptr(Z), _ptr(net),
+                                                 _ptr(out), E, H, W, _dtype_code(net, "net"), _stream(dev)), "gru_conv_candidate")
+    return out
+
+
+def corr_encode(corr, enc_weight, enc_bias):
+    """relu(W corr + b): corr [E,196,H,W] channels-last 16-bit -> [E,128,H,W] channels-last (corr_encoder[0:2])"""
+    _cl(corr, "corr", 196)
+    dev = _dev(corr, enc_weight, enc_bias)
+    E, _, H, W = corr.shape
+    if tuple(enc_weight.shape) != (128, 224) or enc_weight.dtype != corr.dtype or not enc_weight.is_contiguous():
+        raise PvoHipError("enc_weight must be the [128,224] tensor of corr_encoder_weights in the feature dtype")
+    y = _new_cl(E, 128, H, W, corr.dtype, dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_corr_encode(_ptr(corr), _ptr(enc_weight), _bias(enc_bias, 128, "enc_bias"), _ptr(y), E * H * W,
+                                          _dtype_code(corr, "corr"), _stream(dev)), "corr_encode")
     return y
 
 
@@ -753,7 +740,7 @@ def segment_mean(x, seg_ptr, seg_idx, K, in_bias=None):
     if seg_ptr.dtype != torch.int32 or seg_idx.dtype != torch.int32:
         raise PvoHipError("segment_mean: seg_ptr / seg_idx must be int32")
     E, C, H, W = x.shape
-    out = torch.empty(K, H, W, C, dtype=x.dtype, device=dev).permute(0, 3, 1, 2)
+    out = _new_cl(K, C, H, W, x.dtype, dev)
     with torch.cuda.device(dev):
         check(_lib.load().pvo_segment_mean(_ptr(x), _ptr(seg_ptr), _ptr(seg_idx), _bias(in_bias, C, "in_bias"), _ptr(out), K, H * W, C,
                                            _dtype_code(x, "x"), _stream(dev)), "segment_mean")
@@ -768,10 +755,48 @@ def heads_out(h1, bias1, w2, bias2):
     if tuple(w2.shape) != (4, 2, 9, 128) or w2.dtype != h1.dtype or not w2.is_contiguous():
         raise PvoHipError("heads_out: w2 must be a contiguous [4,2,9,128] tensor of the feature dtype")
     E, _, H, W = h1.shape
-    y = torch.empty(E, H, W, 8, dtype=h1.dtype, device=dev).permute(0, 3, 1, 2)
+    y = _new_cl(E, 8, H, W, h1.dtype, dev)
     with torch.cuda.device(dev):
         check(_lib.load().pvo_heads_out(_ptr(h1), _bias(bias1, 512, "bias1"), _ptr(w2), _bias(bias2, 8, "bias2"), _ptr(y),
                                         E, H, W, _dtype_code(h1, "h1"), _stream(dev)), "heads_out")
+    return y
+
+
+def eta_head(x, w_taps, bias, frame=None, pos=None, damping=None, EP=0.0):
+    """GraphAgg's eta head: x [K,128,H,W] channels-last 16-bit, w_taps [9,128], bias f32 [1].
+    frame None -> 0.01 * softplus(conv(x) + bias) [K,H,W] f32 (what GraphAgg returns).
+    frame int64 [R], pos int32 [R], damping f32 [buffer,H,W]: also FactorGraph's damping bookkeeping; returns the BA's
+    eta [R,H,W] = 0.2 * damping[frame] + EP (see pvo_eta_head)."""
+    _cl(x, "x", 128)
+    dev = _dev(x, w_taps, bias, frame, pos, damping)
+    K, _, H, W = x.shape
+    if tuple(w_taps.shape) != (9, 128) or w_taps.dtype != x.dtype or not w_taps.is_contiguous():
+        raise PvoHipError("eta_head: w_taps must be [9,128] in x's dtype")
+    R = K
+    if frame is not None:
+        R = frame.shape[0]
+        if frame.dtype != torch.int64 or pos.dtype != torch.int32 or pos.shape[0] != R or damping.dtype != torch.float32 \
+                or tuple(damping.shape[1:]) != (H, W) or not damping.is_contiguous():
+            raise PvoHipError("eta_head: frame int64 [R], pos int32 [R], damping contiguous f32 [*,H,W]")
+    eta = torch.empty(R, H, W, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_eta_head(_ptr(x), _ptr(w_taps), _bias(bias, 1, "bias"), _ptr(frame), _ptr(pos), _ptr(damping),
+                                       _ptr(eta), R, H, W, float(EP), _dtype_code(x, "x"), _stream(dev)), "eta_head")
+    return eta
+
+
+def conv1x1_c128(x, w, bias=None, relu=False):
+    """act(conv1x1(x) + bias): x [N,128,H,W] channels-last 16-bit, w [Cout,128] (Cout % 192 == 0) -> [N,Cout,H,W] channels-last"""
+    _cl(x, "x", 128)
+    dev = _dev(x, w, bias)
+    N, _, H, W = x.shape
+    if w.dim() != 2 or w.shape[1] != 128 or w.dtype != x.dtype or not w.is_contiguous():
+        raise PvoHipError("conv1x1_c128: w must be a contiguous [Cout,128] tensor in x's dtype")
+    Cout = w.shape[0]
+    y = _new_cl(N, Cout, H, W, x.dtype, dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_conv1x1_c128(_ptr(x), _ptr(w), _bias(bias, Cout, "bias"), _ptr(y), N * H * W, Cout,
+                                           1 if relu else 0, _dtype_code(x, "x"), _stream(dev)), "conv1x1_c128")
     return y
 
 
@@ -789,26 +814,27 @@ def graph_motion(target, coords1, delta_dy, raw_mask, dtype):
     return motn.permute(0, 3, 1, 2)[None]
 
 
-def eta_finish(raw, bias, frame, pos, damping, EP):
-    """eta head + damping bookkeeping: raw [K,1,H,W] 16-bit (bias-free eta convolution), bias f32 [1], frame int64 [R],
-    pos int32 [R] (row of raw, or -1), damping f32 [buffer,H,W] (updated in place) -> eta f32 [R,H,W] for the BA"""
-    dev = _dev(raw, bias, frame, pos, damping)
-    K, _, H, W = raw.shape
-    R = frame.shape[0]
-    if raw.dtype not in (torch.float16, torch.bfloat16) or frame.dtype != torch.int64 or pos.dtype != torch.int32 \
-            or pos.shape[0] != R or damping.dtype != torch.float32 or tuple(damping.shape[1:]) != (H, W):
-        raise PvoHipError("eta_finish: raw 16-bit [K,1,H,W], frame int64 [R], pos int32 [R], damping f32 [*,H,W]")
-    _contig(damping, "damping")
-    eta = torch.empty(R, H, W, dtype=torch.float32, device=dev)
+def segment_hist(segm, raw_mask, heads, max_segments, dy_thresh=0.5):
+    """counting half of the panoptic vote (factor_graph.py:256-261): segm int32 [E,H,W] dense labels in [0, max_segments),
+    raw_mask [1,E,H,W,2] f32 (BEFORE the update), heads [E,8,H,W] channels-last -> (tot, dyn) int32 [E,max_segments]"""
+    _cl(heads, "heads", 8)
+    dev = _dev(segm, raw_mask, heads)
+    _contig(segm, "segm"); _contig(raw_mask, "raw_mask")
+    E, H, W = segm.shape
+    if segm.dtype != torch.int32:
+        raise PvoHipError("segment_hist: segm must be int32")
+    tot = torch.empty(E, max_segments, dtype=torch.int32, device=dev)
+    dyn = torch.empty(E, max_segments, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_eta_finish(_ptr(raw.contiguous()), _bias(bias, 1, "bias"), _ptr(frame), _ptr(pos), _ptr(damping),
-                                         _ptr(eta), R, H * W, float(EP), _dtype_code(raw, "raw"), _stream(dev)), "eta_finish")
-    return eta
+        check(_lib.load().pvo_segment_hist(_ptr(segm), _ptr(raw_mask), _ptr(heads), _ptr(tot), _ptr(dyn), E, H * W, int(max_segments),
+                                           float(dy_thresh), _dtype_code(heads, "heads"), _stream(dev)), "segment_hist")
+    return tot, dyn
 
 
-def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5, force_dyn=None):
+def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5, vote=None):
     """factor_graph.py:249-306 after the update operator.  heads [E,8,H,W] channels-last 16-bit (delta | delta_dy |
     weight | delta_mask); raw_mask [1,E,H,W,2] is updated IN PLACE; target_ba / weight_ba [E,2,H,W] f32 are filled.
+    vote = (segm int32 [E,H,W], tot, dyn int32 [E,S], thresh): the panoptic vote of segment_hist is applied.
     Returns (target_cam, delta_dy, weight, full_flow), each [1,E,H,W,2] f32."""
     _cl(heads, "heads", 8)
     _contig(coords1, "coords1"); _contig(raw_mask, "raw_mask"); _contig(target_ba, "target_ba"); _contig(weight_ba, "weight_ba")
@@ -816,10 +842,178 @@ def graph_post(coords1, heads, raw_mask, target_ba, weight_ba, dy_thresh=0.5, fo
     _, E, H, W, _ = coords1.shape
     new = lambda: torch.empty(1, E, H, W, 2, dtype=torch.float32, device=dev)
     target, delta_dy, weight, full_flow = new(), new(), new(), new()
+    segm = tot = dyn = None
+    S, vth = 0, 0.0
+    if vote is not None:
+        segm, tot, dyn, vth = vote
+        S = tot.shape[1]
+        if segm.dtype != torch.int32 or tuple(segm.shape) != (E, H, W) or not segm.is_contiguous() or tot.dtype != torch.int32 \
+                or tuple(tot.shape) != (E, S) or tuple(dyn.shape) != (E, S) or dyn.dtype != torch.int32:
+            raise PvoHipError("graph_post: vote = (segm int32 [E,H,W], tot int32 [E,S], dyn int32 [E,S], thresh)")
     with torch.cuda.device(dev):
-        if force_dyn is not None and (force_dyn.dtype != torch.uint8 or tuple(force_dyn.shape) != (E, H, W) or not force_dyn.is_contiguous()):
-            raise PvoHipError("graph_post: force_dyn must be a contiguous uint8 [E,H,W] tensor")
         check(_lib.load().pvo_graph_post(_ptr(coords1), _ptr(heads), _ptr(raw_mask), _ptr(target), _ptr(delta_dy), _ptr(weight),
-                                         _ptr(target_ba), _ptr(weight_ba), _ptr(full_flow), E, H, W, float(dy_thresh), _ptr(force_dyn),
+                                         _ptr(target_ba), _ptr(weight_ba), _ptr(full_flow), E, H, W, float(dy_thresh),
+                                         _ptr(segm), _ptr(tot), _ptr(dyn), int(S), float(vth),
                                          _dtype_code(heads, "heads"), _stream(dev)), "graph_post")
     return target, delta_dy, weight, full_flow
+
+
+# --------------------------------------------------------------------------- the operator / the graph update as one call
+class PackedWeights:
+    """pvo_update_weights + the tensors it points to (kept alive here)"""
+
+    FIELDS = [n for n, _ in _lib.UpdateWeights._fields_[2:]]
+
+    def __init__(self, dtype, tensors, flags=0):
+        self.dtype, self.tensors, self.flags = dtype, dict(tensors), flags
+        st = _lib.UpdateWeights()
+        st.dtype, st.flags = _DT[dtype], flags
+        dev = None
+        for n in self.FIELDS:
+            t = self.tensors[n]
+            if not t.is_cuda or not t.is_contiguous():
+                raise PvoHipError("packed weight %s must be a contiguous device tensor" % n)
+            want = torch.float32 if (n.endswith("_b") or n in ("gate_wt",)) else dtype
+            if t.dtype != want:
+                raise PvoHipError("packed weight %s must be %s" % (n, want))
+            dev = t.device if dev is None else dev
+            setattr(st, n, t.data_ptr())
+        self.struct, self.device = st, dev
+
+    # a derived cache entry: copies / pickles of the owning module rebuild it (ctypes structs with pointers cannot be copied)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_none, ())
+
+
+def _none():
+    return None
+
+
+def _vp(t):
+    return t.data_ptr() if t is not None and t.numel() > 0 else None
+
+
+def _fill_operator_args(a, E, H, W, pool_levels, slots, num_slots, coords, corr, motion, net, net_out, inp, P_zr, P_q,
+                        agg, heads, eta_rows, eta, upmask):
+    a.E, a.H, a.W = E, H, W
+    for l in range(4):
+        a.levels[l] = pool_levels[l].data_ptr() if pool_levels is not None else None
+    a.slots, a.num_slots = _vp(slots), int(num_slots)
+    a.coords, a.corr, a.motion = _vp(coords), _vp(corr), _vp(motion)
+    a.net, a.net_out, a.inp, a.P_zr, a.P_q = _vp(net), _vp(net_out), _vp(inp), _vp(P_zr), _vp(P_q)
+    if agg is not None:
+        a.seg_ptr, a.seg_idx, a.K = agg[0].data_ptr(), agg[1].data_ptr(), int(agg[2])
+    else:
+        a.seg_ptr, a.seg_idx, a.K = None, None, 0
+    a.heads = _vp(heads)
+    if eta_rows is not None:
+        frame, pos, damping, EP = eta_rows
+        a.eta_frame, a.eta_pos, a.R, a.damping, a.EP = frame.data_ptr(), pos.data_ptr(), int(frame.shape[0]), damping.data_ptr(), float(EP)
+    else:
+        a.eta_frame, a.eta_pos, a.R, a.damping, a.EP = None, None, 0, None, 0.0
+    a.eta, a.upmask = _vp(eta), _vp(upmask)
+
+
+_op_ws = {}
+
+
+def _op_workspace(key, dev, nbytes):
+    buf = _op_ws.get(key)
+    if buf is None or buf.numel() < nbytes or buf.device != dev:
+        buf = _op_ws[key] = torch.empty(int(nbytes) + (int(nbytes) >> 3), dtype=torch.uint8, device=dev)
+    return buf
+
+
+def update_operator(weights, net, motion, inp=None, P=None, pool=None, coords=None, corr=None, agg=None,
+                    eta_rows=None, want_eta=True, want_upmask=True, net_out=None):
+    """DynamicUpdateModule.forward (droid_net.py:256-314) on the 16-bit inference path as ONE call into libpvo_hip.
+
+    weights: PackedWeights.  net, inp [E,128,H,W], motion [E,8,H,W], corr [E,196,H,W]: channels-last 16-bit.
+    Correlation features come either from `pool` = (tiled level tensors, slots int32 [E], num_slots) + coords [E,H,W,2]
+    f32 (the lookup runs fused with the first encoder layer) or from the sampled tensor `corr`.
+    P = (P_zr, P_q): cached static-input terms; None -> computed from `inp` for this call.
+    agg = (seg_ptr, seg_idx, K) runs GraphAgg; eta_rows = (frame, pos, damping, EP) selects pvo_eta_head's bookkeeping form.
+    Returns (net_out, heads [E,8,H,W], eta f32 or None, upmask [K,576,H,W] or None)."""
+    _cl(net, "net", 128); _cl(motion, "motion", 8)
+    dev = _dev(net, motion, inp, corr, coords)
+    if weights.dtype != net.dtype or weights.device != dev:
+        raise PvoHipError("update_operator: packed weights are %s on %s, net is %s on %s" % (weights.dtype, weights.device, net.dtype, dev))
+    E, _, H, W = net.shape
+    levels = slots = None
+    num_slots = 0
+    if pool is not None:
+        levels, slots, num_slots = pool
+        if coords is None or tuple(coords.shape) != (E, H, W, 2) or coords.dtype != torch.float32 or not coords.is_contiguous():
+            raise PvoHipError("update_operator: coords must be a contiguous f32 [E,H,W,2] tensor")
+        if len(levels) != 4 or levels[0].dtype != net.dtype or slots.dtype != torch.int32 or slots.numel() != E:
+            raise PvoHipError("update_operator: pool = (4 tiled level tensors in net's dtype, slots int32 [E], num_slots)")
+        for l, lv in enumerate(levels):
+            if tuple(lv.shape[1:]) != (H, W) + tiled_level_shape(H, W, l) or not lv.is_contiguous():
+                raise PvoHipError("update_operator: tiled pyramid level %d has shape %s" % (l, tuple(lv.shape)))
+    elif corr is not None:
+        _cl(corr, "corr", 196)
+    else:
+        raise PvoHipError("update_operator: pass pool + coords, or corr")
+    P_zr = P_q = None
+    if P is not None:
+        P_zr, P_q = P
+        _cl(P_zr, "P_zr", 256); _cl(P_q, "P_q", 128)
+    elif inp is None:
+        raise PvoHipError("update_operator: pass inp or P")
+    else:
+        _cl(inp, "inp", 128)
+    if net_out is None:
+        net_out = _new_cl(E, 128, H, W, net.dtype, dev)
+    heads = _new_cl(E, 8, H, W, net.dtype, dev)
+    K = int(agg[2]) if agg is not None else 0
+    eta = upmask = None
+    if K > 0:
+        if agg[0].dtype != torch.int32 or agg[1].dtype != torch.int32 or agg[1].numel() != E or agg[0].numel() != K + 1:
+            raise PvoHipError("update_operator: agg = (seg_ptr int32 [K+1], seg_idx int32 [E], K)")
+        if want_eta:
+            eta = torch.empty(eta_rows[0].shape[0] if eta_rows is not None else K, H, W, dtype=torch.float32, device=dev)
+        if want_upmask:
+            upmask = _new_cl(K, 576, H, W, net.dtype, dev)
+    a = _lib.OperatorArgs()
+    _fill_operator_args(a, E, H, W, levels, slots, num_slots, coords, corr, motion, net, net_out, inp, P_zr, P_q, agg, heads,
+                        eta_rows, eta, upmask)
+    lib = _lib.load()
+    ws = _op_workspace(("op", dev.index), dev, lib.pvo_operator_workspace_bytes(E, K, H, W))
+    with torch.cuda.device(dev):
+        check(lib.pvo_update_operator(ctypes.byref(weights.struct), ctypes.byref(a), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                      _stream(dev)), "update_operator")
+    return net_out, heads, eta, upmask
+
+
+def graph_update_workspace(E, K, R, H, W, max_segments, device):
+    n = _lib.load().pvo_graph_update_workspace_bytes(int(E), int(K), int(R), int(H), int(W), int(max_segments))
+    return _op_workspace(("up", torch.device(device).index), torch.device(device), n)
+
+
+def graph_update(weights, args, workspace):
+    """FactorGraph.update (factor_graph.py:227-307) as ONE call: `args` is a filled _lib.GraphUpdateArgs (the caller -
+    pvo_amd.factor_graph - keeps every tensor it points to alive); see include/pvo_hip.h pvo_graph_update."""
+    dev = workspace.device
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_graph_update(ctypes.byref(weights.struct), ctypes.byref(args), ctypes.c_void_p(workspace.data_ptr()),
+                                           workspace.numel(), _stream(dev)), "graph_update")
+
+
+STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4}
+
+
+def probe_arm(stage, capacity):
+    """record HIP events around `stage` ("lookup" | "gates" | "candidate" | "ba" | "update") of the next native updates"""
+    check(_lib.load().pvo_probe_arm(STAGES[stage], int(capacity)), "probe_arm")
+
+
+def probe_read(capacity):
+    """elapsed milliseconds of the recorded stage occurrences (waits for them); disarms the probe"""
+    buf = (ctypes.c_float * int(capacity))()
+    n = _lib.load().pvo_probe_read(buf, int(capacity))
+    if n < 0:
+        raise PvoHipError("probe_read failed")
+    return [float(buf[i]) for i in range(n)]

@@ -46,12 +46,11 @@ class FactorGraph:
         self.ii_bad, self.jj_bad = torch.zeros(0, **lng), torch.zeros(0, **lng)
         self.target_cam_inac, self.weight_inac, self.delta_dy_inac, self.full_flow_inac = z(2), z(2), z(2), z(2)
         self.raw_mask_inac = z(self.mask_num)
-        self.fused_glue = True      # use the two-kernel glue path when the update operator supports it
+        self.fused_glue = True      # run update() as ONE call into libpvo_hip when the operator and the pool support it
         self._cache = {}            # device index tensors derived from the host edge lists; cleared on any edge change
         self._version = 0           # bumped on every edge change
-        self.fused_encoder = True   # tiled pools: run the lookup fused with the operator's first correlation-encoder layer
-        self.use_graphs = False     # replay repeated updates of an unchanged edge set from a captured HIP graph
-        self._graph_state = None
+        self.P_zr = self.P_q = None  # per-edge static-input terms of the ConvGRU (computed once when an edge is added)
+        self.want_upmask = True     # compute GraphAgg's upsampling mask although update() discards it, as the reference does
         try:
             self._autocast = next(update_op.parameters()).dtype == torch.float32
         except (StopIteration, AttributeError, TypeError):
@@ -132,6 +131,11 @@ class FactorGraph:
                 self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self.video.inps[ii][None]
             self.inp = self._cat_cl(self.inp, inp)   # stored channels-last once, so no update re-lays it out
+            if self._static_ok():
+                # conv(W[:, inp], inp) of the ConvGRU's gate / candidate convolutions, once per edge (inp never changes)
+                pz, pq = self.update_op.static_terms(self._cl5(inp)[0], self._op_dtype())
+                self.P_zr = self._cat_cl(self.P_zr, pz[None])
+                self.P_q = self._cat_cl(self.P_q, pq[None])
         target, _ = self.video.reproject(ii, jj)
         zeros2 = torch.zeros_like(target)
         self.ii, self.jj = torch.cat([self.ii, ii]), torch.cat([self.jj, jj])
@@ -146,13 +150,11 @@ class FactorGraph:
         self.segm = segm if self.segm is None else torch.cat([self.segm, segm], 1)
 
     def _idx(self, values):
-        """host list -> device int64 tensor without draining the stream (pinned staging buffer, asynchronous copy);
-        `torch.tensor(list, device=...)` is a synchronous copy, and boolean-mask indexing synchronises again to size
-        its result - a dozen pipeline drains per keyframe in the reference's bookkeeping"""
-        t = torch.tensor(values, dtype=torch.long)
-        if self.device.type != "cuda":
-            return t
-        return t.pin_memory().to(self.device, non_blocking=True)
+        """host list -> device int64 tensor without draining the stream (persistent pinned staging ring, asynchronous
+        copy); `torch.tensor(list, device=...)` is a synchronous copy, and boolean-mask indexing synchronises again to
+        size its result - a dozen pipeline drains per keyframe in the reference's bookkeeping"""
+        from .droid_backends import to_device_async
+        return to_device_async(values, torch.long, self.device)
 
     def rm_factors(self, mask, store=False):
         """drop edges (factor_graph.py:163-200); mask: bool tensor or list over the active edges"""
@@ -183,6 +185,8 @@ class FactorGraph:
             self.net = self._take_cl(self.net, keep)
         if self.inp is not None:
             self.inp = self._take_cl(self.inp, keep)
+        if self.P_zr is not None:
+            self.P_zr, self.P_q = self._take_cl(self.P_zr, keep), self._take_cl(self.P_q, keep)
         if self.segm is not None:
             self.segm = self.segm[:, keep]
         self.target_cam, self.weight = self.target_cam[:, keep], self.weight[:, keep]
@@ -190,7 +194,7 @@ class FactorGraph:
 
     def clear_edges(self):
         self.rm_factors([True] * len(self._ii_h))
-        self.net = self.inp = None
+        self.net = self.inp = self.P_zr = self.P_q = None
 
     def rm_keyframe(self, ix):
         """drop keyframe ix and every edge touching it (factor_graph.py:202-225)"""
@@ -350,62 +354,39 @@ class FactorGraph:
         keep = ~forced[key].view(1, E, *seg.shape[1:])
         return bin_mask & keep.unsqueeze(-1)
 
+    def _op_dtype(self):
+        """the 16-bit dtype the update operator runs in: the module's own (.half() / .bfloat16()) or fp16 autocast"""
+        dt = next(self.update_op.parameters()).dtype
+        return dt if dt in (torch.float16, torch.bfloat16) else torch.float16
+
     def _fused_ok(self):
-        """the two-kernel glue path: HIP device, an update operator that exposes raw_heads in 16 bit"""
-        if self.device.type != "cuda" or self.corr is None:
+        """update() as one native call: HIP device, resident tiled volume pool, an update operator with packed weights"""
+        return self.fused_glue and self._static_ok()
+
+    def _static_ok(self):
+        if self.device.type != "cuda" or self.corr_impl != "volume":
+            return False
+        if self.corr is not None and not getattr(self.corr, "tiled", False):
+            return False
+        if self.corr is None and not (self.video.fmaps.dtype in (torch.float16, torch.bfloat16)):
             return False
         op = self.update_op
-        if not hasattr(op, "_heads_w2") or getattr(op, "training", True) or not getattr(op, "fused_gru", False):
+        if not hasattr(op, "packed_weights") or getattr(op, "training", True) or not getattr(op, "fused_gru", False) \
+                or getattr(op, "use_aff_bri", False):
             return False
-        return next(op.parameters()).dtype in (torch.float16, torch.bfloat16)
+        if self.corr is None:
+            from . import droid_backends as db
+            return db.tiled_supported(self.ht, self.wd, self.video.fmaps.dtype)
+        return True
 
-    _GRAPH_STATE = ("net", "target_cam", "delta_dy", "weight", "raw_mask", "full_flow")
-
-    @torch.no_grad()
-    def _update_graphed(self, t0, t1, itrs, use_inactive, EP, motion_only):
-        """The frontend runs 4 + 2 updates on an unchanged edge set (droid_frontend.py:50-62).  The first one runs
-        eagerly (it fills the index caches and lets MIOpen pick its solvers); the second is captured into a HIP graph
-        whose inputs and outputs are the same static state buffers; it and every further update of this edge set are
-        graph replays: ~60 kernel launches become one hipGraphLaunch, which is what keeps the GPU busy after the one
-        host synchronisation per keyframe."""
-        key = (self._version, t0, t1, itrs, use_inactive, EP, motion_only, len(self._ii_h))
-        st = self._graph_state
-        if st is None or st["key"] != key:
-            # the previous edge set's graph stays alive until the next capture so that its memory pool can be handed on
-            prev = st.get("graph") or st.get("prev") if st else None
-            self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only)
-            self._graph_state = {"key": key, "graph": None, "prev": prev}
-            return
-        if st["graph"] is None:
-            static = {n: getattr(self, n).clone() for n in self._GRAPH_STATE}
-            for n, b in static.items():
-                setattr(self, n, b)
-            g = torch.cuda.CUDAGraph()
-            prev = st.pop("prev", None)         # same shapes every keyframe: the pool is reused, nothing is hipMalloc'ed
-            with torch.cuda.graph(g, pool=prev.pool() if prev is not None else None):
-                self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only, host_age=False)
-                for n, b in static.items():
-                    b.copy_(getattr(self, n))
-            for n, b in static.items():
-                setattr(self, n, b)
-            st["graph"], st["static"] = g, static
-        else:
-            for n, b in st["static"].items():      # a caller may have re-assigned state tensors (bench snapshot)
-                cur = getattr(self, n)
-                if cur is not b:
-                    b.copy_(cur); setattr(self, n, b)
-        st["graph"].replay()
-        self._age_h = [a + 1 for a in self._age_h]
-
-    def _ba_planned(self, target, weight, eta, ii, jj, t0, t1, itrs, motion_only, n_in):
-        """DepthVideo.ba through the split entry points: the plan (unique depth frames, per-frame edge lists - the
-        reference rebuilds these on the host in every iteration, droid_kernels.cu:1314-1322) depends only on the edge
-        set and the window, so it is built once per edge set instead of once per update; no dx / dz tensors."""
+    def _ba_plan(self, ii, jj, t0, t1, motion_only, n_in, R):
+        """the BA's plan (unique depth frames, per-frame edge lists - the reference rebuilds these on the host in every
+        iteration, droid_kernels.cu:1314-1322) depends only on the edge set and the window: built once per edge set"""
         from . import droid_backends as db
         v = self.video
         F, ht, wd = v.disps.shape
         P = t1 - t0
-        key = (self._version, t0, t1, n_in, bool(motion_only), int(ii.shape[0]), int(eta.shape[0]))
+        key = (self._version, t0, t1, n_in, bool(motion_only), int(ii.shape[0]), int(R))
         st = self.__dict__.get("_ba_state")
         if st is None or st["key"] != key:
             need = db.ba_workspace_bytes(int(ii.shape[0]), P, F, ht * wd)
@@ -414,82 +395,98 @@ class FactorGraph:
             n6 = 6 * P
             sysb = st["sys"] if st is not None and st["sys"].numel() >= n6 * n6 + n6 else \
                 torch.empty(max(n6 * n6 + n6, 1), dtype=torch.float64, device=self.device)
-            db.ba_plan(ii, jj, F, ht * wd, -1 if motion_only else int(eta.shape[0]), t0, t1, ws)
+            db.ba_plan(ii, jj, F, ht * wd, -1 if motion_only else int(R), t0, t1, ws)
             st = self.__dict__["_ba_state"] = {"key": key, "ws": ws, "sys": sysb, "ii": ii, "jj": jj}
-        ii, jj = st["ii"], st["jj"]             # the tensors the plan was built from
-        for _ in range(itrs):
-            db.ba_local(v.poses, v.disps, v.intrinsics[0], target, weight, eta, ii, jj, t0, t1, motion_only, st["sys"], st["ws"])
-            db.ba_finish(v.poses, v.disps, st["sys"], ii, jj, t0, t1, 1e-4, 0.1, motion_only, st["ws"], outputs=False)
-        v.disps.clamp_(min=0.001)
+        return st
 
     @torch.no_grad()
-    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only, host_age=True):
+    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only):
+        """factor_graph.py:227-307 as ONE call into libpvo_hip (pvo_graph_update): reproject, motion features, lookup +
+        update operator, (panoptic vote), mask / weight glue, damping, BA.  Everything that depends only on the edge set
+        (index tensors, the BA plan, the inactive edges' BA rows, output buffers) is prepared once per edge set; per
+        update the host fills one argument struct.  State tensors (net, target_cam, delta_dy, raw_mask, weight,
+        full_flow) are updated IN PLACE."""
         from . import droid_backends as db
+        from ._lib import GraphUpdateArgs
+        from .droid_backends import to_device_async
+        v = self.video
         ht, wd = self.ht, self.wd
         E = len(self._ii_h)
-        dt = next(self.update_op.parameters()).dtype
-        coords1, _ = self.video.reproject(self.ii, self.jj)
-        motn = db.graph_motion(self.target_cam.contiguous(), coords1, self.delta_dy.contiguous(), self.raw_mask.contiguous(), dt)
-        if getattr(self.corr, "tiled", False) and self.fused_encoder:
-            pool = self.corr
-            corr = lambda w, b: pool.encoded(coords1, w, b)       # lookup + corr_encoder[0] + ReLU in one kernel
-        else:
-            corr = self.corr(coords1, channels_last=True)
-        seg = self._cached("agg", self._agg_segments)
-        self.net, heads, damping, upmask = self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj, False,
-                                                          agg_segments=seg, raw_heads=True)
+        dt = self._op_dtype()
         if t0 is None:
             t0 = max(1, min(self._ii_h) + 1)
         if t1 is None:
             t1 = max(max(self._ii_h), max(self._jj_h)) + 1
-        src = sorted(set(self._ii_h))
-        src_t = self._cached("src", lambda: self._idx(src))
-        m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)] if use_inactive else []
-        n_in = sum(m_l)
-        target_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
-        weight_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
-        self.raw_mask = self.raw_mask.contiguous()
-        force = None
-        if self.video.segm_filter:
-            # panoptic vote (factor_graph.py:256-276) on the updated mask: segments that are mostly dynamic on an edge are
-            # forced dynamic; the kernel below redoes the mask update itself and takes the vote's outcome as a byte per pixel
-            raw_new = self.raw_mask + heads[:, 6:8].permute(0, 2, 3, 1).float()[None]
-            bin_mask = torch.sigmoid(raw_new) >= self.dy_thresh
-            force = (self._segment_vote(bin_mask) != bin_mask).any(-1)[0].to(torch.uint8).contiguous()
-        self.target_cam, self.delta_dy, self.weight, self.full_flow = db.graph_post(
-            coords1, heads, self.raw_mask, target_ba[n_in:], weight_ba[n_in:], self.dy_thresh, force_dyn=force)
-        rows = src
-        if n_in:
-            # integer indices from the host mirror: a boolean mask would synchronise to size its result
-            m = self._cached(("inac_idx", t0), lambda: self._idx([k for k, v in enumerate(m_l) if v]))
-            ii, jj = self._cached(("ba_edges", t0), lambda: (torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])))
-            target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)
-            weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
-            rows = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
-        else:
-            ii, jj = self.ii, self.jj
-        if isinstance(damping, tuple):           # raw eta head: softplus, scaling and the damping bookkeeping in one kernel
-            def _rows():
-                from .droid_backends import to_device_async
-                where = {f: k for k, f in enumerate(src)}
-                return self._idx(rows), to_device_async([where.get(f, -1) for f in rows], torch.int32, self.device)
-            frames_t, pos_t = self._cached(("eta_rows", t0 if n_in else None), _rows)
-            eta = db.eta_finish(damping[0], damping[1], frames_t, pos_t, self.damping, EP)
-        else:
-            self.damping[src_t] = damping[0].float()
-            rows_t = self._cached(("src2", t0), lambda: self._idx(rows)) if n_in else src_t
-            eta = 0.2 * self.damping[rows_t] + EP
-        self._ba_planned(target_ba, weight_ba, eta, ii, jj, t0, t1, itrs, motion_only, n_in)
+        key = (self._version, t0, t1, bool(use_inactive), bool(motion_only), E)
+        st = self._cache.get("fused")
+        if st is None or st["key"] != key:
+            src = sorted(set(self._ii_h))
+            m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)] if use_inactive else []
+            n_in = sum(m_l)
+            rows = src
+            target_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
+            weight_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
+            if n_in:
+                # integer indices from the host mirror: a boolean mask would synchronise to size its result
+                m = self._idx([k for k, f in enumerate(m_l) if f])
+                ii_ba, jj_ba = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
+                target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)      # inactive edges do not change
+                weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
+                rows = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
+            else:
+                ii_ba, jj_ba = self.ii.contiguous(), self.jj.contiguous()
+            where = {f: k for k, f in enumerate(src)}
+            frames_t = self._idx(rows)
+            pos_t = to_device_async([where.get(f, -1) for f in rows], torch.int32, self.device)
+            seg = self._cached("agg", self._agg_segments)
+            ba = self._ba_plan(ii_ba, jj_ba, t0, t1, motion_only, n_in, len(rows))
+            S = v.max_segments if v.segm_filter else 0
+            st = self._cache["fused"] = dict(
+                key=key, n_in=n_in, target_ba=target_ba, weight_ba=weight_ba, ii_ba=ba["ii"], jj_ba=ba["jj"], frames=frames_t,
+                pos=pos_t, seg=seg, ba=ba, R=len(rows), S=S, ii=self.ii.contiguous(), jj=self.jj.contiguous(),
+                slots=self.corr.slots_tensor(),
+                segm=self.segm[0, :, 0].contiguous() if v.segm_filter else None,
+                weight=torch.empty(1, E, ht, wd, 2, device=self.device), full_flow=torch.empty(1, E, ht, wd, 2, device=self.device),
+                ws=db.graph_update_workspace(E, seg[2], len(rows), ht, wd, S, self.device), args=GraphUpdateArgs())
+            a = st["args"]
+            db._fill_operator_args(a.op, E, ht, wd, self.corr.levels, st["slots"], self.corr.capacity, None, None, None, None, None,
+                                   None, None, None, seg, None, (frames_t, pos_t, self.damping, EP), None, None)
+            a.nframes = v.disps.shape[0]
+            a.poses, a.disps, a.intrinsics = v.poses.data_ptr(), v.disps.data_ptr(), v.intrinsics.data_ptr()
+            a.ii, a.jj = st["ii"].data_ptr(), st["jj"].data_ptr()
+            a.segm = st["segm"].data_ptr() if st["segm"] is not None else None
+            a.max_segments, a.vote_thresh, a.dy_thresh = S, float(v.thresh), float(self.dy_thresh)
+            a.n_in, a.target_ba, a.weight_ba = n_in, target_ba.data_ptr(), weight_ba.data_ptr()
+            a.ii_ba, a.jj_ba = st["ii_ba"].data_ptr(), st["jj_ba"].data_ptr()
+            a.t0, a.t1, a.motion_only, a.lm, a.ep = t0, t1, 1 if motion_only else 0, 1e-4, 0.1
+            a.sys, a.ba_ws, a.ba_ws_bytes = ba["sys"].data_ptr(), ba["ws"].data_ptr(), ba["ws"].numel()
+            a.clamp_frames, a.disp_min = v.disps.shape[0], 0.001
+            a.want_upmask = 1 if self.want_upmask else 0
+        a = st["args"]
+        # per update: the state tensors (a caller may have re-assigned them) and the scalar arguments
+        for n in ("target_cam", "delta_dy", "raw_mask"):
+            t = getattr(self, n)
+            if not t.is_contiguous():
+                setattr(self, n, t.contiguous())
+        net = self.net[0]
+        if net.dtype != dt or not net.is_contiguous(memory_format=torch.channels_last):
+            net = net.to(dt).contiguous(memory_format=torch.channels_last)
+            self.net = net[None]
+        a.op.net = a.op.net_out = net.data_ptr()
+        a.op.P_zr, a.op.P_q = self.P_zr.data_ptr(), self.P_q.data_ptr()
+        a.op.EP = float(EP)
+        a.target, a.delta_dy, a.raw_mask = self.target_cam.data_ptr(), self.delta_dy.data_ptr(), self.raw_mask.data_ptr()
+        self.weight, self.full_flow = st["weight"], st["full_flow"]
+        a.weight, a.full_flow = self.weight.data_ptr(), self.full_flow.data_ptr()
+        a.itrs = int(itrs)
+        db.graph_update(self.update_op.packed_weights(dt), a, st["ws"])
         self.age += 1
-        if host_age:
-            self._age_h = [a + 1 for a in self._age_h]
+        self._age_h = [x + 1 for x in self._age_h]
 
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
         """one update of the factor graph (factor_graph.py:227-307)"""
-        if self.fused_glue and self._fused_ok():
-            if self.use_graphs:
-                return self._update_graphed(t0, t1, itrs, use_inactive, EP, motion_only)
+        if self._fused_ok() and self.P_zr is not None:
             return self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only)
         ht, wd = self.ht, self.wd
         coords1, _ = self.video.reproject(self.ii, self.jj)

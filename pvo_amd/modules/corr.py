@@ -179,7 +179,7 @@ class CorrVolumePool:
         """fmap1, fmap2: [n,H,W,C] channels-last features of the new edges (appended in order)"""
         n = fmap1.shape[0]
         if n > len(self.free):
-            raise RuntimeError("CorrVolumePool is full (%d slots)" % self.capacity)
+            self._grow(len(self.slots) + n)
         new = [self.free.pop() for _ in range(n)]
         st = db.to_device_async(new, torch.int32, self.device)
         if self.tiled:
@@ -189,6 +189,19 @@ class CorrVolumePool:
         self.slots += new
         self._slots_t = None
 
+    def _grow(self, need):
+        """more edges than slots (the reference's pyramid simply grows, e.g. a long --warmup initialisation): move to
+        larger level tensors; live slots keep their numbers.  Rare, so the one-off copy of the pool is acceptable."""
+        cap = max(need + 16, self.capacity + self.capacity // 2)
+        levels = []
+        for lv in self.levels:
+            new = torch.empty((cap,) + tuple(lv.shape[1:]), dtype=lv.dtype, device=lv.device)
+            new[:self.capacity].copy_(lv)
+            levels.append(new)
+        self.levels = levels
+        self.free = list(range(cap - 1, self.capacity - 1, -1)) + self.free
+        self.capacity = cap
+
     def keep(self, mask):
         """drop the edges whose mask entry is False"""
         for s, m in zip(self.slots, mask):
@@ -197,14 +210,24 @@ class CorrVolumePool:
         self.slots = [s for s, m in zip(self.slots, mask) if m]
         self._slots_t = None
 
-    def encoded(self, coords, enc_weight, enc_bias):
-        """relu(W lookup(coords) + b): the lookup fused with the update operator's first correlation-encoder layer
-        (tiled pools only); [batch*num, 128, ht, wd] channels-last"""
-        batch, num, ht, wd, _ = coords.shape
+    def slots_tensor(self):
         if self._slots_t is None:
             self._slots_t = db.to_device_async(self.slots, torch.int32, self.device)
+        return self._slots_t
+
+    def encoded(self, coords, enc_weight, enc_bias):
+        """relu(W lookup(coords) + b): the lookup fused with the update operator's first correlation-encoder layer
+        (tiled pools only); [batch*num, 128, ht, wd] channels-last.  (The native update runs the same kernel itself.)"""
+        batch, num, ht, wd, _ = coords.shape
         return db.corr_lookup_encode_tiled(self.levels, coords.reshape(batch * num, ht, wd, 2).float().contiguous(),
-                                           enc_weight, enc_bias, slots=self._slots_t)
+                                           enc_weight, enc_bias, slots=self.slots_tensor())
+
+    def at(self, coords):
+        """the pool sampled at `coords` [batch,num,ht,wd,2], as an argument of the fused update operator: the lookup then
+        runs inside libpvo_hip, fused with corr_encoder[0] (tiled pools only)"""
+        from .update import PoolLookup
+        batch, num, ht, wd, _ = coords.shape
+        return PoolLookup(self.levels, self.slots_tensor(), self.capacity, coords.reshape(batch * num, ht, wd, 2).float().contiguous())
 
     def __call__(self, coords, channels_last=False):
         batch, num, ht, wd, _ = coords.shape

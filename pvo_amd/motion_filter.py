@@ -33,7 +33,10 @@ class MotionFilter:
         return (x - self.MEAN) / self.STDV
 
     def _append(self, tstamp, image, pose, disp, intrinsics, gmap, net, inp, segments):
-        self.video.append(tstamp, pose, disp, intrinsics / 8.0, gmap[0], net[0], inp[0], segm=segments, image=image)
+        kw = {}
+        if tuple(gmap.shape[-2:]) == (128, 128):      # a [128,128,128] map: the layout cannot be read off the shape
+            kw["channels_last"] = False
+        self.video.append(tstamp, pose, disp, intrinsics / 8.0, gmap[0], net[0], inp[0], segm=segments, image=image, **kw)
 
     @torch.no_grad()
     def track(self, tstamp, image, depth=None, intrinsics=None, segments=None):

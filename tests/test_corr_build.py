@@ -161,7 +161,7 @@ def _tile(level, th, tw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (24, 128)])
+@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (24, 128), (30, 101), (16, 24), (20, 40), (11, 19)])
 def test_tiled_pool_layout_is_bit_identical_to_row_major(cuda, dtype, H, W):
     """the 8x8-tiled build writes exactly the row-major pyramid's values at the tiled addresses, and the tiled
     lookup returns exactly what the row-major lookup returns (out-of-range, negative and border coordinates)"""
@@ -198,17 +198,18 @@ def test_tiled_pool_layout_is_bit_identical_to_row_major(cuda, dtype, H, W):
 def test_tiled_entry_points_reject_unsupported_shapes(cuda):
     from pvo_amd import droid_backends as db
     from pvo_amd.modules.corr import CorrVolumePool
-    assert not db.tiled_supported(30, 101, torch.float16) and not db.tiled_supported(48, 64, torch.float32)
-    assert not CorrVolumePool(2, 16, 24, cuda).tiled          # falls back to row-major planes
-    f = torch.randn(1, 16, 24, 64, device=cuda).half()
-    lv = [torch.empty((1, 16, 24) + db.tiled_level_shape(16, 24, l), dtype=torch.half, device=cuda) for l in range(4)]
+    assert db.tiled_supported(30, 101, torch.float16) and not db.tiled_supported(48, 64, torch.float32)
+    assert not db.tiled_supported(6, 24, torch.float16)       # level 3 would be empty
+    assert not CorrVolumePool(2, 16, 24, cuda, torch.float32).tiled          # falls back to row-major planes
+    f = torch.randn(1, 6, 24, 64, device=cuda).half()
+    lv = [torch.empty((1, 6, 24) + db.tiled_level_shape(6, 24, l), dtype=torch.half, device=cuda) for l in range(4)]
     with pytest.raises(db.PvoHipError):
         db.corr_build_tiled(f, f, lv, torch.zeros(1, dtype=torch.int32, device=cuda))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H,W", [(48, 64), (8, 64)])
+@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (30, 101), (16, 24)])
 def test_fused_lookup_encoder_matches_lookup_then_conv(cuda, dtype, H, W):
     """pvo_corr_lookup_encode_tiled == relu(conv1x1(lookup) + b): the lookup half is bit-exact (tested above), the
     encoder half is an fp32-accumulated GEMM rounded once to the 16-bit type"""
@@ -231,3 +232,44 @@ def test_fused_lookup_encoder_matches_lookup_then_conv(cuda, dtype, H, W):
     tol = 4e-3 if dtype == torch.float16 else 3e-2
     assert torch.allclose(got.float(), ref, atol=tol, rtol=tol)
     assert (got.float() - ref).abs().mean().item() < tol / 8
+
+
+@pytest.mark.gpu
+def test_tiled_and_fused_lookup_against_the_oracle_at_full_map_size(cuda):
+    """The kernels the bench times - the tiled pool's build, its lookup, and the lookup fused with corr_encoder[0] -
+    DIRECTLY against the CPU oracle at the S-B map size (48x64, C = 128): the oracle's lookup of the volume the pool holds
+    (bit-exact; the volume itself is compared with oracle_corr_build to one unit in the last place, as for the row-major
+    build above), and the encoder layer as an fp64 GEMM of the oracle's lookup."""
+    from oracle import oracle as O
+    from pvo_amd import droid_backends as db
+    from pvo_amd.modules.corr import CorrVolumePool
+    H, W, C, N = 48, 64, 128, 2
+    g = torch.Generator().manual_seed(11)
+    f1 = torch.randn(N, H, W, C, generator=g).half()
+    f2 = torch.randn(N, H, W, C, generator=g).half()
+    base = torch.stack(torch.meshgrid(torch.arange(W).float(), torch.arange(H).float(), indexing="xy"), -1)
+    coords = base[None] + torch.randn(N, H, W, 2, generator=g) * 5.0
+    coords[0, 0, :4] = torch.tensor([[-3.0, -3.0], [W + 2.5, H + 2.5], [0.0, 0.0], [W - 1.0, H - 1.0]])
+    pool = CorrVolumePool(3, H, W, cuda, torch.float16)
+    assert pool.tiled
+    pool.add(f1.to(cuda), f2.to(cuda))
+    # the pool's volumes, un-tiled on the host
+    pyr = []
+    for l in range(4):
+        hl, wl = H >> l, W >> l
+        t = pool.levels[l][pool.slots].cpu()                                              # [N,H,W,th,tw,8,8]
+        pyr.append(t.transpose(-3, -2).reshape(N, H, W, t.shape[3] * 8, t.shape[4] * 8)[..., :hl, :wl].contiguous().numpy())
+    ref_pyr = O.corr_build(f1[:1].permute(0, 3, 1, 2).contiguous().numpy(), f2[:1].permute(0, 3, 1, 2).contiguous().numpy(), 4)
+    r0 = ref_pyr[0].astype(np.float64)      # one fp16 ulp + the fp32 accumulation-order noise of a 128-term sum
+    assert np.all(np.abs(pyr[0][:1].astype(np.float64) - r0) <= 1.01 * 2.0 ** -10 * np.maximum(np.abs(r0), 2.0 ** -14) + 1e-4)
+    for l in range(1, 4):                                                                 # pooled levels: exact functions of the stored level below
+        assert np.array_equal(pyr[l].view(np.uint16), _pool_exact(pyr[l - 1], np.float16).view(np.uint16)), l
+    want = O.corr_pyramid_lookup(pyr, coords.numpy(), 3)                                   # [N,196,H,W] fp16
+    got = pool(coords[None].to(cuda))[0]
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))       # build + tiled lookup: bit-exact
+    w = (torch.randn(128, 196, 1, 1, generator=g) * 0.05).half()
+    b = torch.randn(128, generator=g)
+    enc = pool.encoded(coords[None].to(cuda), db.corr_encoder_weights(w.to(cuda), torch.float16), b.to(cuda))
+    ref = torch.relu(torch.einsum("oc,nchw->nohw", w[:, :, 0, 0].double(), torch.from_numpy(want.astype(np.float64))) + b.double().view(1, -1, 1, 1))
+    err = (enc.cpu().double() - ref).abs()
+    assert err.max().item() < 4e-3 * max(1.0, ref.abs().max().item()) and err.mean().item() < 5e-4
