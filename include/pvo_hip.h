@@ -166,8 +166,12 @@ int pvo_gate_context(const float* glo_part, const float* wg_t, const float* g_bi
  * tensor (the encoders write [corr features | flow features] side by side for the ConvGRU). */
 int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void* y,
                      int E, int H, int W, int Cout, int relu, int ystride, int yoff, int dtype, void* stream);
-/* the same for wide layers (implicit GEMM, 16x16 pixel tile x 128 outputs per workgroup): Cin % 32 == 0, Cout % 128 == 0;
- * w_taps [9][Cout][Cin]. */
+/* the same for wide layers (implicit GEMM, 16x16 pixel tile x 128 outputs per workgroup): Cin % 32 == 0, Cout % 128 == 0.
+ * The filter is read in MFMA-fragment order, [Cout/128][Cin/32 chunks][9 taps][2][2][2][64 lanes][8]: element
+ * (cg, cc, t, wn, nt, ks, lane, j) = W[tap t][output cg*128 + wn*64 + nt*32 + (lane & 31)][input cc*32 + ks*16 + (lane >> 5)*8 + j]
+ * (one coalesced 1 KB load per fragment, no LDS staging of the filter).  pvo_conv3x3_weight_layout() returns 1 for this
+ * layout, 0 when the process runs the tap-major variant [9][Cout][Cin] (environment PVO_WIDE_TAPMAJOR=1, for A/B runs). */
+int pvo_conv3x3_weight_layout(void);
 int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
                 int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream);
 /* The ConvGRU's two large convolutions with the gate arithmetic as their epilogue (modules/gru.py:26-31); the 256 gate
@@ -307,7 +311,7 @@ typedef struct pvo_graph_update_args {
   float* target_ba; float* weight_ba;                        /* [n_in + E,2,H,W] f32: rows [0,n_in) filled by the caller, the rest here */
   const int64_t* ii_ba; const int64_t* jj_ba;                /* [n_in + E] */
   int t0, t1, itrs, motion_only; float lm, ep;
-  double* sys; void* ba_ws; size_t ba_ws_bytes;              /* planned with pvo_ba_plan(ii_ba, jj_ba, ..., K_eta = op.R) */
+  void* sys; void* ba_ws; size_t ba_ws_bytes;                /* [(6P)^2 + 6P] x 8 bytes; planned with pvo_ba_plan(ii_ba, jj_ba, ..., K_eta = op.R) */
   int clamp_frames; float disp_min;                          /* disps[:clamp_frames].clamp_(min=disp_min) (depth_video.py:214) */
   int want_upmask;                                           /* compute agg.upmask_disp although FactorGraph.update discards it */
 } pvo_graph_update_args;
@@ -392,11 +396,18 @@ int pvo_ba(float* poses, float* disps, const float* intrinsics,
 /* Edge-sharded BA: one Gauss-Newton step split at the point where
  * ranks exchange the reduced pose system.
  *   pvo_ba_local : assemble this rank's edges, eliminate its depth maps, and write
- *                  the rank-local reduced system sys[(6P)*(6P) + 6P] (fp64:
- *                  row-major A-S followed by the rhs), no damping applied yet.
- *   -- caller all-reduces (sum) `sys` across ranks --
+ *                  the rank-local reduced system sys[(6P)*(6P) + 6P] (row-major A-S
+ *                  followed by the rhs), no damping applied yet.
+ *   -- caller all-reduces (sum) `sys` across ranks AS 64-BIT INTEGERS --
  *   pvo_ba_finish: damp + factorise + solve on every rank (identical input ->
  *                  identical dx), retract poses, back-substitute this rank's dz.
+ * `sys` holds 64-bit FIXED-POINT numbers (int64, units of 2^-28): integer sums commute, so the
+ * system - and with it every pose and depth - is bitwise reproducible from run to run and
+ * identical for any partition of the edges over ranks (the reference's host-side sum of fp32
+ * block sums has no such guarantee either way; fp64 atomics, used in round 1, did not).
+ * pvo_ba_finish converts to fp64, solves in fp64 (as SparseBlock::solve, droid_kernels.cu:1160-1198)
+ * and leaves `sys` ZEROED; bit 1 of pvo_ba_local's motion_only argument says that `sys` is
+ * already zero (local -> finish -> local chains), otherwise pvo_ba_local clears it first.
  * With one rank pvo_ba == plan + iterations x (local, finish).  pvo_ba_plan must run
  * before the first pvo_ba_local of a graph (same workspace); pass K_eta = -1 for a
  * motion-only plan. */
@@ -407,9 +418,9 @@ int pvo_ba_local(const float* poses, const float* disps, const float* intrinsics
                  const float* targets, const float* weights, const float* eta,
                  const int64_t* ii, const int64_t* jj,
                  int E, int nframes, int ht, int wd, int K_eta, int t0, int t1,
-                 int motion_only, double* sys,
+                 int motion_only, void* sys,
                  void* workspace, size_t workspace_bytes, void* stream);
-int pvo_ba_finish(float* poses, float* disps, const double* sys,
+int pvo_ba_finish(float* poses, float* disps, void* sys,
                   const int64_t* ii, const int64_t* jj,
                   int E, int nframes, int ht, int wd, int t0, int t1,
                   float lm, float ep, int motion_only,

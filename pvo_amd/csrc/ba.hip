@@ -37,6 +37,18 @@
 namespace {
 
 constexpr float kMinDepth = 0.25f;
+
+// The reduced pose system is accumulated in 64-bit FIXED POINT (units of 2^-28): integer atomics commute, so the sums - and
+// with them poses and depths - are bitwise reproducible from run to run, and identical whether the edges sit on one GPU or
+// are sharded over several (fp64 atomics, used before, made the last bits order dependent).  Every addend is an fp32
+// partial sum (|v| <~ 1e8 at most: w J^2 over a chunk of pixels), so 2^-28 = 3.7e-9 absolute resolution is far below its
+// own rounding error, and |sum| < 2^35 leaves 7 bits of headroom.  Non-finite or out-of-range addends raise meta[4]; the
+// solve then takes the reference's failure path (zero update, droid_kernels.cu:1186-1189).
+constexpr double kFix = 268435456.0, kInvFix = 1.0 / 268435456.0;
+__device__ __forceinline__ void fix_add(long long* sys, long long idx, double v, int* meta) {
+  if (!(fabs(v) < 3.0e10)) { meta[4] = 1; return; }
+  atomicAdd(reinterpret_cast<unsigned long long*>(sys + idx), static_cast<unsigned long long>(__double2ll_rn(v * kFix)));
+}
 constexpr int kPPT = 2;                 // pixels per thread in assemble
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
 constexpr int kLdsCholMax = 138;        // (6P) up to which the fp64 system lives in LDS (138*139*8 + 23*21*8 + 208 = 157.5 KB < 160 KB)
@@ -46,7 +58,7 @@ struct Plan {            // int region of the workspace
   int* kx;               // [F]   depth index -> frame
   int* eptr;             // [F+1] CSR over depth index -> edges (ascending edge id)
   int* eidx;             // [E]
-  int* meta;             // [8]   0:K 1:status(non-SPD) 2:eta mismatch 3:row table overflow
+  int* meta;             // [8]   0:K 1:status(non-SPD) 2:eta mismatch 3:row table overflow 4:non-finite / out-of-range system entry
 };
 
 struct Ws {
@@ -56,7 +68,7 @@ struct Ws {
   float *Ei;             // [P][6][HW]
   float *Q, *w;          // [F'][HW]   (F' = min(F, P+E) rows)
   float *dx;             // [P][6]
-  double* sys;           // [(6P)^2 + 6P]
+  long long* sys;        // [(6P)^2 + 6P] fixed point
   double* chol;          // [(6P)^2 + 6P] scratch for the global-memory factorisation
   size_t bytes;
 };
@@ -83,7 +95,7 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.Q = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(Kmax) * HW));
   w.w = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(Kmax) * HW));
   w.dx = reinterpret_cast<float*>(take(sizeof(float) * (n6 + 8)));
-  w.sys = reinterpret_cast<double*>(take(sizeof(double) * (n6 * n6 + n6 + 8)));
+  w.sys = reinterpret_cast<long long*>(take(sizeof(double) * (n6 * n6 + n6 + 8)));
   w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + n6 + 27 * (n6 / 6) + 32 : 8)));
   w.bytes = off;
   return w;
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(256) void ba_plan_kernel(
     pl.meta[0] = K;
     pl.meta[1] = 0;
     pl.meta[3] = 0;
+    pl.meta[4] = 0;
     pl.meta[2] = (!motion_only && K_eta != K && K_eta != 1) ? 1 : 0;
   }
 }
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
     const float* __restrict__ targets, const float* __restrict__ weights,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
     float* __restrict__ Eii, float* __restrict__ Eij, float* __restrict__ Cii, float* __restrict__ bz,
-    double* __restrict__ sys, int HW, int wd, int t0, int P, int motion_only) {
+    long long* __restrict__ sys, int* __restrict__ meta, int HW, int wd, int t0, int P, int motion_only) {
   __shared__ float red[4][90];
   const int e = blockIdx.y;
   const int ix = static_cast<int>(ii[e]), jx = static_cast<int>(jj[e]);
@@ -284,24 +297,24 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
       const int m = t - base;
       if (n < 6) {                                  // (ii,ii), symmetric
         if (iok) {
-          atomicAdd(&sys[static_cast<long long>(6 * pi + n) * n6 + 6 * pi + m], val);
-          if (n != m) atomicAdd(&sys[static_cast<long long>(6 * pi + m) * n6 + 6 * pi + n], val);
+          fix_add(sys, static_cast<long long>(6 * pi + n) * n6 + 6 * pi + m, val, meta);
+          if (n != m) fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pi + n, val, meta);
         }
       } else if (m < 6) {                           // (ii,jj)[m][n-6] and (jj,ii)[n-6][m]
         if (iok && jok) {
-          atomicAdd(&sys[static_cast<long long>(6 * pi + m) * n6 + 6 * pj + (n - 6)], val);
-          atomicAdd(&sys[static_cast<long long>(6 * pj + (n - 6)) * n6 + 6 * pi + m], val);
+          fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pj + (n - 6), val, meta);
+          fix_add(sys, static_cast<long long>(6 * pj + (n - 6)) * n6 + 6 * pi + m, val, meta);
         }
       } else {                                      // (jj,jj), symmetric
         if (jok) {
-          atomicAdd(&sys[static_cast<long long>(6 * pj + n - 6) * n6 + 6 * pj + m - 6], val);
-          if (n != m) atomicAdd(&sys[static_cast<long long>(6 * pj + m - 6) * n6 + 6 * pj + n - 6], val);
+          fix_add(sys, static_cast<long long>(6 * pj + n - 6) * n6 + 6 * pj + m - 6, val, meta);
+          if (n != m) fix_add(sys, static_cast<long long>(6 * pj + m - 6) * n6 + 6 * pj + n - 6, val, meta);
         }
       }
     } else if (t < 84) {
-      if (iok) atomicAdd(&sys[static_cast<long long>(n6) * n6 + 6 * pi + (t - 78)], val);
+      if (iok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pi + (t - 78), val, meta);
     } else {
-      if (jok) atomicAdd(&sys[static_cast<long long>(n6) * n6 + 6 * pj + (t - 84)], val);
+      if (jok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pj + (t - 84), val, meta);
     }
   }
 }
@@ -330,15 +343,11 @@ __device__ __forceinline__ RowRef row_of(int r, int k, const Plan& pl, const flo
 }
 
 // ---- depth: C, w, Q and the window-pose rows Ei for one (pixel, depth frame) ----------
-// (accum_cuda x3 + the Q expression of ba_cuda, droid_kernels.cu:1374-1378)
-__global__ __launch_bounds__(256) void ba_depth_kernel(
-    Plan pl, const float* __restrict__ eta, int K_eta,
-    const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
-    float* __restrict__ Ei, float* __restrict__ Q, float* __restrict__ w, int HW, int t0, int P) {
-  const int k = blockIdx.y;
-  if (k >= pl.meta[0]) return;
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x >= HW) return;
+// (accum_cuda x3 + the Q expression of ba_cuda, droid_kernels.cu:1374-1378).  Runs as the first phase of the Schur
+// kernel: every workgroup prepares Q, w and Ei for exactly the pixels it is about to reduce.
+__device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const float* __restrict__ eta, int K_eta,
+                                            const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
+                                            float* __restrict__ Ei, float* __restrict__ Q, float* __restrict__ w, int HW, int t0, int P) {
   const int e0 = pl.eptr[k], e1 = pl.eptr[k + 1];
   const int pself = pl.kx[k] - t0;
   const bool self_in = pself >= 0 && pself < P;
@@ -395,17 +404,17 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int p, int
 
 // scatter one reduced 16x16 tile (ti,tj) of -S into the pose system
 __device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, int tj, const int* rowout,
-                                             double* __restrict__ sys, int n6) {
+                                             long long* __restrict__ sys, int n6, int* meta) {
   // D[i][j]: i = 4*(lane>>4)+reg (row in tile ti), j = lane&15 (row in tile tj)
   const int oi = rowout[ti * 16 + 4 * (l >> 4) + reg];
   const int oj = rowout[tj * 16 + (l & 15)];
   if (oi < 0) return;
   const double val = -static_cast<double>(v);
   if (oj >= 0) {
-    atomicAdd(&sys[static_cast<long long>(oi) * n6 + oj], val);
-    if (ti != tj) atomicAdd(&sys[static_cast<long long>(oj) * n6 + oi], val);   // mirrored tile
+    fix_add(sys, static_cast<long long>(oi) * n6 + oj, val, meta);
+    if (ti != tj) fix_add(sys, static_cast<long long>(oj) * n6 + oi, val, meta);   // mirrored tile
   } else if (oj == -2) {
-    atomicAdd(&sys[static_cast<long long>(n6) * n6 + oi], val);                 // rhs: - E (Q w)
+    fix_add(sys, static_cast<long long>(n6) * n6 + oi, val, meta);                 // rhs: - E (Q w)
   }
 }
 
@@ -413,7 +422,7 @@ __device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, in
 template <int T, bool VEC4>
 __device__ __forceinline__ void schur_pass(const float* const* rowptr, const int* rowout,
                                            const float* __restrict__ qrow, float* red /*[4][NT*4][64]*/,
-                                           double* __restrict__ sys, int HW, int n6, int pix_base) {
+                                           long long* __restrict__ sys, int HW, int n6, int pix_base, int* meta) {
   constexpr int NT = T * (T + 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int idx = lane & 15, kq = lane >> 4;
@@ -457,15 +466,17 @@ __device__ __forceinline__ void schur_pass(const float* const* rowptr, const int
       const float* r0 = red + static_cast<size_t>(n) * 256 + tid;
       const float v = (r0[0] + r0[static_cast<size_t>(NT) * 256]) +
                       (r0[static_cast<size_t>(2 * NT) * 256] + r0[static_cast<size_t>(3 * NT) * 256]);
-      scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6);
+      scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6, meta);
       ++n;
     }
 }
 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
-    Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ Ei, const float* __restrict__ Eij,
-    const float* __restrict__ Q, const float* __restrict__ w, double* __restrict__ sys,
+    Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
+    const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
+    float* __restrict__ Ei, const float* __restrict__ Eij,
+    float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
     int HW, int t0, int P) {
   __shared__ const float* rowptr[kMaxRows];
   __shared__ int rowout[kMaxRows];        // 6*pose + comp for an M row, -2 for the w row, -1 padding
@@ -475,6 +486,11 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
   if (k >= pl.meta[0]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n6 = 6 * P;
+#pragma unroll
+  for (int h = 0; h < kSchurPix / 256; ++h) {          // depth phase for this workgroup's pixels
+    const int x = blockIdx.x * kSchurPix + h * 256 + tid;
+    if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P);
+  }
 
   if (tid == 0) {                         // row table (a handful of rows: sequential is fine)
     int r = 0;
@@ -502,10 +518,10 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
   const int pix_base = blockIdx.x * kSchurPix + wave * (kSchurPix / 4);
 
   switch (T) {
-    case 1: schur_pass<1, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base); return;
-    case 2: schur_pass<2, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base); return;
-    case 3: schur_pass<3, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base); return;
-    case 4: schur_pass<4, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base); return;
+    case 1: schur_pass<1, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
+    case 2: schur_pass<2, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
+    case 3: schur_pass<3, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
+    case 4: schur_pass<4, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
     default: break;
   }
   // any degree: one tile pair at a time, row tiles re-read from L2
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
       r[lane] = acc.x; r[64 + lane] = acc.y; r[128 + lane] = acc.z; r[192 + lane] = acc.w;
       __syncthreads();
       const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-      scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6);
+      scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6, pl.meta);
       __syncthreads();
     }
   }
@@ -658,7 +674,7 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
 }
 
 __global__ __launch_bounds__(256) void ba_solve_kernel(
-    const double* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
+    long long* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
     float* __restrict__ dx_ws, float* __restrict__ dx_out, int* __restrict__ meta, int* __restrict__ status_out,
     int P, int t0, float lm, float ep, int use_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs]
@@ -670,7 +686,8 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   double* red = Ld + 27 * P;                                                     // [4][6] wave partials
   if (threadIdx.x == 0) fail = 0;
   for (int idx = threadIdx.x; idx < n * n + n; idx += blockDim.x) {
-    double v = sys[idx];
+    double v = static_cast<double>(sys[idx]) * kInvFix;       // fixed point -> fp64
+    sys[idx] = 0;                                             // ready for the next Gauss-Newton step's accumulation
     if (idx < n * n) {
       const int r = idx / n, c = idx - r * n;
       if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
@@ -680,7 +697,7 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   __syncthreads();
   chol_solve_blocked(A, Ld, red, n, &fail);
   __syncthreads();
-  const int failed = fail;
+  const int failed = fail | meta[4];
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
     const float v = failed ? 0.0f : static_cast<float>(b[idx]);    // zeros on failure (:1186-1189)
     dx_ws[idx] = v;
@@ -696,7 +713,9 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
     ps[0] = T.t.x; ps[1] = T.t.y; ps[2] = T.t.z;
     ps[3] = T.q.x; ps[4] = T.q.y; ps[5] = T.q.z; ps[6] = T.q.w;
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    meta[4] = 0;
     if (failed) meta[1] = 1;
     if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
   }
@@ -765,8 +784,9 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
                             const float* targets, const float* weights, const float* eta,
                             const int64_t* ii, const int64_t* jj,
                             int E, int nframes, int ht, int wd, int K_eta, int t0, int t1,
-                            int motion_only, double* sys,
+                            int motion_only, void* sys_,
                             void* workspace, size_t workspace_bytes, void* stream) {
+  long long* sys = static_cast<long long*>(sys_);
   int rc = check_common(E, nframes, ht, wd, t0, t1);
   if (rc != PVO_OK) return rc;
   const int P = t1 - t0, HW = ht * wd;
@@ -776,29 +796,30 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
   if (workspace_bytes < pvo_ba_workspace_bytes(E, P, nframes, HW)) return PVO_EWORKSPACE;
   Ws w = carve(ws_base(workspace), E, P, nframes, HW);
   hipStream_t st = pvo_stream(stream);
+  // pvo_ba_finish leaves `sys` zeroed after reading it; callers that chain local -> finish -> local on the same buffer
+  // say so with bit 1 of motion_only and save the memset
   const size_t n6 = static_cast<size_t>(6) * P;
-  if (hipMemsetAsync(sys, 0, sizeof(double) * (n6 * n6 + n6), st) != hipSuccess) return PVO_ELAUNCH;
+  const bool clean = (motion_only & 2) != 0;
+  motion_only &= 1;
+  if (!clean && hipMemsetAsync(sys, 0, sizeof(long long) * (n6 * n6 + n6), st) != hipSuccess) return PVO_ELAUNCH;
   if (E == 0) return PVO_OK;
   hipLaunchKernelGGL(ba_assemble_kernel, dim3((HW + kChunkA - 1) / kChunkA, E), dim3(256), 0, st,
                      poses, disps, intrinsics, targets, weights, ii, jj, w.Eii, w.Eij, w.Cii, w.bz,
-                     sys, HW, wd, t0, P, motion_only);
+                     sys, w.plan.meta, HW, wd, t0, P, motion_only);
   PVO_CHECK_LAUNCH();
   if (!motion_only) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);
-    hipLaunchKernelGGL(ba_depth_kernel, dim3((HW + 255) / 256, Kmax), dim3(256), 0, st,
-                       w.plan, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Q, w.w, HW, t0, P);
-    PVO_CHECK_LAUNCH();
     const dim3 sgrid((HW + kSchurPix - 1) / kSchurPix, Kmax);
     if ((HW & 3) == 0)
-      hipLaunchKernelGGL(ba_schur_mfma_kernel<true>, sgrid, dim3(256), 0, st, w.plan, jj, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P);
+      hipLaunchKernelGGL(ba_schur_mfma_kernel<true>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P);
     else
-      hipLaunchKernelGGL(ba_schur_mfma_kernel<false>, sgrid, dim3(256), 0, st, w.plan, jj, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P);
+      hipLaunchKernelGGL(ba_schur_mfma_kernel<false>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P);
     PVO_CHECK_LAUNCH();
   }
   return PVO_OK;
 }
 
-extern "C" int pvo_ba_finish(float* poses, float* disps, const double* sys,
+extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
                              const int64_t* ii, const int64_t* jj,
                              int E, int nframes, int ht, int wd, int t0, int t1,
                              float lm, float ep, int motion_only,
@@ -807,6 +828,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, const double* sys,
   int rc = check_common(E, nframes, ht, wd, t0, t1);
   if (rc != PVO_OK) return rc;
   const int P = t1 - t0, HW = ht * wd;
+  long long* sys = static_cast<long long*>(sys_);
   if (!poses || !disps || !sys || !workspace) return PVO_EINVAL;
   if (workspace_bytes < pvo_ba_workspace_bytes(E, P, nframes, HW)) return PVO_EWORKSPACE;
   Ws w = carve(ws_base(workspace), E, P, nframes, HW);
@@ -851,7 +873,7 @@ extern "C" int pvo_ba(float* poses, float* disps, const float* intrinsics,
   PVO_CHECK_LAUNCH();
   for (int it = 0; it < iterations; ++it) {
     rc = pvo_ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, E, nframes, ht, wd, K_eta,
-                      t0, t1, motion_only, w.sys, workspace, workspace_bytes, stream);
+                      t0, t1, (motion_only ? 1 : 0) | (it > 0 ? 2 : 0), w.sys, workspace, workspace_bytes, stream);
     if (rc != PVO_OK) return rc;
     rc = pvo_ba_finish(poses, disps, w.sys, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only,
                        dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes, stream);

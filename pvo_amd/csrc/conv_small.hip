@@ -11,6 +11,7 @@
 //   in LDS; wave w owns output channels [32w, 32w+32) and keeps its 26 weight fragments in registers for all 16 tile rows.
 //   Weights arrive pre-arranged as [52 taps (49 + 3 zero)][128 outputs][8 channels] 16-bit.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -361,25 +362,19 @@ struct BigEpi {
   const uint16_t* seg_p[3]; int seg_stride[3]; int seg_chunks[3];
 };
 
-#ifdef PVO_PROBE_BIG
-// diagnostic build only (tools/big_probe.py): per workgroup {start, main loop end, end} shader-clock stamps and the
-// hardware id of the CU it ran on, to see how many workgroups a CU really holds and what a step costs under contention
-__device__ unsigned long long big_probe[8 * 4096];
-#define BIG_STAMP(slot)                                                                                   \
-  if (tid == 0) {                                                                                         \
-    const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                        \
-    if (wg_ < 4096) big_probe[wg_ * 8 + (slot)] = __builtin_amdgcn_s_memtime();                            \
-  }
-#else
-#define BIG_STAMP(slot)
-#endif
-
 constexpr int kBT = 16;                                   // 16 x 16 pixel tile
 constexpr int kBHalo = (kBT + 2) * (kBT + 2);             // 324 halo positions
 constexpr int kBStride = 80;                              // bytes per halo position / filter row of a 32-channel chunk
-constexpr int kBA = kBHalo * kBStride, kBB = 128 * kBStride;   // 25920 + 10240 bytes per buffer
+constexpr int kBA = 384 * kBStride, kBB = 128 * kBStride;      // 30720 (324 halo positions + 60 dummy ones: every thread stores 6 pieces, no exec branches) + 10240 bytes per buffer
 
-template <typename T>
+// FRAGW: the filter arrives in MFMA-FRAGMENT order (pvo_conv3x3_fragment_weights) and is streamed global -> registers:
+//   [Cout/128][chunk][tap][wave column wn][nt][ks][lane][8] - one coalesced 1 KB load per fragment, requested two steps
+//   ahead into one of three rotating register sets.  The filter then needs no LDS, no ds_write, no ds_read and no barrier:
+//   only the halo (staged once per 32-channel chunk and shared by its 9 taps) crosses LDS, with ONE barrier per chunk
+//   instead of one per (chunk, tap) step, and with the 9 taps unrolled every fragment address is base + immediate.
+//   (The tap-major variant below spends ~160 non-MFMA instructions per 16-MFMA step on staging and addressing; the
+//   matrix pipe hides about 5 per MFMA.)
+template <typename T, bool FRAGW>
 __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                           int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, BigEpi ep) {
@@ -394,16 +389,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kg = lane >> 5;
   const int nC = Cin >> 5;                                // 32-channel chunks
-#ifdef PVO_PROBE_BIG
-  if (tid == 0) {
-    const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (wg_ < 4096) {
-      big_probe[wg_ * 8 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
-      big_probe[wg_ * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
-    }
-  }
-#endif
-  BIG_STAMP(0)
   const uint16_t* xe = x + static_cast<size_t>(e) * H * W * Cin;
   const uint16_t* wb = wt + static_cast<size_t>(cg) * 128 * Cin;
   const size_t tap_stride = static_cast<size_t>(Cout) * Cin;
@@ -425,6 +410,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
   }
   const size_t img = static_cast<size_t>(e) * H * W;
+  // (loads and stores are unconditional - out-of-image pieces read a clamped address and are zeroed by a select when they
+  // are parked: exec-masked branches around VMEM operations make the compiler wait vmcnt(0) at every join)
   auto fetch_a = [&](int cc) {
     const uint16_t* src = xe; int stride = Cin; int coff = cc * 32;
     if (ep.nseg > 0) {                                              // uniform walk over at most three segments
@@ -435,16 +422,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       coff = c0 * 32;
     }
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
-      ra[it] = cs_u32x4{0u, 0u, 0u, 0u};
-      if (apix[it] >= 0) ra[it] = *reinterpret_cast<const cs_u32x4*>(src + static_cast<size_t>(apix[it]) * stride + coff + (tid & 3) * 8);
-    }
+    for (int it = 0; it < 6; ++it)
+      ra[it] = *reinterpret_cast<const cs_u32x4*>(src + static_cast<size_t>(max(apix[it], 0)) * stride + coff + (tid & 3) * 8);
   };
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
       const int id = tid + 256 * it;
-      if ((id >> 2) < kBHalo) *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = ra[it];
+      cs_u32x4 v = ra[it];
+      if (apix[it] < 0) v = cs_u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = v;
     }
   };
   // filter slab of step s = (chunk cc, tap t): rows n = tid >> 2 (+64), quarter q = tid & 3
@@ -513,6 +500,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     __syncthreads();
   };
 
+  if constexpr (FRAGW) {
+    // this wave's fragments of step s: wf + ((cg * S + s) * 8 + wn * 4 + nt * 2 + ks) * 512 + lane * 8   (16-bit elements)
+    const uint16_t* wf = wt + (static_cast<size_t>(cg) * S * 8 + wn * 4) * 512 + lane * 8;
+    cs_u32x4 bset[3][4];                                    // three rotating sets of {nt0 ks0, nt0 ks1, nt1 ks0, nt1 ks1}
+    auto fetch_bf = [&](cs_u32x4 (&r)[4], int s) {          // (clamped, unconditional: exact s_waitcnt vmcnt counts)
+      const uint16_t* p = wf + static_cast<size_t>(min(s, S - 1)) * 4096;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) r[f] = *reinterpret_cast<const cs_u32x4*>(p + f * 512);
+    };
+    fetch_a(0);
+    fetch_bf(bset[0], 0); fetch_bf(bset[1], 1);
+    store_a(0);
+    __syncthreads();
+    const unsigned char* Abase = As + ((arow * (kBT + 2)) + acol) * kBStride + kg * 16;
+#pragma unroll 1
+    for (int cc = 0; cc < nC; ++cc) {
+      const unsigned char* Ac = Abase + (cc & 1) * kBA;
+      fetch_a(min(cc + 1, nC - 1));                         // next chunk's halo: in flight during this chunk's first taps
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * (kBT + 2) + (t % 3)) * kBStride;      // compile-time: ds_read immediates
+        fetch_bf(bset[(t + 2) % 3], cc * 9 + t + 2);
+        cs_u32x4 af[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            af[mt][ks] = *reinterpret_cast<const cs_u32x4*>(Ac + toff + mt * 2 * (kBT + 2) * kBStride + ks * 32);
+        const cs_u32x4 (&bf)[4] = bset[t % 3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(af[mt][ks], bf[nt * 2 + ks], acc[mt][nt]);
+        if (t == 4) store_a((cc + 1) & 1);                  // the other halo buffer was last read before the previous barrier
+      }
+      __syncthreads();
+    }
+  } else {
   // prologue: halo chunk 0 and slab 0 in LDS, slab 1 in rb1 (parked by step 0), slab 2 requested by step 0 into rb0
   fetch_a(0); fetch_b(rb0, 0, 0); fetch_b(rb1, 0, 1);
   store_a(0); store_b(rb0, 0);
@@ -529,8 +556,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       }
     }
   }
+  }
 
-  BIG_STAMP(1)
   if (ep.mode != 0) {
     // fused ConvGRU epilogue: pre-activations cross the workgroup through an fp32 slab [128 px][128 ch] (528-byte pixel
     // stride, 67.6 KB of the 72 KB), then every thread finishes 8 channels of a pixel with coalesced 16-byte accesses
@@ -612,7 +639,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       finish(half, 1);
       __syncthreads();
     }
-    BIG_STAMP(2)
     return;
   }
   // epilogue: two halves of 128 pixels through an LDS slab [128 px][128 ch] (272-byte pixel stride) -> whole-row stores
@@ -645,16 +671,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
     __syncthreads();
   }
-  BIG_STAMP(2)
 }
 
 }  // namespace
-
-#ifdef PVO_PROBE_BIG
-extern "C" int pvo_big_probe_read(void* dst, int n) {
-  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(big_probe), static_cast<size_t>(n) * 8) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
                               int E, int H, int W, int dtype, void* stream) {
@@ -729,6 +748,15 @@ extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* 
   return PVO_OK;
 }
 
+// filter layout of the wide-layer kernel: 1 = MFMA-fragment order (default), 0 = tap-major [9][Cout][Cin] (PVO_WIDE_TAPMAJOR=1,
+// kept for A/B measurements); the host arranges its filters accordingly (pvo_conv3x3_weight_layout)
+static int wide_layout() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PVO_WIDE_TAPMAJOR"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v;
+}
+extern "C" int pvo_conv3x3_weight_layout(void) { return wide_layout(); }
+
 static int launch_big(const void* x, const void* w_taps, const float* bias, void* y,
                       int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream,
                       const BigEpi& ep) {
@@ -742,7 +770,8 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
   if (static_cast<long long>(H) * W * Cin > 0x7fffffffLL) return PVO_EUNSUPPORTED;
   hipStream_t st = pvo_stream(stream);
   const int ntx = (W + kBT - 1) / kBT;
-  const size_t lds = 2 * kBA + 2 * kBB;                    // 72320 B (>= the output slabs)
+  // fragment-order variant: two halo buffers (61440 B) or the fp32 epilogue slab (128 px x 132 floats = 67584 B); tap-major: + two filter slabs
+  const size_t lds = wide_layout() ? 67584 : 2 * kBA + 2 * kBB;
   dim3 grid(ntx * (Cout / 128), (H + kBT - 1) / kBT, E);
   const uint16_t* xp = static_cast<const uint16_t*>(x);
   const uint16_t* wp = static_cast<const uint16_t*>(w_taps);
@@ -750,16 +779,20 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
   static bool attr_set[2] = {false, false};                // hipFuncSetAttribute once per process, not per launch
   if (dtype == PVO_F16) {
     if (!attr_set[0]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
       attr_set[0] = true;
     }
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
+    if (wide_layout()) hipLaunchKernelGGL((conv3x3_big_kernel<pvo_half, true>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
+    else hipLaunchKernelGGL((conv3x3_big_kernel<pvo_half, false>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
   } else if (dtype == PVO_BF16) {
     if (!attr_set[1]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
       attr_set[1] = true;
     }
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
+    if (wide_layout()) hipLaunchKernelGGL((conv3x3_big_kernel<pvo_bf16, true>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
+    else hipLaunchKernelGGL((conv3x3_big_kernel<pvo_bf16, false>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
   } else {
     return PVO_EUNSUPPORTED;
   }

@@ -277,7 +277,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   probe_mark(PVO_STAGE_BA, 0, stream);
   for (int it = 0; it < u->itrs; ++it) {
     RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, s.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
-                     H, W, R, u->t0, u->t1, u->motion_only, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
+                     H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | (it > 0 ? 2 : 0), u->sys, u->ba_ws, u->ba_ws_bytes, stream));
     RUN(pvo_ba_finish(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
                       u->motion_only, nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, stream));
   }

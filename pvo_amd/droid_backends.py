@@ -515,12 +515,16 @@ def ba_plan(ii, jj, nframes, HW, K_eta, t0, t1, workspace):
                                       ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(dev)), "ba_plan")
 
 
-def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, motion_only, sys, workspace):
-    """assemble + eliminate this rank's edges; `sys` (fp64 [(6P)^2+6P]) receives the local reduced system"""
+BA_SYS_DTYPE = torch.int64      # the reduced pose system is 64-bit fixed point (units of 2^-28): all-reduce it as integers
+
+
+def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, motion_only, sys, workspace, sys_is_zero=False):
+    """assemble + eliminate this rank's edges; `sys` (int64 [(6P)^2+6P], fixed point) receives the local reduced system.
+    sys_is_zero: the buffer was left zeroed by ba_finish (skips the clear)."""
     dev = _dev(poses, disps, intrinsics, targets, weights, eta, ii, jj, sys, workspace)
     F, ht, wd = disps.shape
-    if sys.dtype != torch.float64 or sys.numel() < (6 * (t1 - t0)) ** 2 + 6 * (t1 - t0):
-        raise PvoHipError("ba_local: sys must be float64 with (6P)^2 + 6P elements")
+    if sys.dtype != torch.int64 or sys.numel() < (6 * (t1 - t0)) ** 2 + 6 * (t1 - t0):
+        raise PvoHipError("ba_local: sys must be int64 with (6P)^2 + 6P elements")
     K_eta = 1
     if eta is not None:
         eta = eta.contiguous().view(-1, ht * wd)
@@ -528,13 +532,13 @@ def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, mo
     with torch.cuda.device(dev):
         check(_lib.load().pvo_ba_local(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(targets), _ptr(weights),
                                        _ptr(eta) if eta is not None else ctypes.c_void_p(0), _ptr(ii), _ptr(jj),
-                                       ii.shape[0], F, ht, wd, K_eta, int(t0), int(t1), 1 if motion_only else 0,
+                                       ii.shape[0], F, ht, wd, K_eta, int(t0), int(t1), (1 if motion_only else 0) | (2 if sys_is_zero else 0),
                                        _ptr(sys), ctypes.c_void_p(workspace.data_ptr()), workspace.numel(),
                                        _stream(dev)), "ba_local")
 
 
 def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None, outputs=True):
-    """damp + solve the (all-reduced) system, retract poses, back-substitute this rank's depths -> [dx, dz]
+    """damp + solve the (all-reduced) system (left zeroed afterwards), retract poses, back-substitute this rank's depths -> [dx, dz]
     (outputs=False: poses / disps are updated in place and no dx / dz tensors are produced -> [None, None])"""
     dev = _dev(poses, disps, sys, ii, jj, workspace)
     F, ht, wd = disps.shape
@@ -631,15 +635,27 @@ def conv7x7_c8(x, w_taps, bias):
     return y
 
 
-def conv3x3_weights(weight, dtype):
-    """[Cout,Cin,3,3] conv filter -> the [9,Cout,Cin] tap-major layout pvo_conv3x3 / pvo_conv3x3_c128 read"""
+def conv3x3_c128_weights(weight, dtype):
+    """[Cout,128,3,3] conv filter -> the [9,Cout,128] tap-major layout pvo_conv3x3_c128 reads"""
     co, ci, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise PvoHipError("conv3x3: filter must be [Cout,Cin,3,3]")
     return weight.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(dtype).contiguous()
 
 
-conv3x3_c128_weights = conv3x3_weights
+def conv3x3_weights(weight, dtype):
+    """[Cout,Cin,3,3] conv filter (Cin % 32 == 0, Cout % 128 == 0) -> the layout pvo_conv3x3 / pvo_gru_conv_* read, as a
+    [9,Cout,Cin]-shaped tensor: MFMA-fragment order [Cout/128][Cin/32][9][2][2][2][64][8] (include/pvo_hip.h), or tap-major
+    when the library runs its tap-major variant"""
+    co, ci, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or ci % 32 or co % 128:
+        raise PvoHipError("conv3x3: filter must be [Cout,Cin,3,3] with Cin % 32 == 0 and Cout % 128 == 0")
+    taps = weight.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(dtype)
+    if _lib.load().pvo_conv3x3_weight_layout() == 0:
+        return taps.contiguous()
+    # (t, cg, wn, nt, li, cc, ks, kg, j) -> (cg, cc, t, wn, nt, ks, kg, li, j)
+    f = taps.reshape(9, co // 128, 2, 2, 32, ci // 32, 2, 2, 8).permute(1, 5, 0, 2, 3, 6, 7, 4, 8)
+    return f.contiguous().view(9, co, ci)
 
 
 def _out_slice(out, out_offset, E, Cout, H, W, dtype, dev):

@@ -267,7 +267,8 @@ class FactorGraph:
                 eta_rows = torch.ones(len(rows_l), ht, wd, dtype=eta.dtype, device=self.device)
                 eta_rows[row_of_src] = eta
                 sharded.ba(self.video.poses, self.video.disps, self.video.intrinsics[0], target, weight, eta_rows,
-                           self.ii.contiguous(), self.jj.contiguous(), 1, t, itrs=itrs, lm=1e-5, ep=1e-2)
+                           self.ii.contiguous(), self.jj.contiguous(), 1, t, itrs=itrs, lm=1e-5, ep=1e-2,
+                           plan_key=(id(self), self._version, t))
                 self.video.disps.clamp_(min=0.001)                   # DepthVideo.ba's clamp (depth_video.py:214)
             self.video.dirty[:t] = True
 
@@ -394,7 +395,7 @@ class FactorGraph:
                 torch.empty(need + (need >> 2), dtype=torch.uint8, device=self.device)
             n6 = 6 * P
             sysb = st["sys"] if st is not None and st["sys"].numel() >= n6 * n6 + n6 else \
-                torch.empty(max(n6 * n6 + n6, 1), dtype=torch.float64, device=self.device)
+                torch.empty(max(n6 * n6 + n6, 1), dtype=torch.int64, device=self.device)
             db.ba_plan(ii, jj, F, ht * wd, -1 if motion_only else int(R), t0, t1, ws)
             st = self.__dict__["_ba_state"] = {"key": key, "ws": ws, "sys": sysb, "ii": ii, "jj": jj}
         return st

@@ -200,7 +200,9 @@ class DynamicUpdateModule(nn.Module):
         if hit is not None and hit[0] == key and hit[1] is not None:
             return hit[1]
         f32 = lambda t: t.detach().float().contiguous()
-        taps = lambda w: db.conv3x3_weights(w, dt)
+        taps = lambda w: db.conv3x3_weights(w, dt)             # wide-layer kernel (fragment order)
+        taps128 = lambda w: db.conv3x3_c128_weights(w, dt)     # 128-input kernel (tap-major)
+        e128 = taps if _CONV128_WIDE else taps128              # corr_encoder[2] / agg.conv1 run on either
         g = self.gru
         wzr = torch.cat([g.convz.weight, g.convr.weight], 0).detach()
         wq = g.convq.weight.detach()
@@ -212,9 +214,9 @@ class DynamicUpdateModule(nn.Module):
         bconv = torch.cat([g.convz.bias, g.convr.bias, g.convq.bias], 0).detach().float()
         t = {
             "enc0_w": db.corr_encoder_weights(self.corr_encoder[0].weight, dt), "enc0_b": f32(self.corr_encoder[0].bias),
-            "cenc2_w": taps(self.corr_encoder[2].weight), "cenc2_b": f32(self.corr_encoder[2].bias),
+            "cenc2_w": e128(self.corr_encoder[2].weight), "cenc2_b": f32(self.corr_encoder[2].bias),
             "fenc0_w": db.conv7x7_c8_weights(self.flow_encoder[0].weight, dt), "fenc0_b": f32(self.flow_encoder[0].bias),
-            "fenc2_w": taps(self.flow_encoder[2].weight), "fenc2_b": f32(self.flow_encoder[2].bias),
+            "fenc2_w": taps128(self.flow_encoder[2].weight), "fenc2_b": f32(self.flow_encoder[2].bias),
             "glo_w": g.w.weight.detach().reshape(128, 128).to(dt).contiguous(), "glo_b": f32(g.w.bias),
             # g = Wg glo + bg + [bz | br | bq]: the z/r/q convolution biases are per-channel constants too
             "gate_wt": wg.float().t().contiguous(), "gate_b": (bg + bconv).contiguous(),
@@ -224,8 +226,8 @@ class DynamicUpdateModule(nn.Module):
             # [head][out][tap = ky*3+kx][channel]
             "heads2_w": torch.stack([h[2].weight.detach().permute(0, 2, 3, 1).reshape(2, 9, 128) for h in hs]).to(dt).contiguous(),
             "heads2_b": torch.cat([f32(h[2].bias) for h in hs]).contiguous(),
-            "agg1_w": taps(self.agg.conv1.weight), "agg1_b": f32(self.agg.conv1.bias),
-            "agg2_w": taps(self.agg.conv2.weight), "agg2_b": f32(self.agg.conv2.bias),
+            "agg1_w": e128(self.agg.conv1.weight), "agg1_b": f32(self.agg.conv1.bias),
+            "agg2_w": taps128(self.agg.conv2.weight), "agg2_b": f32(self.agg.conv2.bias),
             "eta_w": self.agg.eta[0].weight.detach().permute(0, 2, 3, 1).reshape(9, 128).to(dt).contiguous(),
             "eta_b": f32(self.agg.eta[0].bias),
             "up_w": self.agg.upmask_disp[0].weight.detach().reshape(576, 128).to(dt).contiguous(),

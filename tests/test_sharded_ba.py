@@ -117,7 +117,7 @@ def test_hip_split_entry_points_two_shards_equal_whole_graph(cuda):
                   weight=d(s["weight"][m].contiguous()), eta=d(s["eta"][rows].contiguous()),
                   poses=d(s["poses"].clone()), disps=d(s["disps"].clone()))
         sh["ws"] = db.ba_workspace(sh["ii"].shape[0], P, F, ht * wd, cuda)
-        sh["sys"] = torch.zeros((6 * P) ** 2 + 6 * P, dtype=torch.float64, device=cuda)
+        sh["sys"] = torch.zeros((6 * P) ** 2 + 6 * P, dtype=torch.int64, device=cuda)      # fixed point: integer sums
         db.ba_plan(sh["ii"], sh["jj"], F, ht * wd, sh["eta"].shape[0], s["t0"], s["t1"], sh["ws"])
         shards.append(sh)
     for _ in range(2):
@@ -126,8 +126,27 @@ def test_hip_split_entry_points_two_shards_equal_whole_graph(cuda):
                         s["t0"], s["t1"], False, sh["sys"], sh["ws"])
         total = shards[0]["sys"] + shards[1]["sys"]                        # what the RCCL all-reduce produces
         for sh in shards:
-            db.ba_finish(sh["poses"], sh["disps"], total, sh["ii"], sh["jj"], s["t0"], s["t1"], 1e-4, 0.1, False, sh["ws"])
+            db.ba_finish(sh["poses"], sh["disps"], total.clone(), sh["ii"], sh["jj"], s["t0"], s["t1"], 1e-4, 0.1, False, sh["ws"])
+            sh["sys"].zero_()                                                # (finish zeroes the buffer IT was given)
     assert torch.equal(shards[0]["poses"], shards[1]["poses"])            # replicas bit-identical
-    assert (shards[0]["poses"] - poses_w).abs().max() < 2e-5
+    # ... and, the system being an integer sum, bit-identical to the whole graph on one GPU
+    assert torch.equal(shards[0]["poses"], poses_w)
     merged = s["disps"].clone().to(cuda) + sum(sh["disps"] - d(s["disps"]) for sh in shards)
-    assert (merged - disps_w).abs().max() < 2e-5
+    assert (merged - disps_w).abs().max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_ba_is_bitwise_reproducible(cuda):
+    """the pose system is accumulated with integer (fixed-point) atomics: repeated runs give identical bits"""
+    from pvo_amd import droid_backends as db
+    from test_geom_ba_gpu import _scene
+    s = _scene(7, 8, 48, 64, 3, 1)
+    d = lambda t: t.to(cuda)
+    outs = []
+    for _ in range(4):
+        poses, disps = d(s["poses"].clone()), d(s["disps"].clone())
+        db.ba(poses, disps, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]),
+              s["t0"], s["t1"], 2, 1e-4, 0.1, False)
+        outs.append((poses.clone(), disps.clone()))
+    for p, q in outs[1:]:
+        assert torch.equal(p, outs[0][0]) and torch.equal(q, outs[0][1])
