@@ -37,18 +37,18 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 
 
-def make_window(device, seed=0):
-    """S-B synthetic window."""
+def make_window(device, seed=0, H8=H8, W8=W8, NKF=NKF, buffer=16, corr_impl="volume", intr=(40.0, 40.0, 32.0, 24.0)):
+    """synthetic keyframe window: S-B by default (8 keyframes, 48x64 maps, edges |i-j| <= 3)"""
     from pvo_amd.depth_video import DepthVideo
     from pvo_amd.factor_graph import FactorGraph
     from pvo_amd.geom.se3 import SE3
     from pvo_amd.modules.update import DynamicUpdateModule
     g = torch.Generator().manual_seed(seed)
-    video = DepthVideo(image_size=(H8 * 8, W8 * 8), buffer=16, device=device)
+    video = DepthVideo(image_size=(H8 * 8, W8 * 8), buffer=buffer, device=device)
     xi = torch.tensor([0.05, 0.0, 0.02, 0.0, 0.01, 0.0])
     low = torch.rand(1, 1, 6, 8, generator=g) * 0.8 + 0.2
     disp_gt = torch.nn.functional.interpolate(low, size=(H8, W8), mode="bilinear", align_corners=True)[0, 0]
-    intr = torch.tensor([40.0, 40.0, 32.0, 24.0])
+    intr = torch.tensor(intr)
     for k in range(NKF):
         video.append(float(k), SE3.exp(max(k - 1, 0) * xi).data.to(device), torch.ones(H8, W8, device=device),
                      intr.to(device), torch.randn(H8, W8, 128, generator=g).half().to(device),
@@ -57,12 +57,15 @@ def make_window(device, seed=0):
     video.disps[:NKF] = 1.0
     torch.manual_seed(seed)
     update = DynamicUpdateModule().to(device).eval().half()   # fp16 inference weights (the reference runs this module under fp16 autocast)
-    graph = FactorGraph(video, update, device=device, max_factors=48)
+    graph = FactorGraph(video, update, device=device, max_factors=48 if corr_impl == "volume" else -1, corr_impl=corr_impl)
+    graph.nkf = NKF
+    if corr_impl != "volume":
+        return video, graph
     graph.add_neighborhood_factors(0, NKF, r=RADIUS)
     # targets = ground-truth reprojection + noise, so BA has a well-posed problem
     gt_poses = torch.stack([SE3.exp(k * xi).data for k in range(NKF)]).to(device)
     from pvo_amd import droid_backends as db
-    c, _ = db.reproject(torch.cat([gt_poses, video.poses[NKF:]]), disp_gt[None].repeat(16, 1, 1).to(device).contiguous(),
+    c, _ = db.reproject(torch.cat([gt_poses, video.poses[NKF:]]), disp_gt[None].repeat(buffer, 1, 1).to(device).contiguous(),
                         video.intrinsics, graph.ii, graph.jj)
     graph.target_cam = (c + 0.1 * torch.randn(c.shape, generator=g).to(device))[None]
     graph.weight = torch.rand(graph.target_cam.shape, generator=g).to(device)
@@ -87,7 +90,7 @@ class Snapshot:
 def keyframe_update(video, graph, snap):
     """droid_frontend.py:36-70 on a full window"""
     snap.restore()
-    newest = NKF - 1
+    newest = graph.nkf - 1
     pairs = [(i, j) for i, j in zip(graph._ii_h, graph._jj_h) if i == newest or j == newest]
     graph.rm_factors([(i == newest or j == newest) for i, j in zip(graph._ii_h, graph._jj_h)])
     graph.add_factors([p[0] for p in pairs], [p[1] for p in pairs])
@@ -233,12 +236,177 @@ def synthetic_ate(device):
             "sequence": "synthetic plane scene, 24x32 maps, 14 frames, ground-truth correspondences + 0.05 px noise in place of the learned operator"}
 
 
+def timed_steps(video, graph, snap, steps, world, probe_stage="lookup", updates_per_step=6):
+    """K keyframe updates bracketed as the driver's contract asks: barrier + synchronize on both sides, max over ranks"""
+    from pvo_amd import droid_backends as db
+    if probe_stage:
+        db.probe_arm(probe_stage, steps * updates_per_step)      # HIP events around one kernel, on its stream, in the timed steps
+    host_issue = []
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        th = time.perf_counter()
+        keyframe_update(video, graph, snap)
+        host_issue.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=graph.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    in_step = db.probe_read(steps * updates_per_step) if probe_stage else []
+    return elapsed, host_issue, in_step
+
+
+def prime(video, graph, snap, max_blocks=40):
+    """untimed priming until the step time has converged (clocks, caches, allocator): blocks of 8 steps until two
+    consecutive blocks are within 3 % of the best seen"""
+    best, calm, blocks = None, 0, 0
+    while calm < 2 and blocks < max_blocks:
+        torch.cuda.synchronize(); tb = time.perf_counter()
+        for _ in range(8):
+            keyframe_update(video, graph, snap)
+        torch.cuda.synchronize(); blk = time.perf_counter() - tb
+        calm = calm + 1 if (best is not None and blk < 1.03 * best) else 0
+        best = blk if best is None else min(best, blk)
+        blocks += 1
+    return blocks
+
+
+def lookup_roofline(E, HW, in_step_ms, traffic=None):
+    in_us = sorted(1e3 * v for v in in_step_ms)
+    us = sum(in_us) / max(len(in_us), 1)
+    alg = E * HW * (4 * 64 * 2 + 8 + 128 * 2)      # SURVEY 8d: taps + coords + (encoded) output, fp16
+    ach = alg / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    return {"kernel": "corr_lookup_r3_kernel<half, tiled, enc> (4-level lookup + 196->128 encoder layer, 8x8-tiled resident volumes)",
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": len(in_us),
+            "timing": "HIP events around the kernel on its launch stream, inside the timed steps",
+            "in_step_us_min_median_max": [in_us[0], in_us[len(in_us) // 2], in_us[-1]] if in_us else None}
+
+
+def workload_sa(device, steps):
+    """S-A: the map shape of the reference's own driver - test_vo.py resizes VKITTI2 frames to 240 x 808, i.e.
+    30 x 101 maps (evaluation_scripts/test_vo.py:19,64) - with a 10-keyframe window and the frontend's 48-edge budget
+    (|i-j| <= 3: 48 edges).  Same step as S-B; reported next to it, not as `value`."""
+    video, graph = make_window(device, seed=1, H8=30, W8=101, NKF=10, intr=(90.0, 90.0, 50.5, 15.0))
+    if not graph._fused_ok():
+        return {"error": "native update path not active at 30x101"}
+    snap = Snapshot(video, graph)
+    snap.edge_list = list(zip(graph._ii_h, graph._jj_h))
+    prime(video, graph, snap, max_blocks=6)
+    elapsed, host_issue, in_step = timed_steps(video, graph, snap, steps, 1)
+    E = len(graph._ii_h)
+    return {"workload": "S-A: 30x101 maps (test_vo.py's 240x808 input), 10 keyframes, E=%d, itrs=2, synthetic" % E,
+            "value": steps / elapsed, "unit": "keyframe updates/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "graph_updates_per_s": steps * 6 / elapsed, "roofline": lookup_roofline(E, 30 * 101, in_step)}
+
+
+def edge_sharded_leg(device, rank, world, steps=3):
+    """BASELINE.json configs[3] / north star "partition the factor graph across GPUs with RCCL all-reduce of the pose-block
+    Hessian": a 64-keyframe global update (droid_backend.py:25-41 -> FactorGraph.update_lowmem) whose edges are sharded BY
+    SOURCE KEYFRAME over the ranks (pvo_amd/parallel.py).  Per Gauss-Newton step ONE collective: all-reduce (integer sum)
+    of the reduced pose system; lookup (alt-corr), update operator, damping and depth updates are rank-local.  Strong
+    scaling: the same graph at every N.  Reports global updates/s, the BA-only time, the all-reduce latency and a bitwise
+    cross-rank check of the poses."""
+    import torch.distributed as dist
+    from pvo_amd.parallel import ShardedBA, shard_edges
+    nkf, H, W = 64, H8, W8
+    video, graph = make_window(device, seed=7, NKF=nkf, buffer=80, corr_impl="alt")
+    video.counter = nkf
+    ii = [i for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= RADIUS]
+    jj = [j for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= RADIUS]
+    ii_l, jj_l, _ = shard_edges(ii, jj, world, rank)
+    graph.add_factors(ii_l, jj_l)
+    g = torch.Generator().manual_seed(3)
+    graph.target_cam = graph.target_cam + 0.5 * torch.randn(graph.target_cam.shape, generator=g).to(device)
+    graph.weight = torch.rand(graph.weight.shape, generator=g).to(device)
+    sharded = ShardedBA()
+    if not ii_l:
+        raise RuntimeError("rank %d owns no edges" % rank)
+    poses0, disps0 = video.poses.clone(), video.disps.clone()
+    net0, tgt0, w0 = graph.net.clone(), graph.target_cam.clone(), graph.weight.clone()
+
+    def reset():
+        video.poses.copy_(poses0); video.disps.copy_(disps0)
+        graph.net, graph.target_cam, graph.weight = net0.clone(), tgt0.clone(), w0.clone()
+        graph.raw_mask.zero_(); graph.delta_dy.zero_()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    graph.update_lowmem(steps=1, sharded=sharded)                 # warm-up
+    reset(); sync()
+    t0 = time.perf_counter()
+    graph.update_lowmem(steps=steps, sharded=sharded)
+    sync()
+    el = time.perf_counter() - t0
+    # BA only: the same sharded BA on the final state, 10 calls of 2 Gauss-Newton steps
+    ht, wd = H, W
+    src = sorted(set(graph._ii_h))
+    rows = sorted(set(range(1, nkf)) | set(src))
+    eta = torch.full((len(rows), ht, wd), 1e-4, device=device)
+    target = graph.target_cam.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+    weight = graph.weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
+    bi, bj = graph.ii.contiguous(), graph.jj.contiguous()
+    ba = lambda: sharded.ba(video.poses, video.disps, video.intrinsics[0], target, weight, eta, bi, bj, 1, nkf, itrs=2,
+                            lm=1e-5, ep=1e-2, plan_key=("bench", rank))
+    ba(); sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ba()
+    sync()
+    ba_ms = (time.perf_counter() - t0) / 10 * 1e3
+    # the collective alone: the [(6P)^2 + 6P] int64 system, 50 all-reduces
+    P = nkf - 1
+    msg = torch.zeros((6 * P) ** 2 + 6 * P, dtype=torch.int64, device=device)
+    ar_us = None
+    if world > 1:
+        for _ in range(5):
+            dist.all_reduce(msg)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(msg)
+        torch.cuda.synchronize()
+        ar_us = (time.perf_counter() - t0) / 50 * 1e6
+    # every rank must hold bit-identical poses
+    same = True
+    if world > 1:
+        ref = video.poses.clone()
+        dist.broadcast(ref, 0)
+        flag = torch.tensor([1 if torch.equal(ref, video.poses) else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        same = bool(flag.item())
+    out = {"workload": "S-20: 64 keyframes, 48x64 maps, %d edges (|i-j| <= 3) sharded by source keyframe, global update "
+                       "(alt-corr lookup + update operator + BA x2), strong scaling" % len(ii),
+           "global_updates_per_s": steps / el, "ms_per_global_update": el / steps * 1e3, "edges_this_rank": len(ii_l),
+           "ba_2_steps_ms": ba_ms, "allreduce_us": ar_us, "allreduce_bytes": int(msg.numel() * 8),
+           "backend": dist.get_backend() if world > 1 else None, "world_size": world, "poses_bitwise_equal_across_ranks": same}
+    if world > 1:
+        tt = torch.tensor([el, ba_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out["global_updates_per_s"] = steps / float(tt[0].item()); out["ms_per_global_update"] = float(tt[0].item()) / steps * 1e3
+        out["ba_2_steps_ms"] = float(tt[1].item())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the S-A workload and the edge-sharded leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -246,13 +414,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    local = local % max(torch.cuda.device_count(), 1)      # (a 2-process dry run on a 1-GPU box shares device 0)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # N host processes share the cores
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("PVO_BENCH_BACKEND", "nccl")              # "nccl" is RCCL on ROCm; "gloo" for the dry run above
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from pvo_amd import _lib
     from pvo_amd import droid_backends as db
@@ -263,42 +436,13 @@ def main():
     snap = Snapshot(video, graph)
     snap.edge_list = list(zip(graph._ii_h, graph._jj_h))
 
-    # Untimed priming until the step time has converged (clocks, caches, allocator): blocks of 8 steps until two
-    # consecutive blocks are within 3 % of the best seen, at most 40 blocks.  (No library needs a solver search any
-    # more: every kernel of the step is in libpvo_hip.)
-    best, calm, blocks = None, 0, 0
-    while calm < 2 and blocks < 40:
-        torch.cuda.synchronize(); tb = time.perf_counter()
-        for _ in range(8):
-            keyframe_update(video, graph, snap)
-        torch.cuda.synchronize(); blk = time.perf_counter() - tb
-        calm = calm + 1 if (best is not None and blk < 1.03 * best) else 0
-        best = blk if best is None else min(best, blk)
-        blocks += 1
+    # Untimed priming until the step time has converged (no library needs a solver search any more: every kernel of the
+    # step is in libpvo_hip), then W warm-up steps, then exactly K timed steps.
+    blocks = prime(video, graph, snap)
     for _ in range(args.warmup):
         keyframe_update(video, graph, snap)
     updates_per_step = 6
-    db.probe_arm("lookup", args.steps * updates_per_step)      # HIP events around the lookup kernel, on its stream, in the timed steps
-    host_issue = []
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        th = time.perf_counter()
-        keyframe_update(video, graph, snap)
-        host_issue.append(time.perf_counter() - th)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    in_step_lookup = db.probe_read(args.steps * updates_per_step)
+    elapsed, host_issue, in_step_lookup = timed_steps(video, graph, snap, args.steps, world)
 
     # per-stage durations inside the step, from a few extra untimed steps (one probe at a time)
     stage_us = {}
@@ -359,10 +503,6 @@ def main():
 
     if rank == 0:
         E, HW = len(graph._ii_h), H8 * W8
-        in_us = sorted(1e3 * v for v in in_step_lookup)
-        lookup_us = sum(in_us) / max(len(in_us), 1)          # the roofline is priced on the kernel as the timed steps ran it
-        alg_bytes = E * HW * (4 * 64 * 2 + 8 + 128 * 2)      # taps + coords + (encoded) output, fp16
-        achieved = alg_bytes / (lookup_us * 1e-6) / 1e9 if lookup_us > 0 else 0.0
         traffic = None
         for name in ("r02_lookup_pmc.json", "r01_lookup_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
@@ -384,22 +524,31 @@ def main():
             "graph_updates_per_s": world * args.steps * updates_per_step / elapsed,
             "host": {"issue_ms_per_step_median": 1e3 * hi[len(hi) // 2], "issue_ms_per_step_max": 1e3 * hi[-1],
                      "priming_blocks_of_8_steps": blocks},
-            "roofline": {"kernel": "corr_lookup_r3_kernel<half, tiled, enc> (4-level lookup + 196->128 encoder layer, 8x8-tiled resident volumes)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": lookup_us, "launches_timed": len(in_us),
-                         "timing": "HIP events around the kernel on its launch stream, inside the %d timed steps" % args.steps,
-                         "in_step_us_min_median_max": [in_us[0], in_us[len(in_us) // 2], in_us[-1]] if in_us else None,
-                         "isolated_cold_us": lookup_cold_us, "isolated_cold": "Infinity Cache evicted by a 600 MB read before each of 20 launches",
-                         "warm_back_to_back_us": lookup_b2b_us},
+            "roofline": dict(lookup_roofline(E, HW, in_step_lookup, traffic), isolated_cold_us=lookup_cold_us,
+                             isolated_cold="Infinity Cache evicted by a 600 MB read before each of 20 launches",
+                             warm_back_to_back_us=lookup_b2b_us),
             "roofline_wide_conv": {
                 "kernel": "conv3x3_big_kernel<half> as pvo_gru_conv_gates (3x3 convolution 320 -> 256 on v_mfma_f32_32x32x16_f16 + sigmoid gates)",
                 "bound": "mfma", "achieved": gates_flop / (gates_us * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": gates_flop / (gates_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, "flop_per_launch": gates_flop,
                 "avg_launch_us": gates_us, "launches_timed": 20, "in_step_us": stage_us["gates"],
                 "share_of_update_time": stage_us["gates"] / stage_us["update"] if stage_us["update"] else None},
-            "stage_us_in_step": dict(stage_us, lookup=lookup_us),
+            "stage_us_in_step": dict(stage_us, lookup=1e3 * sum(in_step_lookup) / max(len(in_step_lookup), 1)),
         }
+    # second workload and the edge-sharded mode: reported beside the headline, never part of `value`
+    extra = {}
+    if not args.no_extras:
+        if world == 1:
+            try:
+                extra["workload_S_A"] = workload_sa(device, max(10, args.steps // 2))
+            except Exception as e:      # a failure here must not cost the headline line
+                extra["workload_S_A"] = {"error": repr(e)}
+        try:
+            extra["edge_sharded"] = edge_sharded_leg(device, rank, world)
+        except Exception as e:
+            extra["edge_sharded"] = {"error": repr(e)}
+    if rank == 0:
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["ate_rmse"] = synthetic_ate(device)

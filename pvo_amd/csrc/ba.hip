@@ -51,7 +51,7 @@ __device__ __forceinline__ void fix_add(long long* sys, long long idx, double v,
 }
 constexpr int kPPT = 2;                 // pixels per thread in assemble
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
-constexpr int kLdsCholMax = 138;        // (6P) up to which the fp64 system lives in LDS (138*139*8 + 23*21*8 + 208 = 157.5 KB < 160 KB)
+constexpr int kLdsCholMax = 132;        // (6P) up to which the fp64 system lives in LDS (132*133*8 + 22*27*8 + 208 = 145.4 KB, + the 8 KB envelope table < 160 KB)
 
 struct Plan {            // int region of the workspace
   int* kidx;             // [F]   frame -> depth index, -1 if none
@@ -594,7 +594,13 @@ __device__ __forceinline__ bool chol6(const double D[21], double L[21], double r
   return ok;
 }
 
-__device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, int* fail_flag) {
+// ENVELOPE (skyline) form: first[ib] = first block column of block row ib that holds a non-zero.  Cholesky creates no
+// fill outside the envelope, so every panel / trailing-update / back-substitution term that lies outside it is an exact
+// zero and is skipped - same bits as the dense factorisation, O(P * band^2) block operations instead of O(P^3).  The
+// reduced pose system of a keyframe graph is block-banded up to its loop closures (two poses couple only through a depth
+// frame both observe): at 63 free poses and temporal radius 3 the envelope holds 12 % of the matrix.  (The reference
+// uses a sparse LLT for the same reason, droid_kernels.cu:1178-1184.)
+__device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, int* fail_flag, const int* first) {
   // A: (n+1) x n row-major, row n = rhs.  On return row n holds the solution x.
   const int tid = threadIdx.x, nt = blockDim.x;
   const int tx = tid & 15, ty = tid >> 4, nty = nt >> 4;
@@ -614,8 +620,9 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
 #pragma unroll
       for (int q = 0; q < 6; ++q) Ld[kb * 27 + 21 + q] = rd[q];
     }
-    // (b) panel rows j0+6 .. n (inclusive: the rhs row)
+    // (b) panel rows j0+6 .. n (inclusive: the rhs row), those whose envelope reaches this block column
     for (int i = j0 + 6 + tid; i <= n; i += nt) {
+      if (i < n && first[i / 6] > kb) continue;
       double x[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
@@ -630,11 +637,13 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
     __syncthreads();
     // (c) trailing update, rows i in (j0+6 .. n], columns c in (j0+6 .. min(i, n-1)]
     for (int i = j0 + 6 + ty; i <= n; i += nty) {
+      if (i < n && first[i / 6] > kb) continue;
       double li[6];
 #pragma unroll
       for (int t = 0; t < 6; ++t) li[t] = A[i * n + j0 + t];
       const int cmax = (i < n) ? i : n - 1;
       for (int c = j0 + 6 + tx; c <= cmax; c += 16) {
+        if (first[c / 6] > kb) continue;
         double acc = A[i * n + c];
 #pragma unroll
         for (int t = 0; t < 6; ++t) acc -= li[t] * A[c * n + j0 + t];
@@ -663,7 +672,7 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
     }
     __syncthreads();                                         // everyone has read y[j0..j0+6) before it is overwritten
     if (tid < 6) y[j0 + tid] = x[tid];
-    for (int i = tid; i < j0; i += nt) {
+    for (int i = 6 * first[kb] + tid; i < j0; i += nt) {     // row block kb of L is zero left of its envelope
       double v = y[i];
 #pragma unroll
       for (int c = 0; c < 6; ++c) v -= A[(j0 + c) * n + i] * x[c];
@@ -672,6 +681,8 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
     __syncthreads();
   }
 }
+
+constexpr int kMaxEnvBlocks = 2048;      // poses the envelope table covers (beyond: dense, first = 0)
 
 __global__ __launch_bounds__(256) void ba_solve_kernel(
     long long* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
@@ -684,18 +695,23 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   double* b = A + static_cast<long long>(n) * n;
   double* Ld = b + n;                                                            // [P][21 + 6] factored diagonal blocks + reciprocal diagonals
   double* red = Ld + 27 * P;                                                     // [4][6] wave partials
+  __shared__ int first[kMaxEnvBlocks];                                           // envelope: first non-zero block column per block row
   if (threadIdx.x == 0) fail = 0;
+  for (int b = threadIdx.x; b < P; b += blockDim.x) first[b] = b;
+  __syncthreads();
   for (int idx = threadIdx.x; idx < n * n + n; idx += blockDim.x) {
-    double v = static_cast<double>(sys[idx]) * kInvFix;       // fixed point -> fp64
+    const long long raw = sys[idx];
+    double v = static_cast<double>(raw) * kInvFix;            // fixed point -> fp64
     sys[idx] = 0;                                             // ready for the next Gauss-Newton step's accumulation
     if (idx < n * n) {
       const int r = idx / n, c = idx - r * n;
       if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
+      if (raw != 0 && c < r) atomicMin(&first[r / 6], c / 6);
     }
     A[idx] = v;
   }
   __syncthreads();
-  chol_solve_blocked(A, Ld, red, n, &fail);
+  chol_solve_blocked(A, Ld, red, n, &fail, first);
   __syncthreads();
   const int failed = fail | meta[4];
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
@@ -830,6 +846,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
   const int P = t1 - t0, HW = ht * wd;
   long long* sys = static_cast<long long*>(sys_);
   if (!poses || !disps || !sys || !workspace) return PVO_EINVAL;
+  if (P > kMaxEnvBlocks) return PVO_EUNSUPPORTED;           // (a 12288^2 fp64 system: 1.2 GB)
   if (workspace_bytes < pvo_ba_workspace_bytes(E, P, nframes, HW)) return PVO_EWORKSPACE;
   Ws w = carve(ws_base(workspace), E, P, nframes, HW);
   hipStream_t st = pvo_stream(stream);
@@ -838,7 +855,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
   const size_t lds = 16 + (use_lds ? sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : 0);
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024 - 64) != hipSuccess) return PVO_ELAUNCH;
+                            160 * 1024 - 8192 - 64) != hipSuccess) return PVO_ELAUNCH;
   }
   hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
                      w.plan.meta, status_out, P, t0, lm, ep, use_lds);

@@ -70,6 +70,32 @@ def test_ba_matches_oracle(cuda, cfg, iters):
     assert np.abs(dz - want["dz"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("P,closure", [(30, False), (30, True), (23, True)])
+def test_ba_long_window_envelope_cholesky_matches_oracle(cuda, P, closure):
+    """A long keyframe chain (block-banded reduced pose system; with `closure` two loop-closure edges that create fill
+    inside the envelope): the envelope-form Cholesky of ba_solve_kernel - the LDS path at P = 23 (22 free poses), the
+    global-memory path at P = 30 - against the oracle's dense fp64 solve"""
+    ht, wd = 8, 10
+    s = _scene(P * 7 + int(closure), P, ht, wd, 2, 1)
+    if closure:
+        from pvo_amd.geom.se3 import SE3
+        extra_i, extra_j = torch.tensor([1, P - 2, 3, P - 5]), torch.tensor([P - 2, 1, P - 5, 3])
+        ii, jj = torch.cat([s["ii"], extra_i]), torch.cat([s["jj"], extra_j])
+        F = P
+        c, _ = O.reproject(s["poses_gt"].numpy(), s["disps_gt"].numpy(), s["intr"][None].repeat(F, 1).numpy(), extra_i.numpy(), extra_j.numpy())
+        g = torch.Generator().manual_seed(5)
+        t_extra = (torch.from_numpy(c) + 0.1 * torch.randn(4, ht, wd, 2, generator=g)).permute(0, 3, 1, 2)
+        s = dict(s, ii=ii, jj=jj, target=torch.cat([s["target"], t_extra]).contiguous(),
+                 weight=torch.cat([s["weight"], 0.2 * torch.rand(4, 2, ht, wd, generator=g)]).contiguous())
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
+    assert status[0] == 0 and status[1] == want["K"]
+    assert np.abs(poses - want["poses"]).max() < 1e-4
+    assert np.abs(disps - want["disps"]).max() < 1e-4
+    assert np.abs(dx - want["dx"]).max() < 1e-4
+
+
 def test_ba_matches_reference_python_fixture_poses(cuda):
     """Poses after a native BA step equal the reference geom/ba.py result (the pose update is
     unaffected by EvT6x1's pose-0 skip); fixtures generated from /root/reference."""
