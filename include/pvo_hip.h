@@ -169,9 +169,7 @@ int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* bias, void*
 /* the same for wide layers (implicit GEMM, 16x16 pixel tile x 128 outputs per workgroup): Cin % 32 == 0, Cout % 128 == 0.
  * The filter is read in MFMA-fragment order, [Cout/128][Cin/32 chunks][9 taps][2][2][2][64 lanes][8]: element
  * (cg, cc, t, wn, nt, ks, lane, j) = W[tap t][output cg*128 + wn*64 + nt*32 + (lane & 31)][input cc*32 + ks*16 + (lane >> 5)*8 + j]
- * (one coalesced 1 KB load per fragment, no LDS staging of the filter).  pvo_conv3x3_weight_layout() returns 1 for this
- * layout, 0 when the process runs the tap-major variant [9][Cout][Cin] (environment PVO_WIDE_TAPMAJOR=1, for A/B runs). */
-int pvo_conv3x3_weight_layout(void);
+ * (one coalesced 1 KB load per fragment, no LDS staging of the filter). */
 int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
                 int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream);
 /* The ConvGRU's two large convolutions with the gate arithmetic as their epilogue (modules/gru.py:26-31); the 256 gate
@@ -250,7 +248,8 @@ int pvo_graph_post(const float* coords1, const void* heads, float* raw_mask, flo
 
 enum {
   PVO_OP_CONV128_WIDE = 1,   /* corr_encoder[2] / GraphAgg.conv1 on pvo_conv3x3 instead of pvo_conv3x3_c128 */
-  PVO_OP_SINGLE_STREAM = 2   /* no second stream for the aggregation branch */
+  PVO_OP_SINGLE_STREAM = 2,  /* no second stream at all */
+  PVO_OP_ENC_SIDE_STREAM = 4 /* flow encoder + global context on the second stream beside the lookup and corr_encoder[2] */
 };
 
 /* Device pointers to the update operator's parameters, re-arranged once by the host (pvo_amd/modules/update.py

@@ -29,7 +29,6 @@ SIGNATURES = {
     "pvo_gate_context": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "pvo_gru_conv_gates": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_gru_conv_candidate": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_conv3x3_weight_layout": (_i, []),
     "pvo_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv3x3_c128": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv7x7_c8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -95,7 +94,7 @@ class GraphUpdateArgs(_c.Structure):
                 ("want_upmask", _i)]
 
 
-PVO_OP_CONV128_WIDE, PVO_OP_SINGLE_STREAM = 1, 2
+PVO_OP_CONV128_WIDE, PVO_OP_SINGLE_STREAM, PVO_OP_ENC_SIDE_STREAM = 1, 2, 4
 
 _lib = None
 

@@ -324,16 +324,19 @@ __global__ __launch_bounds__(256) void conv3x3_c128_kernel(const uint16_t* __res
 
 // ---------------------------------------------------------------------------
 // pvo_conv3x3: y = act(conv3x3(x, w) + bias) for wide layers, x [E,H,W,Cin] -> y [E,H,W,Cout], Cin % 32 == 0,
-// Cout % 128 == 0 - the GRU gate / candidate convolutions (320 -> 256, 320 -> 128) and the heads' first stage
-// (128 -> 512), which MIOpen/CK run at 0.69-0.74 PFLOP/s.
+// Cout % 128 == 0 - the GRU gate / candidate convolutions (320 -> 256, 320 -> 128), the heads' first stage (128 -> 512),
+// corr_encoder[2], GraphAgg.conv1 and the static-input terms (MIOpen/CK ran these at 0.69-0.74 PFLOP/s).
 //   Implicit GEMM on v_mfma_f32_32x32x16: workgroup = 16x16 pixel tile (M = 256) x 128 output channels, 4 waves as 2 x 2,
-//   each wave 128 pixels x 64 channels = 8 accumulator tiles (128 AGPRs).  K runs over (32-channel chunk, tap): the
-//   chunk's 18x18 halo (20.7 KB, 80-byte pixel stride) and the (chunk, tap) filter slab (128 x 32, 80-byte row stride) sit
-//   in LDS, both double buffered; the next slab (and, at the last tap, the next halo chunk) travels global -> registers
-//   while the current step's 16 MFMAs per wave run, then registers -> the idle LDS buffer, one barrier per step.
-//   Per step a wave reads 12 KB of fragments for 16 MFMAs: ~94 B/clk per CU at full matrix rate, under the LDS limit;
-//   every filter byte is fetched once per 256 pixels (the 8x16-tile kernel above re-fetched it per 128 and stalled there).
-//   Filters arrive as [9 taps][Cout][Cin] 16-bit.
+//   each wave 128 pixels (8 rows x 16 columns) x 64 channels = 8 accumulator tiles.  K runs over (32-channel chunk, tap).
+//   A: the chunk's 18x18 halo sits in LDS (80-byte position stride, 20-position row pitch), double buffered, staged once
+//      per chunk and shared by its 9 taps; one barrier per CHUNK.  An M-tile is 8 rows x 4 columns of pixels: with the
+//      80-byte stride and the 20-position pitch every ds_read_b128 lane group hits 64 distinct banks (the 2-row x 16-column
+//      M-tile used before had SQ_LDS_BANK_CONFLICT = 47 % of SQ_LDS_IDX_ACTIVE, profiles/r02_kernel_counters.json).
+//   B: the filter arrives in MFMA-FRAGMENT order, [Cout/128][chunk][tap][wave column wn][nt][ks][lane][8] (the host
+//      arranges it once), and is streamed global -> registers: one coalesced 1 KB load per fragment, requested two
+//      steps ahead into one of three rotating register sets.  No LDS, ds_write, ds_read or barrier for the filter, and
+//      with the 9 taps unrolled every fragment address is base + immediate.  (The first version staged tap-major filter
+//      slabs through LDS with a barrier per (chunk, tap): ~160 non-MFMA instructions per 16-MFMA step, 10-14 % slower.)
 // ---------------------------------------------------------------------------
 typedef float cs_v16f __attribute__((ext_vector_type(16)));
 template <typename T> __device__ __forceinline__ cs_v16f cs_mfma32(cs_u32x4 a, cs_u32x4 b, cs_v16f c);
@@ -344,7 +347,7 @@ template <> __device__ __forceinline__ cs_v16f cs_mfma32<pvo_bf16>(cs_u32x4 a, c
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cs_v8b, a), __builtin_bit_cast(cs_v8b, b), c, 0, 0, 0);
 }
 
-// Optional fused ConvGRU epilogues (VO_Module/droid_slam/modules/gru.py:26-31) and a split input:
+// Optional fused ConvGRU epilogues (VO_Module/droid_slam/modules/gru.py:26-31) and a segmented input:
 //   mode 1 (gates, Cout = 256): channel group 0 -> y  = Z  = sigmoid(acc + g[e, c] + P[row, c])                [rows,128]
 //                               channel group 1 -> y2 = RN = sigmoid(acc + g[e,128+c] + P[row,128+c]) * net    [rows,128]
 //   mode 2 (candidate, Cout = 128):               y  = (1 - Z) * net + Z * tanh(acc + g[e,256+c] + P[row, c])  [rows,128]
@@ -364,23 +367,19 @@ struct BigEpi {
 
 constexpr int kBT = 16;                                   // 16 x 16 pixel tile
 constexpr int kBHalo = (kBT + 2) * (kBT + 2);             // 324 halo positions
-constexpr int kBStride = 80;                              // bytes per halo position / filter row of a 32-channel chunk
-constexpr int kBA = 384 * kBStride, kBB = 128 * kBStride;      // 30720 (324 halo positions + 60 dummy ones: every thread stores 6 pieces, no exec branches) + 10240 bytes per buffer
+constexpr int kBPitch = 20;                               // LDS positions per halo row (18 used)
+constexpr int kBStride = 80;                              // bytes per position of a 32-channel chunk
+constexpr int kBA = 420 * kBStride;                       // 18 x 20 positions + 60 dummy ones (every thread parks 6 pieces, no exec branches)
 
-// FRAGW: the filter arrives in MFMA-FRAGMENT order (pvo_conv3x3_fragment_weights) and is streamed global -> registers:
-//   [Cout/128][chunk][tap][wave column wn][nt][ks][lane][8] - one coalesced 1 KB load per fragment, requested two steps
-//   ahead into one of three rotating register sets.  The filter then needs no LDS, no ds_write, no ds_read and no barrier:
-//   only the halo (staged once per 32-channel chunk and shared by its 9 taps) crosses LDS, with ONE barrier per chunk
-//   instead of one per (chunk, tap) step, and with the 9 taps unrolled every fragment address is base + immediate.
-//   (The tap-major variant below spends ~160 non-MFMA instructions per 16-MFMA step on staging and addressing; the
-//   matrix pipe hides about 5 per MFMA.)
-template <typename T, bool FRAGW>
+// pixel (row, column) inside a wave's 8 x 16 block of accumulator row `m` (0..31) of M-tile `mt`
+__device__ __forceinline__ int big_pix(int mt, int m) { return (m >> 2) * 16 + 4 * mt + (m & 3); }
+
+template <typename T>
 __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                           int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, BigEpi ep) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char bs[];      // A[2] | B[2]; later the output slab
+  extern __shared__ __attribute__((aligned(16))) unsigned char bs[];      // halo[2]; later the output slab
   unsigned char* As = bs;
-  unsigned char* Bs = bs + 2 * kBA;
   const int ntx = (W + kBT - 1) / kBT;
   const int cg = blockIdx.x / ntx, tx_ = blockIdx.x - cg * ntx;
   const int e = blockIdx.z, y0 = blockIdx.y * kBT, x0 = tx_ * kBT;
@@ -390,23 +389,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   const int li = lane & 31, kg = lane >> 5;
   const int nC = Cin >> 5;                                // 32-channel chunks
   const uint16_t* xe = x + static_cast<size_t>(e) * H * W * Cin;
-  const uint16_t* wb = wt + static_cast<size_t>(cg) * 128 * Cin;
-  const size_t tap_stride = static_cast<size_t>(Cout) * Cin;
 
-  // global -> register staging: the halo chunk needed next (6 x 16 B per thread) and the filter slabs of the next TWO
-  // steps (2 x 2 x 16 B).  A slab is requested two steps before it is used and parked in LDS one step before: with a
-  // one-step distance the wave sat ~560 cycles per step in s_waitcnt vmcnt (clock64 stamps), L2 latency under load
-  // being longer than one step's 16 MFMAs.
-  cs_u32x4 ra[6], rb0[2], rb1[2];
+  // global -> register -> LDS staging of the halo chunk needed next (6 x 16 B per thread)
+  cs_u32x4 ra[6];
   int apix[6];                                            // pixel index of this thread's halo pieces inside the image, -1 = zero
+  int lpos[6];                                            // their LDS byte offsets
 #pragma unroll
   for (int it = 0; it < 6; ++it) {
     const int id = tid + 256 * it;                        // piece = (position, 16-byte quarter of the 64-byte chunk row)
     const int pos = id >> 2;
     apix[it] = -1;
+    lpos[it] = (360 + (pos - kBHalo)) * kBStride + (id & 3) * 16;      // dummy slot
     if (pos < kBHalo) {
-      const int hy = y0 - 1 + pos / (kBT + 2), hx = x0 - 1 + pos % (kBT + 2);
+      const int hr = pos / (kBT + 2), hc = pos % (kBT + 2);
+      const int hy = y0 - 1 + hr, hx = x0 - 1 + hc;
       if (hy >= 0 && hy < H && hx >= 0 && hx < W) apix[it] = hy * W + hx;
+      lpos[it] = (hr * kBPitch + hc) * kBStride + (id & 3) * 16;
     }
   }
   const size_t img = static_cast<size_t>(e) * H * W;
@@ -428,23 +426,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < 6; ++it) {
-      const int id = tid + 256 * it;
       cs_u32x4 v = ra[it];
       if (apix[it] < 0) v = cs_u32x4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<cs_u32x4*>(As + buf * kBA + (id >> 2) * kBStride + (id & 3) * 16) = v;
+      *reinterpret_cast<cs_u32x4*>(As + buf * kBA + lpos[it]) = v;
     }
-  };
-  // filter slab of step s = (chunk cc, tap t): rows n = tid >> 2 (+64), quarter q = tid & 3
-  const uint16_t* wrow = wb + static_cast<size_t>(tid >> 2) * Cin + (tid & 3) * 8;
-  auto fetch_b = [&](cs_u32x4 (&r)[2], int cc, int t) {
-    const uint16_t* p = wrow + t * tap_stride + cc * 32;
-    r[0] = *reinterpret_cast<const cs_u32x4*>(p);
-    r[1] = *reinterpret_cast<const cs_u32x4*>(p + static_cast<size_t>(64) * Cin);
-  };
-  auto store_b = [&](const cs_u32x4 (&r)[2], int buf) {
-    unsigned char* d = Bs + buf * kBB + (tid >> 2) * kBStride + (tid & 3) * 16;
-    *reinterpret_cast<cs_u32x4*>(d) = r[0];
-    *reinterpret_cast<cs_u32x4*>(d + 64 * kBStride) = r[1];
   };
 
   cs_v16f acc[4][2];
@@ -455,52 +440,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-  // this lane's A rows: M-tile mt of wave-row wm covers tile rows 8*wm + 2*mt + (li >> 4), column li & 15
-  const int arow = 8 * wm + (li >> 4), acol = li & 15;
   const int S = nC * 9;                                   // steps; S >= 9
-
-  // one step: fragments of (chunk cc, tap t) from A[cc & 1] / B[par]; `rload` receives the slab of step s + 2, `rstore`
-  // (the slab of step s + 1, requested one step ago) is parked in B[par ^ 1] before the barrier
-  auto step = [&](int s, int cc, int t, int par, cs_u32x4 (&rload)[2], const cs_u32x4 (&rstore)[2]) {
-    const unsigned char* Ab = As + (cc & 1) * kBA + (((arow + t / 3) * (kBT + 2)) + acol + t % 3) * kBStride + kg * 16;
-    const unsigned char* Bb = Bs + par * kBB + (wn * 64 + li) * kBStride + kg * 16;
-    cs_u32x4 af[4], bf2[2];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const cs_u32x4*>(Ab + mt * 2 * (kBT + 2) * kBStride);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bf2[nt] = *reinterpret_cast<const cs_u32x4*>(Bb + nt * 32 * kBStride);
-    // requests for later steps go out behind this step's first fragment reads
-    if (s + 2 < S) {
-      const int t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2;
-      fetch_b(rload, t + 2 >= 9 ? cc + 1 : cc, t2);
-    }
-    if (t == 7 && cc + 1 < nC) fetch_a(cc + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      cs_u32x4 an[4], bn[2];
-      if (ks == 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) an[mt] = *reinterpret_cast<const cs_u32x4*>(Ab + mt * 2 * (kBT + 2) * kBStride + 32);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bn[nt] = *reinterpret_cast<const cs_u32x4*>(Bb + nt * 32 * kBStride + 32);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(af[mt], bf2[nt], acc[mt][nt]);
-      if (ks == 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) af[mt] = an[mt];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bf2[nt] = bn[nt];
-      }
-    }
-    if (s + 1 < S) store_b(rstore, par ^ 1);
-    if (t == 8 && cc + 1 < nC) store_a((cc + 1) & 1);
-    __syncthreads();
-  };
-
-  if constexpr (FRAGW) {
+  {
     // this wave's fragments of step s: wf + ((cg * S + s) * 8 + wn * 4 + nt * 2 + ks) * 512 + lane * 8   (16-bit elements)
     const uint16_t* wf = wt + (static_cast<size_t>(cg) * S * 8 + wn * 4) * 512 + lane * 8;
     cs_u32x4 bset[3][4];                                    // three rotating sets of {nt0 ks0, nt0 ks1, nt1 ks0, nt1 ks1}
@@ -513,21 +454,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     fetch_bf(bset[0], 0); fetch_bf(bset[1], 1);
     store_a(0);
     __syncthreads();
-    const unsigned char* Abase = As + ((arow * (kBT + 2)) + acol) * kBStride + kg * 16;
+    // this lane's A rows: M-tile mt of wave-row wm = tile rows 8 wm + (li >> 2), columns 4 mt + (li & 3)
+    const unsigned char* Abase = As + ((8 * wm + (li >> 2)) * kBPitch + (li & 3)) * kBStride + kg * 16;
 #pragma unroll 1
     for (int cc = 0; cc < nC; ++cc) {
       const unsigned char* Ac = Abase + (cc & 1) * kBA;
       fetch_a(min(cc + 1, nC - 1));                         // next chunk's halo: in flight during this chunk's first taps
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const int toff = ((t / 3) * (kBT + 2) + (t % 3)) * kBStride;      // compile-time: ds_read immediates
+        const int toff = ((t / 3) * kBPitch + (t % 3)) * kBStride;         // compile-time: ds_read immediates
         fetch_bf(bset[(t + 2) % 3], cc * 9 + t + 2);
         cs_u32x4 af[4][2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
-            af[mt][ks] = *reinterpret_cast<const cs_u32x4*>(Ac + toff + mt * 2 * (kBT + 2) * kBStride + ks * 32);
+            af[mt][ks] = *reinterpret_cast<const cs_u32x4*>(Ac + toff + mt * 4 * kBStride + ks * 32);
         const cs_u32x4 (&bf)[4] = bset[t % 3];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -539,23 +481,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       }
       __syncthreads();
     }
-  } else {
-  // prologue: halo chunk 0 and slab 0 in LDS, slab 1 in rb1 (parked by step 0), slab 2 requested by step 0 into rb0
-  fetch_a(0); fetch_b(rb0, 0, 0); fetch_b(rb1, 0, 1);
-  store_a(0); store_b(rb0, 0);
-  __syncthreads();
-  {
-    int cc = 0, t = 0;
-#pragma unroll 1
-    for (int s = 0; s < S; s += 2) {
-      step(s, cc, t, 0, rb0, rb1);                          // even step: reads B[0]; rb1 -> B[1]; slab s+2 -> rb0
-      if (++t == 9) { t = 0; ++cc; }
-      if (s + 1 < S) {
-        step(s + 1, cc, t, 1, rb1, rb0);                    // odd step: reads B[1]; rb0 -> B[0]; slab s+3 -> rb1
-        if (++t == 9) { t = 0; ++cc; }
-      }
-    }
-  }
   }
 
   if (ep.mode != 0) {
@@ -629,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+              const int m = big_pix(mt, (r & 3) + 8 * (r >> 2) + 4 * kg);
               slab[m * 132 + wn * 64 + nt * 32 + li] = acc[mt][nt][r];
             }
       }
@@ -655,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;            // pixel inside this wave-row's 128
+            const int m = big_pix(mt, (r & 3) + 8 * (r >> 2) + 4 * kg);         // pixel inside this wave-row's 8 x 16 block
             float v = acc[mt][nt][r] + bb[nt];
             if (relu) v = fmaxf(v, 0.0f);
             *reinterpret_cast<uint16_t*>(bs + m * 272 + (wn * 64 + nt * 32 + li) * 2) = static_cast<uint16_t>(cs_bits<T>(v));
@@ -748,15 +673,6 @@ extern "C" int pvo_conv3x3_c128(const void* x, const void* w_taps, const float* 
   return PVO_OK;
 }
 
-// filter layout of the wide-layer kernel: 1 = MFMA-fragment order (default), 0 = tap-major [9][Cout][Cin] (PVO_WIDE_TAPMAJOR=1,
-// kept for A/B measurements); the host arranges its filters accordingly (pvo_conv3x3_weight_layout)
-static int wide_layout() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PVO_WIDE_TAPMAJOR"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v;
-}
-extern "C" int pvo_conv3x3_weight_layout(void) { return wide_layout(); }
-
 static int launch_big(const void* x, const void* w_taps, const float* bias, void* y,
                       int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream,
                       const BigEpi& ep) {
@@ -770,8 +686,7 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
   if (static_cast<long long>(H) * W * Cin > 0x7fffffffLL) return PVO_EUNSUPPORTED;
   hipStream_t st = pvo_stream(stream);
   const int ntx = (W + kBT - 1) / kBT;
-  // fragment-order variant: two halo buffers (61440 B) or the fp32 epilogue slab (128 px x 132 floats = 67584 B); tap-major: + two filter slabs
-  const size_t lds = wide_layout() ? 67584 : 2 * kBA + 2 * kBB;
+  const size_t lds = 67584;      // two halo buffers (67200 B) / the fp32 epilogue slab (128 px x 132 floats = 67584 B)
   dim3 grid(ntx * (Cout / 128), (H + kBT - 1) / kBT, E);
   const uint16_t* xp = static_cast<const uint16_t*>(x);
   const uint16_t* wp = static_cast<const uint16_t*>(w_taps);
@@ -779,20 +694,16 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
   static bool attr_set[2] = {false, false};                // hipFuncSetAttribute once per process, not per launch
   if (dtype == PVO_F16) {
     if (!attr_set[0]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
       attr_set[0] = true;
     }
-    if (wide_layout()) hipLaunchKernelGGL((conv3x3_big_kernel<pvo_half, true>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
-    else hipLaunchKernelGGL((conv3x3_big_kernel<pvo_half, false>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
   } else if (dtype == PVO_BF16) {
     if (!attr_set[1]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
       attr_set[1] = true;
     }
-    if (wide_layout()) hipLaunchKernelGGL((conv3x3_big_kernel<pvo_bf16, true>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
-    else hipLaunchKernelGGL((conv3x3_big_kernel<pvo_bf16, false>), grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
+    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
   } else {
     return PVO_EUNSUPPORTED;
   }

@@ -106,10 +106,26 @@ void* ws_base(void* workspace) {
     if (rc_ != PVO_OK) return rc_;   \
   } while (0)
 
-// everything of the operator up to the new hidden state; the two branches that read it follow in `branches`
+// everything of the operator up to the new hidden state; the two branches that read it follow in run_heads / run_agg.
+// With PVO_OP_ENC_SIDE_STREAM the work that does not depend on the correlation features - the global-context reduction of
+// `net`, the gate context, the flow encoder - runs on the side stream beside the HBM-bound lookup and corr_encoder[2].
 int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, const void** P_zr, const void** P_q) {
   const int E = a->E, H = a->H, W = a->W, dt = w->dtype;
   const long long rows = static_cast<long long>(E) * H * W;
+  hipStream_t st = pvo_stream(stream);
+  SideCtx* sc = (w->flags & PVO_OP_ENC_SIDE_STREAM) && !(w->flags & PVO_OP_SINGLE_STREAM) ? side_ctx() : nullptr;
+  void* s2 = sc ? static_cast<void*>(sc->side) : stream;
+  if (sc) {
+    if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
+    if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
+  }
+  // independent of the correlation features (side stream when enabled)
+  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s2));
+  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s2));
+  RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
+  RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
+  if (sc && hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
+  // correlation features
   if (a->levels[0]) {
     probe_mark(PVO_STAGE_LOOKUP, 0, stream);
     RUN(pvo_corr_lookup_encode_tiled(a->levels, a->coords, w->enc0_w, w->enc0_b, b.c1, E, H, W, dt, a->slots, a->num_slots, stream));
@@ -118,13 +134,11 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     if (!a->corr) return PVO_EINVAL;
     RUN(pvo_corr_encode(a->corr, w->enc0_w, w->enc0_b, b.c1, rows, dt, stream));
   }
-  RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, stream));
   // the encoders' second layers write relu(features + bias) side by side: CF = [corr features (128) | flow features (64)]
   if (w->flags & PVO_OP_CONV128_WIDE)
     RUN(pvo_conv3x3(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 128, 1, 192, 0, dt, stream));
   else
     RUN(pvo_conv3x3_c128(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 1, 192, 0, dt, stream));
-  RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, stream));
   *P_zr = a->P_zr; *P_q = a->P_q;
   if (!a->P_zr || !a->P_q) {       // static-input term not cached by the caller: conv(W[:, inp], inp) for this call
     if (!a->inp) return PVO_EINVAL;
@@ -132,8 +146,7 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     RUN(pvo_conv3x3(a->inp, w->q_inp_w, nullptr, b.P_q, E, H, W, 128, 128, 0, 0, 0, dt, stream));
     *P_zr = b.P_zr; *P_q = b.P_q;
   }
-  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, stream));
-  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), stream));
+  if (sc && hipStreamWaitEvent(st, sc->join, 0) != hipSuccess) return PVO_ELAUNCH;
   probe_mark(PVO_STAGE_GATES, 0, stream);
   RUN(pvo_gru_conv_gates(a->net, b.CF, 192, w->zr_w, b.g, *P_zr, b.Z, b.RN, E, H, W, dt, stream));
   probe_mark(PVO_STAGE_GATES, 1, stream);

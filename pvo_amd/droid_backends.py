@@ -645,14 +645,11 @@ def conv3x3_c128_weights(weight, dtype):
 
 def conv3x3_weights(weight, dtype):
     """[Cout,Cin,3,3] conv filter (Cin % 32 == 0, Cout % 128 == 0) -> the layout pvo_conv3x3 / pvo_gru_conv_* read, as a
-    [9,Cout,Cin]-shaped tensor: MFMA-fragment order [Cout/128][Cin/32][9][2][2][2][64][8] (include/pvo_hip.h), or tap-major
-    when the library runs its tap-major variant"""
+    [9,Cout,Cin]-shaped tensor holding MFMA-fragment order [Cout/128][Cin/32][9][2][2][2][64][8] (include/pvo_hip.h)"""
     co, ci, kh, kw = weight.shape
     if (kh, kw) != (3, 3) or ci % 32 or co % 128:
         raise PvoHipError("conv3x3: filter must be [Cout,Cin,3,3] with Cin % 32 == 0 and Cout % 128 == 0")
     taps = weight.detach().permute(2, 3, 0, 1).reshape(9, co, ci).to(dtype)
-    if _lib.load().pvo_conv3x3_weight_layout() == 0:
-        return taps.contiguous()
     # (t, cg, wn, nt, li, cc, ks, kg, j) -> (cg, cc, t, wn, nt, ks, kg, li, j)
     f = taps.reshape(9, co // 128, 2, 2, 32, ci // 32, 2, 2, 8).permute(1, 5, 0, 2, 3, 6, 7, 4, 8)
     return f.contiguous().view(9, co, ci)

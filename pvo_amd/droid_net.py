@@ -68,9 +68,12 @@ class DroidNet(nn.Module):
         return fmaps, torch.tanh(net), torch.relu(inp)
 
     def forward(self, Gs, images, disps, intrinsics, graph=None, num_steps=12, fixedp=2, ret_flow=False,
-                downsample=False, segments=None):
+                downsample=False, segments=None, corr_dtype=None):
         """Unrolled estimation over a frame graph (droid_net.py:342-439).  Returns per-step lists
-        (Gs, upsampled disps, residuals[, full flows], masks[, affine-brightness params])."""
+        (Gs, upsampled disps, residuals[, full flows], masks[, affine-brightness params]).
+        corr_dtype (e.g. torch.bfloat16, BASELINE.json configs[4]): the all-pairs volume, its pyramid and the lookup
+        (forward and backward, HIP) run in that type - half the volume's HBM footprint and traffic; features, update
+        operator and the BA stay in the module's dtype (the BA in fp32)."""
         ii, jj, _ = graph_to_edge_list(graph)
         ii = ii.to(device=images.device, dtype=torch.long)
         jj = jj.to(device=images.device, dtype=torch.long)
@@ -78,7 +81,10 @@ class DroidNet(nn.Module):
 
         fmaps, net, inp = self.extract_features(images)
         net, inp = net[:, ii], inp[:, ii]
-        corr_fn = CorrBlock(fmaps[:, ii], fmaps[:, jj], num_levels=4, radius=3)
+        if corr_dtype is not None:
+            corr_fn = CorrBlock(fmaps[:, ii].to(corr_dtype), fmaps[:, jj].to(corr_dtype), num_levels=4, radius=3)
+        else:
+            corr_fn = CorrBlock(fmaps[:, ii], fmaps[:, jj], num_levels=4, radius=3)
 
         ht, wd = images.shape[-2:]
         coords0 = pops.coords_grid(ht // 8, wd // 8, device=images.device)
@@ -93,7 +99,7 @@ class DroidNet(nn.Module):
             coords1, target_cam = coords1.detach(), target_cam.detach()
             delta_dy, raw_mask = delta_dy.detach(), raw_mask.detach()
 
-            corr = corr_fn(coords1)
+            corr = corr_fn(coords1).to(net.dtype)
             cam_flow = coords1 - coords0
             motion = torch.cat([cam_flow, cam_flow + delta_dy, target_cam - coords1, raw_mask], dim=-1)
             motion = motion.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)

@@ -67,6 +67,9 @@ _CONV128_WIDE = _os.environ.get("PVO_CONV128_WIDE", "1") == "1"       # corr_enc
 # The aggregation branch (conv1 over the edges, mean per source frame, then small kernels over the K keyframes that leave most
 # of the chip idle) runs on a second HIP stream beside the heads, which only share its input.  "0": one stream.
 _AGG_SIDE_STREAM = _os.environ.get("PVO_AGG_SIDE_STREAM", "1") != "0"
+# the flow encoder, the global-context reduction and the gate context do not depend on the correlation features: second
+# stream beside the HBM-bound lookup and corr_encoder[2]
+_ENC_SIDE_STREAM = _os.environ.get("PVO_ENC_SIDE_STREAM", "1") != "0"
 
 
 class PoolLookup:
@@ -195,7 +198,7 @@ class DynamicUpdateModule(nn.Module):
         (`inp`) input channels, the four heads' first stages side by side.  Cached; rebuilt when a parameter changes."""
         from .. import droid_backends as db
         ps = list(self.parameters())
-        key = (dt, ps[0].device, tuple(p._version for p in ps), _CONV128_WIDE, _AGG_SIDE_STREAM)
+        key = (dt, ps[0].device, tuple(p._version for p in ps), _CONV128_WIDE, _AGG_SIDE_STREAM, _ENC_SIDE_STREAM)
         hit = self.__dict__.get("_packed")
         if hit is not None and hit[0] == key and hit[1] is not None:
             return hit[1]
@@ -233,8 +236,9 @@ class DynamicUpdateModule(nn.Module):
             "up_w": self.agg.upmask_disp[0].weight.detach().reshape(576, 128).to(dt).contiguous(),
             "up_b": f32(self.agg.upmask_disp[0].bias),
         }
-        from .._lib import PVO_OP_CONV128_WIDE, PVO_OP_SINGLE_STREAM
-        flags = (PVO_OP_CONV128_WIDE if _CONV128_WIDE else 0) | (0 if _AGG_SIDE_STREAM else PVO_OP_SINGLE_STREAM)
+        from .._lib import PVO_OP_CONV128_WIDE, PVO_OP_ENC_SIDE_STREAM, PVO_OP_SINGLE_STREAM
+        flags = (PVO_OP_CONV128_WIDE if _CONV128_WIDE else 0) | (0 if _AGG_SIDE_STREAM else PVO_OP_SINGLE_STREAM) | \
+            (PVO_OP_ENC_SIDE_STREAM if _ENC_SIDE_STREAM else 0)
         pw = db.PackedWeights(dt, t, flags)
         self.__dict__["_packed"] = (key, pw)
         return pw

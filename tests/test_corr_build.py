@@ -235,15 +235,17 @@ def test_fused_lookup_encoder_matches_lookup_then_conv(cuda, dtype, H, W):
 
 
 @pytest.mark.gpu
-def test_tiled_and_fused_lookup_against_the_oracle_at_full_map_size(cuda):
+@pytest.mark.parametrize("H,W", [(48, 64), (30, 101)])
+def test_tiled_and_fused_lookup_against_the_oracle_at_full_map_size(cuda, H, W):
     """The kernels the bench times - the tiled pool's build, its lookup, and the lookup fused with corr_encoder[0] -
-    DIRECTLY against the CPU oracle at the S-B map size (48x64, C = 128): the oracle's lookup of the volume the pool holds
+    DIRECTLY against the CPU oracle at the S-B (48x64) and S-A (30x101, VKITTI2 through test_vo.py) map sizes, C = 128: the
+    oracle's lookup of the volume the pool holds
     (bit-exact; the volume itself is compared with oracle_corr_build to one unit in the last place, as for the row-major
     build above), and the encoder layer as an fp64 GEMM of the oracle's lookup."""
     from oracle import oracle as O
     from pvo_amd import droid_backends as db
     from pvo_amd.modules.corr import CorrVolumePool
-    H, W, C, N = 48, 64, 128, 2
+    C, N = 128, 2
     g = torch.Generator().manual_seed(11)
     f1 = torch.randn(N, H, W, C, generator=g).half()
     f2 = torch.randn(N, H, W, C, generator=g).half()

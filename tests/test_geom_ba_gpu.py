@@ -96,6 +96,19 @@ def test_ba_long_window_envelope_cholesky_matches_oracle(cuda, P, closure):
     assert np.abs(dx - want["dx"]).max() < 1e-4
 
 
+def test_ba_matches_oracle_at_SA_size(cuda):
+    """S-A: 30x101 maps, 10 keyframes, 48 edges - the window shape of the reference's own driver"""
+    P, ht, wd = 10, 30, 101
+    s = _scene(77, P, ht, wd, 3, 1)
+    assert s["ii"].shape[0] == 48
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
+    assert status[0] == 0 and status[1] == want["K"]
+    assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
+    assert np.abs(dx - want["dx"]).max() < 1e-4 and np.abs(dz - want["dz"]).max() < 1e-4
+
+
 def test_ba_matches_reference_python_fixture_poses(cuda):
     """Poses after a native BA step equal the reference geom/ba.py result (the pose update is
     unaffected by EvT6x1's pose-0 skip); fixtures generated from /root/reference."""

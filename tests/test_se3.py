@@ -89,3 +89,85 @@ def test_matches_oracle_se3_helpers():
     # the xi[45] read (droid_kernels.cu:154) as "returned 0": translation differs visibly
     lib.oracle_retrSE3(fp(xi), fp(gi), fp(p1), 1)
     assert np.abs(p1[:3] - SE3(Gi).retr(torch.from_numpy(xi)).data.numpy()[:3]).max() > 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent pins (not through this package's quaternion formulas): the matrix exponential of the 4x4 twist
+# (torch.linalg.matrix_exp, fp64), scipy's quaternion -> rotation matrix, and explicit matrix algebra.  These are what
+# keep the reference-BA fixtures (generated with this SE3 class standing in for lietorch) from being self-referential.
+# ---------------------------------------------------------------------------------------------------------------------
+def _hat(phi):
+    z = torch.zeros_like(phi[..., 0])
+    return torch.stack([torch.stack([z, -phi[..., 2], phi[..., 1]], -1),
+                        torch.stack([phi[..., 2], z, -phi[..., 0]], -1),
+                        torch.stack([-phi[..., 1], phi[..., 0], z], -1)], -2)
+
+
+def _twist_matrix(xi):
+    """lietorch's se(3) ordering: xi = (tau, phi)"""
+    T = torch.zeros(xi.shape[:-1] + (4, 4), dtype=xi.dtype)
+    T[..., :3, :3] = _hat(xi[..., 3:])
+    T[..., :3, 3] = xi[..., :3]
+    return T
+
+
+def _check_against_matrices(device, dtype, atol):
+    torch.manual_seed(11)
+    xi = torch.cat([torch.randn(128, 3, dtype=torch.float64), 0.8 * torch.randn(128, 3, dtype=torch.float64)], -1)
+    xi[:8, 3:] *= 1e-7                                                       # the small-angle branch
+    M = torch.linalg.matrix_exp(_twist_matrix(xi))                            # ground truth, fp64
+    X = SE3.exp(xi.to(device=device, dtype=dtype))
+    assert torch.allclose(X.matrix().double().cpu(), M, atol=atol)
+    # quaternion (xyzw) -> rotation: scipy's independent implementation
+    from scipy.spatial.transform import Rotation
+    q = X.data[..., 3:7].double().cpu().numpy()
+    assert np.allclose(Rotation.from_quat(q).as_matrix(), M[:, :3, :3].numpy(), atol=atol)
+    # group operations are matrix operations
+    Y = SE3.exp(torch.flip(xi, [0]).to(device=device, dtype=dtype))
+    MY = torch.flip(M, [0])
+    assert torch.allclose((X * Y).matrix().double().cpu(), M @ MY, atol=10 * atol)
+    assert torch.allclose(X.inv().matrix().double().cpu(), torch.linalg.inv(M), atol=10 * atol)
+    p = torch.randn(128, 4, dtype=torch.float64)
+    assert torch.allclose(X.act(p.to(device=device, dtype=dtype)).double().cpu(), (M @ p[..., None])[..., 0], atol=10 * atol)
+    # Adjoint in the (tau, phi) ordering: [[R, hat(t) R], [0, R]]; adjT is its transpose (droid_kernels.cu:93-107 adjSE3)
+    R, t = M[:, :3, :3], M[:, :3, 3]
+    Ad = torch.zeros(128, 6, 6, dtype=torch.float64)
+    Ad[:, :3, :3] = R; Ad[:, 3:, 3:] = R; Ad[:, :3, 3:] = _hat(t) @ R
+    a = torch.randn(128, 6, dtype=torch.float64)
+    assert torch.allclose(X.adj(a.to(device=device, dtype=dtype)).double().cpu(), (Ad @ a[..., None])[..., 0], atol=20 * atol)
+    assert torch.allclose(X.adjT(a.to(device=device, dtype=dtype)).double().cpu(), (Ad.transpose(1, 2) @ a[..., None])[..., 0], atol=20 * atol)
+    # log is the inverse of the matrix exponential; retr is left multiplication by Exp
+    assert torch.allclose(torch.linalg.matrix_exp(_twist_matrix(X.log().double().cpu())), M, atol=20 * atol)
+    assert torch.allclose(Y.retr(xi.to(device=device, dtype=dtype)).matrix().double().cpu(), M @ MY, atol=10 * atol)
+
+
+import numpy as np
+import pytest
+
+
+def test_se3_against_matrix_exponential_and_scipy_fp64():
+    _check_against_matrices("cpu", torch.float64, 1e-9)
+
+
+def test_se3_against_matrix_exponential_and_scipy_fp32():
+    _check_against_matrices("cpu", torch.float32, 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,atol", [(torch.float64, 1e-9), (torch.float32, 2e-6)])
+def test_se3_on_the_gpu_against_matrix_exponential(cuda, dtype, atol):
+    _check_against_matrices(cuda, dtype, atol)
+
+
+@pytest.mark.gpu
+def test_se3_property_tests_on_the_gpu(cuda):
+    """lietorch's run_tests.py:16-54 with device='cuda' (every test there takes a device argument)"""
+    torch.manual_seed(0)
+    X = SE3.Random(64, sigma=1.0, dtype=torch.float64, device=cuda)
+    a = 0.2 * torch.randn(64, 6, dtype=torch.float64, device=cuda)
+    assert torch.allclose(SE3.exp(a).log(), a, atol=1e-8)
+    assert torch.allclose((X * X.inv()).log(), torch.zeros_like(a), atol=1e-8)
+    Y1, Y2 = X * SE3.exp(a), SE3.exp(X.adj(a)) * X
+    assert torch.allclose((Y1 * Y2.inv()).log(), torch.zeros_like(a), atol=1e-8)
+    p = torch.randn(64, 4, dtype=torch.float64, device=cuda)
+    assert torch.allclose(X.act(p), (X.matrix() @ p[..., None])[..., 0], atol=1e-10)

@@ -1,5 +1,5 @@
 """Back-to-back timings of the wide-layer convolution kernel at the update operator's shapes (S-B: 36 x 48 x 64).
-    python tools/conv_bench.py            (PVO_WIDE_TAPMAJOR=1 selects the tap-major variant)"""
+    python tools/conv_bench.py [E H W]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +23,7 @@ def t(fn, n=30):
     return a.elapsed_time(b) / n * 1e3
 
 
-print("wide layout:", "fragment" if _lib.load().pvo_conv3x3_weight_layout() else "tap-major", "E,H,W =", E, H, W)
+print("E,H,W =", E, H, W)
 for cin, cout in ((128, 128), (128, 256), (128, 512), (320, 128), (320, 256)):
     x = torch.randn(E, cin, H, W, device=dev).half().contiguous(memory_format=cl)
     w = (torch.randn(cout, cin, 3, 3, device=dev) * 0.02).half()

@@ -1,0 +1,28 @@
+"""Workload for the counter passes of tools/pmc_kernels.sh: the wide convolution as the ConvGRU gate launch, the fused
+lookup, and the dense BA, each at the S-B shape, a few dispatches each (counters are read per dispatch)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from pvo_amd import droid_backends as db
+
+dev = torch.device("cuda:0")
+E, H, W = 36, 48, 64
+cl = torch.channels_last
+g = torch.Generator(device=dev).manual_seed(0)
+net = torch.tanh(torch.randn(E, 128, H, W, device=dev, generator=g)).half().contiguous(memory_format=cl)
+cf = torch.relu(torch.randn(E, 192, H, W, device=dev, generator=g)).half().contiguous(memory_format=cl)
+gg = torch.randn(E, 384, device=dev, generator=g)
+P_zr = torch.randn(E, 256, H, W, device=dev, generator=g).half().contiguous(memory_format=cl)
+tzr = db.conv3x3_weights((torch.randn(256, 320, 3, 3, device=dev, generator=g) * 0.02).half(), torch.half)
+for _ in range(6):
+    db.gru_conv_gates(net, cf, tzr, gg, P_zr)
+torch.cuda.synchronize()
+from test_geom_ba_gpu import _scene
+s = _scene(0, 8, H, W, 3, 1)
+d = lambda t: t.to(dev)
+for _ in range(4):
+    poses, disps = d(s["poses"].clone()), d(s["disps"].clone())
+    db.ba(poses, disps, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]), 1, 8, 2, 1e-4, 0.1, False)
+torch.cuda.synchronize()
+print("done")
