@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   const uint16_t* xe = x + static_cast<size_t>(e) * H * W * Cin;
 
   // global -> register -> LDS staging of the halo chunk needed next (6 x 16 B per thread)
-  cs_u32x4 ra[6];
+  cs_u32x4 ra[3];                                         // (three pieces at a time: registers)
   int apix[6];                                            // pixel index of this thread's halo pieces inside the image, -1 = zero
   int lpos[6];                                            // their LDS byte offsets
 #pragma unroll
@@ -410,25 +410,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   const size_t img = static_cast<size_t>(e) * H * W;
   // (loads and stores are unconditional - out-of-image pieces read a clamped address and are zeroed by a select when they
   // are parked: exec-masked branches around VMEM operations make the compiler wait vmcnt(0) at every join)
-  auto fetch_a = [&](int cc) {
-    const uint16_t* src = xe; int stride = Cin; int coff = cc * 32;
+  const uint16_t* a_src = xe; int a_stride = Cin, a_coff = 0;
+  auto select_a = [&](int cc) {                                    // which tensor / channel offset chunk cc comes from
+    a_src = xe; a_stride = Cin; a_coff = cc * 32;
     if (ep.nseg > 0) {                                              // uniform walk over at most three segments
       int sgi = 0, c0 = cc;
       while (sgi + 1 < ep.nseg && c0 >= ep.seg_chunks[sgi]) { c0 -= ep.seg_chunks[sgi]; ++sgi; }
-      stride = ep.seg_stride[sgi];
-      src = ep.seg_p[sgi] + img * stride;
-      coff = c0 * 32;
+      a_stride = ep.seg_stride[sgi];
+      a_src = ep.seg_p[sgi] + img * a_stride;
+      a_coff = c0 * 32;
     }
-#pragma unroll
-    for (int it = 0; it < 6; ++it)
-      ra[it] = *reinterpret_cast<const cs_u32x4*>(src + static_cast<size_t>(max(apix[it], 0)) * stride + coff + (tid & 3) * 8);
   };
-  auto store_a = [&](int buf) {
+  auto fetch_a = [&](int half) {                                   // pieces 3 half .. 3 half + 2
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
-      cs_u32x4 v = ra[it];
-      if (apix[it] < 0) v = cs_u32x4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<cs_u32x4*>(As + buf * kBA + lpos[it]) = v;
+    for (int k = 0; k < 3; ++k)
+      ra[k] = *reinterpret_cast<const cs_u32x4*>(a_src + static_cast<size_t>(max(apix[3 * half + k], 0)) * a_stride + a_coff + (tid & 3) * 8);
+  };
+  auto store_a = [&](int buf, int half) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      cs_u32x4 v = ra[k];
+      if (apix[3 * half + k] < 0) v = cs_u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<cs_u32x4*>(As + buf * kBA + lpos[3 * half + k]) = v;
     }
   };
 
@@ -450,34 +453,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
 #pragma unroll
       for (int f = 0; f < 4; ++f) r[f] = *reinterpret_cast<const cs_u32x4*>(p + f * 512);
     };
+    select_a(0);
     fetch_a(0);
     fetch_bf(bset[0], 0); fetch_bf(bset[1], 1);
-    store_a(0);
+    store_a(0, 0);
+    fetch_a(1);
+    store_a(0, 1);
     __syncthreads();
     // this lane's A rows: M-tile mt of wave-row wm = tile rows 8 wm + (li >> 2), columns 4 mt + (li & 3)
     const unsigned char* Abase = As + ((8 * wm + (li >> 2)) * kBPitch + (li & 3)) * kBStride + kg * 16;
+    // Software pipeline at half-step (k = 16) granularity, pinned with sched_barrier: the four A fragments of the NEXT
+    // half-step are requested before the eight MFMAs of the current one, so a fragment has 8 MFMAs (256 matrix-pipe
+    // cycles) to arrive.  Left to itself the compiler sinks each ds_read next to its first use ("read, wait lgkmcnt(0),
+    // two MFMAs" - the LDS latency exposed eight times per step; SQ_WAIT_ANY was 40 % of the wave cycles).
+    auto read_half = [&](cs_u32x4 (&a)[4], const unsigned char* Ac, int toff, int ks) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const cs_u32x4*>(Ac + toff + mt * 4 * kBStride + ks * 32);
+    };
 #pragma unroll 1
     for (int cc = 0; cc < nC; ++cc) {
       const unsigned char* Ac = Abase + (cc & 1) * kBA;
-      fetch_a(min(cc + 1, nC - 1));                         // next chunk's halo: in flight during this chunk's first taps
+      select_a(min(cc + 1, nC - 1));                        // next chunk's halo: two halves, each in flight for three taps
+      fetch_a(0);
+      cs_u32x4 a0[4], a1[4];
+      read_half(a0, Ac, 0, 0);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int toff = ((t / 3) * kBPitch + (t % 3)) * kBStride;         // compile-time: ds_read immediates
         fetch_bf(bset[(t + 2) % 3], cc * 9 + t + 2);
-        cs_u32x4 af[4][2];
+        read_half(a1, Ac, toff, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const cs_u32x4 (&bf)[4] = bset[t % 3];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-            af[mt][ks] = *reinterpret_cast<const cs_u32x4*>(Ac + toff + mt * 4 * kBStride + ks * 32);
-        const cs_u32x4 (&bf)[4] = bset[t % 3];
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(a0[mt], bf[nt * 2], acc[mt][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < 8) read_half(a0, Ac, ((((t + 1) / 3) * kBPitch) + ((t + 1) % 3)) * kBStride, 0);
+        if (t == 3) { store_a((cc + 1) & 1, 0); fetch_a(1); }   // (the other halo buffer was last read before the previous barrier)
+        if (t == 7) store_a((cc + 1) & 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(af[mt][ks], bf[nt * 2 + ks], acc[mt][nt]);
-        if (t == 4) store_a((cc + 1) & 1);                  // the other halo buffer was last read before the previous barrier
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(a1[mt], bf[nt * 2 + 1], acc[mt][nt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }
