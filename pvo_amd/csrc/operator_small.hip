@@ -60,10 +60,13 @@ __global__ __launch_bounds__(384) void gate_context_kernel(const float* __restri
   }
   __syncthreads();
   float a[4] = {gb[t], 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-  for (int c = 0; c < 128; c += 4) {
+#pragma unroll 1
+  for (int c0 = 0; c0 < 128; c0 += 32) {          // 32 weight loads in flight per thread (L2 latency, not bandwidth, is the cost)
+    float wv[32];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = fmaf(glo[c + q], wg_t[static_cast<size_t>(c + q) * 384 + t], a[q]);
+    for (int q = 0; q < 32; ++q) wv[q] = wg_t[static_cast<size_t>(c0 + q) * 384 + t];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) a[q & 3] = fmaf(glo[c0 + q], wv[q], a[q & 3]);
   }
   g[static_cast<size_t>(e) * 384 + t] = (a[0] + a[1]) + (a[2] + a[3]);
 }
