@@ -262,7 +262,68 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
       // own tap row, and the next one (y offset row+1) from lane+1 of this 8-lane group
       float v[8], vn[8];
       const uint32_t maskn = next_lane(mask);
-      if constexpr (sizeof(S) == 2) {
+      if constexpr (__is_same(T, pvo_half)) {
+        // fp16: NATIVE packed arithmetic, two outputs per instruction.  The reference computes every product and sum in
+        // fp32 and rounds to fp16 (c10::Half operators); fp32 carries 24 >= 2 * 11 + 2 significand bits, so that double
+        // rounding is innocuous and v_pk_mul_f16 / v_pk_add_f16 (one rounding of the exact result each) return the same
+        // bits for every finite input - the bit-exactness tests against the oracle are unchanged.  (The scalar form below -
+        // mul, round, add, round with four fp32 <-> fp16 conversions per tap - made this kernel VALU-bound: a back-to-back
+        // run from the Infinity Cache took 43 us against 49 us from HBM.)  Products and sums stay separate instructions
+        // (contraction is off in this file); a packed FMA would round once.
+        typedef _Float16 lk_h2 __attribute__((ext_vector_type(2)));
+        uint32_t u[5], un[5];
+        if constexpr (TILED)
+          tiled_finish(RA[l], RB[l], ix, u);
+        else
+          fetch_row8_16(reinterpret_cast<const uint16_t*>(L.vol), g, L.total, mask, u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) un[k] = next_lane(u[k]);
+        u[4] = 0u; un[4] = 0u;
+        auto bc = [](float w) { const _Float16 h = static_cast<_Float16>(w); return lk_h2{h, h}; };      // w is already an fp16 value
+        const lk_h2 W00 = bc(Arith<T>::rnd((1.0f - dx) * (1.0f - dy))), W01 = bc(Arith<T>::rnd((1.0f - dx) * dy));
+        const lk_h2 W10 = bc(Arith<T>::rnd(dx * (1.0f - dy))), W11 = bc(Arith<T>::rnd(dx * dy));
+        // per-half select masks: pair k = taps (2k, 2k+1) [aligned] and (2k+1, 2k+2) [shifted by one tap]
+        auto pairmask = [](uint32_t m, int k) {
+          const uint32_t e0 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(m), 2 * k, 1));
+          const uint32_t e1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(m), 2 * k + 1, 1));
+          return __builtin_amdgcn_perm(e1, e0, 0x05040100u);           // (e1.lo16 << 16) | e0.lo16
+        };
+        // wave-uniform: interior windows need no selects (lanes of tap row 7 produce no output: their maskn belongs to a neighbour)
+        const bool full = __all(static_cast<int>(row == 7 || (mask == 0xffu && maskn == 0xffu)));
+        if (row < 7) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t ub = __builtin_amdgcn_alignbyte(u[k + 1], u[k], 2), unb = __builtin_amdgcn_alignbyte(un[k + 1], un[k], 2);
+            const lk_h2 A = __builtin_bit_cast(lk_h2, u[k]), An = __builtin_bit_cast(lk_h2, un[k]);
+            const lk_h2 B = __builtin_bit_cast(lk_h2, ub), Bn = __builtin_bit_cast(lk_h2, unb);
+            lk_h2 acc = {static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)};
+            if (full) {
+              acc = acc + A * W00;
+              acc = acc + An * W01;
+              acc = acc + B * W10;
+              acc = acc + Bn * W11;
+            } else {
+              // order: taps (ax,row) (ax,row+1) (ax+1,row) (ax+1,row+1); skipped taps leave acc untouched
+              const uint32_t mA = pairmask(mask, k), mAn = pairmask(maskn, k);
+              const uint32_t mB = __builtin_amdgcn_alignbyte(k < 3 ? pairmask(mask, k + 1) : 0u, mA, 2);
+              const uint32_t mBn = __builtin_amdgcn_alignbyte(k < 3 ? pairmask(maskn, k + 1) : 0u, mAn, 2);
+              auto sel = [](uint32_t m, lk_h2 t, lk_h2 a) {
+                return __builtin_bit_cast(lk_h2, (__builtin_bit_cast(uint32_t, t) & m) | (__builtin_bit_cast(uint32_t, a) & ~m));
+              };
+              acc = sel(mA, acc + A * W00, acc);
+              acc = sel(mAn, acc + An * W01, acc);
+              acc = sel(mB, acc + B * W10, acc);
+              acc = sel(mBn, acc + Bn * W11, acc);
+            }
+            const uint32_t bits = __builtin_bit_cast(uint32_t, acc);
+            const int ch = l * 49 + (2 * k) * 7 + row;
+            reinterpret_cast<uint16_t*>(stage)[(ENC || a.out_channels_last) ? p * cl_stride + ch : ch * kStripPad + p] = static_cast<uint16_t>(bits & 0xffffu);
+            if (k < 3)
+              reinterpret_cast<uint16_t*>(stage)[(ENC || a.out_channels_last) ? p * cl_stride + ch + 7 : (ch + 7) * kStripPad + p] = static_cast<uint16_t>(bits >> 16);
+          }
+        }
+        continue;
+      } else if constexpr (sizeof(S) == 2) {
         uint32_t u[4], un[4];
         if constexpr (TILED)
           tiled_finish(RA[l], RB[l], ix, u);
