@@ -363,6 +363,23 @@ int pvo_reproject(const float* poses, const float* disps, const float* intrinsic
                   int E, int ht, int wd, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* SE3 element-wise operations (lietorch subset)                              */
+/* ------------------------------------------------------------------------- */
+
+/* The SE3 operations of lietorch the VO path uses (lietorch/groups.py:141-178,199-209; CUDA kernels
+ * lietorch/src/lietorch_gpu.cu:21-296), forward, fp32 / fp64 (`dtype` PVO_F32 / PVO_F64), one thread per element.
+ * Group elements are [n,7] = (tx,ty,tz, qx,qy,qz,qw), tangents [n,6] = (tau, phi).
+ *   pvo_se3_unary : op 0 exp [n,6] -> [n,7];  1 log [n,7] -> [n,6];  2 inv [n,7] -> [n,7]
+ *   pvo_se3_binary: op 3 mul (a b) [7],[7] -> [7];  4 act on homogeneous points [7],[4] -> [4];  5 act on points [7],[3] -> [3];
+ *                   6 adj [7],[6] -> [6];  7 adjT [7],[6] -> [6]
+ *                   element i of the n outputs reads a[i / rep_a] and b[i / rep_b]: an operand with fewer elements is
+ *                   broadcast by index (e.g. one pose per edge acting on H*W points: rep_a = H*W, rep_b = 1) where
+ *                   lietorch materialises it with .repeat (broadcasting.py:27-29). */
+int pvo_se3_unary(int op, const void* x, void* y, long long n, int dtype, void* stream);
+int pvo_se3_binary(int op, const void* a, long long rep_a, const void* b, long long rep_b, void* y, long long n,
+                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Dense bundle adjustment                                                    */
 /* ------------------------------------------------------------------------- */
 

@@ -26,6 +26,7 @@ HIP_SOURCES = [
     "conv_small.hip",
     "operator_small.hip",
     "update_exec.hip",
+    "se3_ops.hip",
     "ba.hip",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -1015,6 +1015,38 @@ def graph_update(weights, args, workspace):
                                            workspace.numel(), _stream(dev)), "graph_update")
 
 
+# --------------------------------------------------------------------------- SE3 element-wise operations
+SE3_OPS = {"exp": 0, "log": 1, "inv": 2, "mul": 3, "act4": 4, "act3": 5, "adj": 6, "adjT": 7}
+_SE3_OUT = {"exp": 7, "log": 6, "inv": 7, "mul": 7, "act4": 4, "act3": 3, "adj": 6, "adjT": 6}
+
+
+def se3_unary(op, x):
+    """exp [n,6] -> [n,7], log [n,7] -> [n,6], inv [n,7] -> [n,7] (lietorch SE3, forward); x contiguous f32 / f64"""
+    dev = _dev(x)
+    _contig(x, "x")
+    if x.dtype not in (torch.float32, torch.float64):
+        raise PvoHipError("se3: float32 / float64 only")
+    n = x.numel() // x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (_SE3_OUT[op],), dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_se3_unary(SE3_OPS[op], _ptr(x), _ptr(y), n, _DT[x.dtype], _stream(dev)), "se3_" + op)
+    return y
+
+
+def se3_binary(op, a, rep_a, b, rep_b, out_batch):
+    """mul / act4 / act3 / adj / adjT with index broadcasting: output element i reads a[i // rep_a], b[i // rep_b]"""
+    dev = _dev(a, b)
+    _contig(a, "a"); _contig(b, "b")
+    if a.dtype != b.dtype or a.dtype not in (torch.float32, torch.float64):
+        raise PvoHipError("se3: both operands float32 or both float64")
+    y = torch.empty(tuple(out_batch) + (_SE3_OUT[op],), dtype=a.dtype, device=dev)
+    n = y.numel() // _SE3_OUT[op]
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_se3_binary(SE3_OPS[op], _ptr(a), int(rep_a), _ptr(b), int(rep_b), _ptr(y), n, _DT[a.dtype],
+                                         _stream(dev)), "se3_" + op)
+    return y
+
+
 STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4}
 
 

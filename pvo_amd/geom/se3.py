@@ -6,13 +6,58 @@ Mirrors `lietorch.SE3` (reference thirdparty/lietorch/lietorch/groups.py:51-231,
 acts on homogeneous points [..., 4]; `inv`, `adjT`, `exp`, `log`, `retr`.
 
 True broadcasting is used (lietorch materialises the pose once per pixel with
-`.repeat`, broadcasting.py:27-29).  Autograd comes from the torch ops themselves.
+`.repeat`, broadcasting.py:27-29).  Two implementations of the same formulas:
+  * on the GPU, when no operand needs a gradient: ONE fused HIP kernel per operation
+    (pvo_amd/csrc/se3_ops.hip, `pvo_se3_unary/_binary`; lietorch's counterpart is its CUDA
+    element-wise kernel set, lietorch_gpu.cu:21-296), a smaller operand indexed i // rep;
+  * otherwise the torch ops below, whose autograd gives the backward passes (CPU, training).
 The native BA / reprojection kernels do not go through this class; it serves the
 differentiable Python path (geom/ba.py, DroidNet.forward) and host-side bookkeeping.
 """
 import torch
 
 EPS = 1e-6  # lietorch include/common.h:7
+
+
+def _native(*ts):
+    """the fused HIP kernels apply: device tensors of one fp32 / fp64 dtype and no gradient to record"""
+    t0 = ts[0]
+    if not t0.is_cuda or t0.dtype not in (torch.float32, torch.float64):
+        return False
+    for t in ts:
+        if not t.is_cuda or t.dtype != t0.dtype or t.device != t0.device:
+            return False
+    return not (torch.is_grad_enabled() and any(t.requires_grad for t in ts))
+
+
+def _bcast(sa, sb):
+    """batch shapes sa, sb -> (out shape, rep_a, rep_b) when the broadcast is an index broadcast (one operand's batch is the
+    other's with trailing 1s, or the two are equal); None otherwise"""
+    n = max(len(sa), len(sb))
+    sa = (1,) * (n - len(sa)) + tuple(sa)
+    sb = (1,) * (n - len(sb)) + tuple(sb)
+    if sa == sb:
+        return sa, 1, 1
+    for x, y, swap in ((sa, sb, False), (sb, sa, True)):
+        k = n
+        while k > 0 and x[k - 1] == 1:
+            k -= 1
+        if x[:k] == y[:k]:
+            rep = 1
+            for d in y[k:]:
+                rep *= d
+            return (y, 1, rep) if swap else (y, rep, 1)
+    return None
+
+
+def _binary(op, g, b):
+    """native group-on-vector / group-on-group operation, or None when the shapes need general broadcasting"""
+    from .. import droid_backends as db
+    bc = _bcast(g.shape[:-1], b.shape[:-1])
+    if bc is None:
+        return None
+    out, rep_a, rep_b = bc
+    return db.se3_binary(op, g.contiguous(), rep_a, b.contiguous(), rep_b, out)
 
 
 def _cross(a, b):
@@ -133,6 +178,9 @@ class SE3:
 
     @classmethod
     def exp(cls, x):
+        if _native(x):
+            from .. import droid_backends as db
+            return cls(db.se3_unary("exp", x.contiguous()))
         tau, phi = x[..., :3], x[..., 3:]
         q = _so3_exp(phi)
         c1, c2 = _left_jacobian_coefs(phi)
@@ -141,6 +189,9 @@ class SE3:
         return cls(torch.cat([t, q], dim=-1))
 
     def log(self):
+        if _native(self.data):
+            from .. import droid_backends as db
+            return db.se3_unary("log", self.data.contiguous())
         t, q = self.data[..., :3], self.data[..., 3:]
         phi = _so3_log(q)
         th2 = (phi * phi).sum(-1, keepdim=True)
@@ -155,11 +206,18 @@ class SE3:
         return torch.cat([tau, phi], dim=-1)
 
     def inv(self):
+        if _native(self.data):
+            from .. import droid_backends as db
+            return SE3(db.se3_unary("inv", self.data.contiguous()))
         t, q = self.data[..., :3], self.data[..., 3:]
         qi = _qconj(q)
         return SE3(torch.cat([-_qrot(qi, t), qi], dim=-1))
 
     def mul(self, other):
+        if _native(self.data, other.data):
+            y = _binary("mul", self.data, other.data)
+            if y is not None:
+                return SE3(y)
         t1, q1 = self.data[..., :3], self.data[..., 3:]
         t2, q2 = other.data[..., :3], other.data[..., 3:]
         return SE3(torch.cat([t1 + _qrot(q1, t2), _qmul(q1, q2)], dim=-1))
@@ -168,6 +226,10 @@ class SE3:
         return SE3.exp(a).mul(self)
 
     def act(self, p):
+        if p.shape[-1] in (3, 4) and _native(self.data, p):
+            y = _binary("act4" if p.shape[-1] == 4 else "act3", self.data, p)
+            if y is not None:
+                return y
         t, q = self.data[..., :3], self.data[..., 3:]
         if p.shape[-1] == 3:
             return _qrot(q, p) + t
@@ -176,11 +238,19 @@ class SE3:
         return torch.cat([xyz, w.expand(xyz.shape[:-1] + (1,))], dim=-1)
 
     def adj(self, a):
+        if _native(self.data, a):
+            y = _binary("adj", self.data, a)
+            if y is not None:
+                return y
         t, q = self.data[..., :3], self.data[..., 3:]
         Rphi = _qrot(q, a[..., 3:])
         return torch.cat([_qrot(q, a[..., :3]) + _cross(t, Rphi), Rphi], dim=-1)
 
     def adjT(self, a):
+        if _native(self.data, a):
+            y = _binary("adjT", self.data, a)
+            if y is not None:
+                return y
         t, q = self.data[..., :3], self.data[..., 3:]
         qi = _qconj(q)
         a_tau, a_phi = a[..., :3], a[..., 3:]

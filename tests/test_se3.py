@@ -171,3 +171,40 @@ def test_se3_property_tests_on_the_gpu(cuda):
     assert torch.allclose((Y1 * Y2.inv()).log(), torch.zeros_like(a), atol=1e-8)
     p = torch.randn(64, 4, dtype=torch.float64, device=cuda)
     assert torch.allclose(X.act(p), (X.matrix() @ p[..., None])[..., 0], atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,atol", [(torch.float64, 1e-12), (torch.float32, 2e-6)])
+def test_native_se3_kernels_equal_the_torch_formulation(cuda, dtype, atol):
+    """pvo_se3_unary / pvo_se3_binary (one fused kernel per operation, index broadcasting) against the differentiable torch
+    formulation of the same class - reached by making an operand require a gradient - for every operation and for the
+    broadcasting patterns the VO path uses (a pose per edge acting on H x W points, equal shapes, scalar pose)"""
+    torch.manual_seed(3)
+    B, N, H, W = 2, 5, 6, 7
+    xi = torch.randn(B, N, 6, dtype=dtype, device=cuda) * 0.7
+    xi[0, 0, 3:] *= 1e-8                                                       # small-angle branches
+    Xn = SE3.exp(xi)                                                           # native
+    xg = xi.clone().requires_grad_(True)
+    Xt = SE3.exp(xg)                                                           # torch ops (autograd)
+    assert Xt.data.requires_grad and not Xn.data.requires_grad
+    assert torch.allclose(Xn.data, Xt.data.detach(), atol=atol)
+    Xt = SE3(Xt.data.detach().requires_grad_(True))
+    Yn = SE3.exp(torch.flip(xi, [1]))
+    assert torch.allclose(Xn.log(), Xt.log().detach(), atol=atol)
+    assert torch.allclose(Xn.inv().data, Xt.inv().data.detach(), atol=atol)
+    assert torch.allclose((Xn * Yn).data, (Xt * Yn).data.detach(), atol=atol)
+    p4 = torch.randn(B, N, H, W, 4, dtype=dtype, device=cuda)
+    got = Xn[:, :, None, None] * p4                                            # one pose per edge, H x W points: index broadcast
+    assert got.shape == p4.shape and torch.allclose(got, (Xt[:, :, None, None] * p4).detach(), atol=atol)
+    p3 = torch.randn(B, N, 3, dtype=dtype, device=cuda)
+    assert torch.allclose(Xn.act(p3), Xt.act(p3).detach(), atol=atol)
+    a = torch.randn(B, N, H, W, 2, 6, dtype=dtype, device=cuda)
+    assert torch.allclose(Xn[:, :, None, None, None].adjT(a), Xt[:, :, None, None, None].adjT(a).detach(), atol=atol)
+    assert torch.allclose(Xn.adj(a[:, :, 0, 0, 0]), Xt.adj(a[:, :, 0, 0, 0]).detach(), atol=atol)
+    one = SE3(Xn.data[0, 0])                                                   # a single pose against a batch
+    assert torch.allclose((one * Yn).data, (SE3(Xt.data[0, 0]) * Yn).data.detach(), atol=atol)
+    assert torch.allclose(Yn.retr(xi).data, SE3.exp(xi).mul(Yn).data, atol=atol)
+    # a broadcast that is not an index broadcast falls back to the torch formulation
+    q = torch.randn(1, N, H, 1, 4, dtype=dtype, device=cuda)
+    out = SE3(Xn.data[:, :1, None, None]) * q
+    assert out.shape == (B, N, H, 1, 4)
