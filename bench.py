@@ -37,7 +37,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 
 
-def make_window(device, seed=0, H8=H8, W8=W8, NKF=NKF, buffer=16, corr_impl="volume", intr=(40.0, 40.0, 32.0, 24.0)):
+def make_window(device, seed=0, H8=H8, W8=W8, NKF=NKF, buffer=16, corr_impl="volume", intr=(40.0, 40.0, 32.0, 24.0),
+                add_edges=True, max_factors=48):
     """synthetic keyframe window: S-B by default (8 keyframes, 48x64 maps, edges |i-j| <= 3)"""
     from pvo_amd.depth_video import DepthVideo
     from pvo_amd.factor_graph import FactorGraph
@@ -57,9 +58,9 @@ def make_window(device, seed=0, H8=H8, W8=W8, NKF=NKF, buffer=16, corr_impl="vol
     video.disps[:NKF] = 1.0
     torch.manual_seed(seed)
     update = DynamicUpdateModule().to(device).eval().half()   # fp16 inference weights (the reference runs this module under fp16 autocast)
-    graph = FactorGraph(video, update, device=device, max_factors=48 if corr_impl == "volume" else -1, corr_impl=corr_impl)
+    graph = FactorGraph(video, update, device=device, max_factors=max_factors, corr_impl=corr_impl)
     graph.nkf = NKF
-    if corr_impl != "volume":
+    if not add_edges:
         return video, graph
     graph.add_neighborhood_factors(0, NKF, r=RADIUS)
     # targets = ground-truth reprojection + noise, so BA has a well-posed problem
@@ -319,7 +320,8 @@ def edge_sharded_leg(device, rank, world, steps=3):
     import torch.distributed as dist
     from pvo_amd.parallel import ShardedBA, shard_edges
     nkf, H, W = 64, H8, W8
-    video, graph = make_window(device, seed=7, NKF=nkf, buffer=80, corr_impl="alt")
+    corr_impl = os.environ.get("PVO_BENCH_GLOBAL_CORR", "volume")      # "alt": the reference's alt-corr path
+    video, graph = make_window(device, seed=7, NKF=nkf, buffer=80, corr_impl=corr_impl, add_edges=False, max_factors=-1)
     video.counter = nkf
     ii = [i for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= RADIUS]
     jj = [j for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= RADIUS]
@@ -388,7 +390,9 @@ def edge_sharded_leg(device, rank, world, steps=3):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         same = bool(flag.item())
     out = {"workload": "S-20: 64 keyframes, 48x64 maps, %d edges (|i-j| <= 3) sharded by source keyframe, global update "
-                       "(alt-corr lookup + update operator + BA x2), strong scaling" % len(ii),
+                       "(%s + update operator + BA x2), strong scaling"
+                       % (len(ii), "resident volume pool, one native call per step" if corr_impl == "volume" else "alt-corr lookup, 8-frame operator chunks"),
+           "correlation": corr_impl,
            "global_updates_per_s": steps / el, "ms_per_global_update": el / steps * 1e3, "edges_this_rank": len(ii_l),
            "ba_2_steps_ms": ba_ms, "allreduce_us": ar_us, "allreduce_bytes": int(msg.numel() * 8),
            "backend": dist.get_backend() if world > 1 else None, "world_size": world, "poses_bitwise_equal_across_ranks": same}

@@ -212,10 +212,11 @@ int pvo_segment_mean(const void* x, const int* seg_ptr, const int* seg_idx, cons
  *   frame == NULL: eta[k] = e for the K = R images (what GraphAgg returns).
  *   frame != NULL: FactorGraph's damping bookkeeping as well (factor_graph.py:281-297): row r of eta belongs to frame
  *     frame[r] (int64 [R]) and takes image pos[r] of x (int32 [R]; -1: the frame only carries inactive edges and keeps
- *     its stored damping):  damping[frame[r]] = e (pos[r] >= 0);  eta[r] = 0.2 * damping[frame[r]] + EP.
+ *     its stored damping):  damping[frame[r]] = e (pos[r] >= 0);  eta[r] = eta_scale * damping[frame[r]] + EP
+ *     (eta_scale = 0.2 in FactorGraph.update, factor_graph.py:297; 1 in update_lowmem, :352).
  * damping f32 [buffer,H,W] (updated in place), eta f32 [R,H,W]. */
 int pvo_eta_head(const void* x, const void* w_taps, const float* bias, const int64_t* frame, const int* pos,
-                 float* damping, float* eta, int R, int H, int W, float EP, int dtype, void* stream);
+                 float* damping, float* eta, int R, int H, int W, float EP, float eta_scale, int dtype, void* stream);
 /* y[rows,Cout] = act(x[rows,128] W^T + b), W [Cout][128] in `dtype`, Cout % 192 == 0: GraphAgg.upmask_disp =
  * Conv2d(128, 576, 1) (droid_net.py:76-77). */
 int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, long long rows, int Cout, int relu,
@@ -287,7 +288,7 @@ typedef struct pvo_operator_args {
   const void* P_zr; const void* P_q;   /* cached static-input terms [E,H,W,256], [E,H,W,128], or NULL */
   const int* seg_ptr; const int* seg_idx; int K;   /* GraphAgg groups: CSR of edges by source frame (K = 0: no aggregation) */
   void* heads;                /* [E,H,W,8] out: delta | delta_dy | weight logits | delta_mask */
-  const int64_t* eta_frame; const int* eta_pos; int R; float* damping; float EP;   /* see pvo_eta_head */
+  const int64_t* eta_frame; const int* eta_pos; int R; float* damping; float EP; float eta_scale;   /* see pvo_eta_head */
   float* eta;                 /* [R or K,H,W] f32 out, or NULL */
   void* upmask;               /* [K,H,W,576] out, or NULL */
 } pvo_operator_args;
@@ -298,7 +299,7 @@ int pvo_update_operator(const pvo_update_weights* weights, const pvo_operator_ar
 
 /* One call of FactorGraph.update (factor_graph.py:227-307) on a resident tiled volume pool. */
 typedef struct pvo_graph_update_args {
-  pvo_operator_args op;       /* coords / corr / motion / heads / eta are supplied from the workspace */
+  pvo_operator_args op;       /* coords / corr / motion / heads are supplied from the workspace; eta too unless op.eta is set */
   int nframes;
   float* poses; float* disps; const float* intrinsics;      /* [nframes,7], [nframes,H,W], [nframes,4]; poses / disps updated in place */
   const int64_t* ii; const int64_t* jj;                      /* active edges [E] */
@@ -309,7 +310,7 @@ typedef struct pvo_graph_update_args {
   int n_in;                                                  /* inactive edges that take part in the BA (use_inactive) */
   float* target_ba; float* weight_ba;                        /* [n_in + E,2,H,W] f32: rows [0,n_in) filled by the caller, the rest here */
   const int64_t* ii_ba; const int64_t* jj_ba;                /* [n_in + E] */
-  int t0, t1, itrs, motion_only; float lm, ep;
+  int t0, t1, itrs, motion_only; float lm, ep;               /* itrs = 0: no BA here (an edge-sharded caller runs it between all-reduces) */
   void* sys; void* ba_ws; size_t ba_ws_bytes;                /* [(6P)^2 + 6P] x 8 bytes; planned with pvo_ba_plan(ii_ba, jj_ba, ..., K_eta = op.R) */
   int clamp_frames; float disp_min;                          /* disps[:clamp_frames].clamp_(min=disp_min) (depth_video.py:214) */
   int want_upmask;                                           /* compute agg.upmask_disp although FactorGraph.update discards it */

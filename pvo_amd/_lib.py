@@ -33,7 +33,7 @@ SIGNATURES = {
     "pvo_conv3x3_c128": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv7x7_c8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_corr_encode": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _vp]),
-    "pvo_eta_head": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
+    "pvo_eta_head": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "pvo_conv1x1_c128": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _i, _vp]),
     "pvo_corr_build_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "pvo_corr_lookup_encode_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -81,7 +81,7 @@ class OperatorArgs(_c.Structure):
     _fields_ = [("E", _i), ("H", _i), ("W", _i), ("levels", _vp * 4), ("slots", _vp), ("num_slots", _i),
                 ("coords", _vp), ("corr", _vp), ("motion", _vp), ("net", _vp), ("net_out", _vp), ("inp", _vp),
                 ("P_zr", _vp), ("P_q", _vp), ("seg_ptr", _vp), ("seg_idx", _vp), ("K", _i), ("heads", _vp),
-                ("eta_frame", _vp), ("eta_pos", _vp), ("R", _i), ("damping", _vp), ("EP", _f), ("eta", _vp),
+                ("eta_frame", _vp), ("eta_pos", _vp), ("R", _i), ("damping", _vp), ("EP", _f), ("eta_scale", _f), ("eta", _vp),
                 ("upmask", _vp)]
 
 

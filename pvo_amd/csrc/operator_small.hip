@@ -86,7 +86,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void eta_head_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                        const float* __restrict__ bias, const long long* __restrict__ frame,
                                                        const int* __restrict__ pos, float* __restrict__ damping,
-                                                       float* __restrict__ eta, int H, int W, float EP) {
+                                                       float* __restrict__ eta, int H, int W, float EP, float eta_scale) {
   const int r = blockIdx.y;
   const int HW = H * W;
   const int pix = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void eta_head_kernel(const uint16_t* __restric
   if (l != 0) return;
   if (frame) {
     if (k >= 0) damping[frame[r] * HW + pix] = e;
-    eta[static_cast<size_t>(r) * HW + pix] = __fadd_rn(__fmul_rn(0.2f, e), EP);
+    eta[static_cast<size_t>(r) * HW + pix] = __fadd_rn(__fmul_rn(eta_scale, e), EP);
   } else {
     eta[static_cast<size_t>(r) * HW + pix] = e;
   }
@@ -282,7 +282,7 @@ extern "C" int pvo_gate_context(const float* glo_part, const float* wg_t, const 
 }
 
 extern "C" int pvo_eta_head(const void* x, const void* w_taps, const float* bias, const int64_t* frame, const int* pos,
-                            float* damping, float* eta, int R, int H, int W, float EP, int dtype, void* stream) {
+                            float* damping, float* eta, int R, int H, int W, float EP, float eta_scale, int dtype, void* stream) {
   if (R < 0 || H < 0 || W < 0) return PVO_EINVAL;
   if (R == 0 || H == 0 || W == 0) return PVO_OK;
   if (!x || !w_taps || !bias || !eta || R > 65535) return PVO_EINVAL;
@@ -292,10 +292,10 @@ extern "C" int pvo_eta_head(const void* x, const void* w_taps, const float* bias
   const dim3 grid((H * W + 15) / 16, R);
   if (dtype == PVO_F16)
     hipLaunchKernelGGL(eta_head_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w_taps),
-                       bias, reinterpret_cast<const long long*>(frame), pos, damping, eta, H, W, EP);
+                       bias, reinterpret_cast<const long long*>(frame), pos, damping, eta, H, W, EP, eta_scale);
   else if (dtype == PVO_BF16)
     hipLaunchKernelGGL(eta_head_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w_taps),
-                       bias, reinterpret_cast<const long long*>(frame), pos, damping, eta, H, W, EP);
+                       bias, reinterpret_cast<const long long*>(frame), pos, damping, eta, H, W, EP, eta_scale);
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;

@@ -174,7 +174,7 @@ int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, vo
   RUN(pvo_segment_mean(b.a1, a->seg_ptr, a->seg_idx, w->agg1_b, b.am, K, H * W, 128, dt, stream));
   RUN(pvo_conv3x3_c128(b.am, w->agg2_w, w->agg2_b, b.a2, K, H, W, 128, 1, 0, 0, dt, stream));
   if (a->eta)
-    RUN(pvo_eta_head(b.a2, w->eta_w, w->eta_b, a->eta_frame, a->eta_pos, a->damping, a->eta, a->eta_frame ? a->R : K, H, W, a->EP, dt, stream));
+    RUN(pvo_eta_head(b.a2, w->eta_w, w->eta_b, a->eta_frame, a->eta_pos, a->damping, a->eta, a->eta_frame ? a->R : K, H, W, a->EP, a->eta_scale, dt, stream));
   if (a->upmask)
     RUN(pvo_conv1x1_c128(b.a2, w->up_w, w->up_b, a->upmask, static_cast<long long>(K) * H * W, 576, 0, dt, stream));
   return PVO_OK;
@@ -273,7 +273,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   RUN(pvo_reproject(u->poses, u->disps, u->intrinsics, u->ii, u->jj, s.coords, s.valid, E, H, W, stream));
   RUN(pvo_graph_motion(u->target, s.coords, u->delta_dy, u->raw_mask, s.motion, E, H, W, dt, stream));
   a.coords = s.coords; a.corr = nullptr; a.motion = s.motion; a.heads = s.heads;
-  a.eta = s.eta;
+  a.eta = u->op.eta ? u->op.eta : s.eta;          // (a caller that runs the BA itself - edge sharding - supplies the buffer)
   if (u->want_upmask && !a.upmask) a.upmask = s.upmask;
   SideCtx* pending = nullptr;
   RUN(run_operator(w, &a, b, stream, &pending));
@@ -289,7 +289,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   const int Eb = u->n_in + E;
   probe_mark(PVO_STAGE_BA, 0, stream);
   for (int it = 0; it < u->itrs; ++it) {
-    RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, s.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
+    RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
                      H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | (it > 0 ? 2 : 0), u->sys, u->ba_ws, u->ba_ws_bytes, stream));
     RUN(pvo_ba_finish(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
                       u->motion_only, nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, stream));

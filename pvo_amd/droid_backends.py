@@ -775,11 +775,11 @@ def heads_out(h1, bias1, w2, bias2):
     return y
 
 
-def eta_head(x, w_taps, bias, frame=None, pos=None, damping=None, EP=0.0):
+def eta_head(x, w_taps, bias, frame=None, pos=None, damping=None, EP=0.0, eta_scale=0.2):
     """GraphAgg's eta head: x [K,128,H,W] channels-last 16-bit, w_taps [9,128], bias f32 [1].
     frame None -> 0.01 * softplus(conv(x) + bias) [K,H,W] f32 (what GraphAgg returns).
     frame int64 [R], pos int32 [R], damping f32 [buffer,H,W]: also FactorGraph's damping bookkeeping; returns the BA's
-    eta [R,H,W] = 0.2 * damping[frame] + EP (see pvo_eta_head)."""
+    eta [R,H,W] = eta_scale * damping[frame] + EP (see pvo_eta_head)."""
     _cl(x, "x", 128)
     dev = _dev(x, w_taps, bias, frame, pos, damping)
     K, _, H, W = x.shape
@@ -794,7 +794,7 @@ def eta_head(x, w_taps, bias, frame=None, pos=None, damping=None, EP=0.0):
     eta = torch.empty(R, H, W, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         check(_lib.load().pvo_eta_head(_ptr(x), _ptr(w_taps), _bias(bias, 1, "bias"), _ptr(frame), _ptr(pos), _ptr(damping),
-                                       _ptr(eta), R, H, W, float(EP), _dtype_code(x, "x"), _stream(dev)), "eta_head")
+                                       _ptr(eta), R, H, W, float(EP), float(eta_scale), _dtype_code(x, "x"), _stream(dev)), "eta_head")
     return eta
 
 
@@ -923,10 +923,11 @@ def _fill_operator_args(a, E, H, W, pool_levels, slots, num_slots, coords, corr,
         a.seg_ptr, a.seg_idx, a.K = None, None, 0
     a.heads = _vp(heads)
     if eta_rows is not None:
-        frame, pos, damping, EP = eta_rows
+        frame, pos, damping, EP = eta_rows[:4]
         a.eta_frame, a.eta_pos, a.R, a.damping, a.EP = frame.data_ptr(), pos.data_ptr(), int(frame.shape[0]), damping.data_ptr(), float(EP)
+        a.eta_scale = float(eta_rows[4]) if len(eta_rows) > 4 else 0.2
     else:
-        a.eta_frame, a.eta_pos, a.R, a.damping, a.EP = None, None, 0, None, 0.0
+        a.eta_frame, a.eta_pos, a.R, a.damping, a.EP, a.eta_scale = None, None, 0, None, 0.0, 0.2
     a.eta, a.upmask = _vp(eta), _vp(upmask)
 
 

@@ -123,7 +123,8 @@ class FactorGraph:
         if self.corr_impl == "volume":
             if self.device.type == "cuda" and self.video.fmaps.dtype in (torch.float16, torch.bfloat16):
                 if self.corr is None:          # resident slot pool: edge changes never move a volume
-                    cap = (self.max_factors if self.max_factors > 0 else 96) + 32
+                    base = self.max_factors if 0 < self.max_factors <= 4096 else 96      # (the backend's budget is 'unlimited')
+                    cap = max(base + 32, len(ii_l) + 32)
                     self.corr = CorrVolumePool(cap, self.ht, self.wd, self.device, self.video.fmaps.dtype)
                 self.corr.add(self.video.fmaps[ii], self.video.fmaps[jj])
             else:
@@ -225,6 +226,16 @@ class FactorGraph:
         from .modules.corr import AltCorrBlock
         t = self.video.counter
         ht, wd = self.ht, self.wd
+        if self.corr_impl == "volume" and self._fused_ok() and self.P_zr is not None:
+            # MI355X: 288 GB of HBM hold the correlation volumes of every edge of a global graph (25 MB each), which the
+            # 11-24 GB GPUs the reference targets cannot - that is the only reason it switches to alt-corr and 8-frame
+            # operator chunks here.  Chunking by source frame does not change a value (GraphAgg averages per source frame),
+            # so with resident volumes this update is update() with its own damping rule and solver constants: the whole
+            # graph in ONE native call per step.  (Correlation values then carry the volume's fp16 rounding, as in update().)
+            for _ in range(steps):
+                self._update_fused(1, t, itrs, False, EP, False, eta_scale=1.0, lm=1e-5, ep=1e-2, sharded=sharded)
+                self.video.dirty[:t] = True
+            return
         corr_op = AltCorrBlock(self.video.fmaps[None, :t], channels_last=True)
         jmax = max(self._jj_h + self._ii_h) if sharded is not None else max(self._jj_h)
         chunks = []
@@ -401,7 +412,7 @@ class FactorGraph:
         return st
 
     @torch.no_grad()
-    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only):
+    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only, eta_scale=0.2, lm=1e-4, ep=0.1, sharded=None):
         """factor_graph.py:227-307 as ONE call into libpvo_hip (pvo_graph_update): reproject, motion features, lookup +
         update operator, (panoptic vote), mask / weight glue, damping, BA.  Everything that depends only on the edge set
         (index tensors, the BA plan, the inactive edges' BA rows, output buffers) is prepared once per edge set; per
@@ -418,7 +429,7 @@ class FactorGraph:
             t0 = max(1, min(self._ii_h) + 1)
         if t1 is None:
             t1 = max(max(self._ii_h), max(self._jj_h)) + 1
-        key = (self._version, t0, t1, bool(use_inactive), bool(motion_only), E)
+        key = (self._version, t0, t1, bool(use_inactive), bool(motion_only), E, float(eta_scale), float(lm), float(ep), sharded is not None)
         st = self._cache.get("fused")
         if st is None or st["key"] != key:
             src = sorted(set(self._ii_h))
@@ -436,11 +447,17 @@ class FactorGraph:
                 rows = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
             else:
                 ii_ba, jj_ba = self.ii.contiguous(), self.jj.contiguous()
+            # one eta row per depth map the BA optimises, in the order of unique([t0, t1) U ii) (droid_kernels.cu:1314-1322);
+            # frames without an active local edge keep their stored damping (pos = -1)
+            rows = sorted(set(rows) | set(range(t0, t1)))
             where = {f: k for k, f in enumerate(src)}
             frames_t = self._idx(rows)
             pos_t = to_device_async([where.get(f, -1) for f in rows], torch.int32, self.device)
             seg = self._cached("agg", self._agg_segments)
-            ba = self._ba_plan(ii_ba, jj_ba, t0, t1, motion_only, n_in, len(rows))
+            if sharded is None:
+                ba = self._ba_plan(ii_ba, jj_ba, t0, t1, motion_only, n_in, len(rows))
+            else:                                                  # the sharded BA plans for itself (pvo_amd/parallel.py)
+                ba = {"ii": ii_ba.contiguous(), "jj": jj_ba.contiguous(), "sys": None, "ws": None}
             S = v.max_segments if v.segm_filter else 0
             st = self._cache["fused"] = dict(
                 key=key, n_in=n_in, target_ba=target_ba, weight_ba=weight_ba, ii_ba=ba["ii"], jj_ba=ba["jj"], frames=frames_t,
@@ -448,10 +465,11 @@ class FactorGraph:
                 slots=self.corr.slots_tensor(),
                 segm=self.segm[0, :, 0].contiguous() if v.segm_filter else None,
                 weight=torch.empty(1, E, ht, wd, 2, device=self.device), full_flow=torch.empty(1, E, ht, wd, 2, device=self.device),
+                eta=torch.empty(len(rows), ht, wd, device=self.device) if sharded is not None else None,
                 ws=db.graph_update_workspace(E, seg[2], len(rows), ht, wd, S, self.device), args=GraphUpdateArgs())
             a = st["args"]
             db._fill_operator_args(a.op, E, ht, wd, self.corr.levels, st["slots"], self.corr.capacity, None, None, None, None, None,
-                                   None, None, None, seg, None, (frames_t, pos_t, self.damping, EP), None, None)
+                                   None, None, None, seg, None, (frames_t, pos_t, self.damping, EP, eta_scale), st["eta"], None)
             a.nframes = v.disps.shape[0]
             a.poses, a.disps, a.intrinsics = v.poses.data_ptr(), v.disps.data_ptr(), v.intrinsics.data_ptr()
             a.ii, a.jj = st["ii"].data_ptr(), st["jj"].data_ptr()
@@ -459,8 +477,12 @@ class FactorGraph:
             a.max_segments, a.vote_thresh, a.dy_thresh = S, float(v.thresh), float(self.dy_thresh)
             a.n_in, a.target_ba, a.weight_ba = n_in, target_ba.data_ptr(), weight_ba.data_ptr()
             a.ii_ba, a.jj_ba = st["ii_ba"].data_ptr(), st["jj_ba"].data_ptr()
-            a.t0, a.t1, a.motion_only, a.lm, a.ep = t0, t1, 1 if motion_only else 0, 1e-4, 0.1
-            a.sys, a.ba_ws, a.ba_ws_bytes = ba["sys"].data_ptr(), ba["ws"].data_ptr(), ba["ws"].numel()
+            a.t0, a.t1, a.motion_only, a.lm, a.ep = t0, t1, 1 if motion_only else 0, float(lm), float(ep)
+            if sharded is None:
+                a.sys, a.ba_ws, a.ba_ws_bytes = ba["sys"].data_ptr(), ba["ws"].data_ptr(), ba["ws"].numel()
+            else:                                                  # itrs = 0 below: the native call stops in front of the BA
+                dummy = st["dummy"] = torch.zeros(64, dtype=torch.int64, device=self.device)
+                a.sys, a.ba_ws, a.ba_ws_bytes = dummy.data_ptr(), dummy.data_ptr(), dummy.numel() * 8
             a.clamp_frames, a.disp_min = v.disps.shape[0], 0.001
             a.want_upmask = 1 if self.want_upmask else 0
         a = st["args"]
@@ -479,8 +501,15 @@ class FactorGraph:
         a.target, a.delta_dy, a.raw_mask = self.target_cam.data_ptr(), self.delta_dy.data_ptr(), self.raw_mask.data_ptr()
         self.weight, self.full_flow = st["weight"], st["full_flow"]
         a.weight, a.full_flow = self.weight.data_ptr(), self.full_flow.data_ptr()
-        a.itrs = int(itrs)
+        a.itrs = int(itrs) if sharded is None else 0
+        a.clamp_frames = v.disps.shape[0] if sharded is None else 0
         db.graph_update(self.update_op.packed_weights(dt), a, st["ws"])
+        if sharded is not None:
+            # edge sharding: assembly + Schur on this rank's edges, ONE integer all-reduce of the reduced pose system per
+            # Gauss-Newton step, identical solve on every rank (pvo_amd/parallel.py)
+            sharded.ba(v.poses, v.disps, v.intrinsics[0], st["target_ba"], st["weight_ba"], st["eta"], st["ii_ba"], st["jj_ba"],
+                       t0, t1, itrs=itrs, lm=lm, ep=ep, motion_only=motion_only, plan_key=(id(self), self._version, t0, t1))
+            v.disps.clamp_(min=0.001)
         self.age += 1
         self._age_h = [x + 1 for x in self._age_h]
 

@@ -147,6 +147,38 @@ def test_native_update_survives_edge_changes(cuda):
         assert dd.mean().item() < 2e-3, k
 
 
+@pytest.mark.gpu
+def test_native_global_update_on_resident_volumes(cuda):
+    """FactorGraph.update_lowmem with corr_impl="volume" (the whole global graph in one pvo_graph_update per step, volumes
+    resident in HBM) against the reference's formulation of the same update (alt-corr lookup, operator in 8-frame chunks,
+    PyTorch glue, DepthVideo.ba) on the same window; and its edge-sharded variant (operator native with itrs=0, BA through
+    ShardedBA) against the unsharded call - integer accumulation makes those two bit-identical."""
+    import bench
+    from pvo_amd.parallel import ShardedBA
+    nkf = 12
+    ii = [i for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= 2]
+    jj = [j for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= 2]
+    res = {}
+    for name, corr_impl, fused, sharded in (("native", "volume", True, None), ("sharded", "volume", True, ShardedBA()),
+                                            ("alt", "alt", False, None)):
+        video, graph = bench.make_window(cuda, seed=5, NKF=nkf, buffer=16, corr_impl=corr_impl, add_edges=False, max_factors=-1)
+        video.counter = nkf
+        graph.fused_glue = fused
+        graph.add_factors(list(ii), list(jj))
+        assert (corr_impl == "volume") == (graph.P_zr is not None and graph._fused_ok())
+        p0 = video.poses.clone()
+        graph.update_lowmem(steps=2, sharded=sharded)
+        torch.cuda.synchronize()
+        assert (video.poses - p0).abs().max() > 1e-4
+        res[name] = dict(poses=video.poses.clone(), disps=video.disps.clone(), net=graph.net.float().clone(),
+                         target=graph.target_cam.clone(), raw=graph.raw_mask.clone(), damping=graph.damping.clone())
+    for k in res["native"]:
+        assert torch.equal(res["native"][k], res["sharded"][k]), k
+        dd = (res["native"][k] - res["alt"][k]).abs()
+        print(k, "max %.3g mean %.3g" % (dd.max().item(), dd.mean().item()))
+        assert dd.mean().item() < 2e-3, k
+
+
 def test_update_lowmem_glue_matches_reference(monkeypatch):
     """FactorGraph.update_lowmem against the reference's own update_lowmem run with the same recorded stand-ins
     (tests/golden/gen_golden.py: gen_lowmem_glue): chunking by source frame, motion features, damping, BA arguments."""
