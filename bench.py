@@ -88,8 +88,8 @@ class Snapshot:
         self.g.damping.copy_(self.damping)
 
 
-def keyframe_update(video, graph, snap):
-    """droid_frontend.py:36-70 on a full window"""
+def keyframe_update(video, graph, snap, clock_probe=None):
+    """droid_frontend.py:36-70 on a full window (clock_probe: diagnostic hook called after the second graph update)"""
     snap.restore()
     newest = graph.nkf - 1
     pairs = [(i, j) for i, j in zip(graph._ii_h, graph._jj_h) if i == newest or j == newest]
@@ -97,8 +97,10 @@ def keyframe_update(video, graph, snap):
     graph.add_factors([p[0] for p in pairs], [p[1] for p in pairs])
     snap_edges_fix(graph, snap)
     d = video.distance(beta=0.3, bidirectional=True)          # NKF x NKF proximity matrix
-    for _ in range(4):
+    for k in range(4):
         graph.update(None, None, use_inactive=True)
+        if k == 1 and clock_probe is not None:
+            clock_probe()
     dk = video.distance([newest - 2], [newest - 1], beta=0.3, bidirectional=True)
     for _ in range(2):
         graph.update(None, None, use_inactive=True)
@@ -493,16 +495,41 @@ def main():
     gw = (torch.randn(9, 256, 320, device=device) * 0.02).half()
     gg = torch.randn(Eg, 384, device=device)
     gp = torch.randn(Eg, H8, W8, 256, device=device).half().permute(0, 3, 1, 2)
-    for _ in range(3):
-        db.gru_conv_gates(gn, gc, gw, gg, gp)
-    gv0, gv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    gv0.record()
-    for _ in range(20):
-        db.gru_conv_gates(gn, gc, gw, gg, gp)
-    gv1.record()
+    # ... and the clock the chip holds meanwhile: MI355X trades clock for power, and this kernel is power-limited - one probe
+    # wave (pvo_clock_probe) on a second stream reads shader cycles against the 100 MHz counter while the launches run;
+    # the same launches on zero-filled operands (no switching in the multipliers) show what the instruction stream
+    # itself sustains
+    side = torch.cuda.Stream(device=device)
+
+    def gates_run(n, zero):
+        a = [torch.zeros_like(t) if zero else t for t in (gn, gc, gw, gg, gp)]
+        for _ in range(3):
+            db.gru_conv_gates(*a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        clk = None
+        for i in range(n):
+            db.gru_conv_gates(*a)
+            if i == 4:
+                side.wait_stream(torch.cuda.current_stream())          # (starts beside the fifth launch, not before the first)
+                clk = db.clock_probe(side, iters=4000)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3, db.clock_ghz(clk)
     torch.cuda.synchronize()
-    gates_us = gv0.elapsed_time(gv1) / 20 * 1e3
+    idle_clk = db.clock_probe(side, iters=4000)
+    torch.cuda.synchronize()
+    idle_ghz = db.clock_ghz(idle_clk)
+    gates_us, gates_ghz = gates_run(20, False)
+    gates_zero_us, gates_zero_ghz = gates_run(20, True)
     gates_flop = 2.0 * Eg * H8 * W8 * 9 * 320 * 256
+    # the clock inside a full step (probe beside the third graph update of an extra, untimed step)
+    step_clk = []
+    for _ in range(2):
+        keyframe_update(video, graph, snap, clock_probe=lambda: step_clk.append(db.clock_probe(side, iters=4000)))
+    torch.cuda.synchronize()
+    step_ghz = sum(db.clock_ghz(c) for c in step_clk) / max(len(step_clk), 1)
     del gn, gc, gw, gg, gp
 
     if rank == 0:
@@ -538,6 +565,12 @@ def main():
                 "avg_launch_us": stage_us["gates"], "launches_timed": 2 * updates_per_step,
                 "timing": "HIP events around the kernel on its launch stream, inside two extra (untimed) steps of the same loop",
                 "isolated_back_to_back_us": gates_us, "isolated_frac": gates_flop / (gates_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                "shader_clock_ghz": {"idle": idle_ghz, "under_this_kernel_random_operands": gates_ghz,
+                                     "under_this_kernel_zero_operands": gates_zero_ghz, "inside_a_step": step_ghz,
+                                     "how": "pvo_clock_probe: one wave on a second stream, s_memtime cycles / s_memrealtime"},
+                "zero_operands_us": gates_zero_us, "zero_operands_frac": gates_flop / (gates_zero_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                "frac_of_peak_at_sustained_clock": gates_flop / (gates_us * 1e-6) / 1e12 / (MFMA_PEAK_TFLOPS * gates_ghz / 2.4),
+                "note": "power-limited: on random operands the chip drops from 2.4 GHz to the clock above, and the dense peak scales with it",
                 "share_of_update_time": stage_us["gates"] / stage_us["update"] if stage_us["update"] else None},
             "stage_us_in_step": dict(stage_us, lookup=1e3 * sum(in_step_lookup) / max(len(in_step_lookup), 1)),
         }

@@ -311,7 +311,8 @@ typedef struct pvo_graph_update_args {
   float* target_ba; float* weight_ba;                        /* [n_in + E,2,H,W] f32: rows [0,n_in) filled by the caller, the rest here */
   const int64_t* ii_ba; const int64_t* jj_ba;                /* [n_in + E] */
   int t0, t1, itrs, motion_only; float lm, ep;               /* itrs = 0: no BA here (an edge-sharded caller runs it between all-reduces) */
-  void* sys; void* ba_ws; size_t ba_ws_bytes;                /* [(6P)^2 + 6P] x 8 bytes; planned with pvo_ba_plan(ii_ba, jj_ba, ..., K_eta = op.R) */
+  void* sys; void* ba_ws; size_t ba_ws_bytes;                /* [(6P)^2 + 6P] x 8 bytes, ZERO on entry (every solve leaves it zero again: allocate it
+                                                                zeroed once); planned with pvo_ba_plan(ii_ba, jj_ba, ..., K_eta = op.R) */
   int clamp_frames; float disp_min;                          /* disps[:clamp_frames].clamp_(min=disp_min) (depth_video.py:214) */
   int want_upmask;                                           /* compute agg.upmask_disp although FactorGraph.update discards it */
 } pvo_graph_update_args;
@@ -324,6 +325,11 @@ size_t pvo_graph_update_workspace_bytes(int E, int K, int R, int H, int W, int m
 enum { PVO_STAGE_LOOKUP = 0, PVO_STAGE_GATES = 1, PVO_STAGE_CANDIDATE = 2, PVO_STAGE_BA = 3, PVO_STAGE_UPDATE = 4 };
 int pvo_probe_arm(int stage, int capacity);
 int pvo_probe_read(float* ms_host, int max_n);
+/* Shader-clock probe: one wave runs iters x 64 dependent v_fma_f32 and writes {s_memtime cycles, s_memrealtime ticks of
+ * 10 ns, (unused)} to out3_u64 (device, 3 x uint64).  Launched on a second stream beside a kernel, cycles / (10 ns x
+ * ticks) is the clock the chip sustains under that kernel's load (the MFMA-bound convolutions run at ~1.35 GHz on random
+ * data, 2.1 GHz on zero-filled operands, 2.4 GHz idle: DESIGN.md section 5). */
+int pvo_clock_probe(void* out3_u64, int iters, void* stream);
 int pvo_graph_update(const pvo_update_weights* weights, const pvo_graph_update_args* args,
                      void* workspace, size_t workspace_bytes, void* stream);
 
@@ -425,6 +431,8 @@ int pvo_ba(float* poses, float* disps, const float* intrinsics,
  * pvo_ba_finish converts to fp64, solves in fp64 (as SparseBlock::solve, droid_kernels.cu:1160-1198)
  * and leaves `sys` ZEROED; bit 1 of pvo_ba_local's motion_only argument says that `sys` is
  * already zero (local -> finish -> local chains), otherwise pvo_ba_local clears it first.
+ * clamp_frames > 0 (pvo_ba_finish, depth BA only): disps[:clamp_frames].clamp_(min=disp_min) in the back-substitution
+ * launch - DepthVideo.ba's clamp (depth_video.py:214) without a launch of its own.
  * With one rank pvo_ba == plan + iterations x (local, finish).  pvo_ba_plan must run
  * before the first pvo_ba_local of a graph (same workspace); pass K_eta = -1 for a
  * motion-only plan. */
@@ -440,7 +448,7 @@ int pvo_ba_local(const float* poses, const float* disps, const float* intrinsics
 int pvo_ba_finish(float* poses, float* disps, void* sys,
                   const int64_t* ii, const int64_t* jj,
                   int E, int nframes, int ht, int wd, int t0, int t1,
-                  float lm, float ep, int motion_only,
+                  float lm, float ep, int motion_only, int clamp_frames, float disp_min,
                   float* dx_out, float* dz_out, int dz_rows, int* status_out,
                   void* workspace, size_t workspace_bytes, void* stream);
 

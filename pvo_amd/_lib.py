@@ -57,12 +57,13 @@ SIGNATURES = {
     "pvo_depth_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_reproject": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_ba_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "pvo_clock_probe": (_i, [_vp, _i, _vp]),
     "pvo_ba": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                     _f, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "pvo_ba_local": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                           _i, _vp, _vp, _sz, _vp]),
-    "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i,
+    "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,
                            _vp, _vp, _i, _vp, _vp, _sz, _vp]),
 }
 

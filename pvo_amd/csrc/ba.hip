@@ -699,16 +699,29 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   if (threadIdx.x == 0) fail = 0;
   for (int b = threadIdx.x; b < P; b += blockDim.x) first[b] = b;
   __syncthreads();
-  for (int idx = threadIdx.x; idx < n * n + n; idx += blockDim.x) {
-    const long long raw = sys[idx];
-    double v = static_cast<double>(raw) * kInvFix;            // fixed point -> fp64
-    sys[idx] = 0;                                             // ready for the next Gauss-Newton step's accumulation
-    if (idx < n * n) {
-      const int r = idx / n, c = idx - r * n;
-      if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
-      if (raw != 0 && c < r) atomicMin(&first[r / 6], c / 6);
+  // (eight loads in flight per thread: one at a time, behind the zeroing store of the previous one, the 1806 entries of a
+  // 7-pose system cost eight serial L2 round trips - a third of this kernel)
+  const int N = n * n + n;
+  for (int base = 0; base < N; base += 8 * blockDim.x) {
+    long long raw[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * blockDim.x + threadIdx.x;
+      raw[u] = idx < N ? sys[idx] : 0;
     }
-    A[idx] = v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * blockDim.x + threadIdx.x;
+      if (idx >= N) continue;
+      double v = static_cast<double>(raw[u]) * kInvFix;       // fixed point -> fp64
+      sys[idx] = 0;                                           // ready for the next Gauss-Newton step's accumulation
+      if (idx < n * n) {
+        const int r = idx / n, c = idx - r * n;
+        if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
+        if (raw[u] != 0 && c < r) atomicMin(&first[r / 6], c / 6);
+      }
+      A[idx] = v;
+    }
   }
   __syncthreads();
   chol_solve_blocked(A, Ld, red, n, &fail, first);
@@ -743,11 +756,18 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
 __global__ __launch_bounds__(256) void ba_backsub_kernel(
     Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ Ei, const float* __restrict__ Eij,
     const float* __restrict__ Q, const float* __restrict__ w, const float* __restrict__ dx,
-    float* __restrict__ disps, float* __restrict__ dz_out, int dz_rows, int HW, int t0, int P, int flags) {
+    float* __restrict__ disps, float* __restrict__ dz_out, int dz_rows, int HW, int t0, int P, int flags,
+    int clamp_frames, float disp_min) {
   const int k = blockIdx.y;
-  if (k >= pl.meta[0]) return;
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x >= HW) return;
+  // clamp_frames > 0: disps[:clamp_frames].clamp_(min=disp_min) in the same launch (depth_video.py:214) - frames this BA
+  // does not optimise here, by frame index; optimised ones below, after their update
+  if (k < clamp_frames && pl.kidx[k] < 0) {
+    const float v = disps[static_cast<long long>(k) * HW + x];
+    if (v < disp_min) disps[static_cast<long long>(k) * HW + x] = disp_min;            // NaN stays NaN, as in torch.clamp
+  }
+  if (k >= pl.meta[0]) return;
   const int e0 = pl.eptr[k], e1 = pl.eptr[k + 1];
   // EvT6x1_kernel returns early for pose index <= 0 (:1084): window pose 0 never reaches dz.
   const int lo = (flags & 1) ? 0 : 1;
@@ -761,7 +781,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
     acc += s;
   }
   const float dz = Q[static_cast<long long>(k) * HW + x] * (w[static_cast<long long>(k) * HW + x] - acc);
-  disps[static_cast<long long>(pl.kx[k]) * HW + x] += dz;          // disp_retr_kernel (:912-925)
+  float d = disps[static_cast<long long>(pl.kx[k]) * HW + x] + dz;  // disp_retr_kernel (:912-925)
+  if (pl.kx[k] < clamp_frames && d < disp_min) d = disp_min;
+  disps[static_cast<long long>(pl.kx[k]) * HW + x] = d;
   if (dz_out && k < dz_rows) dz_out[static_cast<long long>(k) * HW + x] = dz;
 }
 
@@ -838,11 +860,12 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
 extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
                              const int64_t* ii, const int64_t* jj,
                              int E, int nframes, int ht, int wd, int t0, int t1,
-                             float lm, float ep, int motion_only,
+                             float lm, float ep, int motion_only, int clamp_frames, float disp_min,
                              float* dx_out, float* dz_out, int dz_rows, int* status_out,
                              void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_common(E, nframes, ht, wd, t0, t1);
   if (rc != PVO_OK) return rc;
+  if (clamp_frames < 0 || clamp_frames > nframes) return PVO_EINVAL;
   const int P = t1 - t0, HW = ht * wd;
   long long* sys = static_cast<long long*>(sys_);
   if (!poses || !disps || !sys || !workspace) return PVO_EINVAL;
@@ -863,8 +886,8 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
   if (!motion_only && E + P > 0) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);
     const int flags = 0;
-    hipLaunchKernelGGL(ba_backsub_kernel, dim3((HW + 255) / 256, Kmax), dim3(256), 0, st,
-                       w.plan, jj, w.Ei, w.Eij, w.Q, w.w, w.dx, disps, dz_out, dz_rows, HW, t0, P, flags);
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3((HW + 255) / 256, Kmax > clamp_frames ? Kmax : clamp_frames), dim3(256), 0, st,
+                       w.plan, jj, w.Ei, w.Eij, w.Q, w.w, w.dx, disps, dz_out, dz_rows, HW, t0, P, flags, clamp_frames, disp_min);
     PVO_CHECK_LAUNCH();
   }
   return PVO_OK;
@@ -892,7 +915,7 @@ extern "C" int pvo_ba(float* poses, float* disps, const float* intrinsics,
     rc = pvo_ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, E, nframes, ht, wd, K_eta,
                       t0, t1, (motion_only ? 1 : 0) | (it > 0 ? 2 : 0), w.sys, workspace, workspace_bytes, stream);
     if (rc != PVO_OK) return rc;
-    rc = pvo_ba_finish(poses, disps, w.sys, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only,
+    rc = pvo_ba_finish(poses, disps, w.sys, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only, 0, 0.0f,
                        dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes, stream);
     if (rc != PVO_OK) return rc;
   }

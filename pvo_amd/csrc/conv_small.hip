@@ -374,12 +374,32 @@ constexpr int kBA = 420 * kBStride;                       // 18 x 20 positions +
 // pixel (row, column) inside a wave's 8 x 16 block of accumulator row `m` (0..31) of M-tile `mt`
 __device__ __forceinline__ int big_pix(int mt, int m) { return (m >> 2) * 16 + 4 * mt + (m & 3); }
 
+// tools/conv_timeline.py builds this file with -DPVO_CONV_PROBE: every workgroup then records its shader-clock stamps
+// (start, main loop entered, main loop left, end) and the compute unit it ran on; the shipped library has none of it.
+#ifdef PVO_CONV_PROBE
+__device__ unsigned long long* g_conv_probe = nullptr;
+#define CONV_WG ((static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
+#define CONV_PROBE(slot)                                                                                          \
+  do {                                                                                                            \
+    if (g_conv_probe && threadIdx.x == 0) g_conv_probe[CONV_WG * 8 + (slot)] = __builtin_readcyclecounter();      \
+  } while (0)
+#else
+#define CONV_PROBE(slot)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                           int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, BigEpi ep) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bs[];      // halo[2]; later the output slab
   unsigned char* As = bs;
+  CONV_PROBE(0);
+#ifdef PVO_CONV_PROBE
+  if (g_conv_probe && threadIdx.x == 0) {
+    g_conv_probe[CONV_WG * 8 + 4] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (31 << 11))) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    g_conv_probe[CONV_WG * 8 + 5] = wall_clock64();
+  }
+#endif
   const int ntx = (W + kBT - 1) / kBT;
   const int cg = blockIdx.x / ntx, tx_ = blockIdx.x - cg * ntx;
   const int e = blockIdx.z, y0 = blockIdx.y * kBT, x0 = tx_ * kBT;
@@ -460,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     fetch_a(1);
     store_a(0, 1);
     __syncthreads();
+    CONV_PROBE(1);
     // this lane's A rows: M-tile mt of wave-row wm = tile rows 8 wm + (li >> 2), columns 4 mt + (li & 3)
     const unsigned char* Abase = As + ((8 * wm + (li >> 2)) * kBPitch + (li & 3)) * kBStride + kg * 16;
     // Software pipeline at half-step (k = 16) granularity, pinned with sched_barrier: the four A fragments of the NEXT
@@ -477,31 +498,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       fetch_a(0);
       cs_u32x4 a0[4], a1[4];
       read_half(a0, Ac, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int toff = ((t / 3) * kBPitch + (t % 3)) * kBStride;         // compile-time: ds_read immediates
         fetch_bf(bset[(t + 2) % 3], cc * 9 + t + 2);
         read_half(a1, Ac, toff, 1);
-        __builtin_amdgcn_sched_barrier(0);
         const cs_u32x4 (&bf)[4] = bset[t % 3];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(a0[mt], bf[nt * 2], acc[mt][nt]);
+        // issue order inside the half-step: one LDS read / one global load behind each MFMA (an in-order wave hides
+        // about five single-issue instructions in the 32 cycles an MFMA holds the pipe; clumped between the groups of
+        // eight they are exposed)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
         __builtin_amdgcn_sched_barrier(0);
         if (t < 8) read_half(a0, Ac, ((((t + 1) / 3) * kBPitch) + ((t + 1) % 3)) * kBStride, 0);
         if (t == 3) { store_a((cc + 1) & 1, 0); fetch_a(1); }   // (the other halo buffer was last read before the previous barrier)
         if (t == 7) store_a((cc + 1) & 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(a1[mt], bf[nt * 2 + 1], acc[mt][nt]);
+        if (t < 8) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        }
+        if (t == 3 || t == 7) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+        }
+        if (t == 3) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 3, 0); }
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }
   }
+  CONV_PROBE(2);
 
   if (ep.mode != 0) {
     // fused ConvGRU epilogue: pre-activations cross the workgroup through an fp32 slab [128 px][128 ch] (528-byte pixel
@@ -584,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       finish(half, 1);
       __syncthreads();
     }
+    CONV_PROBE(3);
     return;
   }
   // epilogue: two halves of 128 pixels through an LDS slab [128 px][128 ch] (272-byte pixel stride) -> whole-row stores
@@ -616,9 +654,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
     __syncthreads();
   }
+  CONV_PROBE(3);
 }
 
 }  // namespace
+
+#ifdef PVO_CONV_PROBE
+extern "C" int pvo_debug_conv_probe(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_conv_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
                               int E, int H, int W, int dtype, void* stream) {

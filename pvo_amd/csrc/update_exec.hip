@@ -109,7 +109,12 @@ void* ws_base(void* workspace) {
 // everything of the operator up to the new hidden state; the two branches that read it follow in run_heads / run_agg.
 // With PVO_OP_ENC_SIDE_STREAM the work that does not depend on the correlation features - the global-context reduction of
 // `net`, the gate context, the flow encoder - runs on the side stream beside the HBM-bound lookup and corr_encoder[2].
-int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, const void** P_zr, const void** P_q) {
+struct MotionJob {           // pvo_graph_update's motion features: only the flow encoder reads them, so they go with it
+  const float *target, *coords, *delta_dy, *raw_mask; void* motion;
+};
+
+int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, const void** P_zr, const void** P_q,
+              const MotionJob* mj) {
   const int E = a->E, H = a->H, W = a->W, dt = w->dtype;
   const long long rows = static_cast<long long>(E) * H * W;
   hipStream_t st = pvo_stream(stream);
@@ -119,13 +124,7 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
   }
-  // independent of the correlation features (side stream when enabled)
-  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s2));
-  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s2));
-  RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
-  RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
-  if (sc && hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
-  // correlation features
+  // correlation features first: the launch stream's longest early kernel is in flight while the host issues the rest
   if (a->levels[0]) {
     probe_mark(PVO_STAGE_LOOKUP, 0, stream);
     RUN(pvo_corr_lookup_encode_tiled(a->levels, a->coords, w->enc0_w, w->enc0_b, b.c1, E, H, W, dt, a->slots, a->num_slots, stream));
@@ -134,6 +133,13 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     if (!a->corr) return PVO_EINVAL;
     RUN(pvo_corr_encode(a->corr, w->enc0_w, w->enc0_b, b.c1, rows, dt, stream));
   }
+  // independent of the correlation features (side stream when enabled)
+  if (mj) RUN(pvo_graph_motion(mj->target, mj->coords, mj->delta_dy, mj->raw_mask, mj->motion, E, H, W, dt, s2));
+  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s2));
+  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s2));
+  RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
+  RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
+  if (sc && hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
   // the encoders' second layers write relu(features + bias) side by side: CF = [corr features (128) | flow features (64)]
   if (w->flags & PVO_OP_CONV128_WIDE)
     RUN(pvo_conv3x3(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 128, 1, 192, 0, dt, stream));
@@ -192,9 +198,10 @@ int check_op(const pvo_update_weights* w, const pvo_operator_args* a) {
 // trunk on `stream`, then the aggregation branch on the side stream beside the heads on `stream`.  join_now = false
 // leaves the join to the caller (pvo_graph_update joins only in front of the BA, so the K-frame kernels of the
 // aggregation branch, which occupy a fraction of the chip, also overlap the mask / weight glue).
-int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx** pending) {
+int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx** pending,
+                 const MotionJob* mj = nullptr) {
   const void *P_zr, *P_q;
-  RUN(run_trunk(w, a, b, stream, &P_zr, &P_q));
+  RUN(run_trunk(w, a, b, stream, &P_zr, &P_q, mj));
   hipStream_t st = pvo_stream(stream);
   SideCtx* sc = (a->K > 0 && !(w->flags & PVO_OP_SINGLE_STREAM)) ? side_ctx() : nullptr;
   if (sc) {
@@ -271,12 +278,12 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   probe_mark(PVO_STAGE_UPDATE, 0, stream);
   // factor_graph.py:231-237: reprojection and motion features
   RUN(pvo_reproject(u->poses, u->disps, u->intrinsics, u->ii, u->jj, s.coords, s.valid, E, H, W, stream));
-  RUN(pvo_graph_motion(u->target, s.coords, u->delta_dy, u->raw_mask, s.motion, E, H, W, dt, stream));
+  const MotionJob mj{u->target, s.coords, u->delta_dy, u->raw_mask, s.motion};
   a.coords = s.coords; a.corr = nullptr; a.motion = s.motion; a.heads = s.heads;
   a.eta = u->op.eta ? u->op.eta : s.eta;          // (a caller that runs the BA itself - edge sharding - supplies the buffer)
   if (u->want_upmask && !a.upmask) a.upmask = s.upmask;
   SideCtx* pending = nullptr;
-  RUN(run_operator(w, &a, b, stream, &pending));
+  RUN(run_operator(w, &a, b, stream, &pending, &mj));
   // :249-306: mask update, (panoptic vote), weights, targets in the BA's layout, full flow
   if (u->segm)
     RUN(pvo_segment_hist(u->segm, u->raw_mask, s.heads, s.vote_tot, s.vote_dyn, E, HW, S, u->dy_thresh, dt, stream));
@@ -288,14 +295,18 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
   const int Eb = u->n_in + E;
   probe_mark(PVO_STAGE_BA, 0, stream);
+  // `sys` is zero on entry (contract, see the header) and every solve leaves it zero: no memset between updates.  The
+  // depth clamp of depth_video.py:214 rides on the last back-substitution.
   for (int it = 0; it < u->itrs; ++it) {
+    const bool last = it + 1 == u->itrs;
     RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
-                     H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | (it > 0 ? 2 : 0), u->sys, u->ba_ws, u->ba_ws_bytes, stream));
+                     H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | 2, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
     RUN(pvo_ba_finish(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
-                      u->motion_only, nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, stream));
+                      u->motion_only, last && !u->motion_only ? u->clamp_frames : 0, u->disp_min,
+                      nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, stream));
   }
   probe_mark(PVO_STAGE_BA, 1, stream);
-  if (u->clamp_frames > 0) {               // depth_video.py:214 disps.clamp_(min=0.001)
+  if (u->clamp_frames > 0 && (u->itrs == 0 || u->motion_only)) {      // (no back-substitution ran: clamp on its own)
     const long long n = static_cast<long long>(u->clamp_frames) * HW;
     hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, u->disps, n, u->disp_min);
     PVO_CHECK_LAUNCH();

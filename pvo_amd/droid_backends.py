@@ -537,9 +537,11 @@ def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, mo
                                        _stream(dev)), "ba_local")
 
 
-def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None, outputs=True):
+def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None, outputs=True,
+              clamp_frames=0, disp_min=0.001):
     """damp + solve the (all-reduced) system (left zeroed afterwards), retract poses, back-substitute this rank's depths -> [dx, dz]
-    (outputs=False: poses / disps are updated in place and no dx / dz tensors are produced -> [None, None])"""
+    (outputs=False: poses / disps are updated in place and no dx / dz tensors are produced -> [None, None]).
+    clamp_frames > 0: disps[:clamp_frames].clamp_(min=disp_min) in the same launch."""
     dev = _dev(poses, disps, sys, ii, jj, workspace)
     F, ht, wd = disps.shape
     P = int(t1) - int(t0)
@@ -550,7 +552,7 @@ def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace,
     with torch.cuda.device(dev):
         check(_lib.load().pvo_ba_finish(_ptr(poses), _ptr(disps), _ptr(sys), _ptr(ii), _ptr(jj), ii.shape[0], F, ht, wd,
                                         int(t0), int(t1), float(lm), float(ep), 1 if motion_only else 0,
-                                        _ptr(dx), _ptr(dz), int(dz_rows),
+                                        int(clamp_frames), float(disp_min), _ptr(dx), _ptr(dz), int(dz_rows),
                                         _ptr(status) if status is not None else ctypes.c_void_p(0),
                                         ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(dev)),
               "ba_finish")
@@ -1049,6 +1051,23 @@ def se3_binary(op, a, rep_a, b, rep_b, out_batch):
 
 
 STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4}
+
+
+def clock_probe(stream, iters=20000):
+    """launch the shader-clock probe on `stream` (a torch.cuda.Stream); returns the device tensor it fills - after a
+    synchronize, `clock_ghz(t)` is the clock the chip held while the probe ran"""
+    dev = torch.device("cuda", stream.device_index if hasattr(stream, "device_index") else torch.cuda.current_device())
+    with torch.cuda.device(dev), torch.cuda.stream(stream):
+        # (allocated ON `stream`: a block the caching allocator recycles for the current stream may still be in use by
+        # kernels queued there, which is only safe for work ordered behind them)
+        out = torch.zeros(3, dtype=torch.int64, device=dev)
+        check(_lib.load().pvo_clock_probe(_ptr(out), int(iters), ctypes.c_void_p(stream.cuda_stream)), "clock_probe")
+    return out
+
+
+def clock_ghz(t):
+    c, r, _ = t.tolist()
+    return c / (r * 10.0) if r else float("nan")
 
 
 def probe_arm(stage, capacity):

@@ -34,6 +34,7 @@ class FactorGraph:
         self.dy_thresh, self.mask_num = 0.5, 2
         self.coords0 = coords_grid(ht, wd, self.device)
         lng = dict(dtype=torch.long, device=self.device)
+        self._age_lag = 0
         self.ii, self.jj, self.age = (torch.zeros(0, **lng) for _ in range(3))
         self._ii_h, self._jj_h, self._age_h = [], [], []
         self.corr = self.net = self.inp = self.segm = None
@@ -406,7 +407,7 @@ class FactorGraph:
                 torch.empty(need + (need >> 2), dtype=torch.uint8, device=self.device)
             n6 = 6 * P
             sysb = st["sys"] if st is not None and st["sys"].numel() >= n6 * n6 + n6 else \
-                torch.empty(max(n6 * n6 + n6, 1), dtype=torch.int64, device=self.device)
+                torch.zeros(max(n6 * n6 + n6, 1), dtype=torch.int64, device=self.device)   # zero on entry, left zero by every solve
             db.ba_plan(ii, jj, F, ht * wd, -1 if motion_only else int(R), t0, t1, ws)
             st = self.__dict__["_ba_state"] = {"key": key, "ws": ws, "sys": sysb, "ii": ii, "jj": jj}
         return st
@@ -510,8 +511,21 @@ class FactorGraph:
             sharded.ba(v.poses, v.disps, v.intrinsics[0], st["target_ba"], st["weight_ba"], st["eta"], st["ii_ba"], st["jj_ba"],
                        t0, t1, itrs=itrs, lm=lm, ep=ep, motion_only=motion_only, plan_key=(id(self), self._version, t0, t1))
             v.disps.clamp_(min=0.001)
-        self.age += 1
+        self._age_lag += 1                 # (the device copy of `age` is brought up to date when it is next read)
         self._age_h = [x + 1 for x in self._age_h]
+
+    @property
+    def age(self):
+        """per-edge update count (factor_graph.py:35); decisions use the host mirror `_age_h`, so the native update
+        path only counts and the device tensor catches up here, on access"""
+        if self._age_lag:
+            self._age_dev += self._age_lag
+            self._age_lag = 0
+        return self._age_dev
+
+    @age.setter
+    def age(self, t):
+        self._age_dev, self._age_lag = t, 0
 
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
