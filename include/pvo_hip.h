@@ -190,6 +190,17 @@ int pvo_gru_conv_candidate(const void* RN, const void* cf, int cf_channels, cons
  * Conv3x3(128->2) per head applied to relu(h1[..., head*128:(head+1)*128] + bias1), zero padding.
  * h1 [E,H,W,512] is the bias-free output of the four first-stage convolutions; w2 is
  * [4 heads][2 outputs][9 taps (ky*3+kx)][128 channels] in `dtype`; bias1 [512], bias2 [8] f32. */
+/* The same heads WITHOUT the [E,H,W,512] hidden tensor in HBM (what pvo_update_operator / pvo_graph_update run):
+ *   pvo_conv3x3_heads  first-stage convolutions (128 -> 4 x 128, w1_taps as for pvo_conv3x3, bias1 [512]) whose epilogue
+ *                      keeps relu(hidden) in LDS and multiplies every pixel's 128 hidden channels of a head by all nine
+ *                      second-stage tap filters on the matrix cores: z [E,H,W,4,18] f32, z[q][head][2 t + o] =
+ *                      W2[head][o][tap t] . hidden_head(q).  w2_frags: the second-stage filter as MFMA B fragments,
+ *                      [4 heads][8 k-steps][64 lanes][8]: element (h, ks, lane, j) = W2[h][o][t][ks*16 + (lane>>5)*8 + j]
+ *                      for n = lane & 31 = 2 t + o < 18, else 0.
+ *   pvo_heads_gather   y[p][2 head + o] = bias2[2 head + o] + sum_t z[p + tap t][head][2 t + o] (zero padding) -> [E,H,W,8]. */
+int pvo_conv3x3_heads(const void* x, const void* w1_taps, const float* bias1, const void* w2_frags, float* z,
+                      int E, int H, int W, int dtype, void* stream);
+int pvo_heads_gather(const float* z, const float* bias2, void* y, int E, int H, int W, int dtype, void* stream);
 int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const float* bias2, void* y,
                   int E, int H, int W, int dtype, void* stream);
 /* y[E,H,W,128] = relu(conv7x7(x[E,H,W,8], zero padding 3) + bias): the first layer of the update operator's
@@ -267,7 +278,7 @@ typedef struct pvo_update_weights {
   const void* zr_w;     const void* q_w;         /* gru.convz|convr, gru.convq over [net|corr|flow]: taps [9][256][320], [9][128][320] */
   const void* zr_inp_w; const void* q_inp_w;     /* the same filters' `inp` input channels: taps [9][256][128], [9][128][128] */
   const void* heads1_w; const float* heads1_b;   /* delta|delta_dy|weight|delta_mask .0: taps [9][512][128], [512] */
-  const void* heads2_w; const float* heads2_b;   /* ... .2: [4][2][9][128], [8] */
+  const void* heads2_w; const float* heads2_b;   /* ... .2: as pvo_conv3x3_heads' w2_frags [4][8][64][8], [8] */
   const void* agg1_w;   const float* agg1_b;     /* agg.conv1: taps [9][128][128], [128] */
   const void* agg2_w;   const float* agg2_b;     /* agg.conv2 */
   const void* eta_w;    const float* eta_b;      /* agg.eta.0: [9][128], [1] */

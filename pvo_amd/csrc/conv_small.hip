@@ -351,6 +351,13 @@ template <> __device__ __forceinline__ cs_v16f cs_mfma32<pvo_bf16>(cs_u32x4 a, c
 //   mode 1 (gates, Cout = 256): channel group 0 -> y  = Z  = sigmoid(acc + g[e, c] + P[row, c])                [rows,128]
 //                               channel group 1 -> y2 = RN = sigmoid(acc + g[e,128+c] + P[row,128+c]) * net    [rows,128]
 //   mode 2 (candidate, Cout = 128):               y  = (1 - Z) * net + Z * tanh(acc + g[e,256+c] + P[row, c])  [rows,128]
+//   mode 3 (output heads, droid_net.py:184-210: four heads of Conv3x3(128 -> 128) + ReLU + Conv3x3(128 -> 2); Cout = 512,
+//       channel group cg = head): the hidden activations relu(acc + bias) never leave the workgroup.  The second
+//       convolution is linear, so its result at pixel p is the sum over the nine taps t of W2[t] . hidden(p + t): here
+//       every pixel q multiplies its 128 hidden channels by all nine tap filters at once - a [pixels x 128] x [128 x 18]
+//       product on the matrix cores, straight from the fp16 slab of the epilogue - and stores z[q][head][2 t + o]; a
+//       small gather kernel (pvo_heads_gather) adds the nine neighbours.  Instead of writing and re-reading the
+//       [rows, 512] hidden tensor (2 x 113 MB at S-B) the heads move 32 MB, and the 3x3 halo exchange is nine 8-byte reads.
 //   segmented input (nseg > 0 replaces x): the input channels are the concatenation of up to three tensors, each with its
 //       own pixel stride - the ConvGRU reads [net | encoder features] (gates) and [r * net | encoder features]
 //       (candidate) straight from the tensors their producers wrote; no concatenated copy is assembled.
@@ -363,6 +370,8 @@ struct BigEpi {
   uint16_t* y2;              // [rows,128] (mode 1)
   int nseg;
   const uint16_t* seg_p[3]; int seg_stride[3]; int seg_chunks[3];
+  const uint16_t* w2f;       // mode 3: second-stage filter of the heads as MFMA B fragments, [Cout/128][8 k-steps][64 lanes][8]
+  float* z;                  // mode 3: [rows][Cout/128][18] f32 tap contributions
 };
 
 constexpr int kBT = 16;                                   // 16 x 16 pixel tile
@@ -387,7 +396,7 @@ __device__ unsigned long long* g_conv_probe = nullptr;
 #define CONV_PROBE(slot)
 #endif
 
-template <typename T>
+template <typename T, bool HEADS>
 __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                           const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                           int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, BigEpi ep) {
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   }
   CONV_PROBE(2);
 
-  if (ep.mode != 0) {
+  if (!HEADS && ep.mode != 0) {
     // fused ConvGRU epilogue: pre-activations cross the workgroup through an fp32 slab [128 px][128 ch] (528-byte pixel
     // stride, 67.6 KB of the 72 KB), then every thread finishes 8 channels of a pixel with coalesced 16-byte accesses
     float* slab = reinterpret_cast<float*>(bs);
@@ -629,6 +638,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   float bb[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) bb[nt] = bias ? bias[cg * 128 + wn * 64 + nt * 32 + li] : 0.0f;
+  unsigned char* w2s = bs + 36 * 1024;                      // mode 3: this head's second-stage fragments (8 KB) above the slab
+  if (HEADS) {
+    const cs_u32x4* src = reinterpret_cast<const cs_u32x4*>(ep.w2f + static_cast<size_t>(cg) * 4096) + tid;
+    const cs_u32x4 f0 = src[0], f1 = src[256];
+    *reinterpret_cast<cs_u32x4*>(w2s + tid * 16) = f0;        // (the main loop's last barrier is behind every wave: the halo is dead)
+    *reinterpret_cast<cs_u32x4*>(w2s + 4096 + tid * 16) = f1;
+  }
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     if (wm == half) {
@@ -645,12 +661,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
           }
     }
     __syncthreads();
-    for (int id = tid; id < 128 * 16; id += 256) {
-      const int m = id >> 4, c = id & 15;
-      const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
-      if (gy < H && gx < W)
-        *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * ystride + yoff + cg * 128 + c * 8) =
-            *reinterpret_cast<const cs_u32x4*>(bs + m * 272 + c * 16);
+    if (HEADS) {
+      // wave w takes rows 32 w .. 32 w + 31 of the slab: Z[32 px][32 (18 used)] = hidden[32 px][128] . W2'[128][32]
+      cs_v16f zz;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zz[r] = 0.0f;
+      const unsigned char* arow = bs + (32 * wave + li) * 272 + kg * 16;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        zz = cs_mfma32<T>(*reinterpret_cast<const cs_u32x4*>(arow + ks * 32), *reinterpret_cast<const cs_u32x4*>(w2s + (ks * 64 + lane) * 16), zz);
+      if (li < 18) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
+          if (gy < H && gx < W) ep.z[(((static_cast<size_t>(e) * H + gy) * W + gx) * (Cout >> 7) + cg) * 18 + li] = zz[r];
+        }
+      }
+    } else {
+      for (int id = tid; id < 128 * 16; id += 256) {
+        const int m = id >> 4, c = id & 15;
+        const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
+        if (gy < H && gx < W)
+          *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * ystride + yoff + cg * 128 + c * 8) =
+              *reinterpret_cast<const cs_u32x4*>(bs + m * 272 + c * 16);
+      }
     }
     __syncthreads();
   }
@@ -756,22 +791,21 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
   const uint16_t* xp = static_cast<const uint16_t*>(x);
   const uint16_t* wp = static_cast<const uint16_t*>(w_taps);
   uint16_t* yp = static_cast<uint16_t*>(y);
-  static bool attr_set[2] = {false, false};                // hipFuncSetAttribute once per process, not per launch
-  if (dtype == PVO_F16) {
-    if (!attr_set[0]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-      attr_set[0] = true;
+  static bool attr_set[4] = {false, false, false, false};  // hipFuncSetAttribute once per process, not per launch
+  auto go = [&](auto kernel, int slot) -> int {
+    if (!attr_set[slot]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
+      attr_set[slot] = true;
     }
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_half>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
-  } else if (dtype == PVO_BF16) {
-    if (!attr_set[1]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_big_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) return PVO_ELAUNCH;
-      attr_set[1] = true;
-    }
-    hipLaunchKernelGGL(conv3x3_big_kernel<pvo_bf16>, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
-  } else {
-    return PVO_EUNSUPPORTED;
-  }
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, xp, wp, bias, yp, H, W, Cin, Cout, relu, ystride, yoff, ep);
+    return PVO_OK;
+  };
+  const bool heads = ep.mode == 3;
+  int rc;
+  if (dtype == PVO_F16) rc = heads ? go(conv3x3_big_kernel<pvo_half, true>, 2) : go(conv3x3_big_kernel<pvo_half, false>, 0);
+  else if (dtype == PVO_BF16) rc = heads ? go(conv3x3_big_kernel<pvo_bf16, true>, 3) : go(conv3x3_big_kernel<pvo_bf16, false>, 1);
+  else return PVO_EUNSUPPORTED;
+  if (rc != PVO_OK) return rc;
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }
@@ -779,6 +813,14 @@ static int launch_big(const void* x, const void* w_taps, const float* bias, void
 extern "C" int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
                            int E, int H, int W, int Cin, int Cout, int relu, int ystride, int yoff, int dtype, void* stream) {
   return launch_big(x, w_taps, bias, y, E, H, W, Cin, Cout, relu, ystride, yoff, dtype, stream, BigEpi{});
+}
+
+extern "C" int pvo_conv3x3_heads(const void* x, const void* w1_taps, const float* bias1, const void* w2_frags, float* z,
+                                 int E, int H, int W, int dtype, void* stream) {
+  if (!bias1 || !w2_frags || !z || (reinterpret_cast<uintptr_t>(w2_frags) & 15)) return PVO_EINVAL;
+  BigEpi ep{};
+  ep.mode = 3; ep.w2f = static_cast<const uint16_t*>(w2_frags); ep.z = z;
+  return launch_big(x, w1_taps, bias1, z, E, H, W, 128, 512, 1, 0, 0, dtype, stream, ep);      // (y is not written in this mode)
 }
 
 // the ConvGRU input [first(128) | cf(cf_channels)] as two segments: `first` = net (gates) or r*net (candidate), `cf` = the

@@ -266,7 +266,43 @@ __global__ __launch_bounds__(256) void heads_out_kernel(const uint16_t* __restri
   }
 }
 
+// heads, second stage after pvo_conv3x3_heads: y[p][2 head + o] = bias2 + sum over the nine taps t of z[p + t][head][2 t + o]
+// (zero padding: a neighbour outside the image contributes nothing).  One thread per (pixel, head), nine 8-byte reads.
+template <typename T>
+__global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias2,
+                                                           uint16_t* __restrict__ y, int H, int W, long long total) {
+  const long long idx = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int head = static_cast<int>(idx & 3);
+  const long long p = idx >> 2;
+  const int px = static_cast<int>(p % W), py = static_cast<int>((p / W) % H);
+  float a0 = bias2[2 * head], a1 = bias2[2 * head + 1];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int qy = py + t / 3 - 1, qx = px + t % 3 - 1;
+    if (qy < 0 || qy >= H || qx < 0 || qx >= W) continue;
+    const float2 v = *reinterpret_cast<const float2*>(z + (p + (t / 3 - 1) * W + (t % 3 - 1)) * 72 + head * 18 + 2 * t);
+    a0 += v.x; a1 += v.y;
+  }
+  const uint32_t lo = H8<T>::to_bits(Elem<T>::from_f32(a0)), hi = H8<T>::to_bits(Elem<T>::from_f32(a1));
+  *reinterpret_cast<uint32_t*>(y + p * 8 + 2 * head) = lo | (hi << 16);
+}
+
 }  // namespace
+
+extern "C" int pvo_heads_gather(const float* z, const float* bias2, void* y, int E, int H, int W, int dtype, void* stream) {
+  if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
+  if (E == 0 || H == 0 || W == 0) return PVO_OK;
+  if (!z || !bias2 || !y || (reinterpret_cast<uintptr_t>(z) & 7) || (reinterpret_cast<uintptr_t>(y) & 3)) return PVO_EINVAL;
+  const long long total = static_cast<long long>(E) * H * W * 4;
+  const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+  hipStream_t st = pvo_stream(stream);
+  if (dtype == PVO_F16) hipLaunchKernelGGL(heads_gather_kernel<pvo_half>, grid, dim3(256), 0, st, z, bias2, static_cast<uint16_t*>(y), H, W, total);
+  else if (dtype == PVO_BF16) hipLaunchKernelGGL(heads_gather_kernel<pvo_bf16>, grid, dim3(256), 0, st, z, bias2, static_cast<uint16_t*>(y), H, W, total);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
 
 extern "C" int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const float* bias2, void* y,
                              int E, int H, int W, int dtype, void* stream) {

@@ -18,8 +18,8 @@ namespace {
 
 struct SideCtx { hipStream_t side; hipEvent_t fork, join; bool ok; };
 
-// one side stream + two events per device, created on first use (streams and events are host objects: the library still
-// allocates no device memory)
+// one side stream + two events per device, created on first use (streams and events are host objects: the library
+// still allocates no device memory)
 SideCtx* side_ctx() {
   static SideCtx ctx[64] = {};
   int dev = 0;
@@ -60,7 +60,7 @@ OpWs carve_op(void* base, int E, int K, int H, int W, int chunks) {
   auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += al(bytes); return r; };
   const size_t px = static_cast<size_t>(E) * H * W, kpx = static_cast<size_t>(K) * H * W;
   w.c1 = take(px * 128 * 2); w.f1 = take(px * 128 * 2); w.CF = take(px * 192 * 2);
-  w.Z = take(px * 128 * 2); w.RN = take(px * 128 * 2); w.h1 = take(px * 512 * 2);
+  w.Z = take(px * 128 * 2); w.RN = take(px * 128 * 2); w.h1 = take(px * 72 * 4);      // z [px][4 heads][18] f32 (pvo_conv3x3_heads)
   w.a1 = take(px * 128 * 2); w.am = take(kpx * 128 * 2); w.a2 = take(kpx * 128 * 2);
   w.P_zr = take(px * 256 * 2); w.P_q = take(px * 128 * 2);
   w.part = reinterpret_cast<float*>(take(static_cast<size_t>(E) * chunks * 128 * 4));
@@ -119,12 +119,17 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   const long long rows = static_cast<long long>(E) * H * W;
   hipStream_t st = pvo_stream(stream);
   SideCtx* sc = (w->flags & PVO_OP_ENC_SIDE_STREAM) && !(w->flags & PVO_OP_SINGLE_STREAM) ? side_ctx() : nullptr;
+  // two chains meet in front of the gate convolution: the launch stream runs lookup + corr_encoder[0] -> corr_encoder[2]
+  // (the latency-bound lookup first), the side stream the motion features -> flow_encoder, and the global context of
+  // `net` -> gate context.  (A third stream for the context pair changed nothing: rocprofv3 --kernel-trace,
+  // tools/update_timeline.sh, shows the seven kernels of this phase finishing together after ~165 us however they are
+  // spread - about the sum of their stand-alone times.)
   void* s2 = sc ? static_cast<void*>(sc->side) : stream;
+  void* s3 = s2;
   if (sc) {
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
   }
-  // correlation features first: the launch stream's longest early kernel is in flight while the host issues the rest
   if (a->levels[0]) {
     probe_mark(PVO_STAGE_LOOKUP, 0, stream);
     RUN(pvo_corr_lookup_encode_tiled(a->levels, a->coords, w->enc0_w, w->enc0_b, b.c1, E, H, W, dt, a->slots, a->num_slots, stream));
@@ -133,12 +138,11 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     if (!a->corr) return PVO_EINVAL;
     RUN(pvo_corr_encode(a->corr, w->enc0_w, w->enc0_b, b.c1, rows, dt, stream));
   }
-  // independent of the correlation features (side stream when enabled)
   if (mj) RUN(pvo_graph_motion(mj->target, mj->coords, mj->delta_dy, mj->raw_mask, mj->motion, E, H, W, dt, s2));
-  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s2));
-  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s2));
   RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
   RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
+  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s3));
+  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s3));
   if (sc && hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
   // the encoders' second layers write relu(features + bias) side by side: CF = [corr features (128) | flow features (64)]
   if (w->flags & PVO_OP_CONV128_WIDE)
@@ -164,8 +168,9 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
 
 int run_heads(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream) {
   const int E = a->E, H = a->H, W = a->W, dt = w->dtype;
-  RUN(pvo_conv3x3(a->net_out, w->heads1_w, nullptr, b.h1, E, H, W, 128, 512, 0, 0, 0, dt, stream));
-  RUN(pvo_heads_out(b.h1, w->heads1_b, w->heads2_w, w->heads2_b, a->heads, E, H, W, dt, stream));
+  // (b.h1 holds z [E,H,W,4,18] f32: the hidden tensor itself stays in the first launch's LDS)
+  RUN(pvo_conv3x3_heads(a->net_out, w->heads1_w, w->heads1_b, w->heads2_w, reinterpret_cast<float*>(b.h1), E, H, W, dt, stream));
+  RUN(pvo_heads_gather(reinterpret_cast<const float*>(b.h1), w->heads2_b, a->heads, E, H, W, dt, stream));
   return PVO_OK;
 }
 
@@ -291,6 +296,9 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
                      u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW, u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW,
                      u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
                      S, u->vote_thresh, dt, stream));
+  // (the whole aggregation branch, including the upsampling mask the BA does not need: letting the BA start as soon as
+  // the damping existed, beside the mask convolution, saved ~20 us per update and cost the bitwise run-to-run
+  // reproducibility of the poses - 3 to 9 of 12 repeated global updates differed in the last bits, none with the full join)
   RUN(join(pending, stream));
   // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
   const int Eb = u->n_in + E;

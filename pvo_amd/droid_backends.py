@@ -777,6 +777,37 @@ def heads_out(h1, bias1, w2, bias2):
     return y
 
 
+def heads2_fragments(w2, dtype):
+    """second-stage filter of the four heads, [4,2,9,128] ([head][out][tap][channel]), as the MFMA B fragments
+    pvo_conv3x3_heads multiplies the hidden activations with: [4][8 k-steps][64 lanes][8], column n = 2 tap + out"""
+    w = w2.detach().to(dtype)
+    m = torch.zeros(4, 32, 128, dtype=dtype, device=w.device)                 # [head][n][k]
+    m[:, :18] = w.permute(0, 2, 1, 3).reshape(4, 18, 128)                       # n = tap * 2 + out
+    # element (h, ks, lane, j) = m[h][lane & 31][ks*16 + (lane >> 5)*8 + j]
+    f = m.reshape(4, 32, 8, 2, 8).permute(0, 2, 3, 1, 4)                        # [h][ks][kg][n][j]
+    return f.reshape(4, 8, 64, 8).contiguous()
+
+
+def heads_fused(x, w1_taps, bias1, w2_frags, bias2):
+    """the four output heads from the hidden state in two launches and without the [E,512,H,W] intermediate:
+    x [E,128,H,W] channels-last 16-bit, w1_taps = conv3x3_weights of the concatenated first-stage filters [512,128,3,3],
+    w2_frags = heads2_fragments(...).  Returns y [E,8,H,W] channels-last as heads_out does."""
+    _cl(x, "x", 128)
+    dev = _dev(x, w1_taps, bias1, w2_frags, bias2)
+    E, _, H, W = x.shape
+    if tuple(w1_taps.shape) != (9, 512, 128) or w1_taps.dtype != x.dtype or not w1_taps.is_contiguous() or \
+            tuple(w2_frags.shape) != (4, 8, 64, 8) or w2_frags.dtype != x.dtype or not w2_frags.is_contiguous():
+        raise PvoHipError("heads_fused: w1_taps must be [9,512,128] and w2_frags [4,8,64,8] in x's dtype")
+    z = torch.empty(E, H, W, 4, 18, dtype=torch.float32, device=dev)
+    y = _new_cl(E, 8, H, W, x.dtype, dev)
+    with torch.cuda.device(dev):
+        lib = _lib.load()
+        check(lib.pvo_conv3x3_heads(_ptr(x), _ptr(w1_taps), _bias(bias1, 512, "bias1"), _ptr(w2_frags), _ptr(z), E, H, W,
+                                    _dtype_code(x, "x"), _stream(dev)), "conv3x3_heads")
+        check(lib.pvo_heads_gather(_ptr(z), _bias(bias2, 8, "bias2"), _ptr(y), E, H, W, _dtype_code(x, "x"), _stream(dev)), "heads_gather")
+    return y
+
+
 def eta_head(x, w_taps, bias, frame=None, pos=None, damping=None, EP=0.0, eta_scale=0.2):
     """GraphAgg's eta head: x [K,128,H,W] channels-last 16-bit, w_taps [9,128], bias f32 [1].
     frame None -> 0.01 * softplus(conv(x) + bias) [K,H,W] f32 (what GraphAgg returns).

@@ -226,8 +226,8 @@ class DynamicUpdateModule(nn.Module):
             "zr_w": taps(dyn(wzr)), "q_w": taps(dyn(wq)), "zr_inp_w": taps(sta(wzr)), "q_inp_w": taps(sta(wq)),
             "heads1_w": taps(torch.cat([h[0].weight for h in hs], 0).detach()),
             "heads1_b": torch.cat([f32(h[0].bias) for h in hs]).contiguous(),
-            # [head][out][tap = ky*3+kx][channel]
-            "heads2_w": torch.stack([h[2].weight.detach().permute(0, 2, 3, 1).reshape(2, 9, 128) for h in hs]).to(dt).contiguous(),
+            # [head][out][tap = ky*3+kx][channel] -> matrix-core fragments of the fused second stage
+            "heads2_w": db.heads2_fragments(torch.stack([h[2].weight.detach().permute(0, 2, 3, 1).reshape(2, 9, 128) for h in hs]), dt),
             "heads2_b": torch.cat([f32(h[2].bias) for h in hs]).contiguous(),
             "agg1_w": e128(self.agg.conv1.weight), "agg1_b": f32(self.agg.conv1.bias),
             "agg2_w": taps128(self.agg.conv2.weight), "agg2_b": f32(self.agg.conv2.bias),
