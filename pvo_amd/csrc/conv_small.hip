@@ -625,10 +625,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
             }
       }
       __syncthreads();
+      if (half == 0) CONV_PROBE(6);
       finish(half, 0);
       request(half, 1);
       finish(half, 1);
       __syncthreads();
+      if (half == 0) CONV_PROBE(7);
     }
     CONV_PROBE(3);
     return;

@@ -81,6 +81,10 @@ for xc in np.unique(xcc)[:2]:
     dw = (wc0[m].max() - wc0[m].min()) * 10e-9
     if dw > 0:
         print("XCD %d shader clock during the launch: %.2f GHz (s_memtime vs s_memrealtime between first and last entry)" % (xc, (t0[m].max() - t0[m].min()) / dw / 1e9))
+if mode == "gates":
+    t6, t7 = t[:, 6], t[:, 7]
+    print("gate epilogue (kcycles, medians): operands requested + accumulators through the slab %.1f | finish 2 x 4 pixels per thread %.1f | second half %.1f"
+          % (np.median(t6 - t2) * tick, np.median(t7 - t6) * tick, np.median(t3 - t7) * tick))
 cus = np.unique(cuid)
 print("compute units seen: %d; workgroups per CU min %d max %d" % (len(cus), min((cuid == c).sum() for c in cus), max((cuid == c).sum() for c in cus)))
 # the same on the common axis: entry times in units of 10 ns, life converted with the clock the launch averaged
