@@ -591,10 +591,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
         cs_unpack8<T>(pv[k], pp);
         cs_unpack8<T>(nv[k], nn);
         if (ep.mode == 1) {
+          // sigmoid = 1 / (1 + 2^(-x log2 e)) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each; exp -> inf gives 0, exp -> 0 gives 1:
+          // the library exp's denormal-range rescaling - two selects, an add and a multiply per value - buys nothing here)
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(a[q] + gg[q] + pp[q])));      // v_rcp_f32: 1 ulp
-            o[q] = cg == 0 ? sg : sg * nn[q];
+          for (int q = 0; q < 8; ++q) o[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (a[q] + gg[q] + pp[q])));
+          if (cg != 0) {                                    // (workgroup-uniform: the r half of the gates leaves as r * net)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] *= nn[q];
           }
         } else {
           float zz[8];
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
           for (int q = 0; q < 8; ++q) {
             // tanh(x) = 1 - 2 / (1 + exp(2x)): exact limits at both ends (exp -> inf gives 1, exp -> 0 gives -1), ~1e-6
             // absolute error in between - the result is rounded to 16 bits
-            const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * (a[q] + gg[q] + pp[q])));
+            const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * (a[q] + gg[q] + pp[q])));
             o[q] = (1.0f - zz[q]) * nn[q] + zz[q] * th;
           }
         }

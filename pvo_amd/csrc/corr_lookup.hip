@@ -30,7 +30,10 @@
 namespace {
 
 constexpr int kMaxLevels = 4;
-constexpr int kStrip = 64;          // pixels per workgroup
+constexpr int kStrip = 64;          // pixels per workgroup (two passes of 32)
+constexpr int kEncStrip = 32;       // ... of the fused lookup + encoder: one pass; twice the workgroups at half the LDS each fill the
+                                    // CUs' last round (1728 workgroups of 64 pixels were 6.75 per CU at 5 resident: two rounds, the
+                                    // second a third full - in-kernel clock stamps, tools/lookup_timeline.py)
 constexpr int kStripPad = 66;       // LDS row stride in elements (keeps 4-byte alignment, spreads banks)
 constexpr int kEncK = 224;          // ENC: 196 lookup channels padded to 7 MFMA k-steps of 32
 constexpr int kEncStride = 232;     // ENC: staging row of a pixel in elements (464 B: 16-byte aligned, odd multiple of 16 B)
@@ -194,27 +197,44 @@ template <> __device__ __forceinline__ lk_v4f lk_mfma<float>(lk_u32x4, lk_u32x4,
 // layer, relu(W corr + b) with W [128,196] (droid_net.py:172-175: Conv2d(196,128,1) + ReLU), on the matrix cores, and the
 // 128 encoded channels are written instead: 28 MB of output instead of 43 MB, and the 1x1 convolution's 27 us + 9 us
 // (conv, bias/ReLU pass) with their 43 + 28 + 56 MB of traffic disappear.
+// tools/lookup_timeline.py builds this file with -DPVO_LOOKUP_PROBE: every workgroup records shader-clock stamps of its phases
+#ifdef PVO_LOOKUP_PROBE
+__device__ unsigned long long* g_lk_probe = nullptr;
+#define LK_PROBE(slot)                                                                                              \
+  do {                                                                                                              \
+    if (g_lk_probe && threadIdx.x == 0)                                                                             \
+      g_lk_probe[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define LK_PROBE(slot)
+#endif
+
 template <typename T, bool TILED, bool ENC>
-__global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
+__device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
   using S = typename Elem<T>::store_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   S* stage = reinterpret_cast<S*>(smem_raw);  // [nlev*49][kStripPad]
 
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
-  const int pix0 = blockIdx.x * kStrip;
+  constexpr int STRIP = ENC ? kEncStrip : kStrip;
+  const int pix0 = blockIdx.x * STRIP;
   const int row = tid & 7;        // tap row (y offset index) handled by this lane
   const int HW = a.HW;
   const int cl_stride = ENC ? kEncStride : a.nlev * 49 + kPixPad;   // channels-last staging is pixel-major
   if constexpr (ENC) {     // zero the k-padding columns 196..231 of every pixel row (0 x garbage could be NaN)
     uint32_t* z = reinterpret_cast<uint32_t*>(smem_raw) + (tid >> 2) * (kEncStride / 2) + 98 + (tid & 3);
+    if ((tid >> 2) < STRIP) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
-      if (98 + (tid & 3) + 4 * q < kEncStride / 2) z[4 * q] = 0u;
+      for (int q = 0; q < 5; ++q)
+        if (98 + (tid & 3) + 4 * q < kEncStride / 2) z[4 * q] = 0u;
+    }
   }
 
+  LK_PROBE(0);
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < STRIP / 32; ++pass) {
+    if (pass == 1) LK_PROBE(1);
     const int p = pass * 32 + (tid >> 3);
     const int pix = pix0 + p;
     const bool pix_ok = pix < HW;
@@ -360,7 +380,9 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
       }
     }
   }
+  LK_PROBE(2);
   __syncthreads();
+  LK_PROBE(3);
 
   if constexpr (ENC && sizeof(S) == 2) {
     // encoded[px][n] = relu(sum_k corr[px][k] W[n][k] + b[n]); wave w owns outputs [32w, 32w+32), 16 at a time so that
@@ -368,7 +390,8 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     const uint16_t* W16 = reinterpret_cast<const uint16_t*>(a.enc_w);
     unsigned char* oslab = smem_raw;                                     // [64 px][272 B], over the staging once it is consumed
-    lk_v4f dd[2][4];
+    constexpr int MT = STRIP / 16;                                       // 16-pixel M-tiles
+    lk_v4f dd[2][MT];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int nn = wave * 32 + nt * 16 + li;
@@ -377,7 +400,7 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
       for (int ks = 0; ks < kEncK / 32; ++ks)
         wf[ks] = *reinterpret_cast<const lk_u32x4*>(W16 + static_cast<size_t>(nn) * kEncK + ks * 32 + lk * 8);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < MT; ++g) {
         lk_v4f d = {0.f, 0.f, 0.f, 0.f};
         const unsigned char* arow = smem_raw + (g * 16 + li) * (kEncStride * 2) + lk * 16;
 #pragma unroll
@@ -387,28 +410,35 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
       }
       asm volatile("" ::: "memory");      // keep the second tile's weight loads below the first tile's MFMAs (registers)
     }
+    LK_PROBE(4);
     __syncthreads();                                                  // every wave has read its A fragments
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int nn = wave * 32 + nt * 16 + li;
       const float bn = a.enc_b[nn];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < MT; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r)                                   // D rows lk*4 + r = pixels, column li = output nn
           *reinterpret_cast<S*>(oslab + (g * 16 + lk * 4 + r) * (kEncOutStride * 2) + nn * 2) =
               Elem<T>::from_f32(fmaxf(dd[nt][g][r] + bn, 0.0f));
     }
     __syncthreads();
-    const int npix = min(kStrip, HW - pix0);
+    const int npix = min(STRIP, HW - pix0);
     S* o = reinterpret_cast<S*>(a.out) + (static_cast<long long>(n) * HW + pix0) * 128;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {                                  // 64 px x 16 chunks of 16 B: whole 256-byte pixel rows
+    for (int it = 0; it < STRIP / 16; ++it) {                         // STRIP px x 16 chunks of 16 B: whole 256-byte pixel rows
       const int id = tid + 256 * it, px = id >> 4, c = id & 15;
       if (px < npix)
         *reinterpret_cast<lk_u32x4*>(o + static_cast<long long>(px) * 128 + c * 8) =
             *reinterpret_cast<const lk_u32x4*>(oslab + px * (kEncOutStride * 2) + c * 16);
     }
+    LK_PROBE(5);
+#ifdef PVO_LOOKUP_PROBE
+    if (g_lk_probe && threadIdx.x == 0)
+      g_lk_probe[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 6] =
+          (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (31 << 11))) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+#endif
     return;
   }
   // coalesced write-out: channel rows of 64 pixels
@@ -455,6 +485,17 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) {
     const int ch = idx >> 6, c = idx & 63;
     if (c < npix) outp[static_cast<long long>(ch) * HW + pix0 + c] = stage[ch * kStripPad + c];
   }
+}
+
+template <typename T, bool TILED, bool ENC>
+__global__ __launch_bounds__(256) void corr_lookup_r3_kernel(LookupArgs a) { corr_lookup_r3_body<T, TILED, ENC>(a); }
+
+// The fused lookup + encoder as its own entry: left alone the register allocator spends 97 VGPRs + 16 AGPRs on it (four
+// waves per SIMD, 3.3 workgroups resident per CU on average by the in-kernel clock stamps); asked for six to eight waves
+// it needs 56 and no scratch.
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void corr_lookup_r3_enc_kernel(LookupArgs a) {
+  corr_lookup_r3_body<T, true, true>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -578,8 +619,9 @@ int launch_lookup(const LookupArgs& a, int radius, hipStream_t st) {
     if (a.lv[0].plane_elems != 0) {
       if constexpr (sizeof(typename Elem<T>::store_t) == 2) {
         if (a.enc_w) {
-          const size_t lds_enc = static_cast<size_t>(kStrip) * kEncStride * 2;   // 29.7 KB; the output slab reuses it
-          hipLaunchKernelGGL((corr_lookup_r3_kernel<T, true, true>), grid, dim3(256), lds_enc, st, a);
+          const size_t lds_enc = static_cast<size_t>(kEncStrip) * kEncStride * 2;   // 14.8 KB; the output slab reuses it
+          const dim3 grid_enc((a.HW + kEncStrip - 1) / kEncStrip, a.N);
+          hipLaunchKernelGGL(corr_lookup_r3_enc_kernel<T>, grid_enc, dim3(256), lds_enc, st, a);
         } else {
           hipLaunchKernelGGL((corr_lookup_r3_kernel<T, true, false>), grid, dim3(256), lds, st, a);
         }
@@ -617,6 +659,12 @@ int dispatch_lookup(const LookupArgs& a, int radius, int dtype, hipStream_t st) 
 }
 
 }  // namespace
+
+#ifdef PVO_LOOKUP_PROBE
+extern "C" int pvo_debug_lookup_probe(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lk_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int pvo_corr_index_forward(const void* volume, const float* coords, void* corr,
                                       int N, int h1, int w1, int h2, int w2,
