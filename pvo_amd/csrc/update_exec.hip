@@ -120,12 +120,11 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   hipStream_t st = pvo_stream(stream);
   SideCtx* sc = (w->flags & PVO_OP_ENC_SIDE_STREAM) && !(w->flags & PVO_OP_SINGLE_STREAM) ? side_ctx() : nullptr;
   // two chains meet in front of the gate convolution: the launch stream runs lookup + corr_encoder[0] -> corr_encoder[2]
-  // (the latency-bound lookup first), the side stream the motion features -> flow_encoder, and the global context of
-  // `net` -> gate context.  (A third stream for the context pair changed nothing: rocprofv3 --kernel-trace,
-  // tools/update_timeline.sh, shows the seven kernels of this phase finishing together after ~165 us however they are
-  // spread - about the sum of their stand-alone times.)
+  // (the latency-bound lookup first) and then the global context of `net` -> gate context; the side stream the motion
+  // features -> flow_encoder.  Balanced on rocprofv3 --kernel-trace (tools/update_timeline.sh): with the context pair on
+  // the side stream that chain ended ~55 us after corr_encoder[2]; a third stream for it changed nothing.
   void* s2 = sc ? static_cast<void*>(sc->side) : stream;
-  void* s3 = s2;
+  void* s3 = stream;
   if (sc) {
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
@@ -141,14 +140,14 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   if (mj) RUN(pvo_graph_motion(mj->target, mj->coords, mj->delta_dy, mj->raw_mask, mj->motion, E, H, W, dt, s2));
   RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
   RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
-  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s3));
-  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s3));
   if (sc && hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
   // the encoders' second layers write relu(features + bias) side by side: CF = [corr features (128) | flow features (64)]
   if (w->flags & PVO_OP_CONV128_WIDE)
     RUN(pvo_conv3x3(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 128, 1, 192, 0, dt, stream));
   else
     RUN(pvo_conv3x3_c128(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 1, 192, 0, dt, stream));
+  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s3));
+  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s3));
   *P_zr = a->P_zr; *P_q = a->P_q;
   if (!a->P_zr || !a->P_q) {       // static-input term not cached by the caller: conv(W[:, inp], inp) for this call
     if (!a->inp) return PVO_EINVAL;
