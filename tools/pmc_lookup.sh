@@ -17,7 +17,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
             per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for k, v in per.items():
         if "corr_lookup" in k:
-            name = "lookup_enc" if "true, true>" in k else ("lookup_tiled" if "true, false>" in k else "lookup")
+            name = "lookup_enc" if ("true, true>" in k or "enc_kernel" in k) else ("lookup_tiled" if "true, false>" in k else "lookup")
             res.setdefault(name, {})[C] = v
         if "copy" in k.lower() and max(v) > 1e5: res.setdefault("copy", {})[C] = v
 print(json.dumps(res)[:2000])
