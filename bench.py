@@ -82,9 +82,9 @@ class Snapshot:
         self.raw_mask, self.delta_dy, self.damping = graph.raw_mask.clone(), graph.delta_dy.clone(), graph.damping.clone()
 
     def restore(self):
+        # (the per-edge state - net, targets, weights, masks - is put back by snap_edges_fix AFTER the edge rebuild, in
+        # the rebuilt edge order; copying it here as well would only add launches to the timed step)
         self.v.poses.copy_(self.poses); self.v.disps.copy_(self.disps)
-        self.g.net = self.net.clone(); self.g.target_cam = self.target.clone(); self.g.weight = self.weight.clone()
-        self.g.raw_mask = self.raw_mask.clone(); self.g.delta_dy = self.delta_dy.clone()
         self.g.damping.copy_(self.damping)
 
 

@@ -180,11 +180,14 @@ int pvo_conv3x3(const void* x, const void* w_taps, const float* bias, void* y,
  *                           RN = sigmoid(conv3x3([net|cf], w)[:, 128:] + g[e, 128:256] + P_zr[:, 128:]) * net
  *   pvo_gru_conv_candidate: net_out = (1 - Z) * net + Z * tanh(conv3x3([RN|cf], w) + g[e, 256:384] + P_q)
  * w_taps [9][256 or 128][128 + cf_channels], g f32 [E,384], P_zr [E,H,W,256], P_q / net / Z / RN / net_out [E,H,W,128];
- * net_out may alias net. */
+ * net_out may alias net.
+ * p_slots (int32 [E] or NULL): the static terms live in a slot pool, P_zr [slots,H,W,256] / P_q [slots,H,W,128], and edge e
+ * reads image p_slots[e] - the factor graph keeps them in the slots of its volume pool, so they are written once when an edge
+ * is created and never gathered or concatenated when the edge set changes. */
 int pvo_gru_conv_gates(const void* net, const void* cf, int cf_channels, const void* w_taps, const float* g,
-                       const void* P_zr, void* Z, void* RN, int E, int H, int W, int dtype, void* stream);
+                       const void* P_zr, const int* p_slots, void* Z, void* RN, int E, int H, int W, int dtype, void* stream);
 int pvo_gru_conv_candidate(const void* RN, const void* cf, int cf_channels, const void* w_taps, const float* g,
-                           const void* P_q, const void* Z, const void* net, void* net_out,
+                           const void* P_q, const int* p_slots, const void* Z, const void* net, void* net_out,
                            int E, int H, int W, int dtype, void* stream);
 /* Second stage of the four output heads (droid_net.py:184-210) in one launch: y[E,H,W,8] =
  * Conv3x3(128->2) per head applied to relu(h1[..., head*128:(head+1)*128] + bias1), zero padding.
@@ -297,6 +300,7 @@ typedef struct pvo_operator_args {
   void* net_out;              /* [E,H,W,128] new hidden state (may alias net) */
   const void* inp;            /* [E,H,W,128] context features; read only when P_zr / P_q are NULL */
   const void* P_zr; const void* P_q;   /* cached static-input terms [E,H,W,256], [E,H,W,128], or NULL */
+  int static_by_slot;         /* 1: P_zr / P_q are slot pools [num_slots,H,W,C] indexed by `slots` (see pvo_gru_conv_gates) */
   const int* seg_ptr; const int* seg_idx; int K;   /* GraphAgg groups: CSR of edges by source frame (K = 0: no aggregation) */
   void* heads;                /* [E,H,W,8] out: delta | delta_dy | weight logits | delta_mask */
   const int64_t* eta_frame; const int* eta_pos; int R; float* damping; float EP; float eta_scale;   /* see pvo_eta_head */

@@ -27,8 +27,8 @@ SIGNATURES = {
     "pvo_gru_glo_chunks": (_i, [_i]),
     "pvo_gru_glo_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_gate_context": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "pvo_gru_conv_gates": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "pvo_gru_conv_candidate": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_gru_conv_gates": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_gru_conv_candidate": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv3x3_c128": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv7x7_c8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -83,7 +83,7 @@ class OperatorArgs(_c.Structure):
     """pvo_operator_args"""
     _fields_ = [("E", _i), ("H", _i), ("W", _i), ("levels", _vp * 4), ("slots", _vp), ("num_slots", _i),
                 ("coords", _vp), ("corr", _vp), ("motion", _vp), ("net", _vp), ("net_out", _vp), ("inp", _vp),
-                ("P_zr", _vp), ("P_q", _vp), ("seg_ptr", _vp), ("seg_idx", _vp), ("K", _i), ("heads", _vp),
+                ("P_zr", _vp), ("P_q", _vp), ("static_by_slot", _i), ("seg_ptr", _vp), ("seg_idx", _vp), ("K", _i), ("heads", _vp),
                 ("eta_frame", _vp), ("eta_pos", _vp), ("R", _i), ("damping", _vp), ("EP", _f), ("eta_scale", _f), ("eta", _vp),
                 ("upmask", _vp)]
 

@@ -365,6 +365,7 @@ struct BigEpi {
   int mode;
   const float* g;            // [E,384] f32: context of z | r | q (biases folded in)
   const uint16_t* P;         // precomputed static-input term, [rows,256] (mode 1) or [rows,128] (mode 2)
+  const int* p_slots;        // non-null: P is a slot pool [slots,H,W,C] and edge e reads slot p_slots[e] (the volume pool's slot)
   const uint16_t* net;       // [rows,128]
   const uint16_t* Z;         // [rows,128] (mode 2)
   uint16_t* y2;              // [rows,128] (mode 1)
@@ -567,6 +568,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
     }
     uint16_t* const dst = (ep.mode == 1 && cg != 0) ? ep.y2 : y;
+    const int ep_ = ep.p_slots ? ep.p_slots[e] : e;         // image of the static term (workgroup-uniform)
     cs_u32x4 pv[4], nv[4], zv[4];
     auto request = [&](int half, int b) {
 #pragma unroll
@@ -575,7 +577,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
         const int gy = y0 + 8 * half + (m >> 4), gx = x0 + (m & 15);
         const bool in = gy < H && gx < W;
         const size_t rr = in ? (static_cast<size_t>(e) * H + gy) * W + gx : 0;      // a valid address either way; the value is dropped
-        pv[k] = *reinterpret_cast<const cs_u32x4*>(gate_p + rr * pstride);
+        const size_t rp = in ? (static_cast<size_t>(ep_) * H + gy) * W + gx : 0;
+        pv[k] = *reinterpret_cast<const cs_u32x4*>(gate_p + rp * pstride);
         nv[k] = *reinterpret_cast<const cs_u32x4*>(ep.net + rr * 128 + c * 8);
         if (ep.mode == 2) zv[k] = *reinterpret_cast<const cs_u32x4*>(ep.Z + rr * 128 + c * 8);
       }
@@ -841,26 +844,26 @@ static int seg_setup(BigEpi& ep, const void* first, const void* cf, int cf_chann
 }
 
 extern "C" int pvo_gru_conv_gates(const void* net, const void* cf, int cf_channels, const void* w_taps, const float* g,
-                                  const void* P_zr, void* Z, void* RN, int E, int H, int W, int dtype, void* stream) {
+                                  const void* P_zr, const int* p_slots, void* Z, void* RN, int E, int H, int W, int dtype, void* stream) {
   if (!g || !P_zr || !RN) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(P_zr) | reinterpret_cast<uintptr_t>(RN)) & 15) return PVO_EINVAL;
   BigEpi ep{};
   const int rc = seg_setup(ep, net, cf, cf_channels);
   if (rc != PVO_OK) return rc;
-  ep.mode = 1; ep.g = g; ep.P = static_cast<const uint16_t*>(P_zr); ep.net = static_cast<const uint16_t*>(net);
+  ep.mode = 1; ep.g = g; ep.P = static_cast<const uint16_t*>(P_zr); ep.p_slots = p_slots; ep.net = static_cast<const uint16_t*>(net);
   ep.y2 = static_cast<uint16_t*>(RN);
   return launch_big(net, w_taps, nullptr, Z, E, H, W, 128 + cf_channels, 256, 0, 0, 0, dtype, stream, ep);
 }
 
 extern "C" int pvo_gru_conv_candidate(const void* RN, const void* cf, int cf_channels, const void* w_taps, const float* g,
-                                      const void* P_q, const void* Z, const void* net, void* net_out,
+                                      const void* P_q, const int* p_slots, const void* Z, const void* net, void* net_out,
                                       int E, int H, int W, int dtype, void* stream) {
   if (!g || !P_q || !net || !Z) return PVO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(P_q) | reinterpret_cast<uintptr_t>(net) | reinterpret_cast<uintptr_t>(Z)) & 15) return PVO_EINVAL;
   BigEpi ep{};
   const int rc = seg_setup(ep, RN, cf, cf_channels);
   if (rc != PVO_OK) return rc;
-  ep.mode = 2; ep.g = g; ep.P = static_cast<const uint16_t*>(P_q); ep.net = static_cast<const uint16_t*>(net);
+  ep.mode = 2; ep.g = g; ep.P = static_cast<const uint16_t*>(P_q); ep.p_slots = p_slots; ep.net = static_cast<const uint16_t*>(net);
   ep.Z = static_cast<const uint16_t*>(Z);
   return launch_big(RN, w_taps, nullptr, net_out, E, H, W, 128 + cf_channels, 128, 0, 0, 0, dtype, stream, ep);
 }

@@ -161,10 +161,12 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   }
   if (sc && hipStreamWaitEvent(st, sc->join, 0) != hipSuccess) return PVO_ELAUNCH;
   probe_mark(PVO_STAGE_GATES, 0, stream);
-  RUN(pvo_gru_conv_gates(a->net, b.CF, 192, w->zr_w, b.g, *P_zr, b.Z, b.RN, E, H, W, dt, stream));
+  const int* ps = (a->static_by_slot && a->P_zr && a->P_q) ? a->slots : nullptr;
+  if (a->static_by_slot && !a->slots) return PVO_EINVAL;
+  RUN(pvo_gru_conv_gates(a->net, b.CF, 192, w->zr_w, b.g, *P_zr, ps, b.Z, b.RN, E, H, W, dt, stream));
   probe_mark(PVO_STAGE_GATES, 1, stream);
   probe_mark(PVO_STAGE_CANDIDATE, 0, stream);
-  RUN(pvo_gru_conv_candidate(b.RN, b.CF, 192, w->q_w, b.g, *P_q, b.Z, a->net, a->net_out, E, H, W, dt, stream));
+  RUN(pvo_gru_conv_candidate(b.RN, b.CF, 192, w->q_w, b.g, *P_q, ps, b.Z, a->net, a->net_out, E, H, W, dt, stream));
   probe_mark(PVO_STAGE_CANDIDATE, 1, stream);
   return PVO_OK;
 }

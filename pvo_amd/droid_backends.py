@@ -699,24 +699,26 @@ def conv3x3_c128(x, w_taps, bias=None, relu=False, out=None, out_offset=0):
     return ret
 
 
-def gru_conv_gates(net, cf, w_taps, g, P_zr):
+def gru_conv_gates(net, cf, w_taps, g, P_zr, p_slots=None):
     """gate convolution over [net | cf] + sigmoid gates in one kernel -> (Z, RN), each [E,128,H,W] channels-last.
     cf [E,C,H,W] (C % 32 == 0), w_taps [9,256,128+C], g [E,384] f32, P_zr [E,256,H,W]."""
     E, _, H, W = net.shape
     C = cf.shape[1]
     _cl(net, "net", 128); _cl(cf, "cf", C); _cl(P_zr, "P_zr", 256)
-    dev = _dev(net, cf, w_taps, g, P_zr)
+    dev = _dev(net, cf, w_taps, g, P_zr, p_slots)
+    if p_slots is not None and (p_slots.dtype != torch.int32 or p_slots.numel() != E or not p_slots.is_contiguous()):
+        raise PvoHipError("gru_conv_gates: p_slots must be a contiguous int32 [E] tensor")
     _f32(g, "g"); _contig(g, "g")
     if tuple(w_taps.shape) != (9, 256, 128 + C) or w_taps.dtype != net.dtype or not w_taps.is_contiguous():
         raise PvoHipError("gru_conv_gates: w_taps must be [9,256,128+C] in net's dtype")
     Z, RN = _new_cl(E, 128, H, W, net.dtype, dev), _new_cl(E, 128, H, W, net.dtype, dev)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_conv_gates(_ptr(net), _ptr(cf), C, _ptr(w_taps), _ptr(g), _ptr(P_zr), _ptr(Z), _ptr(RN),
+        check(_lib.load().pvo_gru_conv_gates(_ptr(net), _ptr(cf), C, _ptr(w_taps), _ptr(g), _ptr(P_zr), _vp(p_slots), _ptr(Z), _ptr(RN),
                                              E, H, W, _dtype_code(net, "net"), _stream(dev)), "gru_conv_gates")
     return Z, RN
 
 
-def gru_conv_candidate(RN, cf, w_taps, g, P_q, Z, net):
+def gru_conv_candidate(RN, cf, w_taps, g, P_q, Z, net, p_slots=None):
     """candidate convolution over [RN | cf] + the GRU state update in one kernel -> new hidden state"""
     E, _, H, W = net.shape
     C = cf.shape[1]
@@ -727,7 +729,7 @@ def gru_conv_candidate(RN, cf, w_taps, g, P_q, Z, net):
         raise PvoHipError("gru_conv_candidate: w_taps must be [9,128,128+C] in net's dtype")
     out = _new_cl(E, 128, H, W, net.dtype, dev)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_gru_conv_candidate(_ptr(RN), _ptr(cf), C, _ptr(w_taps), _ptr(g), _ptr(P_q), _ptr(Z), _ptr(net),
+        check(_lib.load().pvo_gru_conv_candidate(_ptr(RN), _ptr(cf), C, _ptr(w_taps), _ptr(g), _ptr(P_q), _vp(p_slots), _ptr(Z), _ptr(net),
                                                  _ptr(out), E, H, W, _dtype_code(net, "net"), _stream(dev)), "gru_conv_candidate")
     return out
 
@@ -950,6 +952,7 @@ def _fill_operator_args(a, E, H, W, pool_levels, slots, num_slots, coords, corr,
     a.slots, a.num_slots = _vp(slots), int(num_slots)
     a.coords, a.corr, a.motion = _vp(coords), _vp(corr), _vp(motion)
     a.net, a.net_out, a.inp, a.P_zr, a.P_q = _vp(net), _vp(net_out), _vp(inp), _vp(P_zr), _vp(P_q)
+    a.static_by_slot = 0
     if agg is not None:
         a.seg_ptr, a.seg_idx, a.K = agg[0].data_ptr(), agg[1].data_ptr(), int(agg[2])
     else:

@@ -37,6 +37,7 @@ class FactorGraph:
         self._age_lag = 0
         self.ii, self.jj, self.age = (torch.zeros(0, **lng) for _ in range(3))
         self._ii_h, self._jj_h, self._age_h = [], [], []
+        self._inp = None
         self.corr = self.net = self.inp = self.segm = None
         self.damping = 1e-6 * torch.ones_like(video.disps)
         z = lambda c: torch.zeros(1, 0, ht, wd, c, device=self.device, dtype=torch.float)
@@ -51,6 +52,7 @@ class FactorGraph:
         self._cache = {}            # device index tensors derived from the host edge lists; cleared on any edge change
         self._version = 0           # bumped on every edge change
         self.P_zr = self.P_q = None  # per-edge static-input terms of the ConvGRU (computed once when an edge is added)
+        self._static_by_slot = False  # ... stored [E, ...] in edge order, or by slot in the volume pool ([capacity, ...])
         self.want_upmask = True     # compute GraphAgg's upsampling mask although update() discards it, as the reference does
         try:
             self._autocast = next(update_op.parameters()).dtype == torch.float32
@@ -132,17 +134,25 @@ class FactorGraph:
                 corr = CorrBlock(self.video.fmaps[ii][None], self.video.fmaps[jj][None], channels_last=True)
                 self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self.video.inps[ii][None]
-            self.inp = self._cat_cl(self.inp, inp)   # stored channels-last once, so no update re-lays it out
+            by_slot = isinstance(self.corr, CorrVolumePool) and self._static_ok()
+            if not by_slot:
+                self.inp = self._cat_cl(self.inp, inp)   # stored channels-last once, so no update re-lays it out
             if self._static_ok():
                 # conv(W[:, inp], inp) of the ConvGRU's gate / candidate convolutions, once per edge (inp never changes)
                 pz, pq = self.update_op.static_terms(self._cl5(inp)[0], self._op_dtype())
-                self.P_zr = self._cat_cl(self.P_zr, pz[None])
-                self.P_q = self._cat_cl(self.P_q, pq[None])
+                if by_slot:
+                    # ... kept in the slot the edge's volume owns: like the volume, never moved when edges come and go
+                    # (as [E, ...] tensors they were 85 of the 141 MB gathered and concatenated per keyframe; `inp`
+                    # itself is video.inps[ii], materialised only if the PyTorch formulation of the operator asks)
+                    self.P_zr, self.P_q = self.corr.put("P_zr", pz), self.corr.put("P_q", pq)
+                    self._static_by_slot = True
+                else:
+                    self.P_zr = self._cat_cl(self.P_zr, pz[None])
+                    self.P_q = self._cat_cl(self.P_q, pq[None])
         target, _ = self.video.reproject(ii, jj)
         zeros2 = torch.zeros_like(target)
-        self.ii, self.jj = torch.cat([self.ii, ii]), torch.cat([self.jj, jj])
-        self.age = torch.cat([self.age, torch.zeros_like(ii)])
         self._ii_h += ii_l; self._jj_h += jj_l; self._age_h += [0] * len(ii_l)
+        self._sync_edge_index()
         self.net = self._cat_cl(self.net, net)
         self.target_cam = torch.cat([self.target_cam, target], 1)
         self.weight = torch.cat([self.weight, zeros2], 1)
@@ -150,6 +160,13 @@ class FactorGraph:
         self.delta_dy = torch.cat([self.delta_dy, zeros2], 1)
         segm = self.video.segms[ii][None]
         self.segm = segm if self.segm is None else torch.cat([self.segm, segm], 1)
+
+    def _sync_edge_index(self):
+        """device copies of (ii, jj, age) from the host mirrors: ONE staged upload instead of three gathers or three
+        concatenations per edge-set change (the lists are the source of truth for every decision anyway)"""
+        E = len(self._ii_h)
+        packed = self._idx(self._ii_h + self._jj_h + self._age_h) if E else torch.zeros(0, dtype=torch.long, device=self.device)
+        self.ii, self.jj, self.age = packed[:E], packed[E:2 * E], packed[2 * E:3 * E]
 
     def _idx(self, values):
         """host list -> device int64 tensor without draining the stream (persistent pinned staging ring, asynchronous
@@ -174,10 +191,10 @@ class FactorGraph:
             self.weight_inac = torch.cat([self.weight_inac, self.weight[:, rm]], 1)
             self.raw_mask_inac = torch.cat([self.raw_mask_inac, self.raw_mask[:, rm]], 1)
             self.delta_dy_inac = torch.cat([self.delta_dy_inac, self.delta_dy[:, rm]], 1)
-        self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
         self._ii_h = [self._ii_h[k] for k in keep_l]
         self._jj_h = [self._jj_h[k] for k in keep_l]
         self._age_h = [self._age_h[k] for k in keep_l]
+        self._sync_edge_index()
         if self.corr_impl == "volume" and self.corr is not None:
             if isinstance(self.corr, CorrVolumePool):
                 self.corr.keep([not m for m in mask_l])
@@ -185,9 +202,9 @@ class FactorGraph:
                 self.corr = self.corr[keep]
         if self.net is not None:
             self.net = self._take_cl(self.net, keep)
-        if self.inp is not None:
-            self.inp = self._take_cl(self.inp, keep)
-        if self.P_zr is not None:
+        if self._inp is not None:
+            self._inp = self._take_cl(self._inp, keep)
+        if self.P_zr is not None and not self._static_by_slot:
             self.P_zr, self.P_q = self._take_cl(self.P_zr, keep), self._take_cl(self.P_q, keep)
         if self.segm is not None:
             self.segm = self.segm[:, keep]
@@ -197,6 +214,7 @@ class FactorGraph:
     def clear_edges(self):
         self.rm_factors([True] * len(self._ii_h))
         self.net = self.inp = self.P_zr = self.P_q = None
+        self._static_by_slot = False
 
     def rm_keyframe(self, ix):
         """drop keyframe ix and every edge touching it (factor_graph.py:202-225)"""
@@ -498,6 +516,7 @@ class FactorGraph:
             self.net = net[None]
         a.op.net = a.op.net_out = net.data_ptr()
         a.op.P_zr, a.op.P_q = self.P_zr.data_ptr(), self.P_q.data_ptr()
+        a.op.static_by_slot = 1 if self._static_by_slot else 0
         a.op.EP = float(EP)
         a.target, a.delta_dy, a.raw_mask = self.target_cam.data_ptr(), self.delta_dy.data_ptr(), self.raw_mask.data_ptr()
         self.weight, self.full_flow = st["weight"], st["full_flow"]
@@ -513,6 +532,18 @@ class FactorGraph:
             v.disps.clamp_(min=0.001)
         self._age_lag += 1                 # (the device copy of `age` is brought up to date when it is next read)
         self._age_h = [x + 1 for x in self._age_h]
+
+    @property
+    def inp(self):
+        """per-edge context features (factor_graph.py:33).  With the static terms kept by slot nothing on the native path
+        reads them after an edge is created: they are video.inps[ii], gathered on demand for the PyTorch formulation."""
+        if self._inp is None and self._static_by_slot and self._ii_h:
+            return self._cached("inp", lambda: self._cl5(self.video.inps[self.ii][None]))
+        return self._inp
+
+    @inp.setter
+    def inp(self, t):
+        self._inp = t
 
     @property
     def age(self):

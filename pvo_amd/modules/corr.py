@@ -171,6 +171,8 @@ class CorrVolumePool:
         self.slots = []                       # slot of each active edge, in edge order
         self._slots_t = None
         self.device = device
+        self.extra = {}                       # other per-edge data that never changes over an edge's life, by slot (`put`)
+        self._last = None                     # slots handed out by the most recent add(), as a device tensor
 
     def __len__(self):
         return len(self.slots)
@@ -188,6 +190,18 @@ class CorrVolumePool:
             db.corr_build(fmap1.contiguous(), fmap2.contiguous(), self.num_levels, channels_last=True, out=self.levels, out_slots=st)
         self.slots += new
         self._slots_t = None
+        self._last = st
+
+    def put(self, name, rows):
+        """store `rows` [n, ...] (one row per edge of the most recent add(), same order) in the slots those edges own.
+        The factor graph keeps the ConvGRU's static-input terms here: written once per edge, read by slot
+        (pvo_gru_conv_gates' p_slots), never gathered or concatenated when the edge set changes."""
+        t = self.extra.get(name)
+        if t is None:
+            t = self.extra[name] = torch.empty((self.capacity,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device,
+                                               memory_format=torch.channels_last if rows.dim() == 4 and rows.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format)
+        t.index_copy_(0, self._last.long(), rows)
+        return t
 
     def _grow(self, need):
         """more edges than slots (the reference's pyramid simply grows, e.g. a long --warmup initialisation): move to
@@ -199,6 +213,12 @@ class CorrVolumePool:
             new[:self.capacity].copy_(lv)
             levels.append(new)
         self.levels = levels
+        for name, t in list(self.extra.items()):
+            cl = t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+            new = torch.empty((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device,
+                              memory_format=torch.channels_last if cl else torch.contiguous_format)
+            new[:self.capacity].copy_(t)
+            self.extra[name] = new
         self.free = list(range(cap - 1, self.capacity - 1, -1)) + self.free
         self.capacity = cap
 

@@ -28,5 +28,30 @@ for r in rows[i0:i1 + 1]:
     last_end[q] = e
     print("%9.1f %8.1f %8.1f  %-6s %s  [%s x %s]" % ((s - t0) / 1e3, (e - s) / 1e3, gap, q, short(r["Kernel_Name"]),
           r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?"))))
+# what runs BETWEEN the graph updates of one step (edge rebuild, frame distances, the benchmark's own state restore):
+# the six updates of a keyframe are consecutive entries of starts; take the step that contains update -30
+import collections
+ends = []
+for i in starts:
+    j = i
+    while j + 1 < len(rows) and not ("reproject_kernel" in rows[j + 1]["Kernel_Name"] and j + 1 in set(starts)):
+        if "ba_backsub_kernel" in rows[j]["Kernel_Name"] and j > i + 10 and "ba_backsub" not in rows[j + 1]["Kernel_Name"] and "ba_assemble" not in rows[j + 1]["Kernel_Name"]:
+            break
+        j += 1
+    ends.append(j)
+k0 = len(starts) - 36
+gap_rows = collections.OrderedDict()
+span = 0
+for a in range(k0, k0 + 6):
+    lo, hi = ends[a] + 1, starts[a + 1]
+    if hi > lo:
+        span += int(rows[hi]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"])
+    for r in rows[lo:hi]:
+        e = gap_rows.setdefault(short(r["Kernel_Name"]), [0, 0])
+        e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+print()
+print("between the updates of six consecutive graph updates (one keyframe step): %.1f us of wall time; kernels there:" % (span / 1e3))
+for n, (c, t) in sorted(gap_rows.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("  %-52s x%-3d %8.1f us" % (n, c, t / 1e3))
 PY
 tail -3 /tmp/ut_bench.log | cut -c1-200 >> $OUT
