@@ -76,7 +76,7 @@ __device__ __forceinline__ float pool4(float a, float b, float c, float d) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void corr_build_mfma_kernel(BuildArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void corr_build_mfma_kernel(BuildArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int C = a.C, H = a.H, W = a.W, HW = H * W;
   const int rowB = C * 2 + 16;                       // padded LDS row stride (bytes)
