@@ -564,6 +564,14 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
 // Ld[kb][27] keeps the factored diagonal blocks (row-major lower, 21) and their reciprocal diagonals (6) for the back substitution.
 // 1/sqrt(d) in fp64: hardware estimate (v_rsq_f64) + two Newton steps; the library sqrt and divide are ~30-instruction
 // software sequences each and sit on the serial critical path of the factorisation
+// tools/ba_solve_timeline.py builds this file with -DPVO_BA_PROBE: clock stamps of the solve kernel's phases
+#ifdef PVO_BA_PROBE
+__device__ unsigned long long* g_ba_probe = nullptr;
+#define BA_PROBE(slot) do { if (g_ba_probe && threadIdx.x == 0) g_ba_probe[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BA_PROBE(slot)
+#endif
+
 __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
   y = y * (1.5 - 0.5 * d * y * y);
@@ -652,6 +660,7 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
     }
     __syncthreads();
   }
+  BA_PROBE(2);
   // back substitution L^T x = y (y in row n), block rows from the bottom; x overwrites y.  Right-looking: once the six
   // unknowns of block kb are known, every earlier entry takes its update y[i] -= sum_c L[j0+c][i] x[c] independently, so
   // a block step is one redundant 6x6 triangular solve per thread (registers, reciprocal diagonals, no division), one
@@ -696,6 +705,7 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   double* Ld = b + n;                                                            // [P][21 + 6] factored diagonal blocks + reciprocal diagonals
   double* red = Ld + 27 * P;                                                     // [4][6] wave partials
   __shared__ int first[kMaxEnvBlocks];                                           // envelope: first non-zero block column per block row
+  BA_PROBE(0);
   if (threadIdx.x == 0) fail = 0;
   for (int b = threadIdx.x; b < P; b += blockDim.x) first[b] = b;
   __syncthreads();
@@ -724,8 +734,10 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
     }
   }
   __syncthreads();
+  BA_PROBE(1);
   chol_solve_blocked(A, Ld, red, n, &fail, first);
   __syncthreads();
+  BA_PROBE(4);
   const int failed = fail | meta[4];
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
     const float v = failed ? 0.0f : static_cast<float>(b[idx]);    // zeros on failure (:1186-1189)
@@ -743,6 +755,7 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
     ps[3] = T.q.x; ps[4] = T.q.y; ps[5] = T.q.z; ps[6] = T.q.w;
   }
   __syncthreads();
+  BA_PROBE(5);
   if (threadIdx.x == 0) {
     meta[4] = 0;
     if (failed) meta[1] = 1;
@@ -794,6 +807,10 @@ int check_common(int E, int F, int ht, int wd, int t0, int t1) {
 }
 
 }  // namespace
+
+#ifdef PVO_BA_PROBE
+extern "C" int pvo_debug_ba_probe(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ba_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#endif
 
 extern "C" size_t pvo_ba_workspace_bytes(int E, int P, int nframes, int HW) {
   if (E < 0 || P < 0 || nframes < 0 || HW < 0) return 0;
