@@ -51,7 +51,8 @@ __device__ __forceinline__ void fix_add(long long* sys, long long idx, double v,
 }
 constexpr int kPPT = 2;                 // pixels per thread in assemble
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
-constexpr int kLdsCholMax = 132;        // (6P) up to which the fp64 system lives in LDS (132*133*8 + 22*27*8 + 208 = 145.4 KB, + the 8 KB envelope table < 160 KB)
+constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system lives DENSE in LDS (126*127*8 + 21*27*8 + 208 = 132.7 KB of the 143 KB the
+                                        // solve kernel's static tables leave); beyond, the compact envelope form
 
 struct Plan {            // int region of the workspace
   int* kidx;             // [F]   frame -> depth index, -1 if none
@@ -59,6 +60,7 @@ struct Plan {            // int region of the workspace
   int* eptr;             // [F+1] CSR over depth index -> edges (ascending edge id)
   int* eidx;             // [E]
   int* meta;             // [8]   0:K 1:status(non-SPD) 2:eta mismatch 3:row table overflow 4:non-finite / out-of-range system entry
+  int* env;              // [P]   numeric envelope of a system too large for the dense LDS path (ba_env_kernel; INT_MAX between solves)
 };
 
 struct Ws {
@@ -87,6 +89,7 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.plan.eptr = reinterpret_cast<int*>(take(sizeof(int) * (F + 2)));
   w.plan.eidx = reinterpret_cast<int*>(take(sizeof(int) * (E + 1)));
   w.plan.meta = reinterpret_cast<int*>(take(sizeof(int) * 8));
+  w.plan.env = reinterpret_cast<int*>(take(sizeof(int) * ((P > 0 ? P : 0) + 1)));
   w.Eii = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * 6 * HW));
   w.Eij = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * 6 * HW));
   w.Cii = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * HW));
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void ba_plan_kernel(
     int E, int F, int t0, int t1, int K_eta, int motion_only) {
   __shared__ int seg[257];
   const int tid = threadIdx.x;
+  for (int b = tid; b < t1 - t0; b += 256) pl.env[b] = 0x7fffffff;
   // presence bitmap
   for (int f = tid; f < F; f += 256) pl.kidx[f] = (f >= t0 && f < t1) ? 1 : 0;
   __syncthreads();
@@ -608,18 +612,92 @@ __device__ __forceinline__ bool chol6(const double D[21], double L[21], double r
 // reduced pose system of a keyframe graph is block-banded up to its loop closures (two poses couple only through a depth
 // frame both observe): at 63 free poses and temporal radius 3 the envelope holds 12 % of the matrix.  (The reference
 // uses a sparse LLT for the same reason, droid_kernels.cu:1178-1184.)
-__device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, int* fail_flag, const int* first) {
-  // A: (n+1) x n row-major, row n = rhs.  On return row n holds the solution x.
+// The matrix behind an accessor A(i, c): (n+1) x n, row n = rhs.  Two storages:
+//   DenseMat  row-major, in LDS (up to 22 free poses) or in global memory (anything, slow: every access an L2 round trip);
+//   EnvMat    only the blocks inside the envelope, block row b = blocks first[b] .. b of 36 doubles each at rowbase[b], + the
+//             rhs - what lets a 63-pose system of a radius-3 graph (envelope 12 % of the matrix: 121 KB) live in LDS.
+struct MatRow {            // one row of either storage: element c at base[c + k * (c / 6)]
+  double* base; int k;
+  __device__ __forceinline__ double& operator()(int c) const { return base[c + k * (c / 6)]; }
+};
+template <typename Index>      // int for the LDS copy (32-bit address arithmetic), long long for a matrix in global memory
+struct DenseMat {
+  double* p; Index n;
+  __device__ __forceinline__ MatRow row(int i) const { return MatRow{p + i * n, 0}; }
+};
+struct EnvMat {
+  double* blk; double* rhs; const int* first; const int* rowbase; int n;
+  __device__ __forceinline__ MatRow row(int i) const {
+    if (i == n) return MatRow{rhs, 0};
+    const int ib = i / 6;                                  // block (ib, cb) at rowbase[ib] + (cb - first[ib]) * 36, 6 x 6 row-major
+    return MatRow{blk + rowbase[ib] - first[ib] * 36 + (i - 6 * ib) * 6, 30};
+  }
+};
+
+// Inclusive scan (sum or max) of v[0..P) in place by the whole workgroup, 256 entries at a time with a carry: the serial
+// thread-0 loops this replaces were 50 k cycles of LDS round trips per 63-pose solve.
+template <bool MAX>
+__device__ void block_scan(int* v, int P) {
+  __shared__ int buf[2][256];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry_s = MAX ? -0x7fffffff : 0;
+  __syncthreads();
+  for (int base = 0; base < P; base += 256) {
+    const int i = base + tid;
+    int x = i < P ? v[i] : (MAX ? -0x7fffffff : 0);
+    int cur = 0;
+    buf[0][tid] = x;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      int y = buf[cur][tid];
+      if (tid >= d) { const int z = buf[cur][tid - d]; y = MAX ? (z > y ? z : y) : y + z; }
+      buf[cur ^ 1][tid] = y;
+      cur ^= 1;
+      __syncthreads();
+    }
+    const int c = carry_s;
+    const int r = MAX ? (c > buf[cur][tid] ? c : buf[cur][tid]) : c + buf[cur][tid];
+    if (i < P) v[i] = r;
+    __syncthreads();
+    if (tid == 255) carry_s = r;
+    __syncthreads();
+  }
+}
+
+// reach[kb] = last block row whose envelope reaches block column kb: the rows below it (except the rhs) take no part in
+// step kb, and scanning them - 23 loop trips per thread and step at 63 poses, each an LDS lookup to find out - cost more than
+// the arithmetic (tools/ba_solve_timeline.py: 14 k cycles per block column against 4.5 k at 7 poses)
+__device__ void envelope_reach(const int* first, int* reach, int P) {
+  if (P <= 12) {                                           // (nothing to skip in a window-sized system)
+    for (int b = threadIdx.x; b < P; b += blockDim.x) reach[b] = P - 1;
+    __syncthreads();
+    return;
+  }
+  for (int b = threadIdx.x; b < P; b += blockDim.x) reach[b] = b;
+  __syncthreads();
+  for (int b = threadIdx.x; b < P; b += blockDim.x) atomicMax(&reach[first[b]], b);
+  __syncthreads();
+  block_scan<true>(reach, P);
+}
+
+template <class Mat>
+__device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* reach) {
+  // On return row n holds the solution x.
   const int tid = threadIdx.x, nt = blockDim.x;
   const int tx = tid & 15, ty = tid >> 4, nty = nt >> 4;
   const int P = n / 6;
+  const MatRow Y = A.row(n);
   for (int kb = 0; kb < P; ++kb) {
     const int j0 = 6 * kb;
+    const int iend = 6 * reach[kb] + 5;                    // last matrix row active in this step
     double D[21], L[21], rd[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r) {
+      const MatRow R = A.row(j0 + r);
 #pragma unroll
-      for (int c = 0; c <= r; ++c) D[r * (r + 1) / 2 + c] = A[(j0 + r) * n + j0 + c];
+      for (int c = 0; c <= r; ++c) D[r * (r + 1) / 2 + c] = R(j0 + c);
+    }
     const bool ok = chol6(D, L, rd);
     if (!ok) { if (tid == 0) *fail_flag = 1; __syncthreads(); return; }      // uniform: every thread saw the same block
     if (tid == 0) {
@@ -628,34 +706,39 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
 #pragma unroll
       for (int q = 0; q < 6; ++q) Ld[kb * 27 + 21 + q] = rd[q];
     }
-    // (b) panel rows j0+6 .. n (inclusive: the rhs row), those whose envelope reaches this block column
-    for (int i = j0 + 6 + tid; i <= n; i += nt) {
+    // (b) panel rows j0+6 .. iend and the rhs row n, those whose envelope reaches this block column
+    for (int ii = j0 + 6 + tid; ii <= iend + 1; ii += nt) {
+      const int i = ii <= iend ? ii : n;
       if (i < n && first[i / 6] > kb) continue;
+      const MatRow R = A.row(i);
       double x[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        double v = A[i * n + j0 + c];
+        double v = R(j0 + c);
 #pragma unroll
         for (int k = 0; k < c; ++k) v -= x[k] * L[c * (c + 1) / 2 + k];
         x[c] = v * rd[c];
       }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) A[i * n + j0 + c] = x[c];
+      for (int c = 0; c < 6; ++c) R(j0 + c) = x[c];
     }
     __syncthreads();
-    // (c) trailing update, rows i in (j0+6 .. n], columns c in (j0+6 .. min(i, n-1)]
-    for (int i = j0 + 6 + ty; i <= n; i += nty) {
+    // (c) trailing update, rows i in (j0+6 .. iend] and n, columns c in (j0+6 .. min(i, iend)]
+    for (int ii = j0 + 6 + ty; ii <= iend + 1; ii += nty) {
+      const int i = ii <= iend ? ii : n;
       if (i < n && first[i / 6] > kb) continue;
+      const MatRow R = A.row(i);
       double li[6];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) li[t] = A[i * n + j0 + t];
-      const int cmax = (i < n) ? i : n - 1;
+      for (int t = 0; t < 6; ++t) li[t] = R(j0 + t);
+      const int cmax = (i < n) ? i : iend;
       for (int c = j0 + 6 + tx; c <= cmax; c += 16) {
         if (first[c / 6] > kb) continue;
-        double acc = A[i * n + c];
+        const MatRow C = A.row(c);
+        double acc = R(c);
 #pragma unroll
-        for (int t = 0; t < 6; ++t) acc -= li[t] * A[c * n + j0 + t];
-        A[i * n + c] = acc;
+        for (int t = 0; t < 6; ++t) acc -= li[t] * C(j0 + t);
+        R(c) = acc;
       }
     }
     __syncthreads();
@@ -667,25 +750,24 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
   // parallel update and ONE barrier.  (The left-looking form - dot products over the rows below, 36 wave shuffles of
   // doubles, a serial thread-0 solve with six fp64 divisions, two barriers - cost 20 of the solve's 37 us at P = 7:
   // measured with ablation builds.)
-  double* y = A + static_cast<long long>(n) * n;
   for (int kb = P - 1; kb >= 0; --kb) {
     const int j0 = 6 * kb;
     const double* L = Ld + kb * 27;
     double x[6];
 #pragma unroll
     for (int c = 5; c >= 0; --c) {
-      double v = y[j0 + c];
+      double v = Y(j0 + c);
 #pragma unroll
       for (int k = c + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + c] * x[k];
       x[c] = v * L[21 + c];                                  // reciprocal diagonal
     }
     __syncthreads();                                         // everyone has read y[j0..j0+6) before it is overwritten
-    if (tid < 6) y[j0 + tid] = x[tid];
+    if (tid < 6) Y(j0 + tid) = x[tid];
     for (int i = 6 * first[kb] + tid; i < j0; i += nt) {     // row block kb of L is zero left of its envelope
-      double v = y[i];
+      double v = Y(i);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v -= A[(j0 + c) * n + i] * x[c];
-      y[i] = v;
+      for (int c = 0; c < 6; ++c) v -= A.row(j0 + c)(i) * x[c];
+      Y(i) = v;
     }
     __syncthreads();
   }
@@ -693,54 +775,206 @@ __device__ void chol_solve_blocked(double* A, double* Ld, double* red, int n, in
 
 constexpr int kMaxEnvBlocks = 2048;      // poses the envelope table covers (beyond: dense, first = 0)
 
+// ---- systems beyond the dense LDS path (more than 22 free poses: the global bundle adjustment) --------------------------
+// Two multi-workgroup kernels prepare the one-workgroup solve (inside it, reading 1.1 MB of fixed point through a single CU
+// was 429 k of its 1479 k cycles at 63 poses - tools/ba_solve_timeline.py):
+//   ba_env_kernel      numeric envelope: env[b] = first block column with a non-zero in block row b (atomicMin; the table is
+//                      INT_MAX between solves).  Numeric, not structural: in an edge-sharded BA the system is the all-reduced
+//                      one, whose couplings this rank's edge list does not know.
+//   ba_prepare_kernel  fixed point -> fp64 with the damping, `sys` zeroed, into the layout the solve will use: compact
+//                      envelope blocks if they fit the LDS budget, else dense.
+// env_layout: offsets of the compact layout (block row b = blocks first[b] .. b); returns the number of doubles of all
+// blocks.  Executed by one thread.
+// first[] from the numeric envelope and the offsets of the compact layout (block row b = blocks first[b] .. b); returns the
+// number of doubles of all blocks, or INT_MAX when that does not fit an int.  Whole workgroup; valid after it returns.
+__device__ int env_layout(const int* __restrict__ env, int P, int* first, int* rowbase, int* total_s) {
+  for (int b = threadIdx.x; b < P; b += blockDim.x) {
+    const int e = env[b];
+    const int f = e < b ? e : b;
+    first[b] = f;
+    rowbase[b] = (b - f + 1) * 36;                         // sizes, scanned below
+  }
+  __syncthreads();
+  // (sizes up to 36 * 2048 per row: the running sum can overflow an int only far beyond any LDS budget - clamp)
+  block_scan<false>(rowbase, P);
+  if (threadIdx.x == 0) *total_s = (P > 0 && rowbase[P - 1] >= 0) ? rowbase[P - 1] : 0x7fffffff;
+  __syncthreads();
+  for (int b = threadIdx.x; b < P; b += blockDim.x) {      // inclusive -> exclusive
+    const int sz = (b - first[b] + 1) * 36;
+    rowbase[b] -= sz;
+  }
+  __syncthreads();
+  return *total_s;
+}
+// doubles of LDS the compact path needs: blocks + rhs + Ld (27 per pose) + slack, and (as ints) the offset table
+__device__ __host__ __forceinline__ long long env_lds_bytes(long long blocks, int n, int P) {
+  return 16 + 8 * (blocks + n + 27LL * P + 24) + 4LL * (P + 2);
+}
+
+__global__ __launch_bounds__(256) void ba_env_kernel(const long long* __restrict__ sys, int* __restrict__ env, int n) {
+  const int NN = n * n;
+  const int base = blockIdx.x * 2048;
+  long long raw[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    raw[u] = idx < NN ? sys[idx] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    if (idx >= NN || raw[u] == 0) continue;
+    const int r = idx / n, c = idx - r * n;
+    if (c < r) atomicMin(&env[r / 6], c / 6);
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_prepare_kernel(long long* __restrict__ sys, double* __restrict__ out, const int* __restrict__ env,
+                                                         int n, float lm, float ep, long long lds_budget) {
+  __shared__ int first[kMaxEnvBlocks], rowbase[kMaxEnvBlocks + 1];
+  __shared__ int blocks_s;
+  const int P = n / 6;
+  const int blocks = env_layout(env, P, first, rowbase, &blocks_s);
+  const bool compact = env_lds_bytes(blocks, n, P) <= lds_budget;
+  const int N = n * n + n;
+  const int base = blockIdx.x * 2048;
+  long long raw[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    raw[u] = idx < N ? sys[idx] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    if (idx >= N) continue;
+    double v = static_cast<double>(raw[u]) * kInvFix;       // fixed point -> fp64
+    sys[idx] = 0;                                           // ready for the next Gauss-Newton step's accumulation
+    if (idx >= n * n) {                                     // rhs
+      out[compact ? blocks + (idx - n * n) : idx] = v;
+      continue;
+    }
+    const int r = idx / n, c = idx - r * n;
+    if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
+    if (!compact) { out[idx] = v; continue; }
+    const int rb = r / 6, cb = c / 6;
+    if (cb > rb || cb < first[rb]) continue;                // upper triangle / outside the envelope (exact zeros)
+    out[rowbase[rb] + (cb - first[rb]) * 36 + (r - 6 * rb) * 6 + (c - 6 * cb)] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void ba_solve_kernel(
     long long* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
     float* __restrict__ dx_ws, float* __restrict__ dx_out, int* __restrict__ meta, int* __restrict__ status_out,
-    int P, int t0, float lm, float ep, int use_lds) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs]
+    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs | ...]
   int& fail = *reinterpret_cast<int*>(smem);
   const int n = 6 * P;
-  double* A = use_lds ? reinterpret_cast<double*>(smem + 16) : chol_global;     // (n+1) x n: system, then the rhs row
-  double* b = A + static_cast<long long>(n) * n;
-  double* Ld = b + n;                                                            // [P][21 + 6] factored diagonal blocks + reciprocal diagonals
-  double* red = Ld + 27 * P;                                                     // [4][6] wave partials
   __shared__ int first[kMaxEnvBlocks];                                           // envelope: first non-zero block column per block row
+  __shared__ int reach[kMaxEnvBlocks];                                           // ... and last block row that reaches a block column
+  __shared__ int blocks_s;
   BA_PROBE(0);
   if (threadIdx.x == 0) fail = 0;
-  for (int b = threadIdx.x; b < P; b += blockDim.x) first[b] = b;
-  __syncthreads();
-  // (eight loads in flight per thread: one at a time, behind the zeroing store of the previous one, the 1806 entries of a
-  // 7-pose system cost eight serial L2 round trips - a third of this kernel)
-  const int N = n * n + n;
-  for (int base = 0; base < N; base += 8 * blockDim.x) {
-    long long raw[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * blockDim.x + threadIdx.x;
-      raw[u] = idx < N ? sys[idx] : 0;
+  double* xrow = nullptr;                                                        // where the solution ends up
+  if (!use_lds) {
+    // prepared by ba_env_kernel + ba_prepare_kernel
+    int* rowbase = nullptr;
+    {
+      // the offset table sits behind the doubles of the compact layout; its position depends on the block count, which
+      // thread 0 computes into a scratch copy first
+      int* tmp = reinterpret_cast<int*>(smem + 16);
+      env_layout(env, P, first, tmp, &blocks_s);
     }
+    const int blocks = blocks_s;
+    const bool compact = env_lds_bytes(blocks, n, P) <= lds_budget;
+    if (compact) {
+      double* blk = reinterpret_cast<double*>(smem + 16);
+      double* rhs = blk + blocks;
+      double* Ld = rhs + n;
+      rowbase = reinterpret_cast<int*>(Ld + 27 * P + 24);
+      // (the offsets computed into the scratch copy move to their final place behind the doubles; the scratch is about to be
+      // overwritten by the matrix, so they travel through registers)
+      int rb_keep[kMaxEnvBlocks / 256];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * blockDim.x + threadIdx.x;
-      if (idx >= N) continue;
-      double v = static_cast<double>(raw[u]) * kInvFix;       // fixed point -> fp64
-      sys[idx] = 0;                                           // ready for the next Gauss-Newton step's accumulation
-      if (idx < n * n) {
-        const int r = idx / n, c = idx - r * n;
-        if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
-        if (raw[u] != 0 && c < r) atomicMin(&first[r / 6], c / 6);
+      for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+        const int b = q * 256 + threadIdx.x;
+        rb_keep[q] = b < P ? reinterpret_cast<const int*>(smem + 16)[b] : 0;
       }
-      A[idx] = v;
+      __syncthreads();
+      {
+        // 124 KB at 63 poses through one workgroup: eight 16-byte loads in flight per thread (one 8-byte load at a time
+        // was 57 k cycles of latency)
+        const int nd2 = (blocks + n) >> 1;                                          // blocks is a multiple of 36: pairs cover blocks + n but for an odd n
+        const double2* src = reinterpret_cast<const double2*>(chol_global);
+        double2* dst = reinterpret_cast<double2*>(blk);
+        for (int base = 0; base < nd2; base += 8 * blockDim.x) {
+          double2 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int i = base + u * blockDim.x + threadIdx.x; if (i < nd2) v[u] = src[i]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int i = base + u * blockDim.x + threadIdx.x; if (i < nd2) dst[i] = v[u]; }
+        }
+        if (((blocks + n) & 1) && threadIdx.x == 0) blk[blocks + n - 1] = chol_global[blocks + n - 1];
+      }
+#pragma unroll
+      for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+        const int b = q * 256 + threadIdx.x;
+        if (b < P) rowbase[b] = rb_keep[q];
+      }
+      for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
+      __syncthreads();
+      envelope_reach(first, reach, P);
+      BA_PROBE(1);
+      chol_solve_blocked(EnvMat{blk, rhs, first, rowbase, n}, Ld, n, &fail, first, reach);
+      xrow = rhs;
+    } else {
+      for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
+      double* A = chol_global;
+      __syncthreads();
+      envelope_reach(first, reach, P);
+      BA_PROBE(1);
+      chol_solve_blocked(DenseMat<long long>{A, n}, A + static_cast<long long>(n) * n + n, n, &fail, first, reach);
+      xrow = A + static_cast<long long>(n) * n;
     }
+  } else {
+    double* A = reinterpret_cast<double*>(smem + 16);                              // (n+1) x n: system, then the rhs row
+    for (int b = threadIdx.x; b < P; b += blockDim.x) first[b] = b;
+    __syncthreads();
+    // (eight loads in flight per thread: one at a time, behind the zeroing store of the previous one, the 1806 entries of a
+    // 7-pose system cost eight serial L2 round trips - a third of this kernel)
+    const int N = n * n + n;
+    for (int base = 0; base < N; base += 8 * blockDim.x) {
+      long long raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * blockDim.x + threadIdx.x;
+        raw[u] = idx < N ? sys[idx] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * blockDim.x + threadIdx.x;
+        if (idx >= N) continue;
+        double v = static_cast<double>(raw[u]) * kInvFix;       // fixed point -> fp64
+        sys[idx] = 0;                                           // ready for the next Gauss-Newton step's accumulation
+        if (idx < n * n) {
+          const int r = idx / n, c = idx - r * n;
+          if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
+          if (raw[u] != 0 && c < r) atomicMin(&first[r / 6], c / 6);
+        }
+        A[idx] = v;
+      }
+    }
+    __syncthreads();
+    envelope_reach(first, reach, P);
+    BA_PROBE(1);
+    chol_solve_blocked(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach);
+    xrow = A + n * n;
   }
-  __syncthreads();
-  BA_PROBE(1);
-  chol_solve_blocked(A, Ld, red, n, &fail, first);
   __syncthreads();
   BA_PROBE(4);
   const int failed = fail | meta[4];
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
-    const float v = failed ? 0.0f : static_cast<float>(b[idx]);    // zeros on failure (:1186-1189)
+    const float v = failed ? 0.0f : static_cast<float>(xrow[idx]);    // zeros on failure (:1186-1189)
     dx_ws[idx] = v;
     if (dx_out) dx_out[idx] = v;
   }
@@ -892,13 +1126,25 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
   hipStream_t st = pvo_stream(stream);
   const int n6 = 6 * P;
   const int use_lds = n6 <= kLdsCholMax;
-  const size_t lds = 16 + (use_lds ? sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : 0);
+  constexpr size_t kSolveLdsMax = 143000;      // dynamic LDS of the solve: the CU's 163840 B minus its 20496 B of static tables (envelope, reach, scan buffers)
+  const size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
   if (lds > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024 - 8192 - 64) != hipSuccess) return PVO_ELAUNCH;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(kSolveLdsMax)) != hipSuccess) return PVO_ELAUNCH;
+      attr_set = true;
+    }
+  }
+  if (!use_lds) {
+    hipLaunchKernelGGL(ba_env_kernel, dim3((n6 * n6 + 2047) / 2048), dim3(256), 0, st, sys, w.plan.env, n6);
+    PVO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ba_prepare_kernel, dim3((n6 * n6 + n6 + 2047) / 2048), dim3(256), 0, st, sys, w.chol, w.plan.env, n6, lm, ep,
+                       static_cast<long long>(kSolveLdsMax));
+    PVO_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
-                     w.plan.meta, status_out, P, t0, lm, ep, use_lds);
+                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax));
   PVO_CHECK_LAUNCH();
   if (!motion_only && E + P > 0) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);

@@ -70,23 +70,29 @@ def test_ba_matches_oracle(cuda, cfg, iters):
     assert np.abs(dz - want["dz"]).max() < 1e-4
 
 
-@pytest.mark.parametrize("P,closure", [(30, False), (30, True), (23, True)])
+@pytest.mark.parametrize("P,closure", [(30, False), (30, True), (23, True), (22, True), (64, "many")])
 def test_ba_long_window_envelope_cholesky_matches_oracle(cuda, P, closure):
-    """A long keyframe chain (block-banded reduced pose system; with `closure` two loop-closure edges that create fill
-    inside the envelope): the envelope-form Cholesky of ba_solve_kernel - the LDS path at P = 23 (22 free poses), the
-    global-memory path at P = 30 - against the oracle's dense fp64 solve"""
+    """A long keyframe chain (block-banded reduced pose system; with `closure` loop-closure edges that create fill inside
+    the envelope): the envelope-form Cholesky of ba_solve_kernel against the oracle's dense fp64 solve - dense in LDS at
+    P = 22 (21 free poses), compact envelope blocks in LDS at 23 and 30 (ba_env_kernel + ba_prepare_kernel), and at P = 64
+    with ten frames closing back to frame 1 an envelope that does not fit LDS: the dense global-memory path"""
     ht, wd = 8, 10
-    s = _scene(P * 7 + int(closure), P, ht, wd, 2, 1)
+    s = _scene(P * 7 + int(bool(closure)), P, ht, wd, 2, 1)
     if closure:
         from pvo_amd.geom.se3 import SE3
-        extra_i, extra_j = torch.tensor([1, P - 2, 3, P - 5]), torch.tensor([P - 2, 1, P - 5, 3])
+        if closure == "many":
+            far = list(range(P - 12, P - 2))
+            extra_i, extra_j = torch.tensor([1] * len(far) + far), torch.tensor(far + [1] * len(far))
+        else:
+            extra_i, extra_j = torch.tensor([1, P - 2, 3, P - 5]), torch.tensor([P - 2, 1, P - 5, 3])
         ii, jj = torch.cat([s["ii"], extra_i]), torch.cat([s["jj"], extra_j])
         F = P
         c, _ = O.reproject(s["poses_gt"].numpy(), s["disps_gt"].numpy(), s["intr"][None].repeat(F, 1).numpy(), extra_i.numpy(), extra_j.numpy())
         g = torch.Generator().manual_seed(5)
-        t_extra = (torch.from_numpy(c) + 0.1 * torch.randn(4, ht, wd, 2, generator=g)).permute(0, 3, 1, 2)
+        ne = extra_i.shape[0]
+        t_extra = (torch.from_numpy(c) + 0.1 * torch.randn(ne, ht, wd, 2, generator=g)).permute(0, 3, 1, 2)
         s = dict(s, ii=ii, jj=jj, target=torch.cat([s["target"], t_extra]).contiguous(),
-                 weight=torch.cat([s["weight"], 0.2 * torch.rand(4, 2, ht, wd, generator=g)]).contiguous())
+                 weight=torch.cat([s["weight"], 0.2 * torch.rand(ne, 2, ht, wd, generator=g)]).contiguous())
     want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
                 s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
     poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
