@@ -392,12 +392,17 @@ constexpr int kSchurSteps = kSchurPix / 4 / 16;
 constexpr int kMaxRows = 1024;           // rows of M the LDS row table can describe
 constexpr int kFastTiles = 4;            // up to 4 row tiles (63 rows + w) accumulate in one pass
 
+// Row pointers pass through an LDS table: typed as GLOBAL-address-space pointers, so that what is loaded through them is a
+// global_load (a plain `const float*` read back from LDS is a generic pointer and every access a flat_load: 112 of them in
+// this kernel, each counting against both vmcnt and lgkmcnt)
+typedef const float __attribute__((address_space(1))) gfloat;
+
 template <bool VEC4>
-__device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int p, int HW) {
+__device__ __forceinline__ f32x4 load4(gfloat* __restrict__ row, int p, int HW) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (row == nullptr) return v;
   if (VEC4) {
-    if (p + 3 < HW) return *reinterpret_cast<const f32x4*>(row + p);
+    if (p + 3 < HW) return *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(row + p);
   }
   if (p < HW) v.x = row[p];
   if (p + 1 < HW) v.y = row[p + 1];
@@ -424,13 +429,13 @@ __device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, in
 
 // all T(T+1)/2 tile pairs in ONE pass over the pixels (rows read once, accumulators static)
 template <int T, bool VEC4>
-__device__ __forceinline__ void schur_pass(const float* const* rowptr, const int* rowout,
-                                           const float* __restrict__ qrow, float* red /*[4][NT*4][64]*/,
+__device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* rowout,
+                                           gfloat* __restrict__ qrow, float* red /*[4][NT*4][64]*/,
                                            long long* __restrict__ sys, int HW, int n6, int pix_base, int* meta) {
   constexpr int NT = T * (T + 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int idx = lane & 15, kq = lane >> 4;
-  const float* rows[T];
+  gfloat* rows[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) rows[t] = rowptr[t * 16 + idx];
   f32x4 acc[NT];
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
     int HW, int t0, int P) {
-  __shared__ const float* rowptr[kMaxRows];
+  __shared__ gfloat* rowptr[kMaxRows];
   __shared__ int rowout[kMaxRows];        // 6*pose + comp for an M row, -2 for the w row, -1 padding
   __shared__ int nrows_s;
   __shared__ float red[4 * (kFastTiles * (kFastTiles + 1) / 2) * 256];   // 40 KB
@@ -500,16 +505,16 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     int r = 0;
     const int pself = pl.kx[k] - t0;
     if (pself >= 0 && pself < P) {
-      for (int n = 0; n < 6; ++n) { rowptr[r] = Ei + (static_cast<long long>(pself) * 6 + n) * HW; rowout[r] = 6 * pself + n; ++r; }
+      for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Ei + (static_cast<long long>(pself) * 6 + n) * HW); rowout[r] = 6 * pself + n; ++r; }
     }
     for (int o = pl.eptr[k]; o < pl.eptr[k + 1]; ++o) {
       const int e = pl.eidx[o];
       const int p = static_cast<int>(jj[e]) - t0;
       if (p < 0 || p >= P) continue;      // fixed target pose: drops out (:1125, :1227)
       if (r + 7 > kMaxRows) { pl.meta[3] = 1; break; }   // > 169 free neighbours of one frame: flagged
-      for (int n = 0; n < 6; ++n) { rowptr[r] = Eij + (static_cast<long long>(e) * 6 + n) * HW; rowout[r] = 6 * p + n; ++r; }
+      for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Eij + (static_cast<long long>(e) * 6 + n) * HW); rowout[r] = 6 * p + n; ++r; }
     }
-    if (r > 0) { rowptr[r] = w + static_cast<long long>(k) * HW; rowout[r] = -2; ++r; }
+    if (r > 0) { rowptr[r] = (gfloat*)(w + static_cast<long long>(k) * HW); rowout[r] = -2; ++r; }
     const int padded = (r + 15) & ~15;
     for (int q = r; q < padded; ++q) { rowptr[q] = nullptr; rowout[q] = -1; }
     nrows_s = r;
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
   const int nrows = nrows_s;
   if (nrows == 0) return;
   const int T = (nrows + 15) >> 4;
-  const float* __restrict__ qrow = Q + static_cast<long long>(k) * HW;
+  gfloat* __restrict__ qrow = (gfloat*)(Q + static_cast<long long>(k) * HW);
   const int pix_base = blockIdx.x * kSchurPix + wave * (kSchurPix / 4);
 
   switch (T) {
@@ -531,9 +536,9 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
   // any degree: one tile pair at a time, row tiles re-read from L2
   const int idx = lane & 15, kq = lane >> 4;
   for (int ti = 0; ti < T; ++ti) {
-    const float* __restrict__ ra = rowptr[ti * 16 + idx];
+    gfloat* __restrict__ ra = rowptr[ti * 16 + idx];
     for (int tj = ti; tj < T; ++tj) {
-      const float* __restrict__ rb = rowptr[tj * 16 + idx];
+      gfloat* __restrict__ rb = rowptr[tj * 16 + idx];
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
       for (int s = 0; s < kSchurSteps; ++s) {
