@@ -117,6 +117,10 @@ def load():
         raise PvoHipError(
             "libpvo_hip.so not found at %s - build it with `python -m pvo_amd.build` "
             "(there is no CPU fallback)" % LIB_PATH)
+    # PyTorch first: its wheel carries its own libamdhip64, and the streams / pointers this module passes into the library
+    # are that runtime's.  Loaded before torch, libpvo_hip.so would bind the system ROCm's copy instead - two HIP runtimes
+    # in one process, and every launch on a torch stream fails (seen as "HIP launch error" on the first call).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

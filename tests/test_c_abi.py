@@ -67,3 +67,18 @@ def test_wide_convolution_keeps_its_register_budget(tmp_path):
         scratch = int(re.search(r"; ScratchSize: (\d+)", info).group(1))
         vgprs = int(re.search(r"; NumVgprs: (\d+)", info).group(1))
         assert scratch == 0 and vgprs <= 256 and int(occ) == 2, (name, scratch, vgprs, occ)
+
+
+@pytest.mark.gpu
+def test_library_loaded_before_torch_still_launches():
+    """A process that touches pvo_amd._lib before anything of PyTorch (as __graft_entry__.build() followed by smoke() does)
+    must end up with ONE HIP runtime: torch's wheel ships its own libamdhip64, and libpvo_hip.so loaded first used to bind
+    the system copy - every later launch on a torch stream failed with "HIP launch error"."""
+    import sys
+    code = ("from pvo_amd import _lib; _lib.load(); import torch; from pvo_amd import droid_backends as db; "
+            "d = torch.device('cuda:0'); "
+            "pyr = [torch.randn(2, 6, 10, 8 >> l, 16 >> l, device=d).half() for l in range(4)]; "
+            "c = torch.rand(2, 6, 10, 2, device=d) * 8; "
+            "y = db.corr_pyramid_lookup(pyr, c, 3); torch.cuda.synchronize(); print('ok', tuple(y.shape))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0 and "ok (2, 196, 6, 10)" in out.stdout, out.stdout[-2000:]
