@@ -39,6 +39,8 @@ enum {
 };
 
 const char* pvo_strerror(int code);
+/* text of the HIP error behind this thread's most recent PVO_ELAUNCH (hipGetErrorString) */
+const char* pvo_last_hip_error(void);
 int pvo_version(void);
 
 /* ------------------------------------------------------------------------- */

@@ -18,6 +18,7 @@ _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 SIGNATURES = {
     "pvo_strerror": (_c.c_char_p, [_i]),
     "pvo_version": (_i, []),
+    "pvo_last_hip_error": (_c.c_char_p, []),
     "pvo_corr_index_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_index_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_pyramid_lookup": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -133,4 +134,6 @@ def load():
 def check(status, what):
     if status != 0:
         msg = load().pvo_strerror(status).decode()
+        if status == 2:                                   # PVO_ELAUNCH: say which HIP error
+            msg += " - " + load().pvo_last_hip_error().decode()
         raise PvoHipError("%s failed: %s (status %d)" % (what, msg, status))

@@ -14,6 +14,12 @@ extern "C" const char* pvo_strerror(int code) {
 
 extern "C" int pvo_version(void) { return 100; }
 
+static thread_local int g_last_hip_error = 0;
+extern "C" void pvo_note_hip_error(int code) { g_last_hip_error = code; }
+extern "C" const char* pvo_last_hip_error(void) {
+  return g_last_hip_error ? hipGetErrorString(static_cast<hipError_t>(g_last_hip_error)) : "no HIP error recorded";
+}
+
 // One wave runs a dependent chain of `iters` x 64 v_fma_f32 and reports how many shader cycles (s_memtime) and how many
 // 10 ns ticks of the constant 100 MHz counter (s_memrealtime) it took: launched on a second stream beside a kernel, the
 // ratio is the clock the chip sustains under that kernel's load (MI355X lowers the clock to hold its power budget).

@@ -4,10 +4,12 @@
 #include <stdint.h>
 #include "../../include/pvo_hip.h"
 
+// the HIP error behind the most recent PVO_ELAUNCH (pvo_last_hip_error reports it)
+extern "C" void pvo_note_hip_error(int code);
 #define PVO_CHECK_LAUNCH()                                   \
   do {                                                       \
     hipError_t _e = hipGetLastError();                       \
-    if (_e != hipSuccess) return PVO_ELAUNCH;                \
+    if (_e != hipSuccess) { pvo_note_hip_error(static_cast<int>(_e)); return PVO_ELAUNCH; } \
   } while (0)
 
 static inline hipStream_t pvo_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
