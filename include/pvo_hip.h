@@ -16,6 +16,17 @@
  *     Launch failures are reported from hipGetLastError() after the enqueue.
  *   - no function allocates device memory; scratch comes from the caller
  *     (`workspace`, sized by the matching *_workspace_bytes function)
+ *   - one HIP runtime per process: a host that also loads PyTorch must load torch's
+ *     libamdhip64 before this library
+ *
+ * Limits (PVO_EUNSUPPORTED beyond them)
+ *   - edges / images per call: 65535 (they index a grid's y or z dimension)
+ *   - one image: H * W * channels < 2^31 elements
+ *   - bundle adjustment: at most 2048 free poses; the reduced pose system is factorised by ONE workgroup in envelope
+ *     form (dense in LDS up to 21 free poses, compact envelope blocks in LDS while they fit ~140 KB - 63 poses of a
+ *     radius-3 graph use 121 KB - and dense in global memory beyond that, which is slow: O(P band^2) dependent fp64 steps
+ *     through L2)
+ *   - panoptic segments per frame: `max_segments` of the caller (DepthVideo: 1024 dense labels)
  */
 #ifndef PVO_HIP_H
 #define PVO_HIP_H

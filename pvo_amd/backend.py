@@ -48,6 +48,12 @@ class DroidBackend:
             rank = torch.distributed.get_rank()
             graph.rm_factors([o != rank for o in owner])
             sharded, before = ShardedBA(), self.video.disps.clone()
+        if len(graph._ii_h) > 65535:
+            # include/pvo_hip.h "Limits": an edge index is a grid's y / z coordinate.  (The reference has no such bound;
+            # a 64-keyframe window with radius 3 has 372 edges, a 1000-keyframe sequence at ~50 edges per frame would need
+            # edge sharding - pvo_amd/parallel.py - or a tighter backend_thresh.)
+            raise RuntimeError("global bundle adjustment over %d edges: libpvo_hip handles at most 65535 per call "
+                               "(shard the edges over ranks or lower backend_thresh / backend_radius)" % len(graph._ii_h))
         if graph._ii_h:
             graph.update_lowmem(steps=steps, sharded=sharded)
         elif sharded is not None:
