@@ -17,9 +17,12 @@ so that K steps do identical work.
 N > 1: one process per GPU (torch.distributed, RCCL); every rank tracks its own window
 (independent sequences, no data-path collective), value = N*K / max-over-ranks time.
 
-Extra objects on the JSON line: "roofline_wide_conv" (matrix-core roofline of the wide 3x3 convolution, the kernel with
-the largest share of the step), "roofline" for the dominant hand-written HBM-bound kernel (the fused
-4-level lookup; HBM bound) and "cpu_baseline" (the CPU oracle timed on this host, rank 0, N=1).
+Extra objects on the JSON line: "roofline" for the dominant hand-written HBM-bound kernel (the fused 4-level lookup),
+"roofline_wide_conv" (matrix-core roofline of the wide 3x3 convolution, the kernel with the largest share of the step,
+with the shader clock the chip sustains under it and inside a step: pvo_clock_probe), "stage_us_in_step", "host",
+"workload_S_A" (the reference driver's 30x101 maps), "edge_sharded" (64-keyframe global update, edges sharded over the
+ranks, one integer all-reduce per Gauss-Newton step), "cpu_baseline" (the reference's CPU formulations timed on this host,
+rank 0, N=1) and "ate_rmse" (synthetic closed loop).  DESIGN.md section 5 describes each.
 """
 import argparse
 import json
