@@ -629,14 +629,16 @@ template <typename Index>      // int for the LDS copy (32-bit address arithmeti
 struct DenseMat {
   double* p; Index n;
   __device__ __forceinline__ MatRow row(int i) const { return MatRow{p + i * n, 0}; }
+  __device__ __forceinline__ Index rowstep() const { return n; }      // distance between the same column of rows i and i + 1
 };
 struct EnvMat {
-  double* blk; double* rhs; const int* first; const int* rowbase; int n;
+  double* blk; double* rhs; const int* rowoff; int n;      // rowoff[ib] = rowbase[ib] - 36 first[ib]: block (ib, cb) at rowoff[ib] + 36 cb
   __device__ __forceinline__ MatRow row(int i) const {
     if (i == n) return MatRow{rhs, 0};
-    const int ib = i / 6;                                  // block (ib, cb) at rowbase[ib] + (cb - first[ib]) * 36, 6 x 6 row-major
-    return MatRow{blk + rowbase[ib] - first[ib] * 36 + (i - 6 * ib) * 6, 30};
+    const int ib = i / 6;                                  // 6 x 6 blocks, row-major inside
+    return MatRow{blk + rowoff[ib] + (i - 6 * ib) * 6, 30};
   }
+  __device__ __forceinline__ int rowstep() const { return 6; }         // ... inside one block row
 };
 
 // Inclusive scan (sum or max) of v[0..P) in place by the whole workgroup, 256 entries at a time with a carry: the serial
@@ -699,9 +701,9 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
     double D[21], L[21], rd[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const MatRow R = A.row(j0 + r);
+      const double* rp = &A.row(j0 + r)(j0);               // (six entries of one block row are contiguous in either storage)
 #pragma unroll
-      for (int c = 0; c <= r; ++c) D[r * (r + 1) / 2 + c] = R(j0 + c);
+      for (int c = 0; c <= r; ++c) D[r * (r + 1) / 2 + c] = rp[c];
     }
     const bool ok = chol6(D, L, rd);
     if (!ok) { if (tid == 0) *fail_flag = 1; __syncthreads(); return; }      // uniform: every thread saw the same block
@@ -715,17 +717,17 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
     for (int ii = j0 + 6 + tid; ii <= iend + 1; ii += nt) {
       const int i = ii <= iend ? ii : n;
       if (i < n && first[i / 6] > kb) continue;
-      const MatRow R = A.row(i);
+      double* rp = &A.row(i)(j0);
       double x[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        double v = R(j0 + c);
+        double v = rp[c];
 #pragma unroll
         for (int k = 0; k < c; ++k) v -= x[k] * L[c * (c + 1) / 2 + k];
         x[c] = v * rd[c];
       }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) R(j0 + c) = x[c];
+      for (int c = 0; c < 6; ++c) rp[c] = x[c];
     }
     __syncthreads();
     // (c) trailing update, rows i in (j0+6 .. iend] and n, columns c in (j0+6 .. min(i, iend)]
@@ -734,16 +736,20 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
       if (i < n && first[i / 6] > kb) continue;
       const MatRow R = A.row(i);
       double li[6];
+      {
+        const double* rp = &R(j0);
 #pragma unroll
-      for (int t = 0; t < 6; ++t) li[t] = R(j0 + t);
+        for (int t = 0; t < 6; ++t) li[t] = rp[t];
+      }
       const int cmax = (i < n) ? i : iend;
       for (int c = j0 + 6 + tx; c <= cmax; c += 16) {
         if (first[c / 6] > kb) continue;
-        const MatRow C = A.row(c);
-        double acc = R(c);
+        const double* cp = &A.row(c)(j0);
+        double& dst = R(c);
+        double acc = dst;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) acc -= li[t] * C(j0 + t);
-        R(c) = acc;
+        for (int t = 0; t < 6; ++t) acc -= li[t] * cp[t];
+        dst = acc;
       }
     }
     __syncthreads();
@@ -768,10 +774,12 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
     }
     __syncthreads();                                         // everyone has read y[j0..j0+6) before it is overwritten
     if (tid < 6) Y(j0 + tid) = x[tid];
+    const MatRow R0 = A.row(j0);                             // rows j0 .. j0+5 of one block row: 6 entries apart
     for (int i = 6 * first[kb] + tid; i < j0; i += nt) {     // row block kb of L is zero left of its envelope
+      const double* lp = &R0(i);
       double v = Y(i);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v -= A.row(j0 + c)(i) * x[c];
+      for (int c = 0; c < 6; ++c) v -= lp[c * A.rowstep()] * x[c];
       Y(i) = v;
     }
     __syncthreads();
@@ -924,13 +932,13 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
 #pragma unroll
       for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
         const int b = q * 256 + threadIdx.x;
-        if (b < P) rowbase[b] = rb_keep[q];
+        if (b < P) rowbase[b] = rb_keep[q] - 36 * first[b];                        // (as EnvMat::rowoff)
       }
       for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
       __syncthreads();
       envelope_reach(first, reach, P);
       BA_PROBE(1);
-      chol_solve_blocked(EnvMat{blk, rhs, first, rowbase, n}, Ld, n, &fail, first, reach);
+      chol_solve_blocked(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach);
       xrow = rhs;
     } else {
       for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
