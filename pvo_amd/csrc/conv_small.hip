@@ -465,13 +465,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     }
   };
 
+  // accumulators start from the per-(edge, channel) gate context of the fused GRU epilogues (column li of a tile = one
+  // channel): one addition per value less in the epilogue, which is instruction-bound
+  float ginit[2] = {0.0f, 0.0f};
+  if (!HEADS && ep.mode != 0) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      ginit[nt] = ep.g[static_cast<size_t>(e) * 384 + (ep.mode == 1 ? cg * 128 : 256) + wn * 64 + nt * 32 + li];
+  }
   cs_v16f acc[4][2];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = ginit[nt];
 
   const int S = nC * 9;                                   // steps; S >= 9
   {
@@ -484,11 +492,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
       for (int f = 0; f < 4; ++f) r[f] = *reinterpret_cast<const cs_u32x4*>(p + f * 512);
     };
     select_a(0);
-    fetch_a(0);
-    fetch_bf(bset[0], 0); fetch_bf(bset[1], 1);
-    store_a(0, 0);
-    fetch_a(1);
-    store_a(0, 1);
+    {
+      // prologue: all six halo pieces of chunk 0 and the first two filter sets are requested together (the accumulators do
+      // not exist yet, so the registers are there): ONE exposed memory latency in front of the loop instead of two
+      cs_u32x4 r6[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        r6[k] = *reinterpret_cast<const cs_u32x4*>(a_src + static_cast<size_t>(max(apix[k], 0)) * a_stride + a_coff + (tid & 3) * 8);
+      fetch_bf(bset[0], 0); fetch_bf(bset[1], 1);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        cs_u32x4 v = r6[k];
+        if (apix[k] < 0) v = cs_u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<cs_u32x4*>(As + lpos[k]) = v;
+      }
+    }
     __syncthreads();
     CONV_PROBE(1);
     // this lane's A rows: M-tile mt of wave-row wm = tile rows 8 wm + (li >> 2), columns 4 mt + (li & 3)
@@ -561,12 +579,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     const int c = tid & 15, m0 = tid >> 4;
     const int pstride = ep.mode == 1 ? 256 : 128;
     const uint16_t* gate_p = ep.P + (ep.mode == 1 ? cg * 128 : 0) + c * 8;
-    float gg[8];
-    {
-      const float* gp = ep.g + static_cast<size_t>(e) * 384 + (ep.mode == 1 ? cg * 128 : 256) + c * 8;      // 32-byte aligned
-      const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
-      gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-    }
     uint16_t* const dst = (ep.mode == 1 && cg != 0) ? ep.y2 : y;
     const int ep_ = ep.p_slots ? ep.p_slots[e] : e;         // image of the static term (workgroup-uniform)
     cs_u32x4 pv[4], nv[4], zv[4];
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
           // sigmoid = 1 / (1 + 2^(-x log2 e)) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each; exp -> inf gives 0, exp -> 0 gives 1:
           // the library exp's denormal-range rescaling - two selects, an add and a multiply per value - buys nothing here)
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (a[q] + gg[q] + pp[q])));
+          for (int q = 0; q < 8; ++q) o[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (a[q] + pp[q])));
           if (cg != 0) {                                    // (workgroup-uniform: the r half of the gates leaves as r * net)
 #pragma unroll
             for (int q = 0; q < 8; ++q) o[q] *= nn[q];
@@ -609,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
           for (int q = 0; q < 8; ++q) {
             // tanh(x) = 1 - 2 / (1 + exp(2x)): exact limits at both ends (exp -> inf gives 1, exp -> 0 gives -1), ~1e-6
             // absolute error in between - the result is rounded to 16 bits
-            const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * (a[q] + gg[q] + pp[q])));
+            const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * (a[q] + pp[q])));
             o[q] = (1.0f - zz[q]) * nn[q] + zz[q] * th;
           }
         }
