@@ -111,13 +111,19 @@ def keyframe_update(video, graph, snap, clock_probe=None):
 
 
 def snap_edges_fix(graph, snap):
-    """re-added edges go to the end of the edge list; the restored per-edge state follows the same permutation"""
+    """re-added edges go to the end of the edge list; the restored per-edge state follows the same permutation.  The
+    state is copied INTO the graph's tensors (they stay the rows of the graph's own buffers, as in a real run)."""
+    names = (("net", "net"), ("target_cam", "target"), ("weight", "weight"), ("raw_mask", "raw_mask"), ("delta_dy", "delta_dy"))
     if not hasattr(snap, "perm"):
         old = snap.edge_list
         snap.perm = torch.tensor([old.index(e) for e in zip(graph._ii_h, graph._jj_h)], device=graph.device)
-    p = snap.perm
-    graph.net = snap.net[:, p]; graph.target_cam = snap.target[:, p]; graph.weight = snap.weight[:, p]
-    graph.raw_mask = snap.raw_mask[:, p]; graph.delta_dy = snap.delta_dy[:, p]
+        snap.permuted = {}
+        for gname, sname in names:
+            t = torch.empty_like(getattr(graph, gname))
+            t.copy_(getattr(snap, sname)[:, snap.perm])
+            snap.permuted[gname] = t
+    for gname, _ in names:
+        getattr(graph, gname).copy_(snap.permuted[gname])
 
 
 def _host_cpu():

@@ -346,6 +346,13 @@ typedef struct pvo_graph_update_args {
 } pvo_graph_update_args;
 
 size_t pvo_graph_update_workspace_bytes(int E, int K, int R, int H, int W, int max_segments);
+/* The library's second stream on the current device (created on first use, high priority): the one pvo_update_operator /
+ * pvo_graph_update run their side chains on.  A caller with work of its own that may run beside the launch stream and is
+ * only needed by the NEXT update (the volumes and static GRU terms of newly added edges, factor_graph.py:106-161) can
+ * queue it there instead of creating yet another stream: HIP multiplexes streams onto a handful of hardware queues, and
+ * an extra stream can end up sharing a queue with one of the two that must overlap.  Ordering against the launch
+ * stream is the caller's business (events).  Writes the hipStream_t to *stream_out. */
+int pvo_side_stream(void** stream_out);
 /* Measurement hook: HIP events recorded on the launch stream around one stage of the following pvo_graph_update /
  * pvo_update_operator calls (at most `capacity` occurrences), so a benchmark can read a kernel's duration inside its timed
  * steps.  pvo_probe_read waits for the recorded events, writes their elapsed times in milliseconds to HOST memory,

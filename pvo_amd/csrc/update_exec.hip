@@ -328,6 +328,14 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   return PVO_OK;
 }
 
+extern "C" int pvo_side_stream(void** stream_out) {
+  if (!stream_out) return PVO_EINVAL;
+  SideCtx* sc = side_ctx();
+  if (!sc) return PVO_ELAUNCH;
+  *stream_out = static_cast<void*>(sc->side);
+  return PVO_OK;
+}
+
 extern "C" int pvo_probe_arm(int stage, int capacity) {
   if (capacity < 0) return PVO_EINVAL;
   if (capacity > g_probe.cap) {

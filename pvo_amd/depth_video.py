@@ -30,8 +30,10 @@ class DepthVideo:
         self.disps_up = None
         self.intrinsics = torch.zeros(buffer, 4, dtype=torch.float, **kw)
         self.fmaps = torch.zeros(buffer, h8, w8, 128, dtype=torch.half, **kw)      # channels-last
-        self.nets = torch.zeros(buffer, 128, h8, w8, dtype=torch.half, **kw)
-        self.inps = torch.zeros(buffer, 128, h8, w8, dtype=torch.half, **kw)
+        # [buffer,128,h,w] as the reference has them, stored channels-last: an edge's rows are gathered straight into the
+        # layout the update operator reads (factor_graph.py add_factors)
+        self.nets = torch.zeros(buffer, h8, w8, 128, dtype=torch.half, **kw).permute(0, 3, 1, 2)
+        self.inps = torch.zeros(buffer, h8, w8, 128, dtype=torch.half, **kw).permute(0, 3, 1, 2)
         self.segms = torch.zeros(buffer, 1, h8, w8, dtype=torch.int, **kw)
         self.full_flow = torch.ones(buffer, h8, w8, 2, dtype=torch.float, **kw)
         self.segm_filter, self.thresh = segm_filter, thresh
@@ -159,7 +161,7 @@ class DepthVideo:
             ii, jj = both[:ii_h.numel()], both[ii_h.numel():]
         ii, jj = self.format_indicies(ii, jj, self.device)
         if bidirectional:
-            poses = self.poses[:self.counter].clone()
+            poses = self.poses[:self.counter]              # (the reference clones them, depth_video.py:183; the kernel only reads)
             d1 = db.frame_distance(poses, self.disps, self.intrinsics[0], ii, jj, beta)
             d2 = db.frame_distance(poses, self.disps, self.intrinsics[0], jj, ii, beta)
             d = 0.5 * (d1 + d2)

@@ -99,6 +99,29 @@ def to_device_async(values, dtype, device):
     return out
 
 
+def to_device_packed(parts, device):
+    """several host index lists -> device tensors in ONE staged upload: parts = [(values, dtype), ...]; returns one
+    tensor per part, each a 16-byte aligned view of a single device buffer.  An edge-set change needs about ten small
+    index tables (edge lists, slots, segment CSR, damping rows ...); as separate copies each is a ~4 us blit on the
+    stream, which at 200 keyframes/s is worth counting."""
+    device = torch.device(device)
+    ts = [(v.to(dt) if isinstance(v, torch.Tensor) else torch.tensor(v, dtype=dt)).reshape(-1) for v, dt in parts]
+    if device.type != "cuda":
+        return [t.to(device) for t in ts]
+    offs, total = [], 0
+    for t in ts:
+        offs.append(total)
+        total += (t.numel() * t.element_size() + 15) & ~15
+    if total == 0:
+        return [t.to(device) for t in ts]
+    host = torch.empty(total, dtype=torch.uint8)
+    for t, o in zip(ts, offs):
+        if t.numel():
+            host[o:o + t.numel() * t.element_size()].view(t.dtype).copy_(t)
+    dev = to_device_async(host, torch.uint8, device)
+    return [dev[o:o + t.numel() * t.element_size()].view(t.dtype) for t, o in zip(ts, offs)]
+
+
 def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -1085,6 +1108,23 @@ def se3_binary(op, a, rep_a, b, rep_b, out_batch):
 
 
 STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4}
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    """the library's own second stream on `device` (pvo_side_stream) as a torch stream: work that is only needed by the
+    next update can be queued beside the launch stream without creating another HIP stream"""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        out = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            check(_lib.load().pvo_side_stream(ctypes.byref(out)), "side_stream")
+        st = _side_streams[idx] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", idx))
+    return st
 
 
 def clock_probe(stream, iters=20000):

@@ -14,6 +14,8 @@ What is different, because it is what costs time once the kernels are fast:
     (edge, segment id)) instead of np.unique on the host;
   * reproject, the 4-level lookup and the whole BA are single calls into libpvo_hip.
 """
+import contextlib
+
 import torch
 
 from .modules.corr import CorrBlock, CorrVolumePool
@@ -25,7 +27,75 @@ def coords_grid(ht, wd, device):
     return torch.stack([x, y], dim=-1)
 
 
+class _EdgeRows:
+    """One per-edge state tensor (net, target_cam, weight, raw_mask, delta_dy, segm) as the first E rows of a
+    preallocated [capacity, ...] buffer.
+
+    The reference re-indexes every state tensor when edges are dropped and torch.cat's onto it when edges are added
+    (factor_graph.py:135-161,177-200): per keyframe that moved all of `net` (28 MB for 36 edges) three times.  Here
+      * appending writes the new rows behind the live ones (nothing old is touched);
+      * dropping a SUFFIX of the edges (the edges of the newest keyframe, the common case in the frontend) moves nothing;
+      * any other drop is one row gather into the second buffer of the pair, which then becomes the live one.
+    The graph's attributes stay plain tensors (views of the live buffer).  A caller may assign something else to them
+    (the PyTorch formulation of update() does): a tensor that is not the live view is simply copied in at the next
+    edge change."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.buf = [None, None]
+        self.cur = 0
+
+    def _fits(self, rows):
+        b = self.buf[self.cur]
+        return b is not None and b.dtype == rows.dtype and b.device == rows.device and tuple(b.shape[1:]) == tuple(rows.shape[1:])
+
+    def owns(self, rows):
+        b = self.buf[self.cur]
+        return self._fits(rows) and rows.data_ptr() == b.data_ptr() and rows.is_contiguous() and rows.shape[0] <= b.shape[0]
+
+    def _buffer(self, k, like, need):
+        b = self.buf[k]
+        if b is None or b.dtype != like.dtype or b.device != like.device or tuple(b.shape[1:]) != tuple(like.shape[1:]) \
+                or b.shape[0] < need:
+            self.capacity = max(self.capacity, need + 16 if need > self.capacity else need)
+            b = self.buf[k] = torch.empty((self.capacity,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+        return b
+
+    def keep(self, rows, keep_l, keep_t):
+        """rows[keep_l] (keep_l ascending, keep_t() its device tensor, built only when a gather is needed)"""
+        n = len(keep_l)
+        if self.owns(rows) and (n == 0 or keep_l[-1] == n - 1):
+            return self.buf[self.cur][:n]
+        other = self.cur ^ 1
+        b = self.buf[other]
+        if b is not None and rows.numel() and rows.untyped_storage().data_ptr() == b.untyped_storage().data_ptr():
+            rows = rows.clone()                                    # (a stale view of the spare buffer: do not gather onto itself)
+        dst = self._buffer(other, rows, max(n, self.capacity))
+        if n:
+            torch.index_select(rows, 0, keep_t(), out=dst[:n])
+        self.cur = other
+        return dst[:n]
+
+    def append(self, rows, n, fill):
+        """rows followed by n new rows; fill(dst) writes them (dst = the [n, ...] tail of the live buffer)"""
+        E = rows.shape[0]
+        if not self.owns(rows) or E + n > self.buf[self.cur].shape[0]:
+            other = self.cur ^ 1
+            b = self.buf[other]
+            if b is not None and rows.numel() and rows.untyped_storage().data_ptr() == b.untyped_storage().data_ptr():
+                rows = rows.clone()
+            dst = self._buffer(other, rows, max(E + n, self.capacity))
+            if E:
+                dst[:E].copy_(rows)
+            self.cur = other
+        b = self.buf[self.cur]
+        fill(b[E:E + n])
+        return b[:E + n]
+
+
 class FactorGraph:
+    _index_dirty = False             # host edge lists changed since (ii, jj, age) were last uploaded
+
     def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1):
         self.video, self.update_op = video, update_op
         self.device = torch.device(device)
@@ -38,6 +108,9 @@ class FactorGraph:
         self.ii, self.jj, self.age = (torch.zeros(0, **lng) for _ in range(3))
         self._ii_h, self._jj_h, self._age_h = [], [], []
         self._inp = None
+        self._corr_ready = None     # event: the side-stream build of the most recently added edges (see add_factors)
+        self.build_on_side_stream = True
+        self._rows = {}             # per-edge state tensors as rows of fixed-capacity buffers (_EdgeRows)
         self.corr = self.net = self.inp = self.segm = None
         self.damping = 1e-6 * torch.ones_like(video.disps)
         z = lambda c: torch.zeros(1, 0, ht, wd, c, device=self.device, dtype=torch.float)
@@ -120,53 +193,159 @@ class FactorGraph:
             mask_l = [ix[p] >= self.max_factors - len(ii_l) for p in range(len(order))]
             self.rm_factors(mask_l, store=True)
         self._cache.clear(); self._version += 1
-        both = self._idx(ii_l + jj_l)
-        ii, jj = both[:len(ii_l)], both[len(ii_l):]
-        net = self.video.nets[ii][None]
-        if self.corr_impl == "volume":
-            if self.device.type == "cuda" and self.video.fmaps.dtype in (torch.float16, torch.bfloat16):
-                if self.corr is None:          # resident slot pool: edge changes never move a volume
-                    base = self.max_factors if 0 < self.max_factors <= 4096 else 96      # (the backend's budget is 'unlimited')
-                    cap = max(base + 32, len(ii_l) + 32)
-                    self.corr = CorrVolumePool(cap, self.ht, self.wd, self.device, self.video.fmaps.dtype)
-                self.corr.add(self.video.fmaps[ii], self.video.fmaps[jj])
-            else:
-                corr = CorrBlock(self.video.fmaps[ii][None], self.video.fmaps[jj][None], channels_last=True)
-                self.corr = corr if self.corr is None else self.corr.cat(corr)
-            inp = self.video.inps[ii][None]
-            by_slot = isinstance(self.corr, CorrVolumePool) and self._static_ok()
-            if not by_slot:
-                self.inp = self._cat_cl(self.inp, inp)   # stored channels-last once, so no update re-lays it out
-            if self._static_ok():
-                # conv(W[:, inp], inp) of the ConvGRU's gate / candidate convolutions, once per edge (inp never changes)
-                pz, pq = self.update_op.static_terms(self._cl5(inp)[0], self._op_dtype())
-                if by_slot:
-                    # ... kept in the slot the edge's volume owns: like the volume, never moved when edges come and go
-                    # (as [E, ...] tensors they were 85 of the 141 MB gathered and concatenated per keyframe; `inp`
-                    # itself is video.inps[ii], materialised only if the PyTorch formulation of the operator asks)
-                    self.P_zr, self.P_q = self.corr.put("P_zr", pz), self.corr.put("P_q", pq)
-                    self._static_by_slot = True
+        n, E0 = len(ii_l), len(self._ii_h)
+        pool_path = self.corr_impl == "volume" and self.device.type == "cuda" and \
+            self.video.fmaps.dtype in (torch.float16, torch.bfloat16)
+        if pool_path and self.corr is None:        # resident slot pool: edge changes never move a volume
+            base = self.max_factors if 0 < self.max_factors <= 4096 else 96          # (the backend's budget is 'unlimited')
+            self.corr = CorrVolumePool(max(base + 32, n + 32), self.ht, self.wd, self.device, self.video.fmaps.dtype)
+        if pool_path and isinstance(self.corr, CorrVolumePool):
+            # the new edges' endpoints and the slots their volumes will own: one staged upload
+            from .droid_backends import to_device_packed
+            ii, jj, new_slots = to_device_packed([(ii_l, torch.long), (jj_l, torch.long), (self.corr.reserve(n), torch.int32)],
+                                                 self.device)
+        else:
+            both = self._idx(ii_l + jj_l)
+            ii, jj, new_slots = both[:n], both[n:], None
+        by_slot = isinstance(self.corr, CorrVolumePool) and self._static_ok()
+        # The new edges' volumes and static GRU terms are first read by the next update's lookup / gates: with everything
+        # by slot (nothing of them is concatenated onto the live state) they are built on a second stream, beside the row
+        # appends, the frame distances and the index uploads of this keyframe; update() waits for them (_corr_sync).
+        side = self._build_stream() if by_slot and self.build_on_side_stream else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.device))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if self.corr_impl == "volume":
+                if pool_path:
+                    self.corr.add(self.video.fmaps[ii], self.video.fmaps[jj], new_slots)
                 else:
-                    self.P_zr = self._cat_cl(self.P_zr, pz[None])
-                    self.P_q = self._cat_cl(self.P_q, pq[None])
-        target, _ = self.video.reproject(ii, jj)
-        zeros2 = torch.zeros_like(target)
-        self._ii_h += ii_l; self._jj_h += jj_l; self._age_h += [0] * len(ii_l)
-        self._sync_edge_index()
-        self.net = self._cat_cl(self.net, net)
-        self.target_cam = torch.cat([self.target_cam, target], 1)
-        self.weight = torch.cat([self.weight, zeros2], 1)
-        self.raw_mask = torch.cat([self.raw_mask, zeros2[..., :self.mask_num]], 1)
-        self.delta_dy = torch.cat([self.delta_dy, zeros2], 1)
-        segm = self.video.segms[ii][None]
-        self.segm = segm if self.segm is None else torch.cat([self.segm, segm], 1)
+                    corr = CorrBlock(self.video.fmaps[ii][None], self.video.fmaps[jj][None], channels_last=True)
+                    self.corr = corr if self.corr is None else self.corr.cat(corr)
+                inp = self._frame_rows(self.video.inps, ii)[None]
+                if not by_slot:
+                    self.inp = self._cat_cl(self.inp, inp)   # stored channels-last once, so no update re-lays it out
+                if self._static_ok():
+                    # conv(W[:, inp], inp) of the ConvGRU's gate / candidate convolutions, once per edge (inp never changes)
+                    pz, pq = self.update_op.static_terms(self._cl5(inp)[0], self._op_dtype())
+                    if by_slot:
+                        # ... kept in the slot the edge's volume owns: like the volume, never moved when edges come and go
+                        # (as [E, ...] tensors they were 85 of the 141 MB gathered and concatenated per keyframe; `inp`
+                        # itself is video.inps[ii], materialised only if the PyTorch formulation of the operator asks)
+                        self.P_zr, self.P_q = self.corr.put("P_zr", pz), self.corr.put("P_q", pq)
+                        self._static_by_slot = True
+                    else:
+                        self.P_zr = self._cat_cl(self.P_zr, pz[None])
+                        self.P_q = self._cat_cl(self.P_q, pq[None])
+        if side is not None:
+            for t in (ii, jj, new_slots):
+                t.record_stream(side)
+            self._corr_ready = torch.cuda.Event()
+            self._corr_ready.record(side)
+        self._ii_h += ii_l; self._jj_h += jj_l; self._age_h += [0] * n
+        self._index_dirty = True
+        # per-edge state: the new rows are written behind the live ones (see _EdgeRows)
+        nets = self.video.nets
+        cl = self._net_cl()
+        if self.net is None:
+            self.net = self._net_view(torch.empty((0,) + ((self.ht, self.wd, 128) if cl else (128, self.ht, self.wd)),
+                                                  dtype=nets.dtype, device=self.device))
+        if cl and nets.permute(0, 2, 3, 1).is_contiguous():
+            fill_net = lambda dst: torch.index_select(nets.permute(0, 2, 3, 1), 0, ii, out=dst)      # no temporary
+        elif cl:
+            fill_net = lambda dst: dst.copy_(nets[ii].permute(0, 2, 3, 1))
+        else:
+            fill_net = lambda dst: dst.copy_(nets[ii])
+        self.net = self._net_view(self._edge_rows("net").append(self._net_rows(), n, fill_net))
+
+        def fill_target(dst):
+            target, _ = self.video.reproject(ii, jj)
+            dst.copy_(target[0])
+        zero = lambda dst: dst.zero_()
+        self.target_cam = self._edge_rows("target_cam").append(self.target_cam[0], n, fill_target)[None]
+        self.weight = self._edge_rows("weight").append(self.weight[0], n, zero)[None]
+        self.raw_mask = self._edge_rows("raw_mask").append(self.raw_mask[0], n, zero)[None]
+        self.delta_dy = self._edge_rows("delta_dy").append(self.delta_dy[0], n, zero)[None]
+        segms = self.video.segms
+        if self.segm is None:
+            self.segm = torch.empty((1, 0) + tuple(segms.shape[1:]), dtype=segms.dtype, device=self.device)
+        self.segm = self._edge_rows("segm").append(self.segm[0], n, lambda dst: torch.index_select(segms, 0, ii, out=dst))[None]
+
+    def _build_stream(self):
+        """the library's own second stream (one per device, the one the update's side chains use): a stream of our own
+        per graph changed which hardware queue the later streams of the process landed on - S-A in bench.py then ran
+        with its two update streams serialised (lookup 66 -> 139 us)"""
+        from .droid_backends import side_stream
+        return side_stream(self.device)
+
+    def _corr_sync(self):
+        """order the current stream behind the side-stream build of the newest edges (no host wait)"""
+        if self._corr_ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._corr_ready)
+            self._corr_ready = None
+
+    # -- per-edge state rows (see _EdgeRows)
+    def _edge_rows(self, name):
+        r = self._rows.get(name)
+        if r is None:
+            base = self.max_factors if 0 < self.max_factors <= 4096 else 96
+            r = self._rows[name] = _EdgeRows(base + 32)
+        return r
+
+    def _net_cl(self):
+        """`net` is kept channels-last ([E,H,W,128] rows) on the device, as the NHWC kernels read it"""
+        return self.device.type == "cuda"
+
+    def _net_rows(self):
+        """the physical rows of `net` in the layout its _EdgeRows buffer has (a copy only if a caller assigned another layout)"""
+        t = self.net[0]
+        if self._net_cl():
+            t = t.permute(0, 2, 3, 1)
+        return t if t.is_contiguous() or t.shape[0] == 0 else t.contiguous()
+
+    def _net_view(self, rows):
+        return (rows.permute(0, 3, 1, 2) if self._net_cl() else rows)[None]
+
+    def _frame_rows(self, frames, idx):
+        """frames[idx] for a per-frame [N,C,H,W] buffer; a buffer stored channels-last (DepthVideo's nets / inps) comes
+        back channels-last without a layout pass"""
+        phys = frames.permute(0, 2, 3, 1)
+        if self.device.type == "cuda" and phys.is_contiguous():
+            return phys.index_select(0, idx).permute(0, 3, 1, 2)
+        return frames[idx]
 
     def _sync_edge_index(self):
         """device copies of (ii, jj, age) from the host mirrors: ONE staged upload instead of three gathers or three
-        concatenations per edge-set change (the lists are the source of truth for every decision anyway)"""
+        concatenations per edge-set change (the lists are the source of truth for every decision anyway).  Deferred
+        until something reads them: a drop followed by an add uploads once."""
         E = len(self._ii_h)
         packed = self._idx(self._ii_h + self._jj_h + self._age_h) if E else torch.zeros(0, dtype=torch.long, device=self.device)
-        self.ii, self.jj, self.age = packed[:E], packed[E:2 * E], packed[2 * E:3 * E]
+        self._ii_dev, self._jj_dev, self._age_dev = packed[:E], packed[E:2 * E], packed[2 * E:3 * E]
+        self._age_lag = 0
+        self._index_dirty = False
+
+    @property
+    def ii(self):
+        if self._index_dirty:
+            self._sync_edge_index()
+        return self._ii_dev
+
+    @ii.setter
+    def ii(self, t):
+        if self._index_dirty:
+            self._sync_edge_index()
+        self._ii_dev = t
+
+    @property
+    def jj(self):
+        if self._index_dirty:
+            self._sync_edge_index()
+        return self._jj_dev
+
+    @jj.setter
+    def jj(self, t):
+        if self._index_dirty:
+            self._sync_edge_index()
+        self._jj_dev = t
 
     def _idx(self, values):
         """host list -> device int64 tensor without draining the stream (persistent pinned staging ring, asynchronous
@@ -180,7 +359,12 @@ class FactorGraph:
         mask_l = [bool(v) for v in (mask.tolist() if isinstance(mask, torch.Tensor) else mask)]
         self._cache.clear(); self._version += 1
         keep_l = [k for k, m in enumerate(mask_l) if not m]
-        keep = self._idx(keep_l)
+        made = []
+
+        def keep_t():                                # the device copy of keep_l, uploaded only if some tensor has to be gathered
+            if not made:
+                made.append(self._idx(keep_l))
+            return made[0]
         if store:
             rm = self._idx([k for k, m in enumerate(mask_l) if m])
             self.ii_inac = torch.cat([self.ii_inac, self.ii[rm]])
@@ -194,22 +378,27 @@ class FactorGraph:
         self._ii_h = [self._ii_h[k] for k in keep_l]
         self._jj_h = [self._jj_h[k] for k in keep_l]
         self._age_h = [self._age_h[k] for k in keep_l]
-        self._sync_edge_index()
+        self._index_dirty = True
         if self.corr_impl == "volume" and self.corr is not None:
             if isinstance(self.corr, CorrVolumePool):
                 self.corr.keep([not m for m in mask_l])
             else:
-                self.corr = self.corr[keep]
+                self.corr = self.corr[keep_t()]
         if self.net is not None:
-            self.net = self._take_cl(self.net, keep)
+            self.net = self._net_view(self._edge_rows("net").keep(self._net_rows(), keep_l, keep_t))
         if self._inp is not None:
-            self._inp = self._take_cl(self._inp, keep)
+            self._inp = self._take_cl(self._inp, keep_t())
         if self.P_zr is not None and not self._static_by_slot:
-            self.P_zr, self.P_q = self._take_cl(self.P_zr, keep), self._take_cl(self.P_q, keep)
+            self.P_zr, self.P_q = self._take_cl(self.P_zr, keep_t()), self._take_cl(self.P_q, keep_t())
         if self.segm is not None:
-            self.segm = self.segm[:, keep]
-        self.target_cam, self.weight = self.target_cam[:, keep], self.weight[:, keep]
-        self.raw_mask, self.delta_dy = self.raw_mask[:, keep], self.delta_dy[:, keep]
+            self.segm = self._edge_rows("segm").keep(self.segm[0], keep_l, keep_t)[None]
+        for name in ("target_cam", "weight", "raw_mask", "delta_dy"):
+            t = getattr(self, name)
+            rows = t[0] if t.shape[0] == 1 else None
+            if rows is None or (rows.shape[0] and not rows.is_contiguous()):
+                setattr(self, name, t[:, keep_t()])            # (not the layout this class keeps: plain indexing)
+            else:
+                setattr(self, name, self._edge_rows(name).keep(rows, keep_l, keep_t)[None])
 
     def clear_edges(self):
         self.rm_factors([True] * len(self._ii_h))
@@ -218,12 +407,14 @@ class FactorGraph:
 
     def rm_keyframe(self, ix):
         """drop keyframe ix and every edge touching it (factor_graph.py:202-225)"""
+        self._corr_sync()                  # (the per-frame buffers below are read by a pending side-stream build)
         v = self.video
         for buf in (v.poses, v.disps, v.intrinsics, v.nets, v.inps, v.fmaps) + ((v.segms,) if v.segm_filter else ()):
             buf[ix] = buf[ix + 1].clone()
         m = [(i == ix) or (j == ix) for i, j in zip(self._ii_h, self._jj_h)]
-        for t in (self.ii, self.jj, self.ii_inac, self.jj_inac):     # (masked in-place updates would synchronise)
+        for t in (self.ii_inac, self.jj_inac):                       # (masked in-place updates would synchronise)
             t -= (t >= ix).long()
+        self._index_dirty = True                                      # ii / jj follow the host lists below
         self._cache.clear(); self._version += 1
         dec = lambda l: [a - 1 if a >= ix else a for a in l]
         self._ii_h, self._jj_h = dec(self._ii_h), dec(self._jj_h)
@@ -242,6 +433,7 @@ class FactorGraph:
         then rank-local; the BA's reduced pose system is all-reduced once per Gauss-Newton step, every rank takes the
         identical pose step, and depth maps of frames a rank does not own stay untouched on that rank
         (`ShardedBA.sync_disps` merges them when something needs all of them)."""
+        self._corr_sync()
         from .modules.corr import AltCorrBlock
         t = self.video.counter
         ht, wd = self.ht, self.wd
@@ -311,7 +503,7 @@ class FactorGraph:
                     ii.append(i); jj.append(j)
         self.add_factors(ii, jj)
 
-    def _agg_segments(self):
+    def _agg_segments_host(self):
         """CSR of the active edges grouped by source frame, groups in sorted(unique(ii)) order (what
         torch.unique(ii, return_inverse=True) yields on the device, droid_net.py:83) — built from the host mirror"""
         frames = sorted(set(self._ii_h))
@@ -323,9 +515,13 @@ class FactorGraph:
         for b in buckets:
             idx += b
             ptr.append(len(idx))
+        return ptr, idx, len(frames)
+
+    def _agg_segments(self):
         from .droid_backends import to_device_async
+        ptr, idx, n = self._agg_segments_host()
         both = to_device_async(ptr + idx, torch.int32, self.device)
-        return both[:len(ptr)], both[len(ptr):], len(frames)
+        return both[:len(ptr)], both[len(ptr):], n
 
     def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
         """add edges chosen by frame distance with non-maximum suppression (factor_graph.py:372-429).
@@ -439,7 +635,7 @@ class FactorGraph:
         full_flow) are updated IN PLACE."""
         from . import droid_backends as db
         from ._lib import GraphUpdateArgs
-        from .droid_backends import to_device_async
+        from .droid_backends import to_device_packed
         v = self.video
         ht, wd = self.ht, self.wd
         E = len(self._ii_h)
@@ -454,25 +650,32 @@ class FactorGraph:
             src = sorted(set(self._ii_h))
             m_l = [(i >= t0 - 3) and (j >= t0 - 3) for i, j in zip(self._ii_inac_h, self._jj_inac_h)] if use_inactive else []
             n_in = sum(m_l)
-            rows = src
+            # one eta row per depth map the BA optimises, in the order of unique([t0, t1) U ii) (droid_kernels.cu:1314-1322);
+            # frames without an active local edge keep their stored damping (pos = -1)
+            rows = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k} | set(range(t0, t1)))
+            where = {f: k for k, f in enumerate(src)}
+            seg_ptr, seg_idx, nseg = self._agg_segments_host()
+            # every index table of this edge set in ONE staged upload (they were eight separate ~4 us copies)
+            parts = [(rows, torch.long), ([where.get(f, -1) for f in rows], torch.int32), (seg_ptr, torch.int32),
+                     (seg_idx, torch.int32), (self.corr.slots, torch.int32), ([k for k, f in enumerate(m_l) if f], torch.long)]
+            if self._index_dirty:
+                parts += [(self._ii_h, torch.long), (self._jj_h, torch.long), (self._age_h, torch.long)]
+            up = to_device_packed(parts, self.device)
+            frames_t, pos_t, seg, slots_t, m = up[0], up[1], (up[2], up[3], nseg), up[4], up[5]
+            if self._index_dirty:
+                self._ii_dev, self._jj_dev, self._age_dev = up[6], up[7], up[8]
+                self._age_lag, self._index_dirty = 0, False
+            self._cache["agg"] = seg
+            self.corr._slots_t = slots_t
             target_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
             weight_ba = torch.empty(n_in + E, 2, ht, wd, device=self.device)
             if n_in:
-                # integer indices from the host mirror: a boolean mask would synchronise to size its result
-                m = self._idx([k for k, f in enumerate(m_l) if f])
+                # (integer indices from the host mirror: a boolean mask would synchronise to size its result)
                 ii_ba, jj_ba = torch.cat([self.ii_inac[m], self.ii]), torch.cat([self.jj_inac[m], self.jj])
                 target_ba[:n_in] = self.target_cam_inac[0, m].permute(0, 3, 1, 2)      # inactive edges do not change
                 weight_ba[:n_in] = self.weight_inac[0, m].permute(0, 3, 1, 2)
-                rows = sorted(set(src) | {i for i, k in zip(self._ii_inac_h, m_l) if k})
             else:
                 ii_ba, jj_ba = self.ii.contiguous(), self.jj.contiguous()
-            # one eta row per depth map the BA optimises, in the order of unique([t0, t1) U ii) (droid_kernels.cu:1314-1322);
-            # frames without an active local edge keep their stored damping (pos = -1)
-            rows = sorted(set(rows) | set(range(t0, t1)))
-            where = {f: k for k, f in enumerate(src)}
-            frames_t = self._idx(rows)
-            pos_t = to_device_async([where.get(f, -1) for f in rows], torch.int32, self.device)
-            seg = self._cached("agg", self._agg_segments)
             if sharded is None:
                 ba = self._ba_plan(ii_ba, jj_ba, t0, t1, motion_only, n_in, len(rows))
             else:                                                  # the sharded BA plans for itself (pvo_amd/parallel.py)
@@ -483,7 +686,7 @@ class FactorGraph:
                 pos=pos_t, seg=seg, ba=ba, R=len(rows), S=S, ii=self.ii.contiguous(), jj=self.jj.contiguous(),
                 slots=self.corr.slots_tensor(),
                 segm=self.segm[0, :, 0].contiguous() if v.segm_filter else None,
-                weight=torch.empty(1, E, ht, wd, 2, device=self.device), full_flow=torch.empty(1, E, ht, wd, 2, device=self.device),
+                full_flow=torch.empty(1, E, ht, wd, 2, device=self.device),
                 eta=torch.empty(len(rows), ht, wd, device=self.device) if sharded is not None else None,
                 ws=db.graph_update_workspace(E, seg[2], len(rows), ht, wd, S, self.device), args=GraphUpdateArgs())
             a = st["args"]
@@ -506,10 +709,10 @@ class FactorGraph:
             a.want_upmask = 1 if self.want_upmask else 0
         a = st["args"]
         # per update: the state tensors (a caller may have re-assigned them) and the scalar arguments
-        for n in ("target_cam", "delta_dy", "raw_mask"):
+        for n in ("target_cam", "delta_dy", "raw_mask", "weight"):
             t = getattr(self, n)
-            if not t.is_contiguous():
-                setattr(self, n, t.contiguous())
+            if not t.is_contiguous() or t.dtype != torch.float32:
+                setattr(self, n, t.float().contiguous())
         net = self.net[0]
         if net.dtype != dt or not net.is_contiguous(memory_format=torch.channels_last):
             net = net.to(dt).contiguous(memory_format=torch.channels_last)
@@ -519,7 +722,9 @@ class FactorGraph:
         a.op.static_by_slot = 1 if self._static_by_slot else 0
         a.op.EP = float(EP)
         a.target, a.delta_dy, a.raw_mask = self.target_cam.data_ptr(), self.delta_dy.data_ptr(), self.raw_mask.data_ptr()
-        self.weight, self.full_flow = st["weight"], st["full_flow"]
+        if tuple(self.weight.shape) != (1, E, ht, wd, 2):           # (a caller's own weights of another shape are only an input)
+            self.weight = torch.empty(1, E, ht, wd, 2, device=self.device)
+        self.full_flow = st["full_flow"]
         a.weight, a.full_flow = self.weight.data_ptr(), self.full_flow.data_ptr()
         a.itrs = int(itrs) if sharded is None else 0
         a.clamp_frames = v.disps.shape[0] if sharded is None else 0
@@ -549,6 +754,8 @@ class FactorGraph:
     def age(self):
         """per-edge update count (factor_graph.py:35); decisions use the host mirror `_age_h`, so the native update
         path only counts and the device tensor catches up here, on access"""
+        if self._index_dirty:
+            self._sync_edge_index()
         if self._age_lag:
             self._age_dev += self._age_lag
             self._age_lag = 0
@@ -556,11 +763,14 @@ class FactorGraph:
 
     @age.setter
     def age(self, t):
+        if self._index_dirty:
+            self._sync_edge_index()
         self._age_dev, self._age_lag = t, 0
 
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False):
         """one update of the factor graph (factor_graph.py:227-307)"""
+        self._corr_sync()
         if self._fused_ok() and self.P_zr is not None:
             return self._update_fused(t0, t1, itrs, use_inactive, EP, motion_only)
         ht, wd = self.ht, self.wd

@@ -173,17 +173,30 @@ class CorrVolumePool:
         self.device = device
         self.extra = {}                       # other per-edge data that never changes over an edge's life, by slot (`put`)
         self._last = None                     # slots handed out by the most recent add(), as a device tensor
+        self._reserved = None
 
     def __len__(self):
         return len(self.slots)
 
-    def add(self, fmap1, fmap2):
-        """fmap1, fmap2: [n,H,W,C] channels-last features of the new edges (appended in order)"""
-        n = fmap1.shape[0]
+    def reserve(self, n):
+        """take n free slots for edges about to be added (host list); pass their device copy to add()"""
         if n > len(self.free):
             self._grow(len(self.slots) + n)
-        new = [self.free.pop() for _ in range(n)]
-        st = db.to_device_async(new, torch.int32, self.device)
+        self._reserved = [self.free.pop() for _ in range(n)]
+        return self._reserved
+
+    def add(self, fmap1, fmap2, slots_t=None):
+        """fmap1, fmap2: [n,H,W,C] channels-last features of the new edges (appended in order).  slots_t: device copy of
+        the slots reserve(n) returned (a caller that uploads other index tables anyway packs them into the same copy)"""
+        n = fmap1.shape[0]
+        if slots_t is None:
+            new = self.reserve(n)
+            st = db.to_device_async(new, torch.int32, self.device)
+        else:
+            new, st = self._reserved, slots_t
+            if len(new) != n or st.numel() != n or st.dtype != torch.int32:
+                raise ValueError("CorrVolumePool.add: slots_t does not match the slots of the last reserve()")
+        self._reserved = None
         if self.tiled:
             db.corr_build_tiled(fmap1.contiguous(), fmap2.contiguous(), self.levels, st)
         else:

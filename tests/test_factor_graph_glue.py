@@ -317,3 +317,49 @@ def test_edge_bookkeeping_matches_reference():
     assert np.array_equal(v.poses.numpy(), z["poses"]) and np.array_equal(v.disps.numpy(), z["disps"])
     assert np.array_equal(v.nets[:, 0, 0, 0].numpy(), z["nets"]) and np.array_equal(v.fmaps[:, 0, 0, 0].numpy(), z["fmaps"])
     assert np.array_equal(v.segms[:, 0, 0, 0].numpy(), z["segms"])
+
+
+def test_edge_rows_follow_plain_indexing_and_concatenation():
+    """_EdgeRows (the fixed-capacity row buffers behind net / target_cam / weight / raw_mask / delta_dy / segm) against the
+    reference's formulation of the same bookkeeping - t[:, keep] on a drop, torch.cat on an add - over a random sequence
+    of drops (suffix, prefix, scattered, everything), adds (within and beyond the capacity) and foreign assignments."""
+    import random
+    from pvo_amd.factor_graph import _EdgeRows
+    rng = random.Random(3)
+    g = torch.Generator().manual_seed(5)
+    rows = _EdgeRows(8)
+    model = torch.zeros(0, 3, 2)
+    live = model.clone()
+    moved = 0
+    for step in range(200):
+        op = rng.choice(["suffix", "prefix", "scatter", "all", "add", "add", "add_big", "foreign", "stale"])
+        E = model.shape[0]
+        if op in ("suffix", "prefix", "scatter", "all") and E:
+            k = rng.randint(1, E)
+            if op == "suffix":
+                keep_l = list(range(E - k))
+            elif op == "prefix":
+                keep_l = list(range(k, E))
+            elif op == "scatter":
+                keep_l = sorted(rng.sample(range(E), E - k))
+            else:
+                keep_l = []
+            before = live.data_ptr()
+            live = rows.keep(live, keep_l, lambda: torch.tensor(keep_l, dtype=torch.long))
+            model = model[keep_l] if keep_l else model[:0]
+            if op == "suffix" and rows.owns(live) and live.data_ptr() == before:
+                moved += 1                                            # a dropped suffix moves nothing
+        elif op in ("add", "add_big"):
+            n = rng.randint(1, 4) if op == "add" else rng.randint(10, 30)
+            new = torch.randn(n, 3, 2, generator=g)
+            live = rows.append(live, n, lambda dst: dst.copy_(new))
+            model = torch.cat([model, new])
+        elif op == "foreign" and E:                                   # a caller assigns its own tensor (the PyTorch update path)
+            model = torch.randn(E, 3, 2, generator=g)
+            live = model.clone()
+        elif op == "stale" and E and rows.buf[rows.cur ^ 1] is not None and rows.buf[rows.cur ^ 1].shape[0] >= E:
+            spare = rows.buf[rows.cur ^ 1]                            # ... or a view of the spare buffer
+            spare[:E] = model
+            live = spare[:E]
+        assert live.shape == model.shape and torch.equal(live, model), (step, op)
+    assert moved > 3
