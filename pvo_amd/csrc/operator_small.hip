@@ -97,13 +97,24 @@ __global__ __launch_bounds__(256) void eta_head_kernel(const uint16_t* __restric
     const int py = pix / W, px = pix - py * W;
     const uint16_t* xe = x + static_cast<size_t>(k) * HW * 128 + l * 8;
     float acc = 0.0f;
+    // the nine taps' activations and weights are requested before the first product (an out-of-image tap reads the centre
+    // pixel and is skipped): the tensor is L2 resident, so the kernel's time was nine dependent round trips
+    os_u32x4 av[9], wv[9];
+    bool ok[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      ok[t] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int q = ok[t] ? yy * W + xx : pix;
+      av[t] = *reinterpret_cast<const os_u32x4*>(xe + static_cast<size_t>(q) * 128);
+      wv[t] = *reinterpret_cast<const os_u32x4*>(wt + t * 128 + l * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (ok[t]) {
         float a[8], w[8];
-        os_unpack8<T>(*reinterpret_cast<const os_u32x4*>(xe + (static_cast<size_t>(yy) * W + xx) * 128), a);
-        os_unpack8<T>(*reinterpret_cast<const os_u32x4*>(wt + t * 128 + l * 8), w);
+        os_unpack8<T>(av[t], a);
+        os_unpack8<T>(wv[t], w);
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc = fmaf(a[q], w[q], acc);
       }

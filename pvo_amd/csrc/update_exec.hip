@@ -16,7 +16,7 @@
 
 namespace {
 
-struct SideCtx { hipStream_t side; hipEvent_t fork, join; bool ok; };
+struct SideCtx { hipStream_t side; hipEvent_t fork, join, mid; bool ok; };
 
 // one side stream + two events per device, created on first use (streams and events are host objects: the library
 // still allocates no device memory)
@@ -33,6 +33,7 @@ SideCtx* side_ctx() {
     if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.mid, hipEventDisableTiming) != hipSuccess) return nullptr;
     c.ok = true;
   }
   return &c;
@@ -179,7 +180,7 @@ int run_heads(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   return PVO_OK;
 }
 
-int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream) {
+int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx* mark = nullptr) {
   const int E = a->E, H = a->H, W = a->W, K = a->K, dt = w->dtype;
   if (K <= 0) return PVO_OK;
   if (w->flags & PVO_OP_CONV128_WIDE)
@@ -191,6 +192,7 @@ int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, vo
   RUN(pvo_conv3x3_c128(b.am, w->agg2_w, w->agg2_b, b.a2, K, H, W, 128, 1, 0, 0, dt, stream));
   if (a->eta)
     RUN(pvo_eta_head(b.a2, w->eta_w, w->eta_b, a->eta_frame, a->eta_pos, a->damping, a->eta, a->eta_frame ? a->R : K, H, W, a->EP, a->eta_scale, dt, stream));
+  if (mark && hipEventRecord(mark->mid, pvo_stream(stream)) != hipSuccess) return PVO_ELAUNCH;
   if (a->upmask)
     RUN(pvo_conv1x1_c128(b.a2, w->up_w, w->up_b, a->upmask, static_cast<long long>(K) * H * W, 576, 0, dt, stream));
   return PVO_OK;
@@ -217,7 +219,7 @@ int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& 
   if (sc) {
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
-    RUN(run_agg(w, a, b, sc->side));
+    RUN(run_agg(w, a, b, sc->side, sc));
     if (hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
     RUN(run_heads(w, a, b, stream));
     *pending = sc;
@@ -301,10 +303,12 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
                      u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW, u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW,
                      u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
                      S, u->vote_thresh, dt, stream));
-  // (the whole aggregation branch, including the upsampling mask the BA does not need: letting the BA start as soon as
-  // the damping existed, beside the mask convolution, saved ~20 us per update and cost the bitwise run-to-run
-  // reproducibility of the poses - 3 to 9 of 12 repeated global updates differed in the last bits, none with the full join)
-  RUN(join(pending, stream));
+  // The BA needs the damping, not the upsampling mask: it waits for the aggregation branch up to the eta head (`mid`) and
+  // runs beside the mask convolution; the branch is joined at the end of the update, so nothing of the next call (nor the
+  // caller) meets a side stream still at work.  (~20 us per update.  A first attempt at this waited on a re-recorded
+  // `join` event instead of an event of its own and lost the run-to-run reproducibility of the poses; with `mid` repeated
+  // keyframe and global updates are bit-identical - tests/test_factor_graph_glue.py::test_native_updates_are_reproducible.)
+  if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
   // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
   const int Eb = u->n_in + E;
   probe_mark(PVO_STAGE_BA, 0, stream);
@@ -324,6 +328,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
     hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, u->disps, n, u->disp_min);
     PVO_CHECK_LAUNCH();
   }
+  RUN(join(pending, stream));
   probe_mark(PVO_STAGE_UPDATE, 1, stream);
   return PVO_OK;
 }
