@@ -20,6 +20,8 @@ struct SideCtx { hipStream_t side; hipEvent_t fork, join, mid; bool ok; };
 
 // one side stream + two events per device, created on first use (streams and events are host objects: the library
 // still allocates no device memory)
+// (events with hipEventReleaseToDevice instead of the default system-scope release: the ~6.5 us a record or a satisfied
+// wait costs on the launch stream did not change)
 SideCtx* side_ctx() {
   static SideCtx ctx[64] = {};
   int dev = 0;
@@ -180,7 +182,12 @@ int run_heads(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   return PVO_OK;
 }
 
-int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx* mark = nullptr) {
+int run_upmask(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream) {
+  if (a->K <= 0 || !a->upmask) return PVO_OK;
+  return pvo_conv1x1_c128(b.a2, w->up_w, w->up_b, a->upmask, static_cast<long long>(a->K) * a->H * a->W, 576, 0, w->dtype, stream);
+}
+
+int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx* mark = nullptr, bool with_upmask = true) {
   const int E = a->E, H = a->H, W = a->W, K = a->K, dt = w->dtype;
   if (K <= 0) return PVO_OK;
   if (w->flags & PVO_OP_CONV128_WIDE)
@@ -193,8 +200,7 @@ int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, vo
   if (a->eta)
     RUN(pvo_eta_head(b.a2, w->eta_w, w->eta_b, a->eta_frame, a->eta_pos, a->damping, a->eta, a->eta_frame ? a->R : K, H, W, a->EP, a->eta_scale, dt, stream));
   if (mark && hipEventRecord(mark->mid, pvo_stream(stream)) != hipSuccess) return PVO_ELAUNCH;
-  if (a->upmask)
-    RUN(pvo_conv1x1_c128(b.a2, w->up_w, w->up_b, a->upmask, static_cast<long long>(K) * H * W, 576, 0, dt, stream));
+  if (with_upmask) RUN(run_upmask(w, a, b, stream));
   return PVO_OK;
 }
 
@@ -211,7 +217,7 @@ int check_op(const pvo_update_weights* w, const pvo_operator_args* a) {
 // leaves the join to the caller (pvo_graph_update joins only in front of the BA, so the K-frame kernels of the
 // aggregation branch, which occupy a fraction of the chip, also overlap the mask / weight glue).
 int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx** pending,
-                 const MotionJob* mj = nullptr) {
+                 const MotionJob* mj = nullptr, bool upmask_on_side = true) {
   const void *P_zr, *P_q;
   RUN(run_trunk(w, a, b, stream, &P_zr, &P_q, mj));
   hipStream_t st = pvo_stream(stream);
@@ -219,13 +225,13 @@ int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& 
   if (sc) {
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
-    RUN(run_agg(w, a, b, sc->side, sc));
+    RUN(run_agg(w, a, b, sc->side, sc, upmask_on_side));
     if (hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
     RUN(run_heads(w, a, b, stream));
     *pending = sc;
   } else {
     RUN(run_heads(w, a, b, stream));
-    RUN(run_agg(w, a, b, stream));
+    RUN(run_agg(w, a, b, stream, nullptr, upmask_on_side));
     *pending = nullptr;
   }
   return PVO_OK;
@@ -295,7 +301,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   a.eta = u->op.eta ? u->op.eta : s.eta;          // (a caller that runs the BA itself - edge sharding - supplies the buffer)
   if (u->want_upmask && !a.upmask) a.upmask = s.upmask;
   SideCtx* pending = nullptr;
-  RUN(run_operator(w, &a, b, stream, &pending, &mj));
+  RUN(run_operator(w, &a, b, stream, &pending, &mj, false));
   // :249-306: mask update, (panoptic vote), weights, targets in the BA's layout, full flow
   if (u->segm)
     RUN(pvo_segment_hist(u->segm, u->raw_mask, s.heads, s.vote_tot, s.vote_dyn, E, HW, S, u->dy_thresh, dt, stream));
@@ -303,12 +309,16 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
                      u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW, u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW,
                      u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
                      S, u->vote_thresh, dt, stream));
-  // The BA needs the damping, not the upsampling mask: it waits for the aggregation branch up to the eta head (`mid`) and
-  // runs beside the mask convolution; the branch is joined at the end of the update, so nothing of the next call (nor the
-  // caller) meets a side stream still at work.  (~20 us per update.  A first attempt at this waited on a re-recorded
-  // `join` event instead of an event of its own and lost the run-to-run reproducibility of the poses; with `mid` repeated
-  // keyframe and global updates are bit-identical - tests/test_factor_graph_glue.py::test_native_updates_are_reproducible.)
+  // The aggregation branch ends at the eta head on the side stream (`mid`); the upsampling mask - which nothing here reads -
+  // is computed on THIS stream between the mask / weight glue and the BA.  By then `mid` is long recorded (a satisfied wait
+  // costs ~6 us on the stream, one that has to be woken ~19), the convolution takes 17 us alone instead of 27 beside the
+  // glue kernels, and the BA starts ~20 us earlier than behind a join of the whole branch - while still running with the
+  // side stream idle.  (Letting the BA run beside the mask convolution hides those 17 us too, but one of ~290 repeated
+  // two-update runs then differed in the last bits of the poses; starting the BA's edge-block assembly before `mid`, with
+  // the wait in front of the Schur step only, made 13 of 13 differ - no buffer is shared (addresses checked), agent-scope
+  // loads of eta changed nothing; cause not found.  tools/update_poison_check.py, tests/...::test_native_updates_are_reproducible.)
   if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
+  RUN(run_upmask(w, &a, b, stream));
   // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
   const int Eb = u->n_in + E;
   probe_mark(PVO_STAGE_BA, 0, stream);
