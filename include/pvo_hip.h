@@ -378,6 +378,11 @@ int pvo_graph_update(const pvo_update_weights* weights, const pvo_graph_update_a
 int pvo_frame_distance(const float* poses, const float* disps, const float* intrinsics,
                        const int64_t* ii, const int64_t* jj, float* dist,
                        int M, int ht, int wd, float beta, void* stream);
+/* DepthVideo.distance(bidirectional=True) (depth_video.py:183-193: two frame_distance calls and 0.5 * (d1 + d2)) in one
+ * launch; dist[m] equals that formulation bit for bit. */
+int pvo_frame_distance_bidirectional(const float* poses, const float* disps, const float* intrinsics,
+                                     const int64_t* ii, const int64_t* jj, float* dist,
+                                     int M, int ht, int wd, float beta, void* stream);
 
 /* droid_backends.projmap (droid.cpp:136-151; droid_kernels.cu:406-495,1439-1464).
  * coords [E,ht,wd,3] (channel 2 left 0, as the reference does), valid [E,ht,wd,1]. */

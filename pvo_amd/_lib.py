@@ -56,6 +56,7 @@ SIGNATURES = {
     "pvo_probe_arm": (_i, [_i, _i]),
     "pvo_probe_read": (_i, [_vp, _i]),
     "pvo_frame_distance": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "pvo_frame_distance_bidirectional": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "pvo_projmap": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_iproj": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_depth_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -20,18 +20,15 @@ constexpr float kMinDepthPy = 0.2f;       // projective_ops.py:6  MIN_DEPTH
 struct Intr { float fx, fy, cx, cy; };
 __device__ __forceinline__ Intr load_intr(const float* p) { return {p[0], p[1], p[2], p[3]}; }
 
-__global__ __launch_bounds__(256) void frame_distance_kernel(
-    const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intrinsics,
-    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, float* __restrict__ dist,
-    int HW, int wd, float beta) {
-  const int m = blockIdx.x;
-  const int ix = static_cast<int>(ii[m]), jx = static_cast<int>(jj[m]);
-  const Intr K = load_intr(intrinsics);
+// one direction of the frame distance for the pair (ix -> jx), computed by the 256 threads `tid` of one group; `red` is
+// that group's [3][4] reduction buffer.  Returns the distance in the group's thread 0 (droid_kernels.cu:497-636).
+__device__ __forceinline__ float pair_distance(const float* __restrict__ poses, const float* __restrict__ disps, const Intr K,
+                                               int ix, int jx, int HW, int wd, float beta, int tid, float (*red)[4]) {
   const Pose G = rel_pose(load_pose(poses + 7 * static_cast<long long>(ix)), load_pose(poses + 7 * static_cast<long long>(jx)));
   const float* __restrict__ d_i = disps + static_cast<long long>(ix) * HW;
 
   float accum = 0.f, valid = 0.f, total = 0.f;
-  for (int k = threadIdx.x; k < HW; k += 256) {
+  for (int k = tid; k < HW; k += 256) {
     const int i = k / wd, j = k - i * wd;
     const float u = static_cast<float>(j), v = static_cast<float>(i);
     float Xi[4] = {(u - K.cx) / K.fx, (v - K.cy) / K.fy, 1.0f, d_i[k]};
@@ -52,18 +49,44 @@ __global__ __launch_bounds__(256) void frame_distance_kernel(
     total += (1.0f - beta);
     if (Xj[2] > kMinDepthNative) { accum += (1.0f - beta) * d; valid += (1.0f - beta); }
   }
-  __shared__ float red[3][4];
   accum = pvo_wave_sum(accum); valid = pvo_wave_sum(valid); total = pvo_wave_sum(total);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[0][wave] = accum; red[1][wave] = valid; red[2][wave] = total; }
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) { red[0][wave] = accum; red[1][wave] = valid; red[2][wave] = total; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    const float va = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    const float to = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-    // droid_kernels.cu:634 (the 1e-8 literal makes the comparison double precision)
-    dist[m] = (static_cast<double>(va) / (static_cast<double>(to) + 1e-8) < 0.75) ? 1000.0f : a / va;
-  }
+  const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  const float va = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const float to = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  // droid_kernels.cu:634 (the 1e-8 literal makes the comparison double precision)
+  return (static_cast<double>(va) / (static_cast<double>(to) + 1e-8) < 0.75) ? 1000.0f : a / va;
+}
+
+__global__ __launch_bounds__(256) void frame_distance_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intrinsics,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, float* __restrict__ dist,
+    int HW, int wd, float beta) {
+  const int m = blockIdx.x;
+  __shared__ float red[3][4];
+  const float d = pair_distance(poses, disps, load_intr(intrinsics), static_cast<int>(ii[m]), static_cast<int>(jj[m]), HW, wd, beta,
+                                threadIdx.x, red);
+  if (threadIdx.x == 0) dist[m] = d;
+}
+
+// 0.5 * (distance(ii -> jj) + distance(jj -> ii)) in one launch (depth_video.py:183-193 runs the kernel twice and averages
+// with two more element-wise kernels): threads 0..255 of a workgroup take one direction, 256..511 the other, each exactly as
+// frame_distance_kernel does, so the result equals the two-launch formulation bit for bit.
+__global__ __launch_bounds__(512) void frame_distance_bidir_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intrinsics,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, float* __restrict__ dist,
+    int HW, int wd, float beta) {
+  const int m = blockIdx.x;
+  const int g = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  __shared__ float red[2][3][4];
+  __shared__ float both[2];
+  const int a = static_cast<int>(ii[m]), b = static_cast<int>(jj[m]);
+  const float d = pair_distance(poses, disps, load_intr(intrinsics), g ? b : a, g ? a : b, HW, wd, beta, tid, red[g]);
+  if (tid == 0) both[g] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) dist[m] = __fmul_rn(0.5f, __fadd_rn(both[0], both[1]));
 }
 
 __global__ __launch_bounds__(256) void projmap_kernel(
@@ -190,6 +213,18 @@ extern "C" int pvo_frame_distance(const float* poses, const float* disps, const 
   if (M == 0) return PVO_OK;
   PVO_REQ(poses && disps && intrinsics && ii && jj && dist);
   hipLaunchKernelGGL(frame_distance_kernel, dim3(M), dim3(256), 0, pvo_stream(stream),
+                     poses, disps, intrinsics, ii, jj, dist, ht * wd, wd, beta);
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_frame_distance_bidirectional(const float* poses, const float* disps, const float* intrinsics,
+                                                const int64_t* ii, const int64_t* jj, float* dist,
+                                                int M, int ht, int wd, float beta, void* stream) {
+  PVO_REQ(M >= 0 && ht >= 0 && wd >= 0);
+  if (M == 0) return PVO_OK;
+  PVO_REQ(poses && disps && intrinsics && ii && jj && dist);
+  hipLaunchKernelGGL(frame_distance_bidir_kernel, dim3(M), dim3(512), 0, pvo_stream(stream),
                      poses, disps, intrinsics, ii, jj, dist, ht * wd, wd, beta);
   PVO_CHECK_LAUNCH();
   return PVO_OK;

@@ -148,19 +148,33 @@ class DepthVideo:
         coords, valid = db.reproject(self.poses, self.disps, self.intrinsics, ii, jj)
         return coords[None], valid[None]
 
+    def reproject_into(self, ii, jj, coords_out):
+        """reproject(ii, jj)[0][0] written into coords_out [E,h,w,2] (device tensors only)"""
+        ii, jj = self.format_indicies(ii, jj, self.device)
+        db.reproject(self.poses, self.disps, self.intrinsics, ii, jj, out=coords_out)
+
     def distance(self, ii=None, jj=None, beta=0.3, bidirectional=True):
         """frame distance metric (depth_video.py:165-195)"""
         return_matrix = ii is None
         if return_matrix:
             N = self.counter
-            ii, jj = torch.meshgrid(torch.arange(N), torch.arange(N), indexing="ij")
+            grid = self.__dict__.get("_grid")
+            if grid is None or grid[0] != N:                       # (the N x N index grid: uploaded once per window size)
+                gi, gj = torch.meshgrid(torch.arange(N), torch.arange(N), indexing="ij")
+                both = db.to_device_async(torch.cat([gi.reshape(-1), gj.reshape(-1)]), torch.long, self.device)
+                grid = self.__dict__["_grid"] = (N, both[:N * N], both[N * N:])
+            ii, jj = grid[1], grid[2]
         if not (isinstance(ii, torch.Tensor) and ii.is_cuda):      # host index lists: staged through the pinned ring, no stream drain
             ii_h = torch.as_tensor(ii, dtype=torch.long).reshape(-1)
             jj_h = torch.as_tensor(jj, dtype=torch.long).reshape(-1)
             both = db.to_device_async(torch.cat([ii_h, jj_h]), torch.long, self.device)
             ii, jj = both[:ii_h.numel()], both[ii_h.numel():]
         ii, jj = self.format_indicies(ii, jj, self.device)
-        if bidirectional:
+        if bidirectional and self.poses.is_cuda:
+            # both directions and their mean in one launch, bit-identical to the two calls below (which remain the host /
+            # test formulation: the reference's call sequence is pinned on them)
+            d = db.frame_distance_bidirectional(self.poses, self.disps, self.intrinsics[0], ii, jj, beta)
+        elif bidirectional:
             poses = self.poses[:self.counter]              # (the reference clones them, depth_video.py:183; the kernel only reads)
             d1 = db.frame_distance(poses, self.disps, self.intrinsics[0], ii, jj, beta)
             d2 = db.frame_distance(poses, self.disps, self.intrinsics[0], jj, ii, beta)

@@ -404,6 +404,22 @@ def frame_distance(poses, disps, intrinsics, ii, jj, beta):
     return dist
 
 
+def frame_distance_bidirectional(poses, disps, intrinsics, ii, jj, beta):
+    """0.5 * (frame_distance(ii, jj) + frame_distance(jj, ii)) - DepthVideo.distance's bidirectional metric
+    (depth_video.py:183-193) - in one launch, bit-identical to the two-call formulation -> dist [M]."""
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _contig(t, n)
+    dev = _dev(poses, disps, intrinsics, ii, jj)
+    _f32(poses, "poses"); _f32(disps, "disps"); _f32(intrinsics, "intrinsics"); _long(ii, "ii"); _long(jj, "jj")
+    M = ii.shape[0]
+    dist = torch.empty(M, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_frame_distance_bidirectional(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj),
+                                                           _ptr(dist), M, disps.shape[1], disps.shape[2], float(beta),
+                                                           _stream(dev)), "frame_distance_bidirectional")
+    return dist
+
+
 def projmap(poses, disps, intrinsics, ii, jj):
     """droid.cpp:136-151 -> [coords [E,ht,wd,3], valid [E,ht,wd,1]]."""
     for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
@@ -446,15 +462,21 @@ def depth_filter(poses, disps, intrinsics, ix, thresh):
     return counter
 
 
-def reproject(poses, disps, intrinsics, ii, jj):
+def reproject(poses, disps, intrinsics, ii, jj, out=None):
     """DepthVideo.reproject (depth_video.py:154-163): poses [F,7], disps [F,ht,wd],
-    intrinsics [F,4] -> coords [E,ht,wd,2], valid [E,ht,wd,1]."""
+    intrinsics [F,4] -> coords [E,ht,wd,2], valid [E,ht,wd,1].  out: a contiguous fp32 [E,ht,wd,2] tensor to write the
+    coordinates into (e.g. the rows of a state buffer)."""
     for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
         _contig(t, n)
     dev = _dev(poses, disps, intrinsics, ii, jj)
     _long(ii, "ii"); _long(jj, "jj")
     E, ht, wd = ii.shape[0], disps.shape[1], disps.shape[2]
-    coords = torch.empty(E, ht, wd, 2, dtype=torch.float32, device=dev)
+    if out is not None:
+        if tuple(out.shape) != (E, ht, wd, 2) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise ValueError("reproject: out must be a contiguous float32 [E,ht,wd,2] tensor on the inputs' device")
+        coords = out
+    else:
+        coords = torch.empty(E, ht, wd, 2, dtype=torch.float32, device=dev)
     valid = torch.empty(E, ht, wd, 1, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         check(_lib.load().pvo_reproject(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj),

@@ -111,6 +111,7 @@ class FactorGraph:
         self._corr_ready = None     # event: the side-stream build of the most recently added edges (see add_factors)
         self.build_on_side_stream = True
         self._rows = {}             # per-edge state tensors as rows of fixed-capacity buffers (_EdgeRows)
+        self._segm = None
         self.corr = self.net = self.inp = self.segm = None
         self.damping = 1e-6 * torch.ones_like(video.disps)
         z = lambda c: torch.zeros(1, 0, ht, wd, c, device=self.device, dtype=torch.float)
@@ -258,17 +259,23 @@ class FactorGraph:
         self.net = self._net_view(self._edge_rows("net").append(self._net_rows(), n, fill_net))
 
         def fill_target(dst):
-            target, _ = self.video.reproject(ii, jj)
-            dst.copy_(target[0])
+            if hasattr(self.video, "reproject_into"):
+                self.video.reproject_into(ii, jj, dst)               # (no temporary, no copy)
+            else:
+                target, _ = self.video.reproject(ii, jj)
+                dst.copy_(target[0])
         zero = lambda dst: dst.zero_()
         self.target_cam = self._edge_rows("target_cam").append(self.target_cam[0], n, fill_target)[None]
         self.weight = self._edge_rows("weight").append(self.weight[0], n, zero)[None]
         self.raw_mask = self._edge_rows("raw_mask").append(self.raw_mask[0], n, zero)[None]
         self.delta_dy = self._edge_rows("delta_dy").append(self.delta_dy[0], n, zero)[None]
-        segms = self.video.segms
-        if self.segm is None:
-            self.segm = torch.empty((1, 0) + tuple(segms.shape[1:]), dtype=segms.dtype, device=self.device)
-        self.segm = self._edge_rows("segm").append(self.segm[0], n, lambda dst: torch.index_select(segms, 0, ii, out=dst))[None]
+        if getattr(self.video, "segm_filter", True):     # (without the panoptic filter nothing reads them: `segm` gathers on demand)
+            segms = self.video.segms
+            if self._segm is None:
+                self._segm = torch.empty((1, 0) + tuple(segms.shape[1:]), dtype=segms.dtype, device=self.device)
+            self._segm = self._edge_rows("segm").append(self._segm[0], n, lambda dst: torch.index_select(segms, 0, ii, out=dst))[None]
+        else:
+            self._segm = None
 
     def _build_stream(self):
         """the library's own second stream (one per device, the one the update's side chains use): a stream of our own
@@ -390,8 +397,8 @@ class FactorGraph:
             self._inp = self._take_cl(self._inp, keep_t())
         if self.P_zr is not None and not self._static_by_slot:
             self.P_zr, self.P_q = self._take_cl(self.P_zr, keep_t()), self._take_cl(self.P_q, keep_t())
-        if self.segm is not None:
-            self.segm = self._edge_rows("segm").keep(self.segm[0], keep_l, keep_t)[None]
+        if self._segm is not None:
+            self._segm = self._edge_rows("segm").keep(self._segm[0], keep_l, keep_t)[None]
         for name in ("target_cam", "weight", "raw_mask", "delta_dy"):
             t = getattr(self, name)
             rows = t[0] if t.shape[0] == 1 else None
@@ -749,6 +756,18 @@ class FactorGraph:
     @inp.setter
     def inp(self, t):
         self._inp = t
+
+    @property
+    def segm(self):
+        """per-edge panoptic labels of the source frames (factor_graph.py:34): kept as rows while the video filters by
+        segments; otherwise video.segms[ii], gathered only if somebody asks"""
+        if self._segm is None and self._ii_h and not getattr(self.video, "segm_filter", True):
+            return self._cached("segm", lambda: self.video.segms[self.ii][None])
+        return self._segm
+
+    @segm.setter
+    def segm(self, t):
+        self._segm = t
 
     @property
     def age(self):

@@ -198,6 +198,10 @@ def test_reprojection_kernels_match_oracle(cuda):
     assert np.allclose(got, O.frame_distance(poses_n, disps_n, intr_n, ii.numpy(), jj.numpy(), 0.3), rtol=1e-5, atol=1e-5)
     far = poses.clone(); far[1, 2] -= 100.0
     assert db.frame_distance(d(far), d(disps), d(intr), d(torch.tensor([0])), d(torch.tensor([1])), 0.3).item() == 1000.0
+    # DepthVideo.distance's bidirectional metric in one launch: bit-identical to two calls and their mean
+    d1 = db.frame_distance(d(poses), d(disps), d(intr), d(ii), d(jj), 0.3)
+    d2 = db.frame_distance(d(poses), d(disps), d(intr), d(jj), d(ii), 0.3)
+    assert torch.equal(db.frame_distance_bidirectional(d(poses), d(disps), d(intr), d(ii), d(jj), 0.3), 0.5 * (d1 + d2))
     # projmap
     c, v = db.projmap(d(poses), d(disps), d(intr), d(ii), d(jj))
     wc, wv = O.projmap(poses_n, disps_n, intr_n, ii.numpy(), jj.numpy())
