@@ -403,3 +403,27 @@ def test_native_updates_are_reproducible(cuda):
     for r in range(1, 6):
         for a, b in zip(outs[r], outs[0]):
             assert torch.equal(a, b), r
+
+
+def test_packed_index_upload_keeps_parts_apart():
+    """to_device_packed: several index tables in one staging buffer, each part its own dtype, 16-byte aligned, empty parts allowed
+    (the CPU branch shares the packing arithmetic's contract: one tensor per part, same values)"""
+    from pvo_amd.droid_backends import to_device_packed
+    parts = [([5, 6, 7], torch.long), ([], torch.int32), ([1], torch.int32), (torch.tensor([9, 8]), torch.long), ([3] * 37, torch.int32)]
+    out = to_device_packed(parts, "cpu")
+    assert len(out) == len(parts)
+    for (v, dt), t in zip(parts, out):
+        assert t.dtype == dt and t.tolist() == (v.tolist() if isinstance(v, torch.Tensor) else list(v))
+
+
+def test_pool_reserve_and_add_must_agree():
+    """CorrVolumePool.add with a caller-uploaded slot tensor refuses one that does not belong to the last reserve()"""
+    from pvo_amd.modules.corr import CorrVolumePool
+    pool = CorrVolumePool.__new__(CorrVolumePool)
+    pool.free, pool.slots, pool._reserved, pool.capacity = [3, 2, 1, 0], [], None, 4
+    assert pool.reserve(2) == [0, 1] and pool.free == [3, 2]
+    with pytest.raises(ValueError):
+        pool.add(torch.zeros(3, 2, 2, 8), torch.zeros(3, 2, 2, 8), torch.zeros(2, dtype=torch.int32))      # 3 edges, 2 slots
+    pool._reserved = [0, 1]
+    with pytest.raises(ValueError):
+        pool.add(torch.zeros(2, 2, 2, 8), torch.zeros(2, 2, 2, 8), torch.zeros(2, dtype=torch.int64))      # wrong dtype
