@@ -250,7 +250,7 @@ class FactorGraph:
         if self.net is None:
             self.net = self._net_view(torch.empty((0,) + ((self.ht, self.wd, 128) if cl else (128, self.ht, self.wd)),
                                                   dtype=nets.dtype, device=self.device))
-        if cl and nets.permute(0, 2, 3, 1).is_contiguous():
+        if cl and nets.permute(0, 2, 3, 1).is_contiguous() and self.net.dtype == nets.dtype:
             fill_net = lambda dst: torch.index_select(nets.permute(0, 2, 3, 1), 0, ii, out=dst)      # no temporary
         elif cl:
             fill_net = lambda dst: dst.copy_(nets[ii].permute(0, 2, 3, 1))
@@ -273,7 +273,9 @@ class FactorGraph:
             segms = self.video.segms
             if self._segm is None:
                 self._segm = torch.empty((1, 0) + tuple(segms.shape[1:]), dtype=segms.dtype, device=self.device)
-            self._segm = self._edge_rows("segm").append(self._segm[0], n, lambda dst: torch.index_select(segms, 0, ii, out=dst))[None]
+            same = self._segm.dtype == segms.dtype                 # (a caller may have assigned labels of another integer type)
+            self._segm = self._edge_rows("segm").append(
+                self._segm[0], n, (lambda dst: torch.index_select(segms, 0, ii, out=dst)) if same else (lambda dst: dst.copy_(segms[ii])))[None]
         else:
             self._segm = None
 
