@@ -5,14 +5,15 @@
 
 One STEP = one keyframe update of the frontend on an 8-keyframe window at 512x384 (48x64
 maps, 36 edges |i-j|<=3), following droid_frontend.py:36-70 of the reference:
-    re-create the newest keyframe's edges  (volume + pyramid build for 6 edges, reproject)
-    frame distances over the window         (proximity search input, 2 x 56 pairs)
+    re-create the newest keyframe's edges  (volume + pyramid build and static GRU terms for 6 edges - on the library's
+                                            side stream, beside the rest -, reproject, state rows appended in place)
+    frame distances over the window         (proximity search input: the 8 x 8 matrix and one pair, both directions)
     4 graph updates, keyframe-distance test, 2 more graph updates
 where one graph update = reproject -> 4-level correlation lookup -> update operator (fp16) ->
 mask/weight glue -> dense BA x2 (factor_graph.py:227-307), issued as ONE native call (pvo_graph_update).
 Inputs are synthetic (seeded), resident in HBM before the timed region; the update operator has
 random-init weights of the reference architecture.  State is restored at the start of every step
-so that K steps do identical work.
+so that K steps do identical work (8 device copies inside the timed step that a real run does not have).
 
 N > 1: one process per GPU (torch.distributed, RCCL); every rank tracks its own window
 (independent sequences, no data-path collective), value = N*K / max-over-ranks time.
