@@ -50,26 +50,30 @@ class _PinnedRing:
     device-wide lock - in the middle of the update loop.  Small index lists are copied into this ring instead; a quarter
     of the ring is reused only after the copies issued from it have completed (an event per quarter)."""
 
-    def __init__(self, nbytes=1 << 20):
-        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    def __init__(self, nbytes=1 << 20, pin=True):
+        buf = torch.empty(nbytes, dtype=torch.uint8)
+        self.buf = buf.pin_memory() if pin else buf
         self.nbytes, self.quarter = nbytes, nbytes // 4
-        self.off = 0
-        self.events = [None] * 4
+        self.off = 0                  # next free byte, always inside quarter `self.q`
+        self.q = 0                    # the quarter allocations currently come from (tracked, not derived from `off`:
+        self.events = [None] * 4      # an allocation that ends exactly on a boundary leaves `off` in the next quarter's range)
+
+    def _record(self, device):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return ev
 
     def take(self, n, device):
         n = (n + 15) & ~15
         if n > self.quarter:
             return None
-        q0 = self.off // self.quarter
-        if self.off + n > (q0 + 1) * self.quarter:            # does not fit in the current quarter: move on
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(device))
-            self.events[q0] = ev
-            q0 = (q0 + 1) % 4
-            self.off = q0 * self.quarter
-            if self.events[q0] is not None:                   # copies issued from this quarter one lap ago
-                self.events[q0].synchronize()
-                self.events[q0] = None
+        if self.off + n > (self.q + 1) * self.quarter:        # does not fit in what is left of the current quarter: move on
+            self.events[self.q] = self._record(device)        # copies issued from the quarter being left
+            self.q = (self.q + 1) % 4
+            self.off = self.q * self.quarter
+            if self.events[self.q] is not None:               # copies issued from this quarter one lap ago
+                self.events[self.q].synchronize()
+                self.events[self.q] = None
         seg = self.buf[self.off:self.off + n]
         self.off += n
         return seg

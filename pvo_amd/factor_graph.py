@@ -203,6 +203,10 @@ class FactorGraph:
         if pool_path and isinstance(self.corr, CorrVolumePool):
             # the new edges' endpoints and the slots their volumes will own: one staged upload
             from .droid_backends import to_device_packed
+            if n > len(self.corr.free):
+                # reserve() is about to grow the pool: its copies run on THIS stream and drop the old tensors, which a pending
+                # side-stream build (two add_factors calls without an update between them) may still be writing
+                self._corr_sync()
             ii, jj, new_slots = to_device_packed([(ii_l, torch.long), (jj_l, torch.long), (self.corr.reserve(n), torch.int32)],
                                                  self.device)
         else:
@@ -453,7 +457,7 @@ class FactorGraph:
             # so with resident volumes this update is update() with its own damping rule and solver constants: the whole
             # graph in ONE native call per step.  (Correlation values then carry the volume's fp16 rounding, as in update().)
             for _ in range(steps):
-                self._update_fused(1, t, itrs, False, EP, False, eta_scale=1.0, lm=1e-5, ep=1e-2, sharded=sharded)
+                self._update_fused(1, t, itrs, False, EP, False, eta_scale=1.0, lm=1e-5, ep=1e-2, sharded=sharded, segm_vote=False)
                 self.video.dirty[:t] = True
             return
         corr_op = AltCorrBlock(self.video.fmaps[None, :t], channels_last=True)
@@ -636,12 +640,14 @@ class FactorGraph:
         return st
 
     @torch.no_grad()
-    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only, eta_scale=0.2, lm=1e-4, ep=0.1, sharded=None):
+    def _update_fused(self, t0, t1, itrs, use_inactive, EP, motion_only, eta_scale=0.2, lm=1e-4, ep=0.1, sharded=None,
+                      segm_vote=True):
         """factor_graph.py:227-307 as ONE call into libpvo_hip (pvo_graph_update): reproject, motion features, lookup +
         update operator, (panoptic vote), mask / weight glue, damping, BA.  Everything that depends only on the edge set
         (index tensors, the BA plan, the inactive edges' BA rows, output buffers) is prepared once per edge set; per
         update the host fills one argument struct.  State tensors (net, target_cam, delta_dy, raw_mask, weight,
-        full_flow) are updated IN PLACE."""
+        full_flow) are updated IN PLACE.  segm_vote=False: no panoptic vote even when the video filters by segments
+        (update_lowmem: the reference's global update never votes, factor_graph.py:309-360)."""
         from . import droid_backends as db
         from ._lib import GraphUpdateArgs
         from .droid_backends import to_device_packed
@@ -653,7 +659,9 @@ class FactorGraph:
             t0 = max(1, min(self._ii_h) + 1)
         if t1 is None:
             t1 = max(max(self._ii_h), max(self._jj_h)) + 1
-        key = (self._version, t0, t1, bool(use_inactive), bool(motion_only), E, float(eta_scale), float(lm), float(ep), sharded is not None)
+        vote = bool(segm_vote and v.segm_filter)
+        key = (self._version, t0, t1, bool(use_inactive), bool(motion_only), E, float(eta_scale), float(lm), float(ep), sharded is not None,
+               vote)
         st = self._cache.get("fused")
         if st is None or st["key"] != key:
             src = sorted(set(self._ii_h))
@@ -689,12 +697,13 @@ class FactorGraph:
                 ba = self._ba_plan(ii_ba, jj_ba, t0, t1, motion_only, n_in, len(rows))
             else:                                                  # the sharded BA plans for itself (pvo_amd/parallel.py)
                 ba = {"ii": ii_ba.contiguous(), "jj": jj_ba.contiguous(), "sys": None, "ws": None}
-            S = v.max_segments if v.segm_filter else 0
+            S = v.max_segments if vote else 0
             st = self._cache["fused"] = dict(
                 key=key, n_in=n_in, target_ba=target_ba, weight_ba=weight_ba, ii_ba=ba["ii"], jj_ba=ba["jj"], frames=frames_t,
                 pos=pos_t, seg=seg, ba=ba, R=len(rows), S=S, ii=self.ii.contiguous(), jj=self.jj.contiguous(),
                 slots=self.corr.slots_tensor(),
-                segm=self.segm[0, :, 0].contiguous() if v.segm_filter else None,
+                # (labels of another integer type - add_factors keeps a caller's dtype - are converted: the kernel reads int32)
+                segm=self.segm[0, :, 0].to(torch.int32).contiguous() if vote else None,
                 full_flow=torch.empty(1, E, ht, wd, 2, device=self.device),
                 eta=torch.empty(len(rows), ht, wd, device=self.device) if sharded is not None else None,
                 ws=db.graph_update_workspace(E, seg[2], len(rows), ht, wd, S, self.device), args=GraphUpdateArgs())

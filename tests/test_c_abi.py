@@ -82,3 +82,17 @@ def test_library_loaded_before_torch_still_launches():
             "y = db.corr_pyramid_lookup(pyr, c, 3); torch.cuda.synchronize(); print('ok', tuple(y.shape))")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert out.returncode == 0 and "ok (2, 196, 6, 10)" in out.stdout, out.stdout[-2000:]
+
+
+def test_top_level_droid_backends_module_has_the_reference_surface():
+    """`import droid_backends` (modules/corr.py:4, depth_video.py:8 of the reference) resolves to this build with the
+    repository root on sys.path, exporting the nine functions of PYBIND11_MODULE(droid_backends) (droid.cpp:234-247)"""
+    import importlib
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    mod = importlib.import_module("droid_backends")
+    from pvo_amd import droid_backends as inner
+    for name in ("ba", "frame_distance", "projmap", "iproj", "depth_filter", "corr_index_forward", "corr_index_backward",
+                 "altcorr_forward", "altcorr_backward"):
+        assert getattr(mod, name) is getattr(inner, name), name

@@ -427,3 +427,43 @@ def test_pool_reserve_and_add_must_agree():
     pool._reserved = [0, 1]
     with pytest.raises(ValueError):
         pool.add(torch.zeros(2, 2, 2, 8), torch.zeros(2, 2, 2, 8), torch.zeros(2, dtype=torch.int64))      # wrong dtype
+
+
+def test_pinned_ring_exact_fit_and_wraparound():
+    """_PinnedRing.take: an allocation that ends exactly on a quarter boundary (or on the end of the ring) must still
+    record the event of the quarter being left, wait for the event of the quarter being entered, wrap, and never hand
+    out an empty or overlapping segment while copies from it may be in flight (ADVICE r2: `off // quarter` named the
+    NEXT quarter after an exact fit; 64 x 16 KB then take(64) raised, and every later upload failed)."""
+    from pvo_amd.droid_backends import _PinnedRing
+
+    class Ev:
+        def __init__(self, log, q): self.log, self.q, self.done = log, q, False
+        def synchronize(self): self.done = True; self.log.append(("sync", self.q))
+
+    ring = _PinnedRing(nbytes=1 << 12, pin=False)          # quarters of 1024 B
+    log = []
+    ring._record = lambda device: (log.append(("record", ring.q)), Ev(log, ring.q))[1]
+    base = ring.buf.data_ptr()
+    live = {}                                              # quarter -> list of (lo, hi) handed out since its last wait
+    import random
+    rnd = random.Random(0)
+    sizes = [1024] * 9 + [16] * 64 + [1024, 64, 960, 1024] + [rnd.choice([16, 48, 64, 512, 1008, 1024]) for _ in range(4000)]
+    for n in sizes:
+        before = len(log)
+        seg = ring.take(n, "cpu")
+        assert seg is not None and seg.numel() == ((n + 15) & ~15), n
+        lo = seg.data_ptr() - base
+        hi = lo + seg.numel()
+        q = lo // 1024
+        assert q == (hi - 1) // 1024 == ring.q and hi <= 4096        # inside one quarter, the one the ring says is current
+        for kind, qq in log[before:]:
+            if kind == "sync":
+                live[qq] = []                                        # its copies have completed: reusable
+        if any(k == "record" for k, _ in log[before:]):              # moved on: the entered quarter must be clean
+            assert not live.get(q), "quarter %d reused without waiting for its copies" % q
+        for a, b in live.setdefault(q, []):
+            assert hi <= a or lo >= b, "overlapping segments in quarter %d" % q
+        live[q].append((lo, hi))
+    assert ring.take(1025, "cpu") is None                             # larger than a quarter: caller's one-off path
+    recs = [q for k, q in log if k == "record"]
+    assert all((b - a) % 4 == 1 for a, b in zip(recs, recs[1:]))      # quarters are left in order 0,1,2,3,0,...
