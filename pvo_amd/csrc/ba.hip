@@ -1059,6 +1059,19 @@ int check_common(int E, int F, int ht, int wd, int t0, int t1) {
 extern "C" int pvo_debug_ba_probe(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ba_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
 #endif
 
+#ifdef PVO_SCHED_DEBUG
+// byte offsets of the workspace's parts (tools/sched_bisect.py names the first buffer that differs between two runs)
+extern "C" int pvo_debug_ba_layout(int E, int P, int nframes, int HW, size_t* out /*[16]*/) {
+  char* base = reinterpret_cast<char*>(4096);
+  Ws w = carve(base, E, P, nframes, HW);
+  const void* parts[14] = {w.plan.kidx, w.plan.kx, w.plan.eptr, w.plan.eidx, w.plan.meta, w.plan.env, w.Eii, w.Eij, w.Cii, w.bz, w.Ei, w.Q, w.w, w.dx};
+  for (int i = 0; i < 14; ++i) out[i] = static_cast<size_t>(static_cast<const char*>(parts[i]) - base);
+  out[14] = static_cast<size_t>(reinterpret_cast<char*>(w.sys) - base);
+  out[15] = w.bytes;
+  return 0;
+}
+#endif
+
 extern "C" size_t pvo_ba_workspace_bytes(int E, int P, int nframes, int HW) {
   if (E < 0 || P < 0 || nframes < 0 || HW < 0) return 0;
   return carve(nullptr, E, P, nframes, HW).bytes + 256;
@@ -1102,14 +1115,16 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
   // say so with bit 1 of motion_only and save the memset
   const size_t n6 = static_cast<size_t>(6) * P;
   const bool clean = (motion_only & 2) != 0;
+  const bool only_assemble = (motion_only & 4) != 0, only_schur = (motion_only & 8) != 0;   // (halves of this call: schedule experiments)
   motion_only &= 1;
-  if (!clean && hipMemsetAsync(sys, 0, sizeof(long long) * (n6 * n6 + n6), st) != hipSuccess) return PVO_ELAUNCH;
+  if (!clean && !only_schur && hipMemsetAsync(sys, 0, sizeof(long long) * (n6 * n6 + n6), st) != hipSuccess) return PVO_ELAUNCH;
   if (E == 0) return PVO_OK;
+  if (!only_schur)
   hipLaunchKernelGGL(ba_assemble_kernel, dim3((HW + kChunkA - 1) / kChunkA, E), dim3(256), 0, st,
                      poses, disps, intrinsics, targets, weights, ii, jj, w.Eii, w.Eij, w.Cii, w.bz,
                      sys, w.plan.meta, HW, wd, t0, P, motion_only);
   PVO_CHECK_LAUNCH();
-  if (!motion_only) {
+  if (!motion_only && !only_assemble) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);
     const dim3 sgrid((HW + kSchurPix - 1) / kSchurPix, Kmax);
     if ((HW & 3) == 0)

@@ -22,8 +22,10 @@ struct SideCtx { hipStream_t side; hipEvent_t fork, join, mid; bool ok; };
 // still allocates no device memory)
 // (events with hipEventReleaseToDevice instead of the default system-scope release: the ~6.5 us a record or a satisfied
 // wait costs on the launch stream did not change)
+unsigned g_event_flags = hipEventDisableTiming;
+SideCtx g_side_ctx[64] = {};
 SideCtx* side_ctx() {
-  static SideCtx ctx[64] = {};
+  SideCtx* ctx = g_side_ctx;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideCtx& c = ctx[dev];
@@ -33,9 +35,9 @@ SideCtx* side_ctx() {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
     if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&c.mid, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.fork, g_event_flags) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.join, g_event_flags) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.mid, g_event_flags) != hipSuccess) return nullptr;
     c.ok = true;
   }
   return &c;
@@ -106,6 +108,14 @@ UpWs carve_up(void* base, int E, int K, int R, int H, int W, int S, size_t op_by
 void* ws_base(void* workspace) {
   return reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
 }
+
+// tools/sched_bisect.py builds this file with -DPVO_SCHED_DEBUG: alternative stream arrangements of the BA inside
+// pvo_graph_update (round 2 found two of them irreproducible in the last bits of the poses) and a tap that copies the
+// BA's intermediate buffers after every stage, so that the first buffer that differs between two runs can be named.
+#ifdef PVO_SCHED_DEBUG
+struct SchedDebug { int mode; char* tap; size_t tap_bytes; size_t slot; int n; int no_marker; };
+SchedDebug g_sched = {0, nullptr, 0, 0, 0, 0};
+#endif
 
 #define RUN(call)                    \
   do {                               \
@@ -317,8 +327,23 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // two-update runs then differed in the last bits of the poses; starting the BA's edge-block assembly before `mid`, with
   // the wait in front of the Schur step only, made 13 of 13 differ - no buffer is shared (addresses checked), agent-scope
   // loads of eta changed nothing; cause not found.  tools/update_poison_check.py, tests/...::test_native_updates_are_reproducible.)
+#ifdef PVO_SCHED_DEBUG
+  // mode 1: the mask convolution on the side stream behind the eta head, the BA beside it;  mode 2: additionally the first
+  // assembly launched BEFORE the wait on `mid` (arranged below);  mode 3: as shipped but the mask convolution after the BA
+  if (g_sched.mode == 1 || g_sched.mode == 2) {
+    if (pending) {
+      RUN(run_upmask(w, &a, b, pending->side));
+      if (!g_sched.no_marker && hipEventRecord(pending->join, pending->side) != hipSuccess) return PVO_ELAUNCH;
+    } else RUN(run_upmask(w, &a, b, stream));
+    if (g_sched.mode == 1 && pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
+  } else if (g_sched.mode == 3) {
+    if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
+  } else
+#endif
+  {
   if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
   RUN(run_upmask(w, &a, b, stream));
+  }
   // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
   const int Eb = u->n_in + E;
   probe_mark(PVO_STAGE_BA, 0, stream);
@@ -326,13 +351,42 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // depth clamp of depth_video.py:214 rides on the last back-substitution.
   for (int it = 0; it < u->itrs; ++it) {
     const bool last = it + 1 == u->itrs;
+#ifdef PVO_SCHED_DEBUG
+    if (g_sched.mode == 2 && it == 0 && pending) {
+      // assembly (does not read the damping) before the wait, Schur behind it
+      RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
+                       H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | 2 | 4, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
+      if (hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
+      RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
+                       H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | 2 | 8, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
+    } else
+#endif
     RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
                      H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | 2, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
+#ifdef PVO_SCHED_DEBUG
+    auto tap = [&]() -> int {
+      if (!g_sched.tap) return PVO_OK;
+      const size_t n6 = static_cast<size_t>(6) * (u->t1 - u->t0), sb = 8 * (n6 * n6 + n6);
+      if ((g_sched.n + 1) * g_sched.slot > g_sched.tap_bytes || sb + u->ba_ws_bytes > g_sched.slot) return PVO_OK;
+      char* dst = g_sched.tap + g_sched.n * g_sched.slot;
+      if (hipMemcpyAsync(dst, u->sys, sb, hipMemcpyDeviceToDevice, st) != hipSuccess) return PVO_ELAUNCH;
+      if (hipMemcpyAsync(dst + ((sb + 255) & ~size_t(255)), u->ba_ws, u->ba_ws_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PVO_ELAUNCH;
+      ++g_sched.n;
+      return PVO_OK;
+    };
+    RUN(tap());
+#endif
     RUN(pvo_ba_finish(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
                       u->motion_only, last && !u->motion_only ? u->clamp_frames : 0, u->disp_min,
                       nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, stream));
+#ifdef PVO_SCHED_DEBUG
+    RUN(tap());
+#endif
   }
   probe_mark(PVO_STAGE_BA, 1, stream);
+#ifdef PVO_SCHED_DEBUG
+  if (g_sched.mode == 3) RUN(run_upmask(w, &a, b, stream));
+#endif
   if (u->clamp_frames > 0 && (u->itrs == 0 || u->motion_only)) {      // (no back-substitution ran: clamp on its own)
     const long long n = static_cast<long long>(u->clamp_frames) * HW;
     hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, u->disps, n, u->disp_min);
@@ -342,6 +396,27 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   probe_mark(PVO_STAGE_UPDATE, 1, stream);
   return PVO_OK;
 }
+
+#ifdef PVO_SCHED_DEBUG
+// recreate the library's fork / join / mid events with other flags (hipEventDisableSystemFence, hipEventReleaseToDevice ...)
+extern "C" int pvo_debug_event_flags(unsigned flags) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  g_event_flags = flags;
+  for (SideCtx& c : g_side_ctx) {
+    if (!c.ok) continue;
+    (void)hipEventDestroy(c.fork); (void)hipEventDestroy(c.join); (void)hipEventDestroy(c.mid);
+    if (hipEventCreateWithFlags(&c.fork, flags) != hipSuccess || hipEventCreateWithFlags(&c.join, flags) != hipSuccess ||
+        hipEventCreateWithFlags(&c.mid, flags) != hipSuccess) return 2;
+  }
+  return 0;
+}
+extern "C" int pvo_debug_sched(int mode, void* tap, size_t tap_bytes, size_t slot_bytes) {
+  g_sched.no_marker = (mode >> 8) & 1; mode &= 255;
+  g_sched.mode = mode; g_sched.tap = static_cast<char*>(tap); g_sched.tap_bytes = tap_bytes; g_sched.slot = slot_bytes; g_sched.n = 0;
+  return 0;
+}
+extern "C" int pvo_debug_sched_taps(void) { return g_sched.n; }
+#endif
 
 extern "C" int pvo_side_stream(void** stream_out) {
   if (!stream_out) return PVO_EINVAL;

@@ -116,6 +116,13 @@ def projective_transform(poses, depths, intrinsics, ii, jj, jacobian=False, retu
     return x1, valid, (Ji, Jj, Jz.unsqueeze(-1))
 
 
+def projective_transform_unsup(poses, depths, intrinsics, ii, jj):
+    """coords, the points' inverse depth in frame j, valid (projective_ops.py:133-163): what the unsupervised occlusion
+    masks compare with frame j's own depth map"""
+    x1, valid = projective_transform(poses, depths, intrinsics, ii, jj, jacobian=False, return_depth=True)
+    return x1[..., 0:2], x1[..., 2:3], valid
+
+
 def induced_flow(poses, disps, intrinsics, ii, jj):
     """Optical flow induced by camera motion (projective_ops.py, `induced_flow`)."""
     ht, wd = disps.shape[2:]

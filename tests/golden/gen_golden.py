@@ -8,6 +8,7 @@ What is executed is the reference's code, imported from /root/reference/VO_Modul
   modules/gru.py, droid_net.py (DynamicUpdateModule sub-modules, GraphAgg) -> update_op.npz
   geom/graph_utils.py graph_to_edge_list                            -> graph_edges.npz
   factor_graph.py FactorGraph.update (with recorded callees)        -> factor_graph_glue_*.npz
+  geom/losses.py (every loss train.py combines, SSIM, unsupervised labels) -> train_losses.npz
 
 Three native dependencies of that Python cannot be built in this image (lietorch's C++
 extension needs Eigen/Core, which the vendored Eigen lacks; torch_scatter and the
@@ -825,6 +826,107 @@ def gen_depth_video():
     print("depth_video_calls: %d native calls" % len(log))
 
 
+def losses_case(seed=21):
+    """inputs of the training-loss fixture, regenerated from the seed by generator and test alike: a 4-frame clip at
+    48x64 (6x8 maps), 3 unrolled steps, the |i-j| <= 2 graph"""
+    from collections import OrderedDict
+    from pvo_amd.geom.se3 import SE3
+    g = torch.Generator().manual_seed(seed)
+    N, H, W, n = 4, 48, 64, 3
+    h, w = H // 8, W // 8
+    graph = OrderedDict((i, [j for j in range(N) if i != j and abs(i - j) <= 2]) for i in range(N))
+    E = sum(len(v) for v in graph.values())
+    xi = torch.tensor([0.05, 0.01, 0.02, 0.004, 0.01, -0.006])
+    Ps = SE3(torch.stack([SE3.exp(k * xi).data for k in range(N)])[None])
+    low = torch.rand(1, N, 6, 8, generator=g) * 0.6 + 0.4
+    disps = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=True)
+    intr = torch.tensor([50.0, 50.0, W / 2.0, H / 2.0]).view(1, 1, 4).repeat(1, N, 1)
+    images = torch.nn.functional.interpolate(torch.rand(N, 3, 12, 16, generator=g) * 255, size=(H, W), mode="bilinear")[None]
+    poses_est = [SE3(Ps.data + 0.02 * (n - k) * torch.randn(1, N, 7, generator=g) * torch.tensor([1, 1, 1, .2, .2, .2, 0.0])) for k in range(n)]
+    for G in poses_est:
+        G.data[..., 3:] = G.data[..., 3:] / G.data[..., 3:].norm(dim=-1, keepdim=True)
+    disps_est = [disps * (1 + 0.05 * (n - k) * torch.randn(1, N, H, W, generator=g)).clamp(0.5, 1.5) for k in range(n)]
+    residuals = [torch.randn(1, E, h, w, 2, generator=g) * (n - k) for k in range(n)]
+    full_flows = [torch.randn(1, E, h, w, 2, generator=g) * 1.5 for _ in range(n)]
+    masks = [torch.sigmoid(torch.randn(1, E, H, W, 2, generator=g)) for _ in range(n)]
+    gt_masks = (torch.rand(1, N, H, W, 1, generator=g) > 0.3).float()
+    gt_vals = (torch.rand(1, N, H, W, 1, generator=g) > 0.1).float()
+    fo = torch.cat([torch.randn(1, E // 2, h, w, 2, generator=g), (torch.rand(1, E // 2, h, w, 1, generator=g) > 0.2).float()], -1)
+    bo = torch.cat([torch.randn(1, E // 2, h, w, 2, generator=g), (torch.rand(1, E // 2, h, w, 1, generator=g) > 0.2).float()], -1)
+    aff = [torch.cat([1 + 0.1 * torch.randn(1, E, 1, generator=g), 0.5 + 0.05 * torch.randn(1, E, 1, generator=g)], -1) for _ in range(n)]
+    return dict(graph=graph, Ps=Ps, disps=disps, intr=intr, images=images, poses_est=poses_est, disps_est=disps_est,
+                residuals=residuals, full_flows=full_flows, masks=masks, gt_masks=gt_masks, gt_vals=gt_vals, fo=fo, bo=bo, aff=aff, N=N)
+
+
+def gen_losses():
+    """the reference's training losses (geom/losses.py) on losses_case(): every loss train.py can combine, with its
+    metrics.  Fixture-time stand-ins for the two lietorch groups the METRICS of geodesic_loss touch (losses.py:12-22,71):
+    Sim3(X) keeps X's translation / rotation and a unit scale, SO3(q).log() is the rotation part of SE3's log."""
+    import lietorch
+    from pvo_amd.geom.se3 import SE3
+
+    class Sim3:
+        def __init__(self, X):
+            self.data = torch.cat([X.data, torch.ones_like(X.data[..., :1])], -1)
+        def detach(self):
+            return self
+
+    class SO3:
+        def __init__(self, q):
+            self.q = q
+        def log(self):
+            return SE3(torch.cat([torch.zeros_like(self.q[..., :3]), self.q], -1)).log()[..., 3:]
+    lietorch.Sim3, lietorch.SO3 = Sim3, SO3
+    import importlib
+    import geom.losses as L
+    L = importlib.reload(L)
+    L.Sim3, L.SO3 = Sim3, SO3
+    c = losses_case()
+    out = {}
+
+    def put(name, res):
+        loss, metrics = res
+        out[name] = np.float64(float(loss))
+        for k, v in metrics.items():
+            out[name + "/" + k] = np.float64(v)
+    ssim = L.SSIM()
+    put("residual", L.residual_loss(c["residuals"]))
+    put("geodesic", L.geodesic_loss(c["Ps"], c["poses_est"], c["graph"], do_scale=False))
+    put("cam_flow", L.cam_flow_loss(c["Ps"], c["disps"], c["poses_est"], c["disps_est"], c["intr"], c["graph"]))
+    put("flow", L.flow_loss(c["fo"], c["bo"], c["full_flows"], c["graph"]))
+    put("photo_sup_ds", L.photo_loss(c["images"], c["full_flows"], c["gt_vals"], c["graph"], "semisup", ssim=None, aff_params=None, downsample=True))
+    put("photo_aff_ssim", L.photo_loss(c["images"], c["full_flows"], c["gt_vals"], c["graph"], "sup", ssim=ssim, aff_params=c["aff"], downsample=True, mean_mask=True))
+    put("photo_cam", L.photo_loss_cam(c["images"], c["poses_est"], c["disps_est"], c["intr"], c["graph"], "semisup", c["gt_masks"], ssim=ssim))
+    put("gt_label", L.gt_label_loss(c["gt_masks"], c["gt_vals"], c["masks"], c["graph"]))
+    put("gt_label_mean_mask", L.gt_label_loss(c["gt_masks"], c["gt_vals"], c["masks"], c["graph"], mean_mask=True))
+    put("ce_reg", L.ce_reg_loss(c["masks"]))
+    put("consistency", L.consistency_loss(c["masks"], c["N"], c["graph"]))
+    # the unsupervised mode's label / occlusion machinery (CPU tensors: the reference moves them there itself)
+    art = L.unsup_art_label(c["poses_est"], c["disps_est"], c["intr"].clone(), c["full_flows"], c["graph"], downsample=True)
+    for k, a in enumerate(art):
+        out["art_label_%d" % k] = a.numpy()
+    masks_cpu = c["masks"]
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self                  # (losses.py:445,447 call .cuda() on the labels)
+    try:
+        put("art_label", L.art_label_loss(art, masks_cpu, downsample=True))
+    finally:
+        torch.Tensor.cuda = real_cuda
+    for tag in ("ph_loss", "cam_ph_loss"):
+        ds = tag == "ph_loss"
+        vals = L.unsup_occ_vals(c["poses_est"], c["disps_est"], c["intr"].clone(), ds, c["graph"] if ds else None, tag)
+        for k, v in enumerate(vals):
+            out["occ_%s_%d" % (tag, k)] = v.numpy()
+        if ds:
+            dy = L.unsup_dy_vals(vals, c["gt_masks"][..., 0], c["graph"])
+            for k, v in enumerate(dy):
+                out["dy_%d" % k] = v.numpy()
+    x, y = c["images"][0, :2] / 255.0, c["images"][0, 1:3] / 255.0
+    out["ssim_map"] = ssim(x, y).numpy()
+    np.savez_compressed(os.path.join(HERE, "train_losses.npz"), **out)
+    print("train_losses.npz:", len(out), "entries")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -843,3 +945,4 @@ if __name__ == "__main__":
     gen_frontend()
     gen_motion_filter()
     gen_depth_video()
+    gen_losses()

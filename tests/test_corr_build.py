@@ -161,7 +161,7 @@ def _tile(level, th, tw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (24, 128), (30, 101), (16, 24), (20, 40), (11, 19)])
+@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (24, 128), (30, 101), (16, 24), (20, 40), (11, 19), (47, 156)])
 def test_tiled_pool_layout_is_bit_identical_to_row_major(cuda, dtype, H, W):
     """the 8x8-tiled build writes exactly the row-major pyramid's values at the tiled addresses, and the tiled
     lookup returns exactly what the row-major lookup returns (out-of-range, negative and border coordinates)"""
@@ -209,7 +209,7 @@ def test_tiled_entry_points_reject_unsupported_shapes(cuda):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (30, 101), (16, 24)])
+@pytest.mark.parametrize("H,W", [(48, 64), (8, 64), (30, 101), (16, 24), (47, 156)])
 def test_fused_lookup_encoder_matches_lookup_then_conv(cuda, dtype, H, W):
     """pvo_corr_lookup_encode_tiled == relu(conv1x1(lookup) + b): the lookup half is bit-exact (tested above), the
     encoder half is an fp32-accumulated GEMM rounded once to the 16-bit type"""
@@ -235,10 +235,11 @@ def test_fused_lookup_encoder_matches_lookup_then_conv(cuda, dtype, H, W):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,W", [(48, 64), (30, 101)])
+@pytest.mark.parametrize("H,W", [(48, 64), (30, 101), (47, 156)])
 def test_tiled_and_fused_lookup_against_the_oracle_at_full_map_size(cuda, H, W):
     """The kernels the bench times - the tiled pool's build, its lookup, and the lookup fused with corr_encoder[0] -
-    DIRECTLY against the CPU oracle at the S-B (48x64) and S-A (30x101, VKITTI2 through test_vo.py) map sizes, C = 128: the
+    DIRECTLY against the CPU oracle at the S-B (48x64), S-A (30x101, VKITTI2 through test_vo.py) and S-1 (47x156 = 376x1248 / 8,
+    VKITTI2 through test_vo2.py - BASELINE configs[0]) map sizes, C = 128: the
     oracle's lookup of the volume the pool holds
     (bit-exact; the volume itself is compared with oracle_corr_build to one unit in the last place, as for the row-major
     build above), and the encoder layer as an fp64 GEMM of the oracle's lookup."""

@@ -103,8 +103,8 @@ def test_pyramid_lookup_config_shapes(cuda, dt):
 
 
 def test_pyramid_lookup_full_size_sb(cuda):
-    """S-B (BASELINE configs[1]): 48x64 maps, fp16; 4 of the 36 edges against the oracle bit-exactly,
-    all 36 through a size-independent property (a constant volume returns the in-bounds bilinear mass)."""
+    """S-B (BASELINE configs[1]): 48x64 maps, fp16; ALL 36 edges against the oracle bit-exactly (round 2 compared 4),
+    and a size-independent property (a constant volume returns the in-bounds bilinear mass)."""
     from pvo_amd import droid_backends as db
     g = torch.Generator().manual_seed(0)
     N, H, W = 36, 48, 64
@@ -113,9 +113,8 @@ def test_pyramid_lookup_full_size_sb(cuda):
     coords = base[None] + torch.randn(N, H, W, 2, generator=g) * 4
     got = db.corr_pyramid_lookup([p.to(cuda) for p in pyr], coords.to(cuda), 3).cpu()
     assert tuple(got.shape) == (N, 196, H, W)
-    sel = [0, 7, 20, 35]
-    want = O.corr_pyramid_lookup([p[sel].numpy() for p in pyr], coords[sel].numpy(), 3)
-    assert np.array_equal(_bits(got[sel].numpy()), _bits(want))
+    want = O.corr_pyramid_lookup([p.numpy() for p in pyr], coords.numpy(), 3)
+    assert np.array_equal(_bits(got.numpy()), _bits(want))
     ones = [torch.ones_like(p).to(cuda) for p in pyr]
     o = db.corr_pyramid_lookup(ones, coords.to(cuda), 3).cpu().float()
     inside = (coords[..., 0] > 4) & (coords[..., 0] < W - 5) & (coords[..., 1] > 4) & (coords[..., 1] < H - 5)
@@ -134,3 +133,40 @@ def test_corr_index_backward_bit_exact(cuda, dt, r):
     got, = db.corr_index_backward(torch.from_numpy(vol.astype(npd)).to(cuda), torch.from_numpy(coords).to(cuda),
                                   torch.from_numpy(g).to(cuda), r)
     assert np.array_equal(_bits(got.cpu().numpy()), _bits(want))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_pyramid_lookup_full_size_s1(cuda, dt):
+    """S-1 (BASELINE configs[0], evaluation_scripts/test_vo2.py: VKITTI2 376x1248 / 8 = 47x156 maps, 2 frames, 2 edges):
+    the 4-level lookup in the reference's own volume layout at FULL map size against the oracle, bit-exact, fp32 (what
+    DroidNet.forward correlates in) and fp16."""
+    from pvo_amd import droid_backends as db
+    npd, td = DT[dt]
+    g = np.random.default_rng(5)
+    N, h1, w1 = 2, 47, 156
+    pyr = [g.standard_normal((N, h1, w1, h1 >> l, w1 >> l), dtype=np.float32).astype(npd) for l in range(4)]
+    coords = (np.stack(np.meshgrid(np.arange(w1), np.arange(h1)), -1)[None].astype(np.float32)
+              + g.uniform(-9, 9, (N, h1, w1, 2)).astype(np.float32))
+    coords[0, 0, :4] = np.array([[-3.0, -3.0], [w1 + 2.5, h1 + 2.5], [0.0, 0.0], [w1 - 1.0, h1 - 1.0]], np.float32)
+    want = O.corr_pyramid_lookup(pyr, coords, 3)
+    got = db.corr_pyramid_lookup([torch.from_numpy(p).to(cuda) for p in pyr], torch.from_numpy(coords).to(cuda), 3)
+    assert tuple(got.shape) == (N, 196, h1, w1)
+    assert np.array_equal(_bits(got.cpu().numpy()), _bits(want))
+
+
+@pytest.mark.parametrize("dt,N,H,W", [("f16", 2, 48, 64), ("f32", 1, 48, 64), ("f16", 1, 30, 101), ("f32", 1, 47, 156)])
+def test_corr_index_backward_bit_exact_at_full_map_size(cuda, dt, N, H, W):
+    """corr_index_backward (correlation_kernels.cu:73-124) at the S-B / S-A / S-1 map sizes (round 2 checked 6x9 only): the
+    dense volume gradient of level 0 and of level 2 (odd pooled sizes), bit for bit against the oracle."""
+    from pvo_amd import droid_backends as db
+    npd, td = DT[dt]
+    g = np.random.default_rng(H * W)
+    for l in (0, 2):
+        h2, w2 = H >> l, W >> l
+        coords = (np.stack(np.meshgrid(np.arange(W), np.arange(H)), 0)[None].astype(np.float32) / (1 << l)
+                  + g.uniform(-5, 5, (N, 2, H, W)).astype(np.float32)).astype(np.float32)
+        gr = g.standard_normal((N, 7, 7, H, W), dtype=np.float32).astype(npd)
+        want = O.corr_index_backward((N, H, W, h2, w2), coords, gr, 3)
+        vol = torch.empty(N, H, W, h2, w2, dtype=td, device=cuda)
+        got, = db.corr_index_backward(vol, torch.from_numpy(coords).to(cuda), torch.from_numpy(gr).to(cuda), 3)
+        assert np.array_equal(_bits(got.cpu().numpy()), _bits(want)), l

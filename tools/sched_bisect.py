@@ -1,0 +1,163 @@
+"""Which buffer differs first when the BA runs beside other kernels of the update?   (on the GPU box)
+
+    python tools/sched_bisect.py --build            # here: tools/_probe/libpvo_hip_sched.so  (-DPVO_SCHED_DEBUG)
+    python tools/sched_bisect.py [runs]             # on the GPU
+
+Round 2 found two stream arrangements of pvo_graph_update whose poses were not bitwise reproducible:
+the BA beside the upsampling-mask convolution (1 of ~290 two-update runs) and the first edge-block assembly launched before
+the wait on the eta head (13 of 13).  The debug build selects the arrangement (pvo_debug_sched: 0 shipped, 1 BA beside the
+mask convolution, 2 = 1 + assembly before the wait, 3 mask convolution after the BA) and copies the pose system and the whole
+BA workspace after every assembly+Schur and after every solve+back-substitution into a tap; runs are repeated from one fixed
+state and compared bit for bit with the first run of the same arrangement: final state, then the taps in order, and inside
+the first differing tap the named parts of the workspace (Eii, Eij, Cii, bz | Ei, Q, w | dx ...) and the BA's inputs.
+"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROBE_DIR = os.path.join(ROOT, "tools", "_probe")
+PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_sched.so")
+if "--build" in sys.argv:
+    from pvo_amd import build
+    build.build_hip()
+    os.makedirs(PROBE_DIR, exist_ok=True)
+    objs = []
+    for s in build.HIP_SOURCES:
+        if s in ("update_exec.hip", "ba.hip"):
+            obj = os.path.join(PROBE_DIR, "sched_" + s.replace(".hip", ".o"))
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_SCHED_DEBUG", "-c", os.path.join(build.CSRC, s), "-o", obj])
+        else:
+            obj = os.path.join(build.CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_LIB] + objs)
+    print(PROBE_LIB); sys.exit(0)
+
+import torch
+from pvo_amd import _lib
+_lib.LIB_PATH = PROBE_LIB
+import bench                                           # noqa: E402
+sys.argv = [sys.argv[0]] + [a for a in sys.argv[1:] if not a.startswith("--")]
+RUNS = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+N_UPD = int(os.environ.get("PVO_CHECK_UPDATES", "2"))
+# mode[:flags]  flags: s = events without the system-scope fence (hipEventDisableSystemFence), d = device-scope release
+# (hipEventReleaseToDevice), n = mode 1/2 without the event record on the side stream behind the mask convolution
+# h = "fence hammer": while the updates run, a third stream executes a train of default-flag event records (each a marker with a
+# system-scope cache writeback + invalidate) and nothing else
+MODES = os.environ.get("PVO_SCHED_MODES", "0,0:s,1:s,0:h,0:sh,1:sh").split(",")
+EVF = {"": 0x2, "s": 0x2 | 0x20000000, "d": 0x2 | 0x40000000, "n": 0x2, "h": 0x2, "sh": 0x2 | 0x20000000}
+hammer_stream = torch.cuda.Stream(dev)
+HAMMER = False
+dev = torch.device("cuda:0")
+lib = _lib.load()
+lib.pvo_debug_sched.restype = ctypes.c_int
+lib.pvo_debug_sched.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+lib.pvo_debug_sched_taps.restype = ctypes.c_int
+lib.pvo_debug_event_flags.restype = ctypes.c_int
+lib.pvo_debug_event_flags.argtypes = [ctypes.c_uint]
+lib.pvo_debug_ba_layout.restype = ctypes.c_int
+lib.pvo_debug_ba_layout.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
+
+video, graph = bench.make_window(dev, seed=0)
+names = ("net", "target_cam", "weight", "raw_mask", "delta_dy")
+state = {n: getattr(graph, n).clone() for n in names}
+p0, d0, dm0 = video.poses.clone(), video.disps.clone(), graph.damping.clone()
+graph.update(None, None, use_inactive=True)            # builds the per-edge-set cache (BA plan, workspaces)
+torch.cuda.synchronize()
+st = graph._cache["fused"]
+ba = st["ba"]
+E_ba, P = int(st["ii_ba"].shape[0]), None
+a = st["args"]
+P = a.t1 - a.t0
+F, HW = video.disps.shape[0], graph.ht * graph.wd
+lay = (ctypes.c_size_t * 16)()
+assert lib.pvo_debug_ba_layout(E_ba, P, F, HW, lay) == 0
+PARTS = ["kidx", "kx", "eptr", "eidx", "meta", "env", "Eii", "Eij", "Cii", "bz", "Ei", "Q", "w", "dx", "sys(ws)"]
+offs = list(lay)[:15] + [lay[15]]
+n6 = 6 * P
+sys_bytes = 8 * (n6 * n6 + n6)
+sys_pad = (sys_bytes + 255) & ~255
+ws_bytes = ba["ws"].numel()
+ws_skew = (-ba["ws"].data_ptr()) % 256                  # the library aligns the workspace base up to 256 bytes
+slot = (sys_pad + ws_bytes + 255) & ~255
+n_slots = 2 * 2 * N_UPD                                 # (itrs = 2) x (after local, after finish) x updates
+tap = torch.zeros(slot * n_slots, dtype=torch.uint8, device=dev)
+STAGE = ["assemble+schur", "solve+backsub"]
+
+
+def run(mode, with_tap=True):
+    for n in names:
+        getattr(graph, n).copy_(state[n])
+    video.poses.copy_(p0); video.disps.copy_(d0); graph.damping.copy_(dm0)
+    tap.zero_()
+    torch.cuda.synchronize()
+    lib.pvo_debug_sched(mode, tap.data_ptr() if with_tap else None, tap.numel(), slot)
+    if HAMMER:
+        evs = [torch.cuda.Event() for _ in range(int(os.environ.get("PVO_HAMMER_N", "400")))]
+        hammer_stream.wait_stream(torch.cuda.current_stream(dev))
+        for e in evs:
+            e.record(hammer_stream)
+    for _ in range(N_UPD):
+        graph.update(None, None, use_inactive=True)
+    torch.cuda.synchronize()
+    out = dict(net=graph.net.clone(), target=graph.target_cam.clone(), weight=graph.weight.clone(), raw_mask=graph.raw_mask.clone(),
+               damping=graph.damping.clone(), poses=video.poses.clone(), disps=video.disps.clone(),
+               target_ba=st["target_ba"].clone(), weight_ba=st["weight_ba"].clone())
+    return out, (tap.clone() if with_tap else None)
+
+
+def bits(t):
+    return t.view({1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[t.element_size()])
+
+
+def first_diff(ref_tap, got_tap):
+    for k in range(n_slots):
+        r, g = ref_tap[k * slot:(k + 1) * slot], got_tap[k * slot:(k + 1) * slot]
+        if torch.equal(r, g):
+            continue
+        upd, it, stage = k // 4, (k // 2) % 2, k % 2
+        what = []
+        if not torch.equal(r[:sys_bytes], g[:sys_bytes]):
+            d = (r[:sys_bytes].view(torch.int64) != g[:sys_bytes].view(torch.int64)).nonzero().flatten()
+            what.append("sys (%d of %d entries, first %d = row %d col %d)" % (d.numel(), sys_bytes // 8, d[0], d[0] // n6, d[0] % n6))
+        wr, wg = r[sys_pad + ws_skew:sys_pad + ws_bytes], g[sys_pad + ws_skew:sys_pad + ws_bytes]
+        for i, name in enumerate(PARTS):
+            lo, hi = offs[i], offs[i + 1]
+            if hi <= wr.numel() and not torch.equal(wr[lo:hi], wg[lo:hi]):
+                d = (wr[lo:hi].view(torch.int32) != wg[lo:hi].view(torch.int32)).nonzero().flatten()
+                fr, fg = wr[lo:hi].view(torch.float32)[d[:4]], wg[lo:hi].view(torch.float32)[d[:4]]
+                what.append("%s (%d words; first at %d: %s vs %s)" % (name, d.numel(), d[0], fr.tolist(), fg.tolist()))
+        return "update %d, iteration %d, after %s: %s" % (upd, it, STAGE[stage], "; ".join(what) or "padding only")
+    return None
+
+
+for spec in MODES:
+    mode, _, fl = spec.partition(":")
+    mode = int(mode) | (256 if fl == "n" else 0)
+    HAMMER = "h" in fl
+    assert lib.pvo_debug_event_flags(EVF[fl]) == 0
+    run(mode)
+    ref, ref_tap = run(mode)
+    bad = 0
+    for r in range(RUNS):
+        out, t = run(mode)
+        diff = [k for k in ref if not torch.equal(bits(out[k]), bits(ref[k]))]
+        fd = first_diff(ref_tap, t)
+        if fd and fd.endswith(": dx (42 words" + fd.split(": dx (42 words")[-1]) and "; " not in fd.split("after ")[-1] and "assemble" in fd:
+            fd = None          # (dx in front of the first solve of a run is the PREVIOUS run's: not a difference of this run)
+        if diff or fd:
+            bad += 1
+            if bad <= 6:
+                print("mode %s run %d: final state differs in [%s]; first tap: %s" % (
+                    spec, r, ", ".join("%s (max %.3g)" % (k, (out[k].float() - ref[k].float()).abs().max().item()) for k in diff), fd), flush=True)
+    # the same arrangement WITHOUT the tap copies (they change what runs beside what)
+    ref2, _ = run(mode, False)
+    bad2 = 0
+    for r in range(RUNS):
+        out, _ = run(mode, False)
+        bad2 += any(not torch.equal(bits(out[k]), bits(ref2[k])) for k in ref2)
+    # ... and against the shipped arrangement: the arrangement must not change a bit either
+    print("mode %s: %d of %d runs differ with the tap, %d of %d without" % (spec, bad, RUNS, bad2, RUNS), flush=True)
+    if spec == MODES[0]:
+        base = ref2
+    else:
+        d = [k for k in base if not torch.equal(bits(ref2[k]), bits(base[k]))]
+        print("mode %s vs mode %s (no tap): %s" % (spec, MODES[0], "bitwise equal" if not d else "DIFFERS in " + ", ".join(d)), flush=True)
