@@ -54,6 +54,16 @@ constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
 constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system lives DENSE in LDS (126*127*8 + 21*27*8 + 208 = 132.7 KB of the 143 KB the
                                         // solve kernel's static tables leave); beyond, the compact envelope form
 
+// tools/sched_bisect.py --build-fences: explicit agent-scope acquire at the start and release at the end of every BA kernel
+// (buffer_inv sc1 / buffer_wbl2 sc1), an experiment on where the cross-queue irreproducibility comes from
+#ifdef PVO_BA_FENCES
+#define BA_ACQ() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define BA_REL() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#else
+#define BA_ACQ()
+#define BA_REL()
+#endif
+
 struct Plan {            // int region of the workspace
   int* kidx;             // [F]   frame -> depth index, -1 if none
   int* kx;               // [F]   depth index -> frame
@@ -246,6 +256,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
     float* __restrict__ Eii, float* __restrict__ Eij, float* __restrict__ Cii, float* __restrict__ bz,
     long long* __restrict__ sys, int* __restrict__ meta, int HW, int wd, int t0, int P, int motion_only) {
   __shared__ float red[4][90];
+  BA_ACQ();
   const int e = blockIdx.y;
   const int ix = static_cast<int>(ii[e]), jx = static_cast<int>(jj[e]);
   EdgeGeom g;
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
       if (jok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pj + (t - 84), val, meta);
     }
   }
+  BA_REL();
 }
 
 // ---------------------------------------------------------------------------
@@ -481,8 +493,8 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
 }
 
 template <bool VEC4>
-__global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
-    Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
+__device__ __forceinline__ void ba_schur_body(
+    const Plan& pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
@@ -559,6 +571,18 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
       __syncthreads();
     }
   }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
+    Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
+    const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
+    float* __restrict__ Ei, const float* __restrict__ Eij,
+    float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
+    int HW, int t0, int P) {
+  BA_ACQ();
+  ba_schur_body<VEC4>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P);
+  BA_REL();
 }
 
 // ---------------------------------------------------------------------------
@@ -886,6 +910,7 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
   __shared__ int first[kMaxEnvBlocks];                                           // envelope: first non-zero block column per block row
   __shared__ int reach[kMaxEnvBlocks];                                           // ... and last block row that reaches a block column
   __shared__ int blocks_s;
+  BA_ACQ();
   BA_PROBE(0);
   if (threadIdx.x == 0) fail = 0;
   double* xrow = nullptr;                                                        // where the solution ends up
@@ -1008,13 +1033,14 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
     if (failed) meta[1] = 1;
     if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
   }
+  BA_REL();
 }
 
 // ---------------------------------------------------------------------------
 // backsub: dz = Q (w - sum_r E_r^T dx[pose(r)]), disps += dz
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ba_backsub_kernel(
-    Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ Ei, const float* __restrict__ Eij,
+__device__ __forceinline__ void ba_backsub_body(
+    const Plan& pl, const int64_t* __restrict__ jj, const float* __restrict__ Ei, const float* __restrict__ Eij,
     const float* __restrict__ Q, const float* __restrict__ w, const float* __restrict__ dx,
     float* __restrict__ disps, float* __restrict__ dz_out, int dz_rows, int HW, int t0, int P, int flags,
     int clamp_frames, float disp_min) {
@@ -1045,6 +1071,16 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
   if (pl.kx[k] < clamp_frames && d < disp_min) d = disp_min;
   disps[static_cast<long long>(pl.kx[k]) * HW + x] = d;
   if (dz_out && k < dz_rows) dz_out[static_cast<long long>(k) * HW + x] = dz;
+}
+
+__global__ __launch_bounds__(256) void ba_backsub_kernel(
+    Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ Ei, const float* __restrict__ Eij,
+    const float* __restrict__ Q, const float* __restrict__ w, const float* __restrict__ dx,
+    float* __restrict__ disps, float* __restrict__ dz_out, int dz_rows, int HW, int t0, int P, int flags,
+    int clamp_frames, float disp_min) {
+  BA_ACQ();
+  ba_backsub_body(pl, jj, Ei, Eij, Q, w, dx, disps, dz_out, dz_rows, HW, t0, P, flags, clamp_frames, disp_min);
+  BA_REL();
 }
 
 int check_common(int E, int F, int ht, int wd, int t0, int t1) {

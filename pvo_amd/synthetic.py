@@ -11,6 +11,7 @@ as test_vo.py:162-163 does with evo) and compared between the HIP path and the C
 import math
 
 import torch
+import torch.utils.data
 
 from .geom.se3 import SE3
 
@@ -109,3 +110,49 @@ def run_sequence(scene, video, frontend, operator, n_frames=None):
             operator.frame_of.pop(slot, None)
             operator.bind(video.counter - 1, k)
     return video.poses[:video.counter].detach().cpu(), [operator.frame_of.get(s, s) for s in range(video.counter)]
+
+
+class TrainClips(torch.utils.data.Dataset):
+    """Synthetic training clips in the item layout of the reference's VKITTI2 reader as train.py consumes it
+    (train.py:113-116, mode 'semisup'): images [N,3,H,W] (0..255), poses [N,7] world-to-camera, disps [N,H,W], intrinsics
+    [N,4] at image resolution, gt_masks [N,H,W,1] (1 static), gt_vals [N,H,W,1], segments [N,H,W].  The world is
+    PlaneScene's planes with a texture that is a function of the 3-D surface point, so photometric and geometric losses
+    are consistent; a rectangle that carries its own texture phase per frame plays the dynamic object.  No dataset can be
+    read in this environment (datasets/ holds a README only); `crop_size` defaults to train.py's [200, 400] (S-T)."""
+
+    def __init__(self, n_frames=6, crop_size=(200, 400), length=64, seed=0, step=0.05):
+        self.n, (self.ht, self.wd), self.length, self.seed, self.step = n_frames, crop_size, length, seed, step
+
+    def __len__(self):
+        return self.length
+
+    def _texture(self, pts, phase):
+        k = torch.tensor([[2.1, 0.7, 1.3], [0.9, 2.6, 0.4], [1.7, 1.1, 2.3]])
+        s = torch.sin(pts @ k.T * 3.0 + phase) * torch.cos(pts @ k.flip(0).T * 1.7)
+        return 127.5 + 110.0 * s                                                         # [H,W,3]
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(self.seed * 100003 + idx)
+        scene = PlaneScene(self.ht, self.wd, self.n, seed=idx, step=self.step * (0.6 + 0.8 * torch.rand(1, generator=g).item()))
+        ht, wd = self.ht, self.wd
+        fx, fy, cx, cy = scene.intr.tolist()
+        y, x = torch.meshgrid(torch.arange(ht).float(), torch.arange(wd).float(), indexing="ij")
+        rays = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(x), torch.zeros_like(x)], -1)
+        images, masks = [], []
+        y0, x0 = int(ht * 0.55), int(wd * (0.2 + 0.5 * torch.rand(1, generator=g).item()))
+        for k in range(self.n):
+            Gi = SE3(scene.poses[k]).inv()
+            pts_c = rays.clone()
+            pts_c[..., :3] = rays[..., :3] / scene.disps[k][..., None]                    # camera-frame points
+            pts_c[..., 3] = 1.0
+            pts_w = Gi.act(pts_c)[..., :3]
+            img = self._texture(pts_w, torch.tensor([0.0, 1.0, 2.0]))
+            m = torch.ones(ht, wd, 1)
+            ys, xs = slice(y0, y0 + ht // 6), slice(x0 + 3 * k, x0 + 3 * k + wd // 8)     # the moving patch
+            img[ys, xs] = self._texture(pts_w[ys, xs] * 2.0, torch.tensor([0.5 * k, 1.0, 3.0]))
+            m[ys, xs] = 0.0
+            images.append(img.permute(2, 0, 1).clamp(0, 255))
+            masks.append(m)
+        segments = torch.zeros(self.n, ht, wd, dtype=torch.int32)
+        return (torch.stack(images), scene.poses.clone(), scene.disps.clone(), scene.intr[None].repeat(self.n, 1),
+                torch.stack(masks), torch.ones(self.n, ht, wd, 1), segments)

@@ -927,6 +927,43 @@ def gen_losses():
     print("train_losses.npz:", len(out), "entries")
 
 
+def frame_graph_case(seed=31, N=7, H=64, W=96):
+    """a clip for the training-time frame graph (shared by generator and test): poses drift unevenly so that some
+    non-neighbours are co-visible and others are not"""
+    from pvo_amd.geom.se3 import SE3
+    g = torch.Generator().manual_seed(seed)
+    xi = torch.tensor([0.09, 0.01, 0.03, 0.004, 0.02, -0.006])
+    steps = torch.cumsum(torch.rand(N, generator=g) * 1.5, 0)
+    poses = torch.stack([SE3.exp(float(t) * xi).data for t in steps])[None]
+    low = torch.rand(1, N, 4, 6, generator=g) * 0.6 + 0.3
+    disps = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=True)
+    intr = torch.tensor([80.0, 80.0, W / 2.0, H / 2.0]).view(1, 1, 4).repeat(1, N, 1)
+    return poses, disps, intr
+
+
+def gen_frame_graph():
+    """geom/graph_utils.py build_frame_graph + data_readers/rgbd_utils.py compute_distance_matrix_flow (the reference
+    calls .cuda() on its inputs: a no-op at fixture time)"""
+    import geom.graph_utils as gu
+    from data_readers import rgbd_utils as ru
+    poses, disps, intr = frame_graph_case()
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        out = {}
+        for need_inv in (False, True):
+            d = ru.compute_distance_matrix_flow(poses[0].numpy(), disps[0][:, 3::8, 3::8].numpy(), (intr[0] / 8.0).numpy(), need_inv)
+            out["dist_inv%d" % need_inv] = d
+            for num, thresh in ((20, 24.0), (40, 24.0), (30, 6.0)):
+                g = gu.build_frame_graph(poses, disps, intr, num=num, thresh=thresh, need_inv=need_inv)
+                ii, jj, _ = gu.graph_to_edge_list(g)
+                out["edges_inv%d_%d_%g" % (need_inv, num, thresh)] = torch.stack([ii, jj]).numpy()
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(HERE, "frame_graph.npz"), **out)
+    print("frame_graph.npz:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -946,3 +983,4 @@ if __name__ == "__main__":
     gen_motion_filter()
     gen_depth_video()
     gen_losses()
+    gen_frame_graph()

@@ -93,3 +93,23 @@ def test_losses_are_differentiable_through_the_network_outputs(case):
     loss.backward()
     for group in (res, flows, masks, pd, de):
         assert all(t.grad is not None and torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0 for t in group)
+
+
+def test_training_frame_graph_matches_the_reference():
+    """build_frame_graph / compute_distance_matrix_flow (geom/graph_utils.py:37-68, data_readers/rgbd_utils.py:110-152) on
+    frame_graph_case(): the flow-distance matrix and the chosen edges, in order, for three (num, thresh) settings and both
+    pose conventions"""
+    import gen_golden as G
+    from pvo_amd.geom.graph_utils import build_frame_graph, compute_distance_matrix_flow, graph_to_edge_list
+    ref = np.load(os.path.join(HERE, "golden", "frame_graph.npz"))
+    poses, disps, intr = G.frame_graph_case()
+    for need_inv in (False, True):
+        d = compute_distance_matrix_flow(poses[0], disps[0][:, 3::8, 3::8], intr[0] / 8.0, need_inv).numpy()
+        want = ref["dist_inv%d" % need_inv]
+        assert np.array_equal(np.isinf(d), np.isinf(want))
+        fin = np.isfinite(want)
+        assert np.allclose(d[fin], want[fin], rtol=1e-4, atol=1e-4)
+        for num, thresh in ((20, 24.0), (40, 24.0), (30, 6.0)):
+            g = build_frame_graph(poses, disps, intr, num=num, thresh=thresh, need_inv=need_inv)
+            ii, jj, _ = graph_to_edge_list(g)
+            assert np.array_equal(torch.stack([ii, jj]).numpy(), ref["edges_inv%d_%d_%g" % (need_inv, num, thresh)]), (need_inv, num, thresh)

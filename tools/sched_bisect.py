@@ -15,16 +15,18 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROBE_DIR = os.path.join(ROOT, "tools", "_probe")
-PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_sched.so")
-if "--build" in sys.argv:
+FENCES = "--build-fences" in sys.argv or os.environ.get("PVO_BA_FENCES") == "1"
+PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_sched_fences.so" if FENCES else "libpvo_hip_sched.so")
+if "--build" in sys.argv or "--build-fences" in sys.argv:
     from pvo_amd import build
     build.build_hip()
     os.makedirs(PROBE_DIR, exist_ok=True)
     objs = []
     for s in build.HIP_SOURCES:
         if s in ("update_exec.hip", "ba.hip"):
-            obj = os.path.join(PROBE_DIR, "sched_" + s.replace(".hip", ".o"))
-            subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_SCHED_DEBUG", "-c", os.path.join(build.CSRC, s), "-o", obj])
+            obj = os.path.join(PROBE_DIR, ("schedf_" if FENCES else "sched_") + s.replace(".hip", ".o"))
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_SCHED_DEBUG"] + (["-DPVO_BA_FENCES"] if FENCES else []) +
+                                  ["-c", os.path.join(build.CSRC, s), "-o", obj])
         else:
             obj = os.path.join(build.CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
@@ -44,9 +46,9 @@ N_UPD = int(os.environ.get("PVO_CHECK_UPDATES", "2"))
 # system-scope cache writeback + invalidate) and nothing else
 MODES = os.environ.get("PVO_SCHED_MODES", "0,0:s,1:s,0:h,0:sh,1:sh").split(",")
 EVF = {"": 0x2, "s": 0x2 | 0x20000000, "d": 0x2 | 0x40000000, "n": 0x2, "h": 0x2, "sh": 0x2 | 0x20000000}
-hammer_stream = torch.cuda.Stream(dev)
 HAMMER = False
 dev = torch.device("cuda:0")
+hammer_stream = torch.cuda.Stream(dev)
 lib = _lib.load()
 lib.pvo_debug_sched.restype = ctypes.c_int
 lib.pvo_debug_sched.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
