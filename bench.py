@@ -342,7 +342,7 @@ def edge_sharded_leg(device, rank, world, steps=3):
     g = torch.Generator().manual_seed(3)
     graph.target_cam = graph.target_cam + 0.5 * torch.randn(graph.target_cam.shape, generator=g).to(device)
     graph.weight = torch.rand(graph.weight.shape, generator=g).to(device)
-    sharded = ShardedBA()
+    sharded = ShardedBA(structure=(ii, jj))        # envelope all-reduce: every rank knows the whole edge list
     if not ii_l:
         raise RuntimeError("rank %d owns no edges" % rank)
     poses0, disps0 = video.poses.clone(), video.disps.clone()

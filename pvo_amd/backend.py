@@ -46,8 +46,9 @@ class DroidBackend:
             from .parallel import ShardedBA, partition_by_source
             owner, _ = partition_by_source(graph._ii_h, torch.distributed.get_world_size())
             rank = torch.distributed.get_rank()
+            whole = (list(graph._ii_h), list(graph._jj_h))               # the structure of the all-reduced pose system
             graph.rm_factors([o != rank for o in owner])
-            sharded, before = ShardedBA(), self.video.disps.clone()
+            sharded, before = ShardedBA(structure=whole), self.video.disps.clone()
         if len(graph._ii_h) > 65535:
             # include/pvo_hip.h "Limits": an edge index is a grid's y / z coordinate.  (The reference has no such bound;
             # a 64-keyframe window with radius 3 has 372 edges, a 1000-keyframe sequence at ~50 edges per frame would need

@@ -22,7 +22,13 @@ struct SideCtx { hipStream_t side; hipEvent_t fork, join, mid; bool ok; };
 // still allocates no device memory)
 // (events with hipEventReleaseToDevice instead of the default system-scope release: the ~6.5 us a record or a satisfied
 // wait costs on the launch stream did not change)
-unsigned g_event_flags = hipEventDisableTiming;
+// The library's fork / join / mid events carry NO system-scope fence (hipEventDisableSystemFence): they order work between two
+// streams of one device, where the producing kernel's own end-of-kernel release and the consuming kernel's acquire already
+// make the data visible; the default flags add a system-scope cache writeback + invalidate to every record.  Measured
+// (tools/sched_bisect.py, profiles/r03_sched_bisect.txt): bit-identical results over 1500 two-update runs either way, the update
+// 1 % shorter without the fences - and cache-maintenance operations in flight beside a resident kernel of ANOTHER queue are
+// exactly what made the BA irreproducible in the overlapped arrangements.
+unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;
 SideCtx g_side_ctx[64] = {};
 SideCtx* side_ctx() {
   SideCtx* ctx = g_side_ctx;
@@ -33,6 +39,8 @@ SideCtx* side_ctx() {
     // HIGH priority: in both places it is used the side stream carries the chain the launch stream ends up waiting for
     // (GraphAgg beside the heads: conv1 84 us instead of 105 when its workgroups are dispatched first; update 757 -> 728 us)
     int least = 0, greatest = 0;
+    if (const char* e = getenv("PVO_EVENT_SYSTEM_FENCE"))       // A/B switch for the measurement in DESIGN.md section 5
+      g_event_flags = (e[0] == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
     if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.fork, g_event_flags) != hipSuccess) return nullptr;

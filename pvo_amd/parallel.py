@@ -43,30 +43,74 @@ def local_eta_rows(ii_all, ii_local, t0, t1):
     return [pos[f] for f in kx_local]
 
 
+def envelope_structure(ii_all, jj_all, t0, t1):
+    """first[b] for every free pose b in [t0, t1): the lowest free pose its block row of the reduced pose system can couple
+    with - STRUCTURALLY, from the global edge list, so that every rank derives the same table without communication.
+    Two poses couple through an edge between them (the Hii/Hij/Hjj blocks of droid_kernels.cu:309-357) or through a depth
+    map both observe: source k and every target of an edge leaving k (the Schur terms, :1236-1246)."""
+    P = t1 - t0
+    first = list(range(P))
+    groups = {}
+    for i, j in zip(ii_all, jj_all):
+        groups.setdefault(int(i), {int(i)}).add(int(j))
+    for members in groups.values():
+        ps = sorted(m - t0 for m in members if t0 <= m < t1)
+        for p in ps[1:]:
+            first[p] = min(first[p], ps[0])
+    return first
+
+
+def envelope_index(first, device):
+    """flat positions inside `sys` = [(6P)^2 row-major | 6P rhs] of the entries that are all-reduced: the lower-triangle
+    blocks (b, first[b] .. b) and the right-hand side.  Cholesky reads the lower triangle only and creates no fill outside
+    the envelope, and every entry outside it is a structural zero on EVERY rank - so reducing just these entries gives the
+    same factorisation, bit for bit, as reducing the dense system (63 free poses of a radius-3 graph: 127 KB instead of
+    1.15 MB)."""
+    P = len(first)
+    n6 = 6 * P
+    idx = []
+    for b in range(P):
+        for cb in range(first[b], b + 1):
+            for r in range(6):
+                base = (6 * b + r) * n6 + 6 * cb
+                idx.extend(range(base, base + 6))
+    idx.extend(range(n6 * n6, n6 * n6 + n6))
+    return torch.tensor(idx, dtype=torch.long, device=device)
+
+
 class ShardedBA:
     """Dense BA over this rank's edge shard.  `backend` supplies the three native steps
     (default: pvo_amd.droid_backends); the oracle-backed variant in tests/ exercises the same
     partition / reduction logic on CPU with gloo."""
 
-    def __init__(self, group=None, backend=None):
+    def __init__(self, group=None, backend=None, structure=None):
         self.group = group
+        self.structure = structure      # (ii_all, jj_all) of the whole graph: default of ba()'s `structure`
         if backend is None:
             from . import droid_backends as backend
         self.db = backend
         self._ws = None
         self._plan_key = None
+        self._env_idx = None
+        self.always_pack = False        # tests: run the pack / unpack pair on a single rank too
+        self.last_message_bytes = 0
 
     def ba(self, poses, disps, intrinsics, targets, weights, eta_local, ii_local, jj_local, t0, t1,
-           itrs=2, lm=1e-4, ep=0.1, motion_only=False, plan_key=None):
+           itrs=2, lm=1e-4, ep=0.1, motion_only=False, plan_key=None, structure=None):
         """poses/disps updated in place (disps: only the maps this rank owns change).
         targets/weights/ii/jj/eta_local describe THIS RANK's edges (see partition_by_source,
         local_eta_rows).  Returns dx [P,6] of the last step.
         plan_key: any hashable that identifies the edge set (e.g. (id(graph), graph._version)); while it stays the same
-        the BA plan and the system buffer of the previous call are reused instead of rebuilt."""
+        the BA plan and the system buffer of the previous call are reused instead of rebuilt.
+        structure: (ii_all, jj_all) host lists of the WHOLE graph's edges (every rank knows them: the partition is computed
+        from them).  When given, only the envelope of the pose system is all-reduced (`envelope_index`) instead of the
+        dense (6P)^2 matrix; the result is bit-identical."""
         F, ht, wd = disps.shape
         P = t1 - t0
         E = ii_local.shape[0]
         n6 = 6 * P
+        if structure is None:
+            structure = self.structure
         if self._ws is None or self._ws[0] != (E, P, F, ht * wd):
             self._ws = ((E, P, F, ht * wd), self.db.ba_workspace(E, P, F, ht * wd, disps.device))
         ws = self._ws[1]
@@ -76,6 +120,10 @@ class ShardedBA:
             self._sys = torch.zeros(n6 * n6 + n6, dtype=getattr(self.db, "BA_SYS_DTYPE", torch.float64), device=disps.device)
             self.db.ba_plan(ii_local, jj_local, F, ht * wd, K_eta, t0, t1, ws)
             self._plan_key, self._plan_edges = key, (ii_local, jj_local)
+            self._env_idx = None
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if structure is not None and self._env_idx is None and (multi or self.always_pack):
+            self._env_idx = envelope_index(envelope_structure(structure[0], structure[1], t0, t1), disps.device)
         sys_buf = self._sys
         dx = None
         ii_local, jj_local = self._plan_edges          # the tensors the plan was built from
@@ -84,8 +132,15 @@ class ShardedBA:
             kw = {"sys_is_zero": True} if fixed and it > 0 else {}
             self.db.ba_local(poses, disps, intrinsics, targets, weights, eta_local, ii_local, jj_local, t0, t1,
                              motion_only, sys_buf, ws, **kw)
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if structure is not None and self._env_idx is not None:
+                msg = sys_buf.index_select(0, self._env_idx)                       # envelope blocks + rhs: one gather
+                if multi:
+                    dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=self.group)   # the one collective per step
+                sys_buf.index_copy_(0, self._env_idx, msg)
+                self.last_message_bytes = msg.numel() * msg.element_size()
+            elif multi:
                 dist.all_reduce(sys_buf, op=dist.ReduceOp.SUM, group=self.group)   # the one collective per step
+                self.last_message_bytes = sys_buf.numel() * sys_buf.element_size()
             dx, _ = self.db.ba_finish(poses, disps, sys_buf, ii_local, jj_local, t0, t1, lm, ep, motion_only, ws)
         return dx
 

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.dirname(__file__))
 from oracle import oracle as O
-from pvo_amd.parallel import ShardedBA, local_eta_rows, partition_by_source
+from pvo_amd.parallel import ShardedBA, envelope_index, envelope_structure, local_eta_rows, partition_by_source
 
 
 class OracleBackend:
@@ -39,6 +39,7 @@ class OracleBackend:
         # iteration with dx forced to the global solution: depth back-substitution is rank-local
         n = 6 * (t1 - t0)
         A = sys_buf[:n * n].view(n, n).numpy().copy(); b = sys_buf[n * n:].numpy().copy()
+        A = np.tril(A) + np.tril(A, -1).T              # a Cholesky reads the lower triangle only (what the envelope all-reduce completes)
         A[np.diag_indices(n)] += ep + lm * np.diag(A)
         dx = np.linalg.solve(A, b).astype(np.float32).reshape(-1, 6)
         intr, targets, weights, eta = ws["args"]
@@ -67,6 +68,14 @@ def _worker(rank, world, port, out):
     sb.ba(poses, disps, s["intr"], s["target"][mine].contiguous(), s["weight"][mine].contiguous(),
           s["eta"][rows].contiguous(), ii.contiguous(), jj.contiguous(), s["t0"], s["t1"], itrs=2)
     sb.sync_disps(disps, before)
+    # the same with only the ENVELOPE of the pose system all-reduced (structure from the global edge list)
+    poses2, disps2 = s["poses"].clone(), s["disps"].clone()
+    sb2 = ShardedBA(backend=OracleBackend(), structure=(s["ii"].tolist(), s["jj"].tolist()))
+    sb2.ba(poses2, disps2, s["intr"], s["target"][mine].contiguous(), s["weight"][mine].contiguous(),
+           s["eta"][rows].contiguous(), ii.contiguous(), jj.contiguous(), s["t0"], s["t1"], itrs=2)
+    sb2.sync_disps(disps2, before)
+    assert 0 < sb2.last_message_bytes <= sb.last_message_bytes
+    assert torch.equal(poses2, poses) and torch.equal(disps2, disps)      # bit-identical to the dense all-reduce
     out[rank] = (poses.numpy().copy(), disps.numpy().copy())
     dist.destroy_process_group()
 
@@ -80,6 +89,33 @@ def test_partition_is_deterministic_and_balanced():
     assert abs(loads[0] - loads[1]) <= 2
     assert local_eta_rows([0, 1, 2, 3], [0, 2], 1, 4) == [0, 1, 2, 3]      # window frames are always present
     assert local_eta_rows([0, 5, 6], [6], 1, 4) == [1, 2, 3, 5]
+
+
+def test_envelope_structure_covers_every_coupling_of_the_pose_system():
+    """first[b] from the edge list must bound the numeric envelope of the assembled + Schur-reduced system (oracle, dense):
+    window graphs, long chains with loop closures, fixed poses below t0"""
+    from test_geom_ba_gpu import _scene
+    rng = np.random.default_rng(0)
+    for seed, P, radius, t0, extra in ((1, 6, 2, 1, []), (2, 9, 3, 2, [(1, 7), (7, 1)]), (3, 12, 1, 1, [(0, 11), (11, 0), (3, 9)])):
+        s = _scene(seed, P, 6, 8, radius, t0)
+        ii = s["ii"].tolist() + [e[0] for e in extra]; jj = s["jj"].tolist() + [e[1] for e in extra]
+        E = len(ii)
+        tgt = torch.cat([s["target"], s["target"][:len(extra)]]); wgt = torch.cat([s["weight"], s["weight"][:len(extra)]])
+        r = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), tgt.numpy(), wgt.numpy(), s["eta"].numpy(),
+                 np.asarray(ii), np.asarray(jj), s["t0"], s["t1"], 1, 0.0, 1.0, want_sys=True)
+        n = 6 * (s["t1"] - s["t0"])
+        A = r["sys"][:n * n].reshape(n, n)
+        first = envelope_structure(ii, jj, s["t0"], s["t1"])
+        assert len(first) == n // 6 and all(0 <= f <= b for b, f in enumerate(first))
+        blk = np.abs(A).reshape(n // 6, 6, n // 6, 6).max(axis=(1, 3)) > 0
+        for b in range(n // 6):
+            cols = np.nonzero(blk[b, :b + 1])[0]
+            assert cols.min() >= first[b], (seed, b, cols.min(), first[b])
+        idx = envelope_index(first, "cpu")
+        assert idx.numel() == 36 * sum(b - f + 1 for b, f in enumerate(first)) + n and idx.unique().numel() == idx.numel()
+        lower = np.tril(A)
+        keep = np.zeros(n * n + n, bool); keep[idx.numpy()] = True
+        assert not lower.reshape(-1)[~keep[:n * n]].any()                 # nothing of the lower triangle is left out
 
 
 def test_two_rank_sharded_ba_equals_single_process_gloo():
@@ -150,3 +186,24 @@ def test_ba_is_bitwise_reproducible(cuda):
         outs.append((poses.clone(), disps.clone()))
     for p, q in outs[1:]:
         assert torch.equal(p, outs[0][0]) and torch.equal(q, outs[0][1])
+
+
+@pytest.mark.gpu
+def test_envelope_allreduce_path_is_bit_identical_on_the_hip_solver(cuda):
+    """ShardedBA with the pack -> (all-reduce) -> unpack of the envelope forced on one rank, 64-keyframe radius-3 graph with a
+    loop closure (the envelope Cholesky's compact LDS path): poses and depths bit-identical to the dense message."""
+    from test_geom_ba_gpu import _scene
+    s = _scene(13, 64, 16, 24, 3, 1)
+    d = lambda t: t.to(cuda)
+    outs = []
+    for structure in (None, (s["ii"].tolist(), s["jj"].tolist())):
+        poses, disps = d(s["poses"].clone()), d(s["disps"].clone())
+        sb = ShardedBA(structure=structure)
+        sb.always_pack = True
+        sb.ba(poses, disps, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]), s["t0"], s["t1"], itrs=2,
+              lm=1e-5, ep=1e-2)
+        outs.append((poses.clone(), disps.clone(), sb.last_message_bytes))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[0][0] - d(s["poses"])).abs().max() > 1e-4
+    n6 = 6 * (s["t1"] - s["t0"])
+    assert 0 < outs[1][2] < 0.2 * 8 * (n6 * n6 + n6)                      # 63 free poses, radius 3: ~12 % of the dense message
