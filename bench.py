@@ -21,9 +21,12 @@ N > 1: one process per GPU (torch.distributed, RCCL); every rank tracks its own 
 Extra objects on the JSON line: "roofline" for the dominant hand-written HBM-bound kernel (the fused 4-level lookup),
 "roofline_wide_conv" (matrix-core roofline of the wide 3x3 convolution, the kernel with the largest share of the step,
 with the shader clock the chip sustains under it and inside a step: pvo_clock_probe), "stage_us_in_step", "host",
-"workload_S_A" (the reference driver's 30x101 maps), "edge_sharded" (64-keyframe global update, edges sharded over the
-ranks, one integer all-reduce per Gauss-Newton step), "cpu_baseline" (the reference's CPU formulations timed on this host,
-rank 0, N=1) and "ate_rmse" (synthetic closed loop).  DESIGN.md section 5 describes each.
+"workload_S_A" (the reference driver's 30x101 maps), "workload_S_1" (configs[0]: one tools/test_vo2.py clip at 47x156 maps),
+"train_step" (configs[4]: one tools/train.py optimizer step at S-T size, bf16 volume), "edge_sharded" (64-keyframe global
+update, edges sharded over the ranks, one integer all-reduce of the pose system's envelope per Gauss-Newton step; at N > 1
+with the one-GPU time of the same job and the speed-up against it), "cpu_baseline" (the reference's CPU formulations timed on
+this host, rank 0, N=1), "ate_rmse" (synthetic closed loop; ground-truth correspondences stand in for the learned operator -
+no weights exist here) and "chained_update_drift" (six native updates against the CPU fp32 chain).  DESIGN.md section 5.
 """
 import argparse
 import json
@@ -322,97 +325,261 @@ def workload_sa(device, steps):
             "graph_updates_per_s": steps * 6 / elapsed, "roofline": lookup_roofline(E, 30 * 101, in_step)}
 
 
+def workload_s1(device, reps=3):
+    """BASELINE.json configs[0] (S-1) on the GPU: one clip of tools/test_vo2.py - 2 frames at 376x1248 (47x156 maps), 2 edges,
+    DroidNet.forward with num_steps=15, fixedp=2 (volume build + 15 four-level lookups on the HIP kernels, fp32; a
+    depth-only BA), random-init weights.  Wall time per clip, first clip excluded."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import test_vo2 as T
+    from pvo_amd.droid_net import DroidNet
+    from pvo_amd.synthetic import TrainClips
+    torch.manual_seed(0)
+    net = DroidNet().to(device).eval()
+    clips = TrainClips(2, (376, 1248), length=reps + 1, seed=5, step=0.03)
+    ts = []
+    for k in range(reps + 1):
+        images, poses, disps, intr, gt_masks, gt_vals, _ = [x[None].to(device) for x in clips[k]]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = T.estimate_clip(net, images, poses, intr, gt_vals, num_steps=15)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    # the lookup alone at this map size, in the reference's volume layout (fp32, what DroidNet.forward correlates in)
+    from pvo_amd import droid_backends as db
+    pyr = [torch.randn(2, 47, 156, 47 >> l, 156 >> l, device=device) for l in range(4)]
+    c = (torch.stack(torch.meshgrid(torch.arange(156.0), torch.arange(47.0), indexing="xy"), -1)[None].repeat(2, 1, 1, 1).to(device)
+         + 4 * torch.randn(2, 47, 156, 2, device=device)).contiguous()
+    for _ in range(3):
+        db.corr_pyramid_lookup(pyr, c, 3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        db.corr_pyramid_lookup(pyr, c, 3)
+    e1.record(); torch.cuda.synchronize()
+    lk_us = e0.elapsed_time(e1) / 20 * 1e3
+    lk_bytes = 2 * 47 * 156 * (4 * 64 * 4 + 8 + 196 * 4)
+    ms = 1e3 * sorted(ts[1:])[len(ts[1:]) // 2]
+    return {"workload": "S-1: BASELINE.json configs[0] on the GPU (tools/test_vo2.py clip: 2 frames 376x1248 -> 47x156 maps, 2 edges, "
+                        "num_steps=15, fixedp=2, fp32, random-init weights)", "ms_per_clip": ms, "clips_per_s": 1e3 / ms,
+            "lookup_fp32_us": lk_us, "lookup_fp32_gbps": lk_bytes / (lk_us * 1e-6) / 1e9,
+            "final_depth_change_mean": float((out["disps"] - 1.0).abs().mean())}
+
+
+def train_step_leg(device, reps=3):
+    """BASELINE.json configs[4] (S-T) at N = 1: one optimizer step of tools/train.py - 6 frames at 200x400 (25x50 maps), the
+    20-edge co-visibility graph, 15 unrolled updates, semi-supervised objective, bf16 correlation volume (HIP lookup
+    forward + backward), fp32 operator and BA, Adam.  Median wall time of `reps` steps after one warm-up step, and the
+    lookup-backward kernel alone at this size."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train as T
+    from pvo_amd import droid_backends as db
+    from pvo_amd.droid_net import DroidNet
+    from pvo_amd.geom import losses as L
+    from pvo_amd.geom.graph_utils import build_frame_graph
+    from pvo_amd.geom.se3 import SE3
+    from pvo_amd.synthetic import TrainClips
+    args = T.parse_args(["--device", "cuda"])
+    torch.manual_seed(0)
+    net = DroidNet().to(device).train()
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr, weight_decay=1e-5)
+    ssim = L.SSIM().to(device)
+    clips = TrainClips(6, (200, 400), length=reps + 1)
+    ts, loss = [], None
+    for k in range(reps + 1):
+        images, poses, disps, intr, gt_masks, gt_vals, segments = [x[None].to(device) for x in clips[k]]
+        graph = build_frame_graph(poses, disps, intr, num=20, need_inv=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        Ps = SE3(poses)
+        Gs = SE3.IdentityLike(Ps)
+        Gs.data[:, 0] = Ps.data[:, 0]; Gs.data[:, 1:] = Ps.data[:, [1]]
+        out = net(Gs, images, torch.ones_like(disps[:, :, 3::8, 3::8]), intr / 8.0, graph, num_steps=15, fixedp=2, ret_flow=True,
+                  downsample=True, segments=segments, corr_dtype=torch.bfloat16)
+        loss, _ = T.objective(args, L, out, (images, Ps, disps, intr, gt_masks, gt_vals), graph, ssim, 0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), args.clip)
+        opt.step()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    E = sum(len(v) for v in graph.values())
+    vol = torch.empty(E, 25, 50, 25, 50, dtype=torch.bfloat16, device=device)
+    c = (torch.stack(torch.meshgrid(torch.arange(50.0), torch.arange(25.0), indexing="xy"), 0)[None].repeat(E, 1, 1, 1).to(device)
+         + 3 * torch.randn(E, 2, 25, 50, device=device)).contiguous()
+    gr = torch.randn(E, 7, 7, 25, 50, device=device).to(torch.bfloat16)
+    for _ in range(3):
+        db.corr_index_backward(vol, c, gr, 3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        db.corr_index_backward(vol, c, gr, 3)
+    e1.record(); torch.cuda.synchronize()
+    bw_us = e0.elapsed_time(e1) / 20 * 1e3
+    ms = 1e3 * sorted(ts[1:])[len(ts[1:]) // 2]
+    return {"workload": "S-T: BASELINE.json configs[4] at N=1 (tools/train.py step: 6 frames 200x400 -> 25x50 maps, %d edges, 15 unrolled "
+                        "updates, semisup objective, bf16 volume + HIP lookup fwd/bwd, fp32 operator / BA, Adam), random-init weights" % E,
+            "ms_per_step": ms, "steps_per_s": 1e3 / ms, "loss": float(loss),
+            "lookup_backward_level0_us": bw_us, "lookup_backward_level0_gbps": vol.numel() * 2 / (bw_us * 1e-6) / 1e9,
+            "data_parallel": "DDP over RCCL, one clip per rank (tools/train.py --gpus 0,1,2,3); gradient all-reduce 17.3 MB per step"}
+
+
+def chained_drift_leg(device):
+    """six chained native graph updates on S-B against the CPU fp32 chain (oracle lookup -> fp32 operator -> oracle BA,
+    oracle/chain.py): the drift of poses / depths / flow targets, and the CPU chain's time (the CPU port of the whole update)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import chain
+    from test_chained_updates import structured_operator
+    video, graph = make_window(device, seed=0)
+    structured_operator(graph.update_op, 0.1)
+    ov, cg = chain.cpu_twin(video, graph, graph.nkf)
+    t_cpu = 0.0
+    for _ in range(6):
+        graph.update(None, None, use_inactive=True)
+        t0 = time.perf_counter()
+        cg.update(None, None, use_inactive=True)
+        t_cpu += time.perf_counter() - t0
+    torch.cuda.synchronize()
+    n = graph.nkf
+    return {"updates": 6, "operator": "random init, last layer of the two flow heads x 0.1 (sub-pixel revisions)",
+            "pose_max_abs": float((video.poses[:n].cpu() - ov.poses[:n]).abs().max()),
+            "disp_mean_abs": float((video.disps[:n].cpu() - ov.disps[:n]).abs().mean()),
+            "flow_epe_mean_px": float((graph.target_cam.cpu() - cg.target_cam).norm(dim=-1).mean()),
+            "reference": "CPU fp32 chain: C-oracle lookup of an fp32 volume -> fp32 update operator (PyTorch) -> C-oracle BA",
+            "cpu_chain_s_per_update": t_cpu / 6}
+
+
+def lookup_traffic():
+    """HBM bytes per launch of the fused lookup from the committed PMC profile - only if that profile was taken on THIS source
+    of the kernel (it records the sha256 of corr_lookup.hip); otherwise None: a counter value is not carried over a code change"""
+    import hashlib
+    sha = hashlib.sha256(open(os.path.join(ROOT, "pvo_amd", "csrc", "corr_lookup.hip"), "rb").read()).hexdigest()
+    for name in ("r03_lookup_pmc.json", "r02_lookup_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        j = json.load(open(path))
+        if j.get("kernel_source_sha256") in (None, sha):
+            return j.get("fused_encoder", j).get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "kernel_source_sha256": j.get("kernel_source_sha256"),
+                                                                            "matches_this_source": j.get("kernel_source_sha256") == sha}
+    return None, None
+
+
 def edge_sharded_leg(device, rank, world, steps=3):
     """BASELINE.json configs[3] / north star "partition the factor graph across GPUs with RCCL all-reduce of the pose-block
     Hessian": a 64-keyframe global update (droid_backend.py:25-41 -> FactorGraph.update_lowmem) whose edges are sharded BY
     SOURCE KEYFRAME over the ranks (pvo_amd/parallel.py).  Per Gauss-Newton step ONE collective: all-reduce (integer sum)
-    of the reduced pose system; lookup (alt-corr), update operator, damping and depth updates are rank-local.  Strong
-    scaling: the same graph at every N.  Reports global updates/s, the BA-only time, the all-reduce latency and a bitwise
-    cross-rank check of the poses."""
+    of the ENVELOPE of the reduced pose system; lookup, update operator, damping and depth updates are rank-local.  Strong
+    scaling: the same graph at every N - and, at N > 1, every rank first runs the WHOLE graph alone on its GPU, so that the
+    line carries the speed-up against one GPU measured in the same job (`speedup_vs_one_gpu`, global update and BA only).
+    Reports global updates/s, the BA-only time, the all-reduce latency and a bitwise cross-rank check of the poses."""
     import torch.distributed as dist
     from pvo_amd.parallel import ShardedBA, shard_edges
     nkf, H, W = 64, H8, W8
     corr_impl = os.environ.get("PVO_BENCH_GLOBAL_CORR", "volume")      # "alt": the reference's alt-corr path
-    video, graph = make_window(device, seed=7, NKF=nkf, buffer=80, corr_impl=corr_impl, add_edges=False, max_factors=-1)
-    video.counter = nkf
     ii = [i for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= RADIUS]
     jj = [j for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= RADIUS]
-    ii_l, jj_l, _ = shard_edges(ii, jj, world, rank)
-    graph.add_factors(ii_l, jj_l)
-    g = torch.Generator().manual_seed(3)
-    graph.target_cam = graph.target_cam + 0.5 * torch.randn(graph.target_cam.shape, generator=g).to(device)
-    graph.weight = torch.rand(graph.weight.shape, generator=g).to(device)
-    sharded = ShardedBA(structure=(ii, jj))        # envelope all-reduce: every rank knows the whole edge list
-    if not ii_l:
-        raise RuntimeError("rank %d owns no edges" % rank)
-    poses0, disps0 = video.poses.clone(), video.disps.clone()
-    net0, tgt0, w0 = graph.net.clone(), graph.target_cam.clone(), graph.weight.clone()
 
-    def reset():
-        video.poses.copy_(poses0); video.disps.copy_(disps0)
-        graph.net, graph.target_cam, graph.weight = net0.clone(), tgt0.clone(), w0.clone()
-        graph.raw_mask.zero_(); graph.delta_dy.zero_()
-
-    def sync():
+    def sync(collective):
         torch.cuda.synchronize()
-        if world > 1:
+        if collective and world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    graph.update_lowmem(steps=1, sharded=sharded)                 # warm-up
-    reset(); sync()
-    t0 = time.perf_counter()
-    graph.update_lowmem(steps=steps, sharded=sharded)
-    sync()
-    el = time.perf_counter() - t0
-    # BA only: the same sharded BA on the final state, 10 calls of 2 Gauss-Newton steps
-    ht, wd = H, W
-    src = sorted(set(graph._ii_h))
-    rows = sorted(set(range(1, nkf)) | set(src))
-    eta = torch.full((len(rows), ht, wd), 1e-4, device=device)
-    target = graph.target_cam.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
-    weight = graph.weight.view(-1, ht, wd, 2).permute(0, 3, 1, 2).contiguous()
-    bi, bj = graph.ii.contiguous(), graph.jj.contiguous()
-    ba = lambda: sharded.ba(video.poses, video.disps, video.intrinsics[0], target, weight, eta, bi, bj, 1, nkf, itrs=2,
-                            lm=1e-5, ep=1e-2, plan_key=("bench", rank))
-    ba(); sync()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        ba()
-    sync()
-    ba_ms = (time.perf_counter() - t0) / 10 * 1e3
-    # the collective alone: the [(6P)^2 + 6P] int64 system, 50 all-reduces
+
+    def run(ii_l, jj_l, collective):
+        """the global update over the given edges; collective=False: this process alone (no group communication)"""
+        video, graph = make_window(device, seed=7, NKF=nkf, buffer=80, corr_impl=corr_impl, add_edges=False, max_factors=-1)
+        video.counter = nkf
+        graph.add_factors(ii_l, jj_l)
+        g = torch.Generator().manual_seed(3)
+        # (per-edge noise drawn for the WHOLE graph and indexed by edge, so that shards and the whole graph see the same values)
+        noise = 0.5 * torch.randn(len(ii), H, W, 2, generator=g)
+        wts = torch.rand(len(ii), H, W, 2, generator=g)
+        pos = {e: k for k, e in enumerate(zip(ii, jj))}
+        sel = torch.tensor([pos[e] for e in zip(graph._ii_h, graph._jj_h)])
+        graph.target_cam = graph.target_cam + noise[sel].to(device)[None]
+        graph.weight = wts[sel].to(device)[None].contiguous()
+        sharded = ShardedBA(structure=(ii, jj), communicate=collective)
+        poses0, disps0 = video.poses.clone(), video.disps.clone()
+        net0, tgt0, w0 = graph.net.clone(), graph.target_cam.clone(), graph.weight.clone()
+
+        def reset():
+            video.poses.copy_(poses0); video.disps.copy_(disps0)
+            graph.net, graph.target_cam, graph.weight = net0.clone(), tgt0.clone(), w0.clone()
+            graph.raw_mask.zero_(); graph.delta_dy.zero_()
+        graph.update_lowmem(steps=1, sharded=sharded)                 # warm-up
+        reset(); sync(collective)
+        t0 = time.perf_counter()
+        graph.update_lowmem(steps=steps, sharded=sharded)
+        sync(collective)
+        el = time.perf_counter() - t0
+        poses_after = video.poses.clone()
+        # BA only: the same sharded BA on the final state, 10 calls of 2 Gauss-Newton steps
+        src = sorted(set(graph._ii_h))
+        rows = sorted(set(range(1, nkf)) | set(src))
+        eta = torch.full((len(rows), H, W), 1e-4, device=device)
+        target = graph.target_cam.view(-1, H, W, 2).permute(0, 3, 1, 2).contiguous()
+        weight = graph.weight.view(-1, H, W, 2).permute(0, 3, 1, 2).contiguous()
+        bi, bj = graph.ii.contiguous(), graph.jj.contiguous()
+        ba = lambda: sharded.ba(video.poses, video.disps, video.intrinsics[0], target, weight, eta, bi, bj, 1, nkf, itrs=2,
+                                lm=1e-5, ep=1e-2, plan_key=("bench", rank, collective))
+        ba(); sync(collective)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ba()
+        sync(collective)
+        ba_ms = (time.perf_counter() - t0) / 10 * 1e3
+        msg_bytes = sharded.last_message_bytes
+        del graph, video
+        torch.cuda.empty_cache()
+        return el, ba_ms, poses_after, msg_bytes
+
+    whole = None
+    if world > 1:
+        # every rank alone on the whole graph (identical work on every GPU): the one-GPU reference of this job
+        whole = run(ii, jj, False)
+    ii_l, jj_l, _ = shard_edges(ii, jj, world, rank)
+    if not ii_l:
+        raise RuntimeError("rank %d owns no edges" % rank)
+    el, ba_ms, poses_after, msg_bytes = run(ii_l, jj_l, True)
+    # the collective alone: the envelope message, 50 all-reduces
     P = nkf - 1
-    msg = torch.zeros((6 * P) ** 2 + 6 * P, dtype=torch.int64, device=device)
+    dense_bytes = 8 * ((6 * P) ** 2 + 6 * P)
     ar_us = None
     if world > 1:
+        msg = torch.zeros(max(msg_bytes // 8, 1), dtype=torch.int64, device=device)
         for _ in range(5):
             dist.all_reduce(msg)
-        sync()
+        sync(True)
         t0 = time.perf_counter()
         for _ in range(50):
             dist.all_reduce(msg)
         torch.cuda.synchronize()
         ar_us = (time.perf_counter() - t0) / 50 * 1e6
-    # every rank must hold bit-identical poses
-    same = True
+    # every rank must hold bit-identical poses - and, the pose system being an integer sum, the poses of the whole graph on one GPU
+    same, same_as_whole = True, None
     if world > 1:
-        ref = video.poses.clone()
+        ref = poses_after.clone()
         dist.broadcast(ref, 0)
-        flag = torch.tensor([1 if torch.equal(ref, video.poses) else 0], device=device)
+        flag = torch.tensor([1 if torch.equal(ref, poses_after) else 0, 1 if torch.equal(whole[2], poses_after) else 0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        same = bool(flag.item())
+        same, same_as_whole = bool(flag[0].item()), bool(flag[1].item())
     out = {"workload": "S-20: 64 keyframes, 48x64 maps, %d edges (|i-j| <= 3) sharded by source keyframe, global update "
                        "(%s + update operator + BA x2), strong scaling"
                        % (len(ii), "resident volume pool, one native call per step" if corr_impl == "volume" else "alt-corr lookup, 8-frame operator chunks"),
            "correlation": corr_impl,
            "global_updates_per_s": steps / el, "ms_per_global_update": el / steps * 1e3, "edges_this_rank": len(ii_l),
-           "ba_2_steps_ms": ba_ms, "allreduce_us": ar_us, "allreduce_bytes": int(msg.numel() * 8),
+           "ba_2_steps_ms": ba_ms, "allreduce_us": ar_us, "allreduce_bytes": int(msg_bytes) if world > 1 else None,
+           "allreduce_bytes_dense": dense_bytes, "allreduce_message": "envelope blocks of the lower triangle + rhs, int64 fixed point",
            "backend": dist.get_backend() if world > 1 else None, "world_size": world, "poses_bitwise_equal_across_ranks": same}
     if world > 1:
-        tt = torch.tensor([el, ba_ms], device=device, dtype=torch.float64)
+        tt = torch.tensor([el, ba_ms, whole[0], whole[1]], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        out["global_updates_per_s"] = steps / float(tt[0].item()); out["ms_per_global_update"] = float(tt[0].item()) / steps * 1e3
-        out["ba_2_steps_ms"] = float(tt[1].item())
+        el, ba_ms, w_el, w_ba = [float(x) for x in tt.tolist()]
+        out["global_updates_per_s"] = steps / el; out["ms_per_global_update"] = el / steps * 1e3
+        out["ba_2_steps_ms"] = ba_ms
+        out["one_gpu_same_job"] = {"ms_per_global_update": w_el / steps * 1e3, "ba_2_steps_ms": w_ba}
+        out["speedup_vs_one_gpu"] = {"global_update": w_el / el, "ba_only": w_ba / ba_ms, "n_gpus": world}
+        out["poses_bitwise_equal_to_one_gpu"] = same_as_whole
     return out
 
 
@@ -544,13 +711,7 @@ def main():
 
     if rank == 0:
         E, HW = len(graph._ii_h), H8 * W8
-        traffic = None
-        for name in ("r02_lookup_pmc.json", "r01_lookup_pmc.json"):
-            pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc):
-                j = json.load(open(pmc))
-                traffic = j.get("fused_encoder", j).get("hbm_bytes_per_launch")
-                break
+        traffic, traffic_src = lookup_traffic()
         hi = sorted(host_issue)
         out = {
             "metric": "VO keyframe updates/sec (8-keyframe window, 512x384, 36 edges; 6 graph updates + edge rebuild per keyframe)",
@@ -567,7 +728,7 @@ def main():
                      "priming_blocks_of_8_steps": blocks},
             "roofline": dict(lookup_roofline(E, HW, in_step_lookup, traffic), isolated_cold_us=lookup_cold_us,
                              isolated_cold="Infinity Cache evicted by a 600 MB read before each of 20 launches",
-                             warm_back_to_back_us=lookup_b2b_us),
+                             warm_back_to_back_us=lookup_b2b_us, traffic_source=traffic_src),
             "roofline_wide_conv": {
                 "kernel": "conv3x3_big_kernel<half> as pvo_gru_conv_gates (3x3 convolution 320 -> 256 on v_mfma_f32_32x32x16_f16 + sigmoid gates)",
                 "bound": "mfma", "achieved": gates_flop / (stage_us["gates"] * 1e-6) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -588,10 +749,13 @@ def main():
     extra = {}
     if not args.no_extras:
         if world == 1:
-            try:
-                extra["workload_S_A"] = workload_sa(device, max(10, args.steps // 2))
-            except Exception as e:      # a failure here must not cost the headline line
-                extra["workload_S_A"] = {"error": repr(e)}
+            for key, leg in (("workload_S_A", lambda: workload_sa(device, max(10, args.steps // 2))), ("workload_S_1", lambda: workload_s1(device)),
+                             ("train_step", lambda: train_step_leg(device))):
+                try:
+                    extra[key] = leg()
+                except Exception as e:      # a failure here must not cost the headline line
+                    extra[key] = {"error": repr(e)}
+                torch.cuda.empty_cache()
         try:
             extra["edge_sharded"] = edge_sharded_leg(device, rank, world)
         except Exception as e:
@@ -601,6 +765,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["ate_rmse"] = synthetic_ate(device)
+            try:
+                out["chained_update_drift"] = chained_drift_leg(device)
+            except Exception as e:
+                out["chained_update_drift"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -33,6 +33,7 @@
 // update when the factorisation fails, EvT6x1's skip of window pose 0 in the depth
 // back-substitution (:1084).  Deviation: expSE3 uses xi[5], not xi[45] (:154).
 #include "se3.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -654,6 +655,9 @@ struct DenseMat {
   double* p; Index n;
   __device__ __forceinline__ MatRow row(int i) const { return MatRow{p + i * n, 0}; }
   __device__ __forceinline__ Index rowstep() const { return n; }      // distance between the same column of rows i and i + 1
+  // six contiguous (16-byte aligned) entries: row r of 6 x 6 block (ib, cb); the rhs entries of block cb
+  __device__ __forceinline__ double* brow(int ib, int r, int cb) const { return p + static_cast<Index>(6 * ib + r) * n + 6 * cb; }
+  __device__ __forceinline__ double* yrow(int cb) const { return p + n * n + 6 * cb; }
 };
 struct EnvMat {
   double* blk; double* rhs; const int* rowoff; int n;      // rowoff[ib] = rowbase[ib] - 36 first[ib]: block (ib, cb) at rowoff[ib] + 36 cb
@@ -663,6 +667,8 @@ struct EnvMat {
     return MatRow{blk + rowoff[ib] + (i - 6 * ib) * 6, 30};
   }
   __device__ __forceinline__ int rowstep() const { return 6; }         // ... inside one block row
+  __device__ __forceinline__ double* brow(int ib, int r, int cb) const { return blk + rowoff[ib] + 36 * cb + 6 * r; }
+  __device__ __forceinline__ double* yrow(int cb) const { return rhs + 6 * cb; }
 };
 
 // Inclusive scan (sum or max) of v[0..P) in place by the whole workgroup, 256 entries at a time with a carry: the serial
@@ -747,7 +753,7 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
       for (int c = 0; c < 6; ++c) {
         double v = rp[c];
 #pragma unroll
-        for (int k = 0; k < c; ++k) v -= x[k] * L[c * (c + 1) / 2 + k];
+        for (int k = 0; k < c; ++k) v = fma(-x[k], L[c * (c + 1) / 2 + k], v);
         x[c] = v * rd[c];
       }
 #pragma unroll
@@ -772,7 +778,7 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
         double& dst = R(c);
         double acc = dst;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) acc -= li[t] * cp[t];
+        for (int t = 0; t < 6; ++t) acc = fma(-li[t], cp[t], acc);
         dst = acc;
       }
     }
@@ -793,7 +799,7 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
     for (int c = 5; c >= 0; --c) {
       double v = Y(j0 + c);
 #pragma unroll
-      for (int k = c + 1; k < 6; ++k) v -= L[k * (k + 1) / 2 + c] * x[k];
+      for (int k = c + 1; k < 6; ++k) v = fma(-L[k * (k + 1) / 2 + c], x[k], v);
       x[c] = v * L[21 + c];                                  // reciprocal diagonal
     }
     __syncthreads();                                         // everyone has read y[j0..j0+6) before it is overwritten
@@ -803,10 +809,153 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
       const double* lp = &R0(i);
       double v = Y(i);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v -= lp[c * A.rowstep()] * x[c];
+      for (int c = 0; c < 6; ++c) v = fma(-lp[c * A.rowstep()], x[c], v);
       Y(i) = v;
     }
     __syncthreads();
+  }
+}
+
+// ---- the same factorisation by ONE wave, without workgroup barriers (matrices that live in LDS) ------------------------------
+// The block steps of a Cholesky factorisation are a serial chain; with four waves every step paid two s_barriers, a scan of
+// the candidate rows by 256 threads and element-wise LDS traffic through the row accessor (tools/ba_solve_timeline.py: 3.8 k
+// cycles per block column at 7 poses, 7.6 k at 63).  One wave needs no barrier - LDS operations of a wave are performed in
+// program order, only the COMPILER has to be kept from reordering them (wave_lds_sync) - and the step's work is small: at
+// most a few hundred 6-element row tasks.  Per block column kb:
+//   (a) every lane factors the 6 x 6 diagonal block redundantly in registers (as before);
+//   (b) the active block rows (envelope reaches column kb) are compacted into a list by ballot;
+//   (c) panel: one lane per row of the active blocks and the rhs row;
+//   (d) trailing update: one lane per (block pair, row): six entries of the pair's block, 36 FMAs, operands as 16-byte reads.
+// Every entry sees exactly the operations of chol_solve_blocked in the same order (t = 0..5 within a step, steps ascending),
+// so the result is bit-identical to it - and to the dense factorisation, for the reason given at EnvMat.
+constexpr int kMaxActiveRows = 512;      // active block rows of one step (each owns a stored block: the LDS budget holds < 490)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void ld6(const double* p, double (&v)[6]) {
+  const double2 a = reinterpret_cast<const double2*>(p)[0], b = reinterpret_cast<const double2*>(p)[1], c = reinterpret_cast<const double2*>(p)[2];
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+}
+__device__ __forceinline__ void st6(double* p, const double (&v)[6]) {
+  reinterpret_cast<double2*>(p)[0] = double2{v[0], v[1]};
+  reinterpret_cast<double2*>(p)[1] = double2{v[2], v[3]};
+  reinterpret_cast<double2*>(p)[2] = double2{v[4], v[5]};
+}
+
+template <class Mat>
+__device__ void chol_solve_wave(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* reach, unsigned short* rows) {
+  // executed by the 64 lanes of ONE wave; on return the rhs holds the solution x
+  const int lane = threadIdx.x & 63;
+  const int P = n / 6;
+  for (int kb = 0; kb < P; ++kb) {
+    double D[21], L[21], rd[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double* rp = A.brow(kb, r, kb);
+#pragma unroll
+      for (int c = 0; c <= r; ++c) D[r * (r + 1) / 2 + c] = rp[c];
+    }
+    const bool ok = chol6(D, L, rd);
+    if (!ok) { if (lane == 0) *fail_flag = 1; return; }                // uniform: every lane saw the same block
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 21; ++q) Ld[kb * 27 + q] = L[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Ld[kb * 27 + 21 + q] = rd[q];
+    }
+    // (b) the block rows below kb whose envelope reaches this block column
+    const int lo = kb + 1, hi = reach[kb];
+    int m = 0;
+    for (int base = lo; base <= hi; base += 64) {
+      const int ib = base + lane;
+      const bool act = ib <= hi && first[ib] <= kb;
+      const unsigned long long mask = __ballot(act);
+      if (act) rows[m + __popcll(mask & ((1ull << lane) - 1ull))] = static_cast<unsigned short>(ib);
+      m += __popcll(mask);
+    }
+    wave_lds_sync();
+    // (c) panel: x = row L^-T, in place; task 6 m is the rhs row
+    for (int t = lane; t <= 6 * m; t += 64) {
+      const int q = t / 6;
+      double* rp = (t < 6 * m) ? A.brow(rows[q], t - 6 * q, kb) : A.yrow(kb);
+      double v[6], x[6];
+      ld6(rp, v);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double u = v[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) u = fma(-x[k], L[c * (c + 1) / 2 + k], u);
+        x[c] = u * rd[c];
+      }
+      st6(rp, x);
+    }
+    wave_lds_sync();
+    // (d) trailing update: block (a, b) of the active list, a >= b, row r: A(a,b)[r][:] -= L(a,kb)[r][:] L(b,kb)^T; then
+    // one task per active block for the rhs row
+    const int npair = m * (m + 1) / 2;
+    const int ntask = 6 * npair + m;
+    for (int t = lane; t < ntask; t += 64) {
+      double li[6];
+      double* dst;
+      int cb, cmax = 5;
+      if (t < 6 * npair) {
+        const int pr = t / 6, r = t - 6 * pr;
+        int a = static_cast<int>((sqrtf(8.0f * static_cast<float>(pr) + 1.0f) - 1.0f) * 0.5f);
+        while ((a + 1) * (a + 2) / 2 <= pr) ++a;
+        while (a * (a + 1) / 2 > pr) --a;
+        const int b = pr - a * (a + 1) / 2;
+        const int ib = rows[a];
+        cb = rows[b];
+        ld6(A.brow(ib, r, kb), li);
+        dst = A.brow(ib, r, cb);
+        if (a == b) cmax = r;                                          // lower triangle of a diagonal block
+      } else {
+        cb = rows[t - 6 * npair];
+        ld6(A.yrow(kb), li);
+        dst = A.yrow(cb);
+      }
+      double acc[6];
+      ld6(dst, acc);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double cp[6];
+        ld6(A.brow(cb, c, kb), cp);
+        double u = acc[c];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) u = fma(-li[q], cp[q], u);
+        acc[c] = (c <= cmax) ? u : acc[c];
+      }
+      st6(dst, acc);
+    }
+    wave_lds_sync();
+  }
+  BA_PROBE(2);
+  // back substitution L^T x = y, block rows from the bottom (right-looking, as in chol_solve_blocked)
+  for (int kb = P - 1; kb >= 0; --kb) {
+    const double* L = Ld + kb * 27;
+    double* y = A.yrow(kb);
+    double x[6];
+#pragma unroll
+    for (int c = 5; c >= 0; --c) {
+      double v = y[c];
+#pragma unroll
+      for (int k = c + 1; k < 6; ++k) v = fma(-L[k * (k + 1) / 2 + c], x[k], v);
+      x[c] = v * L[21 + c];                                            // reciprocal diagonal
+    }
+    wave_lds_sync();                                                   // every lane has read y before it is overwritten
+    if (lane < 6) y[lane] = x[lane];
+    for (int i = 6 * first[kb] + lane; i < 6 * kb; i += 64) {          // row block kb of L is zero left of its envelope
+      const int cbk = i / 6, c2 = i - 6 * cbk;
+      double* yp = A.yrow(cbk) + c2;
+      double v = *yp;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v = fma(-A.brow(kb, c, cbk)[c2], x[c], v);
+      *yp = v;
+    }
+    wave_lds_sync();
   }
 }
 
@@ -903,12 +1052,13 @@ __global__ __launch_bounds__(256) void ba_prepare_kernel(long long* __restrict__
 __global__ __launch_bounds__(256) void ba_solve_kernel(
     long long* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
     float* __restrict__ dx_ws, float* __restrict__ dx_out, int* __restrict__ meta, int* __restrict__ status_out,
-    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget) {
+    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget, int solver_wave) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs | ...]
   int& fail = *reinterpret_cast<int*>(smem);
   const int n = 6 * P;
   __shared__ int first[kMaxEnvBlocks];                                           // envelope: first non-zero block column per block row
   __shared__ int reach[kMaxEnvBlocks];                                           // ... and last block row that reaches a block column
+  __shared__ unsigned short act_rows[kMaxActiveRows];                            // chol_solve_wave's list of active block rows
   __shared__ int blocks_s;
   BA_ACQ();
   BA_PROBE(0);
@@ -963,7 +1113,8 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
       __syncthreads();
       envelope_reach(first, reach, P);
       BA_PROBE(1);
-      chol_solve_blocked(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach);
+      if (solver_wave) { if (threadIdx.x < 64) chol_solve_wave(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach, act_rows); }
+      else chol_solve_blocked(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach);
       xrow = rhs;
     } else {
       for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
@@ -1005,7 +1156,8 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
     __syncthreads();
     envelope_reach(first, reach, P);
     BA_PROBE(1);
-    chol_solve_blocked(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach);
+    if (solver_wave) { if (threadIdx.x < 64) chol_solve_wave(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach, act_rows); }
+    else chol_solve_blocked(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach);
     xrow = A + n * n;
   }
   __syncthreads();
@@ -1190,7 +1342,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
   hipStream_t st = pvo_stream(stream);
   const int n6 = 6 * P;
   const int use_lds = n6 <= kLdsCholMax;
-  constexpr size_t kSolveLdsMax = 143000;      // dynamic LDS of the solve: the CU's 163840 B minus its 20496 B of static tables (envelope, reach, scan buffers)
+  constexpr size_t kSolveLdsMax = 142000;      // dynamic LDS of the solve: the CU's 163840 B minus its 21520 B of static tables (envelope, reach, active rows, scan buffers)
   const size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
@@ -1200,6 +1352,12 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
       attr_set = true;
     }
   }
+  // Two bit-identical factorisations of a system that lives in LDS (chol_solve_blocked: four waves and barriers;
+  // chol_solve_wave: one wave, none).  Measured with tools/ba_solve_timeline.py: 7 free poses 44.0 k cycles blocked / 47.6 k
+  // wave, 63 free poses 615 k / 537 k - the wave form wins once the envelope makes most of a step's candidate rows inactive.
+  // PVO_BA_SOLVER = blocked | wave overrides (tests compare the two bit for bit).
+  static const int solver_env = [] { const char* e = getenv("PVO_BA_SOLVER"); return !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
+  const int solver_wave = solver_env == 1 ? 1 : (solver_env == 2 ? 0 : (P > 12 ? 1 : 0));
   if (!use_lds) {
     hipLaunchKernelGGL(ba_env_kernel, dim3((n6 * n6 + 2047) / 2048), dim3(256), 0, st, sys, w.plan.env, n6);
     PVO_CHECK_LAUNCH();
@@ -1208,7 +1366,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
     PVO_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
-                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax));
+                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax), solver_wave);
   PVO_CHECK_LAUNCH();
   if (!motion_only && E + P > 0) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);

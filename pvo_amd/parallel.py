@@ -83,8 +83,9 @@ class ShardedBA:
     (default: pvo_amd.droid_backends); the oracle-backed variant in tests/ exercises the same
     partition / reduction logic on CPU with gloo."""
 
-    def __init__(self, group=None, backend=None, structure=None):
+    def __init__(self, group=None, backend=None, structure=None, communicate=True):
         self.group = group
+        self.communicate = communicate  # False: this process holds the whole graph although a process group exists (bench reference)
         self.structure = structure      # (ii_all, jj_all) of the whole graph: default of ba()'s `structure`
         if backend is None:
             from . import droid_backends as backend
@@ -121,7 +122,7 @@ class ShardedBA:
             self.db.ba_plan(ii_local, jj_local, F, ht * wd, K_eta, t0, t1, ws)
             self._plan_key, self._plan_edges = key, (ii_local, jj_local)
             self._env_idx = None
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        multi = self.communicate and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         if structure is not None and self._env_idx is None and (multi or self.always_pack):
             self._env_idx = envelope_index(envelope_structure(structure[0], structure[1], t0, t1), disps.device)
         sys_buf = self._sys
@@ -148,7 +149,7 @@ class ShardedBA:
         """make the depth replicas identical again (only needed when something reads maps a rank does
         not own, e.g. writing results): all-reduce of the per-rank updates."""
         delta = disps - disps_before
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self.communicate and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
         disps.copy_(disps_before + delta)
         return disps

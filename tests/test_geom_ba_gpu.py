@@ -228,3 +228,28 @@ def test_reproject_matches_reference_python_fixture(cuda):
     c, v = db.reproject(t(d["poses"]), t(d["disps"]), t(np.tile(d["intr"][None], (P, 1))), t(d["ii"]), t(d["jj"]))
     assert np.allclose(c.cpu().numpy(), d["reproj_coords"], atol=5e-5)
     assert np.array_equal(v.cpu().numpy(), d["reproj_valid"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,ht,wd,radius", [(8, 24, 32, 3), (22, 12, 16, 3), (40, 10, 12, 2), (64, 8, 12, 3)])
+def test_wave_and_blocked_cholesky_are_bit_identical(P, ht, wd, radius):
+    """the one-wave (barrier-free) and the four-wave blocked factorisation of the pose system perform the same operations
+    on every entry in the same order: poses and depths agree bit for bit (dense-in-LDS and compact-envelope storage,
+    with a loop closure in the long windows).  Each solver in its own process: the choice is read once per process."""
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); from test_geom_ba_gpu import _scene; from pvo_amd import droid_backends as db; "
+            "s = _scene(3, %d, %d, %d, %d, 1); d = lambda t: t.cuda(); p, q = d(s['poses'].clone()), d(s['disps'].clone()); "
+            "db.ba(p, q, d(s['intr']), d(s['target']), d(s['weight']), d(s['eta']), d(s['ii']), d(s['jj']), s['t0'], s['t1'], 2, 1e-4, 0.1, False); "
+            "torch.save((p.cpu(), q.cpu()), sys.argv[1])") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), P, ht, wd, radius)
+    import tempfile
+    outs = []
+    for solver in ("wave", "blocked"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, PVO_BA_SOLVER=solver), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout[-2000:]
+            outs.append(torch.load(f.name))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    from test_geom_ba_gpu import _scene as sc
+    assert (outs[0][0] - sc(3, P, ht, wd, radius, 1)["poses"]).abs().max() > 1e-5

@@ -6,7 +6,8 @@ mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/pk_$i
   timeout 300 rocprofv3 --pmc $SET --kernel-trace -f csv -d /tmp/pk_$i -- python $GRAFT_REPO_ROOT/tools/pmc_workload.py > /tmp/pk_$i.log 2>&1
   cp /tmp/pk_$i/*/*counter_collection.csv $OUT/set${i}_counter_collection.csv 2>/dev/null || tail -5 /tmp/pk_$i.log
@@ -17,8 +18,9 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/set*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for key in ("conv3x3_big_kernel", "ba_assemble_kernel", "ba_schur_mfma_kernel", "ba_solve_kernel", "ba_backsub_kernel"):
-            if key in k:
+        for key in ("conv3x3_big_kernel<pvo_half, false>", "conv3x3_big_kernel<pvo_half, true>", "corr_lookup_r3_enc_kernel",
+                    "ba_assemble_kernel", "ba_schur_mfma_kernel", "ba_solve_kernel", "ba_backsub_kernel"):
+            if key in k.replace("(anonymous namespace)::", ""):
                 res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 for extra in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"):
                     if extra in r: res[key]["_" + extra] = [float(r[extra])]

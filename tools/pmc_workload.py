@@ -18,6 +18,28 @@ tzr = db.conv3x3_weights((torch.randn(256, 320, 3, 3, device=dev, generator=g) *
 for _ in range(6):
     db.gru_conv_gates(net, cf, tzr, gg, P_zr)
 torch.cuda.synchronize()
+# the heads' first stage (128 -> 4 x 128 with the second stage in its epilogue): the <pvo_half, true> instantiation
+w1 = db.conv3x3_weights((torch.randn(512, 128, 3, 3, device=dev, generator=g) * 0.03).half(), torch.half)
+b1 = torch.randn(512, device=dev, generator=g) * 0.1
+w2 = db.heads2_fragments(torch.randn(4, 2, 9, 128, device=dev, generator=g) * 0.05, torch.half)
+b2 = torch.randn(8, device=dev, generator=g)
+for _ in range(6):
+    db.heads_fused(net, w1, b1, w2, b2)
+torch.cuda.synchronize()
+# the fused lookup (lookup + corr_encoder[0]) on the resident tiled pool, Infinity Cache evicted between launches
+from pvo_amd.modules.corr import CorrVolumePool
+pool = CorrVolumePool(E, H, W, dev)
+pool.add(torch.randn(E, H, W, 128, device=dev, generator=g).half(), torch.randn(E, H, W, 128, device=dev, generator=g).half())
+base = torch.stack(torch.meshgrid(torch.arange(W), torch.arange(H), indexing="xy"), -1).float().to(dev)
+coords = (base[None] + torch.randn(E, H, W, 2, device=dev, generator=g) * 4).contiguous()
+we = db.corr_encoder_weights(torch.randn(128, 196, 1, 1, device=dev, generator=g) * 0.05, torch.half)
+be = torch.randn(128, device=dev, generator=g)
+flush = torch.empty(600 * 1024 * 1024, device=dev, dtype=torch.uint8)
+for _ in range(6):
+    flush.zero_()
+    pool.encoded(coords[None], we, be)
+    torch.cuda.synchronize()
+del flush
 from test_geom_ba_gpu import _scene
 s = _scene(0, 8, H, W, 3, 1)
 d = lambda t: t.to(dev)
