@@ -48,9 +48,16 @@ constexpr float kMinDepth = 0.25f;
 constexpr double kFix = 268435456.0, kInvFix = 1.0 / 268435456.0;
 __device__ __forceinline__ void fix_add(long long* sys, long long idx, double v, int* meta) {
   if (!(fabs(v) < 3.0e10)) { meta[4] = 1; return; }
+#ifdef PVO_ABL_NOATOMIC      // ablation build (tools/ba_ablate.sh): what do the atomics cost?  (results are wrong)
+  sys[idx] = __double2ll_rn(v * kFix);
+  return;
+#endif
   atomicAdd(reinterpret_cast<unsigned long long*>(sys + idx), static_cast<unsigned long long>(__double2ll_rn(v * kFix)));
 }
-constexpr int kPPT = 2;                 // pixels per thread in assemble
+#ifndef PVO_ASM_PPT
+#define PVO_ASM_PPT 2
+#endif
+constexpr int kPPT = PVO_ASM_PPT;       // pixels per thread in assemble
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
 constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system lives DENSE in LDS (126*127*8 + 21*27*8 + 208 = 132.7 KB of the 143 KB the
                                         // solve kernel's static tables leave); beyond, the compact envelope form
@@ -293,7 +300,11 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   // 90 sums: wave shuffle reduce, 4 partials through LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
+#ifdef PVO_ABL_NOREDUCE      // ablation build: what do the 90 wave reductions cost?  (results are wrong)
+  for (int l = 0; l < 78; ++l) { if (lane == 0) red[wave][l] = h[l]; }
+#else
   for (int l = 0; l < 78; ++l) { const float s = pvo_wave_sum(h[l]); if (lane == 0) red[wave][l] = s; }
+#endif
 #pragma unroll
   for (int n = 0; n < 6; ++n) {
     const float a = pvo_wave_sum(vi[n]), b = pvo_wave_sum(vj[n]);
@@ -400,7 +411,10 @@ __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const 
 // The reference enumerates (a,b,k) triples on the host and launches one 256-thread block per
 // triple with 36 LDS tree reductions each (schur_block :1201-1290, EEt6x6 :980-1035).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kSchurPix = 512;           // pixels per workgroup (128 per wave)
+#ifndef PVO_SCHUR_PIX
+#define PVO_SCHUR_PIX 256      // 512: 48 workgroups at S-B, 19.9 us; 256: 96 workgroups, 18.1 us (tools/ba_ablate.sh)
+#endif
+constexpr int kSchurPix = PVO_SCHUR_PIX; // pixels per workgroup (a quarter per wave)
 constexpr int kSchurSteps = kSchurPix / 4 / 16;
 constexpr int kMaxRows = 1024;           // rows of M the LDS row table can describe
 constexpr int kFastTiles = 4;            // up to 4 row tiles (63 rows + w) accumulate in one pass

@@ -96,6 +96,15 @@ class ShardedBA:
         self.always_pack = False        # tests: run the pack / unpack pair on a single rank too
         self.last_message_bytes = 0
 
+    # the two places that touch the process group (tests substitute an in-process exchange)
+    def _world(self):
+        if not (self.communicate and dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
+
+    def _allreduce(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def ba(self, poses, disps, intrinsics, targets, weights, eta_local, ii_local, jj_local, t0, t1,
            itrs=2, lm=1e-4, ep=0.1, motion_only=False, plan_key=None, structure=None):
         """poses/disps updated in place (disps: only the maps this rank owns change).
@@ -122,7 +131,7 @@ class ShardedBA:
             self.db.ba_plan(ii_local, jj_local, F, ht * wd, K_eta, t0, t1, ws)
             self._plan_key, self._plan_edges = key, (ii_local, jj_local)
             self._env_idx = None
-        multi = self.communicate and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        multi = self._world() > 1
         if structure is not None and self._env_idx is None and (multi or self.always_pack):
             self._env_idx = envelope_index(envelope_structure(structure[0], structure[1], t0, t1), disps.device)
         sys_buf = self._sys
@@ -136,11 +145,11 @@ class ShardedBA:
             if structure is not None and self._env_idx is not None:
                 msg = sys_buf.index_select(0, self._env_idx)                       # envelope blocks + rhs: one gather
                 if multi:
-                    dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=self.group)   # the one collective per step
+                    self._allreduce(msg)                                           # the one collective per step
                 sys_buf.index_copy_(0, self._env_idx, msg)
                 self.last_message_bytes = msg.numel() * msg.element_size()
             elif multi:
-                dist.all_reduce(sys_buf, op=dist.ReduceOp.SUM, group=self.group)   # the one collective per step
+                self._allreduce(sys_buf)                                           # the one collective per step
                 self.last_message_bytes = sys_buf.numel() * sys_buf.element_size()
             dx, _ = self.db.ba_finish(poses, disps, sys_buf, ii_local, jj_local, t0, t1, lm, ep, motion_only, ws)
         return dx
@@ -149,8 +158,8 @@ class ShardedBA:
         """make the depth replicas identical again (only needed when something reads maps a rank does
         not own, e.g. writing results): all-reduce of the per-rank updates."""
         delta = disps - disps_before
-        if self.communicate and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
+        if self._world() > 1:
+            self._allreduce(delta)
         disps.copy_(disps_before + delta)
         return disps
 

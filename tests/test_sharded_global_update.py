@@ -125,3 +125,96 @@ def test_two_rank_sharded_global_update_equals_single_process():
         assert np.abs(out[r][0] - whole.poses.numpy()).max() < 5e-5
         assert np.abs(out[r][1] - whole.disps.numpy()).max() < 5e-5
     assert np.array_equal(out[0][0], out[1][0])                                        # pose replicas bit-identical
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_hip_sharded_global_update_two_virtual_ranks_bit_identical_to_whole_graph(cuda):
+    """The NATIVE path (resident volumes, pvo_graph_update per step, pvo_ba_local / _finish around the all-reduce of the
+    envelope) for a 24-keyframe global update: two virtual ranks in ONE process - two threads that take turns on the device
+    (a lock around every stretch of GPU work, so that no kernel of one rank is resident beside a kernel of the other; two
+    processes sharing one GPU is exactly the co-residency DESIGN.md section 5 shows to be unsafe for the BA) and exchange the
+    pose system through memory - must give the poses of the whole graph on one GPU BIT FOR BIT, and its depth maps after the
+    per-rank updates are merged."""
+    import threading
+    import bench
+    from pvo_amd.parallel import ShardedBA, shard_edges
+    nkf, H, W, steps = 24, 16, 24, 2
+    ii = [i for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= 3] + [2, 20]
+    jj = [j for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= 3] + [20, 2]       # + a loop closure
+    g = torch.Generator().manual_seed(3)
+    noise = 0.5 * torch.randn(len(ii), H, W, 2, generator=g)
+    wts = torch.rand(len(ii), H, W, 2, generator=g)
+    pos = {e: k for k, e in enumerate(zip(ii, jj))}
+    turn = threading.Lock()
+
+    def build(ii_l, jj_l):
+        video, graph = bench.make_window(cuda, seed=7, H8=H, W8=W, NKF=nkf, buffer=32, corr_impl="volume", add_edges=False, max_factors=-1,
+                                         intr=(15.0, 15.0, 12.0, 8.0))
+        video.counter = nkf
+        graph.add_factors(ii_l, jj_l)
+        sel = torch.tensor([pos[e] for e in zip(graph._ii_h, graph._jj_h)])
+        graph.target_cam = graph.target_cam + noise[sel].to(cuda)[None]
+        graph.weight = wts[sel].to(cuda)[None].contiguous()
+        torch.cuda.synchronize()
+        return video, graph
+
+    # the whole graph on one GPU (ShardedBA without communication: the same code path)
+    video, graph = build(ii, jj)
+    d0 = video.disps.clone()
+    graph.update_lowmem(steps=steps, sharded=ShardedBA(structure=(ii, jj), communicate=False))
+    torch.cuda.synchronize()
+    whole_p, whole_d = video.poses.clone(), video.disps.clone()
+    assert (whole_p[:nkf] - bench.make_window(cuda, seed=7, H8=H, W8=W, NKF=nkf, buffer=32, add_edges=False)[0].poses[:nkf]).abs().max() > 1e-4
+
+    world = 2
+    box, meet = [None] * world, threading.Barrier(world)
+
+    class Virtual(ShardedBA):
+        def __init__(self, rank):
+            super().__init__(structure=(ii, jj))
+            self.rank = rank
+
+        def _world(self):
+            return world
+
+        def _allreduce(self, t):
+            torch.cuda.synchronize()
+            box[self.rank] = t.clone()
+            turn.release()                                    # hand the device over while waiting for the other rank
+            meet.wait()
+            total = box[0] + box[1]
+            meet.wait()
+            turn.acquire()
+            t.copy_(total)
+
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            ii_l, jj_l, _ = shard_edges(ii, jj, world, r)
+            with turn:
+                v, gph = build(ii_l, jj_l)
+            turn.acquire()
+            try:
+                gph.update_lowmem(steps=steps, sharded=Virtual(r))
+                torch.cuda.synchronize()
+            finally:
+                turn.release()
+            out[r] = (v.poses.clone(), v.disps.clone(), len(ii_l))
+        except Exception as e:                                # noqa: BLE001
+            errs.append(repr(e))
+            meet.abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert out[0][2] + out[1][2] == len(ii) and min(out[0][2], out[1][2]) > 0
+    assert torch.equal(out[0][0], out[1][0])                  # replicas agree ...
+    assert torch.equal(out[0][0], whole_p)                    # ... with the whole graph, bit for bit
+    merged = d0 + (out[0][1] - d0) + (out[1][1] - d0)
+    assert (merged - whole_d).abs().max() < 1e-6
