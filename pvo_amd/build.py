@@ -40,6 +40,34 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _digest(paths, extra=()):
+    """sha256 over file contents + the command line: what an object file was built FROM.  Modification times say nothing on a
+    box that received the tree as a snapshot (every file has the copy's time) or after a checkout that restored an old file."""
+    import hashlib
+    h = hashlib.sha256()
+    for x in extra:
+        h.update(x.encode() + b"\0")
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, deps, extra=()):
+    """target missing, or built from other inputs than the present ones (stamp file `<target>.sha256` beside it)"""
+    stamp = target + ".sha256"
+    if not os.path.exists(target) or not os.path.exists(stamp):
+        return True
+    with open(stamp) as f:
+        return f.read().strip() != _digest(deps, extra)
+
+
+def _stamp(target, deps, extra=()):
+    with open(target + ".sha256", "w") as f:
+        f.write(_digest(deps, extra) + "\n")
+
+
 def _run(cmd):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -58,20 +86,22 @@ def build_hip(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _newer(o, [s] + headers):
+        if force or _stale(o, [s] + headers, HIPCC_FLAGS):
             cmd = [hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for cmd, p in procs:
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), (o, [s] + headers)))
+    for cmd, p, (o, deps) in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(" ".join(cmd) + "\n" + out + "\n")
             raise RuntimeError("hipcc failed on " + cmd[-3])
+        _stamp(o, deps, HIPCC_FLAGS)
         if verbose and out.strip():
             print(out)
-    if force or procs or _newer(LIB, objs):
+    if force or procs or _stale(LIB, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        _stamp(LIB, objs)
     return LIB
 
 
@@ -80,10 +110,11 @@ def build_oracle(force=False):
     hdrs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".h")]
     if not srcs:
         return None
-    if force or _newer(ORACLE_LIB, srcs + hdrs):
+    if force or _stale(ORACLE_LIB, srcs + hdrs):
         # -ffp-contract=off: the oracle states every rounding explicitly
         _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
               "-Wall", "-o", ORACLE_LIB] + srcs + ["-lm"])
+        _stamp(ORACLE_LIB, srcs + hdrs)
     return ORACLE_LIB
 
 

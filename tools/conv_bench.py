@@ -4,6 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pvo_amd import droid_backends as db, _lib
+if os.environ.get("PVO_LIB_PATH"):
+    _lib.LIB_PATH = os.environ["PVO_LIB_PATH"]          # a probe / experiment build of the library
 
 dev = torch.device("cuda:0")
 E, H, W = 36, 48, 64
