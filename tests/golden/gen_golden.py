@@ -964,6 +964,37 @@ def gen_frame_graph():
     print("frame_graph.npz:", {k: v.shape for k, v in out.items()})
 
 
+def gen_frame_distance():
+    """frame_distance's two terms (droid_kernels.cu:497-636) from the reference's Python geometry: the reprojection term is
+    the mean norm of pops.induced_flow; the TRANSLATION-ONLY term projects X + d t_ij, which is what pops.projective_transform
+    computes for a relative pose with identity rotation - evaluated here edge by edge on the two-frame pose set
+    [identity, (t_ij, identity)] with t_ij the translation of G_j G_i^-1 (lietorch operators -> pvo_amd.geom.se3, pinned)."""
+    from pvo_amd.geom.se3 import SE3
+    import geom.projective_ops as pops
+    out = {}
+    for name, seed, P, ht, wd in (("a", 40, 5, 8, 10), ("b", 41, 6, 6, 9)):
+        s = make_scene(seed, P, ht, wd)
+        G = SE3(s["poses"][None])
+        intr_all = s["intr"][None, None].repeat(1, P, 1)
+        flow, _ = pops.induced_flow(G, s["disps"][None], intr_all, s["ii"], s["jj"])
+        full = flow[0].norm(dim=-1).mean(dim=(1, 2))
+        Gij = G[:, s["jj"]] * G[:, s["ii"]].inv()
+        tonly = []
+        for e in range(s["ii"].shape[0]):
+            two = torch.zeros(1, 2, 7); two[..., 6] = 1.0
+            two[0, 1, :3] = Gij.data[0, e, :3]
+            d2 = torch.stack([s["disps"][s["ii"][e]], s["disps"][s["ii"][e]]])[None]
+            f, v = pops.induced_flow(SE3(two), d2, intr_all[:, :2], torch.tensor([0]), torch.tensor([1]))
+            assert bool((v == 1).all())
+            tonly.append(f[0, 0].norm(dim=-1).mean())
+        for k in ("poses", "disps", "intr", "ii", "jj"):
+            out[name + "_" + k] = s[k].numpy()
+        out[name + "_full_mean"] = full.numpy()
+        out[name + "_tonly_mean"] = torch.stack(tonly).numpy()
+    np.savez_compressed(os.path.join(HERE, "frame_distance_terms.npz"), **out)
+    print("frame_distance_terms.npz:", {k: v.shape for k, v in out.items() if k.endswith("mean")})
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
@@ -984,3 +1015,4 @@ if __name__ == "__main__":
     gen_depth_video()
     gen_losses()
     gen_frame_graph()
+    gen_frame_distance()

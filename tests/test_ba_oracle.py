@@ -121,3 +121,18 @@ def test_frame_distance_reprojection_term_matches_reference_python(fx):
     d = _load(fx)
     dist = O.frame_distance(d["poses"], d["disps"], d["intr"], d["ii"], d["jj"], 1.0)
     assert np.allclose(dist, d["induced_flow_mean"], rtol=1e-5, atol=1e-5)
+
+
+def test_frame_distance_translation_only_term_and_blend_match_reference_python():
+    """frame_distance (droid_kernels.cu:497-636) = beta x (mean reprojection flow) + (1 - beta) x (mean flow of X + d t_ij) when
+    every point is valid.  Both means come from the reference's pops.projective_transform (frame_distance_terms.npz: the
+    translation-only term as the induced flow of a relative pose with identity rotation); round 2 had pinned the first term only."""
+    d = np.load(os.path.join(G, "frame_distance_terms.npz"))
+    for name in ("a", "b"):
+        args = (d[name + "_poses"], d[name + "_disps"], d[name + "_intr"], d[name + "_ii"], d[name + "_jj"])
+        full, tonly = d[name + "_full_mean"], d[name + "_tonly_mean"]
+        assert np.allclose(O.frame_distance(*args, 1.0), full, rtol=1e-5, atol=1e-5)
+        assert np.allclose(O.frame_distance(*args, 0.0), tonly, rtol=1e-5, atol=1e-5)
+        for beta in (0.3, 0.6):
+            assert np.allclose(O.frame_distance(*args, beta), beta * full + (1 - beta) * tonly, rtol=2e-5, atol=2e-5)
+        assert np.abs(full - tonly).max() > 1e-2                      # the two terms are different quantities on these scenes
