@@ -373,6 +373,12 @@ int pvo_probe_read(float* ms_host, int max_n);
  * ticks) is the clock the chip sustains under that kernel's load (the MFMA-bound convolutions run at ~1.35 GHz on random
  * data, 2.1 GHz on zero-filled operands, 2.4 GHz idle: DESIGN.md section 5). */
 int pvo_clock_probe(void* out3_u64, int iters, void* stream);
+/* Memory-request probe (measurement): one launch of `blocks` x 256 lanes, each lane 8 x iters independent 16-byte loads from
+ * `buf` (device, 128-byte aligned, `bytes` long; use >= 1 GiB so that neither L2 nor the Infinity Cache holds it) -
+ * mode 0: consecutive 128-byte lines (streaming), 1: one RANDOM 128-byte line per 8 lanes, 2: one random 64-byte half line per
+ * 4 lanes.  Returns the number of bytes the launch fetches (lines x line size), or -1; the caller times it.  The rate of mode 2
+ * is the ceiling of the correlation lookup, whose traffic is scattered partial lines.  sink: >= 4 bytes. */
+long long pvo_mem_probe(const void* buf, size_t bytes, int mode, int iters, int blocks, void* sink, void* stream);
 int pvo_graph_update(const pvo_update_weights* weights, const pvo_graph_update_args* args,
                      void* workspace, size_t workspace_bytes, void* stream);
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pvo_reproject": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_ba_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pvo_clock_probe": (_i, [_vp, _i, _vp]),
+    "pvo_mem_probe": (_c.c_longlong, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "pvo_ba": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                     _f, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

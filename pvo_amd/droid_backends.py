@@ -1165,6 +1165,29 @@ def clock_probe(stream, iters=20000):
     return out
 
 
+def mem_probe_gbps(device, nbytes=1 << 30, iters=16, blocks=8192, reps=5):
+    """GB/s of fetched lines for consecutive 128-byte lines, random 128-byte lines and random 64-byte half lines
+    (pvo_mem_probe; HIP events on the current stream): what this part's memory system sustains for scattered lines"""
+    dev = torch.device(device)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    lib, out = _lib.load(), {}
+    with torch.cuda.device(dev):
+        for name, mode in (("streaming_128B", 0), ("random_128B", 1), ("random_64B", 2)):
+            run = lambda: lib.pvo_mem_probe(_ptr(buf), nbytes, mode, iters, blocks, _ptr(sink), _stream(dev))
+            for _ in range(2):
+                fetched = run()
+            if fetched < 0:
+                raise PvoHipError("mem_probe failed")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record(); torch.cuda.synchronize(dev)
+            out[name] = fetched / (e0.elapsed_time(e1) / reps) / 1e6
+    return out
+
+
 def clock_ghz(t):
     c, r, _ = t.tolist()
     return c / (r * 10.0) if r else float("nan")
