@@ -308,7 +308,7 @@ def scattered_ceiling(device, traffic_bytes, write_bytes, lookup_us):
     return {"probe_gbps": g, "how": "pvo_mem_probe: 1 GiB buffer, 8 independent 16-byte loads in flight per lane, full occupancy; bytes counted as fetched",
             "lookup_read_bytes_64B_fetches": read, "lookup_write_bytes": write_bytes,
             "time_at_ceiling_us": t_us, "frac_of_scattered_ceiling": t_us / lookup_us if lookup_us else None,
-            "note": "reads priced at the random-64-byte-line rate, writes at the streaming rate; `roofline.frac` stays priced on algorithmic bytes against the 8 TB/s peak"}
+            "note": "reads priced at the random-64-byte-line rate (an upper bound on the time: the rate is per line touched, and some of the 64-byte fetches share a line), writes at the streaming rate; `roofline.frac` stays priced on algorithmic bytes against the 8 TB/s peak"}
 
 
 def lookup_roofline(E, HW, in_step_ms, traffic=None):

@@ -467,3 +467,39 @@ def test_pinned_ring_exact_fit_and_wraparound():
     assert ring.take(1025, "cpu") is None                             # larger than a quarter: caller's one-off path
     recs = [q for k, q in log if k == "record"]
     assert all((b - a) % 4 == 1 for a, b in zip(recs, recs[1:]))      # quarters are left in order 0,1,2,3,0,...
+
+
+@pytest.mark.gpu
+def test_global_update_never_applies_the_panoptic_vote(cuda):
+    """with segm_filter on, update_lowmem's resident-volume branch (one pvo_graph_update per step) applied the
+    panoptic segment vote although the reference's global update never does (factor_graph.py:309-360).  Both branches on a
+    video that filters by segments, from a mask for which the vote WOULD force whole segments: they must agree to the
+    operator's fp16 rounding, weights and residual flow included."""
+    import bench
+    nkf = 8
+    ii = [i for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= 2]
+    jj = [j for i in range(nkf) for j in range(nkf) if i != j and abs(i - j) <= 2]
+    res = {}
+    for name, corr_impl, fused in (("volume", "volume", True), ("alt", "alt", False)):
+        video, graph = bench.make_window(cuda, seed=5, H8=16, W8=24, NKF=nkf, buffer=16, corr_impl=corr_impl, add_edges=False, max_factors=-1,
+                                         intr=(15.0, 15.0, 12.0, 8.0))
+        video.counter = nkf
+        video.segm_filter, video.thresh, video.max_segments = True, 0.4, 16
+        blocks = ((torch.arange(16)[:, None] // 4) * 3 + torch.arange(24)[None] // 8).int().to(cuda)          # ids 0..11, 0 = no segment
+        video.segms[:nkf] = blocks[None, None]
+        graph.fused_glue = fused
+        graph.add_factors(list(ii), list(jj))
+        g = torch.Generator().manual_seed(9)
+        start = (torch.rand(1, len(ii), 4, 3, generator=g) < 0.5).float()
+        start = torch.nn.functional.interpolate(start, size=(16, 24))[..., None].to(cuda)
+        graph.raw_mask = (1.0 - 2.0 * start) * 0.3 + 0.05 * torch.randn(graph.raw_mask.shape, generator=g).to(cuda)
+        b = torch.sigmoid(graph.raw_mask) >= graph.dy_thresh
+        assert (graph._segment_vote(b) != b).sum().item() > 50           # the vote would change this mask
+        graph.update_lowmem(steps=1)
+        torch.cuda.synchronize()
+        res[name] = dict(weight=graph.weight.clone(), delta_dy=graph.delta_dy.clone(), raw=graph.raw_mask.clone(), poses=video.poses.clone())
+    far = (res["volume"]["raw"].abs() > 5e-3) & (res["alt"]["raw"].abs() > 5e-3)       # (pixels on the hard threshold may flip: excluded)
+    for k in ("weight", "delta_dy"):
+        dd = ((res["volume"][k] - res["alt"][k]).abs() * far)
+        assert dd.max().item() < 2e-2 and dd.mean().item() < 1e-3, (k, dd.max().item(), dd.mean().item())
+    assert (res["volume"]["poses"] - res["alt"]["poses"]).abs().max() < 1e-3
