@@ -490,9 +490,11 @@ def test_global_update_never_applies_the_panoptic_vote(cuda):
         graph.fused_glue = fused
         graph.add_factors(list(ii), list(jj))
         g = torch.Generator().manual_seed(9)
+        # half of the panoptic blocks are 70 % dynamic (above the 0.4 threshold): a vote would force their remaining 30 %
         start = (torch.rand(1, len(ii), 4, 3, generator=g) < 0.5).float()
-        start = torch.nn.functional.interpolate(start, size=(16, 24))[..., None].to(cuda)
-        graph.raw_mask = (1.0 - 2.0 * start) * 0.3 + 0.05 * torch.randn(graph.raw_mask.shape, generator=g).to(cuda)
+        start = torch.nn.functional.interpolate(start, size=(16, 24))[..., None]
+        start = (start * (torch.rand(1, len(ii), 16, 24, 1, generator=g) < 0.7).float()).to(cuda)
+        graph.raw_mask = ((1.0 - 2.0 * start) * 0.3).expand(graph.raw_mask.shape).contiguous()
         b = torch.sigmoid(graph.raw_mask) >= graph.dy_thresh
         assert (graph._segment_vote(b) != b).sum().item() > 50           # the vote would change this mask
         graph.update_lowmem(steps=1)
