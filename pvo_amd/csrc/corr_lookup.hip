@@ -209,6 +209,12 @@ __device__ unsigned long long* g_lk_probe = nullptr;
 #define LK_PROBE(slot)
 #endif
 
+#if defined(PVO_LK_ABL) && PVO_LK_ABL == 3      // ablation: no workgroup barriers in the fused path (wrong results): how much do they couple the waves?
+#define LK_SYNC() do { } while (0)
+#else
+#define LK_SYNC() __syncthreads()
+#endif
+
 template <typename T, bool TILED, bool ENC>
 __device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
   using S = typename Elem<T>::store_t;
@@ -390,7 +396,7 @@ __device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
     }
   }
   LK_PROBE(2);
-  __syncthreads();
+  LK_SYNC();
   LK_PROBE(3);
 
   if constexpr (ENC && sizeof(S) == 2) {
@@ -420,7 +426,7 @@ __device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
       asm volatile("" ::: "memory");      // keep the second tile's weight loads below the first tile's MFMAs (registers)
     }
     LK_PROBE(4);
-    __syncthreads();                                                  // every wave has read its A fragments
+    LK_SYNC();                                                        // every wave has read its A fragments
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int nn = wave * 32 + nt * 16 + li;
@@ -432,7 +438,7 @@ __device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
           *reinterpret_cast<S*>(oslab + (g * 16 + lk * 4 + r) * (kEncOutStride * 2) + nn * 2) =
               Elem<T>::from_f32(fmaxf(dd[nt][g][r] + bn, 0.0f));
     }
-    __syncthreads();
+    LK_SYNC();
     const int npix = min(STRIP, HW - pix0);
     S* o = reinterpret_cast<S*>(a.out) + (static_cast<long long>(n) * HW + pix0) * 128;
 #pragma unroll

@@ -5,7 +5,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROBE_DIR = os.path.join(ROOT, "tools", "_probe")
-VARIANTS = (("base", []), ("loads_only", ["-DPVO_LK_ABL=1"]), ("no_loads", ["-DPVO_LK_ABL=2"]))
+VARIANTS = (("base", []), ("loads_only", ["-DPVO_LK_ABL=1"]), ("no_loads", ["-DPVO_LK_ABL=2"]), ("no_barriers", ["-DPVO_LK_ABL=3"]))
 if "--build" in sys.argv:
     from pvo_amd import build
     build.build_hip()
