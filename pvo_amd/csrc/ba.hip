@@ -887,9 +887,11 @@ __device__ void chol_solve_wave(Mat A, double* Ld, int n, int* fail_flag, const 
       const int ib = base + lane;
       const bool act = ib <= hi && first[ib] <= kb;
       const unsigned long long mask = __ballot(act);
-      if (act) rows[m + __popcll(mask & ((1ull << lane) - 1ull))] = static_cast<unsigned short>(ib);
+      const int at = m + __popcll(mask & ((1ull << lane) - 1ull));
+      if (act && at < kMaxActiveRows) rows[at] = static_cast<unsigned short>(ib);
       m += __popcll(mask);
     }
+    if (m > kMaxActiveRows) { if (lane == 0) *fail_flag = 1; return; }   // (cannot happen for a matrix that fits the LDS budget: every active row owns a stored block)
     wave_lds_sync();
     // (c) panel: x = row L^-T, in place; task 6 m is the rhs row
     for (int t = lane; t <= 6 * m; t += 64) {

@@ -61,6 +61,8 @@ def parse_args(argv=None):
     p.add_argument("--corr_dtype", default="bfloat16", choices=["float32", "bfloat16", "float16"])
     p.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu: gloo, for the plumbing tests")
     p.add_argument("--port", type=int, default=12356)
+    p.add_argument("--dist_backend", default="auto", choices=["auto", "nccl", "gloo"],
+                   help="auto: nccl (RCCL) on the GPU, gloo on the CPU; gloo with --device cuda lets several ranks share one GPU (tests)")
     p.add_argument("--save_every", type=int, default=2000)
     p.add_argument("--log_every", type=int, default=100)
     p.add_argument("--out_dir", default="checkpoints")
@@ -158,7 +160,8 @@ def train(rank, args, report=None):
     dev = torch.device("cuda", local) if cuda else torch.device("cpu")
     if cuda:
         torch.cuda.set_device(dev)
-    dist.init_process_group("nccl" if cuda else "gloo", rank=rank, world_size=world, **({"device_id": dev} if cuda else {}))
+    backend = ("nccl" if cuda else "gloo") if args.dist_backend == "auto" else args.dist_backend
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
     torch.manual_seed(0)                                             # train.py:40: every rank starts from the same weights
     rng = np.random.default_rng(12345)                               # restarts (train.py:52)
     graph_rng = np.random.default_rng(777 + rank)
@@ -190,8 +193,9 @@ def train(rank, args, report=None):
                 Gs.data[:, 0] = Ps.data[:, 0].clone()                 # train.py:143-145: first pose fixed, the rest start at pose 1
                 Gs.data[:, 1:] = Ps.data[:, [1]].clone()
                 disp0 = torch.ones_like(disps[:, :, 3::8, 3::8])
-                r = 0.0
-                while r < args.restart_prob:                          # random restarts (train.py:148-150)
+                r, first = 0.0, True
+                while first or r < args.restart_prob:                 # random restarts (train.py:148-150; at least one pass,
+                    first = False                                     #  also for restart_prob = 0, where the reference's loop never runs)
                     r = rng.random()
                     want_flow = args.flow_label or args.ph_loss
                     out = ddp(Gs, images, disp0, intrinsics / 8.0, graph, num_steps=args.iters, fixedp=2, ret_flow=want_flow,
