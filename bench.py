@@ -252,11 +252,16 @@ def synthetic_ate(device):
             "sequence": "synthetic plane scene, 24x32 maps, 14 frames, ground-truth correspondences + 0.05 px noise in place of the learned operator"}
 
 
+PROBE_EVERY = 5
+
+
 def timed_steps(video, graph, snap, steps, world, probe_stage="lookup", updates_per_step=6):
     """K keyframe updates bracketed as the driver's contract asks: barrier + synchronize on both sides, max over ranks"""
     from pvo_amd import droid_backends as db
     if probe_stage:
-        db.probe_arm(probe_stage, steps * updates_per_step)      # HIP events around one kernel, on its stream, in the timed steps
+        # HIP events around one kernel, on its stream, in the timed steps: one launch in PROBE_EVERY (co-prime with the updates
+        # per step, so every position inside the step is sampled) - the event pair costs the launch stream ~7 us, 2 % of a step
+        db.probe_arm(probe_stage, steps * updates_per_step, every=PROBE_EVERY)
     host_issue = []
     torch.cuda.synchronize()
     if world > 1:
@@ -319,7 +324,7 @@ def lookup_roofline(E, HW, in_step_ms, traffic=None):
     return {"kernel": "corr_lookup_r3_kernel<half, tiled, enc> (4-level lookup + 196->128 encoder layer, 8x8-tiled resident volumes)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": len(in_us),
-            "timing": "HIP events around the kernel on its launch stream, inside the timed steps",
+            "timing": "HIP events around the kernel on its launch stream, inside the timed steps (every %dth launch)" % PROBE_EVERY,
             "in_step_us_min_median_max": [in_us[0], in_us[len(in_us) // 2], in_us[-1]] if in_us else None}
 
 
@@ -433,7 +438,7 @@ def train_step_leg(device, reps=3):
     ms = 1e3 * sorted(ts[1:])[len(ts[1:]) // 2]
     return {"workload": "S-T: BASELINE.json configs[4] at N=1 (tools/train.py step: 6 frames 200x400 -> 25x50 maps, %d edges, 15 unrolled "
                         "updates, semisup objective, bf16 volume + HIP lookup fwd/bwd, fp32 operator / BA, Adam), random-init weights" % E,
-            "ms_per_step": ms, "steps_per_s": 1e3 / ms, "loss": float(loss),
+            "ms_per_step": ms, "steps_per_s": 1e3 / ms, "loss": float(loss.detach()),
             "lookup_backward_level0_us": bw_us, "lookup_backward_level0_gbps": vol.numel() * 2 / (bw_us * 1e-6) / 1e9,
             "data_parallel": "DDP over RCCL, one clip per rank (tools/train.py --gpus 0,1,2,3); gradient all-reduce 17.3 MB per step"}
 

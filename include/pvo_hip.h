@@ -367,6 +367,8 @@ int pvo_side_stream(void** stream_out);
  * disarms the probe and returns the number of samples (or -1). */
 enum { PVO_STAGE_LOOKUP = 0, PVO_STAGE_GATES = 1, PVO_STAGE_CANDIDATE = 2, PVO_STAGE_BA = 3, PVO_STAGE_UPDATE = 4 };
 int pvo_probe_arm(int stage, int capacity);
+/* The same, sampling one occurrence in `every` (>= 1): the event pair costs the launch stream a few microseconds per occurrence. */
+int pvo_probe_arm_every(int stage, int capacity, int every);
 int pvo_probe_read(float* ms_host, int max_n);
 /* Shader-clock probe: one wave runs iters x 64 dependent v_fma_f32 and writes {s_memtime cycles, s_memrealtime ticks of
  * 10 ns, (unused)} to out3_u64 (device, 3 x uint64).  Launched on a second stream beside a kernel, cycles / (10 ns x

@@ -54,6 +54,7 @@ SIGNATURES = {
     "pvo_se3_binary": (_i, [_i, _vp, _c.c_longlong, _vp, _c.c_longlong, _vp, _c.c_longlong, _i, _vp]),
     "pvo_side_stream": (_i, [_c.POINTER(_vp)]),
     "pvo_probe_arm": (_i, [_i, _i]),
+    "pvo_probe_arm_every": (_i, [_i, _i, _i]),
     "pvo_probe_read": (_i, [_vp, _i]),
     "pvo_frame_distance": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "pvo_frame_distance_bidirectional": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

@@ -619,6 +619,13 @@ __device__ unsigned long long* g_ba_probe = nullptr;
 #else
 #define BA_PROBE(slot)
 #endif
+// ... and (-DPVO_BA_PROBE=2) of one block column (P / 2) of the pipelined factorisation's wave 0, slots 8..: every stamp is a
+// scalar load + s_waitcnt lgkmcnt(0), which drains the LDS queue - the split it shows is of a step ~30 % longer than the real one
+#if defined(PVO_BA_PROBE) && PVO_BA_PROBE == 2
+#define BA_PROBE_STEP(slot) do { if (g_ba_probe && lane == 0 && kb == P / 2) g_ba_probe[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BA_PROBE_STEP(slot)
+#endif
 
 __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
@@ -669,6 +676,7 @@ struct DenseMat {
   double* p; Index n;
   __device__ __forceinline__ MatRow row(int i) const { return MatRow{p + i * n, 0}; }
   __device__ __forceinline__ Index rowstep() const { return n; }      // distance between the same column of rows i and i + 1
+  __device__ __forceinline__ int blockstep() const { return 6; }       // ... between the same entry of blocks (ib, cb) and (ib, cb + 1)
   // six contiguous (16-byte aligned) entries: row r of 6 x 6 block (ib, cb); the rhs entries of block cb
   __device__ __forceinline__ double* brow(int ib, int r, int cb) const { return p + static_cast<Index>(6 * ib + r) * n + 6 * cb; }
   __device__ __forceinline__ double* yrow(int cb) const { return p + n * n + 6 * cb; }
@@ -681,16 +689,21 @@ struct EnvMat {
     return MatRow{blk + rowoff[ib] + (i - 6 * ib) * 6, 30};
   }
   __device__ __forceinline__ int rowstep() const { return 6; }         // ... inside one block row
+  __device__ __forceinline__ int blockstep() const { return 36; }
   __device__ __forceinline__ double* brow(int ib, int r, int cb) const { return blk + rowoff[ib] + 36 * cb + 6 * r; }
   __device__ __forceinline__ double* yrow(int cb) const { return rhs + 6 * cb; }
 };
 
 // Inclusive scan (sum or max) of v[0..P) in place by the whole workgroup, 256 entries at a time with a carry: the serial
 // thread-0 loops this replaces were 50 k cycles of LDS round trips per 63-pose solve.
+__device__ __forceinline__ int* scan_scratch() {             // one copy for both instantiations of block_scan (LDS is scarce in the solve)
+  __shared__ int scratch[2 * 256 + 1];
+  return scratch;
+}
 template <bool MAX>
 __device__ void block_scan(int* v, int P) {
-  __shared__ int buf[2][256];
-  __shared__ int carry_s;
+  int (*buf)[256] = reinterpret_cast<int (*)[256]>(scan_scratch());
+  int& carry_s = scan_scratch()[512];
   const int tid = threadIdx.x;
   if (tid == 0) carry_s = MAX ? -0x7fffffff : 0;
   __syncthreads();
@@ -842,6 +855,7 @@ __device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, con
 //   (d) trailing update: one lane per (block pair, row): six entries of the pair's block, 36 FMAs, operands as 16-byte reads.
 // Every entry sees exactly the operations of chol_solve_blocked in the same order (t = 0..5 within a step, steps ascending),
 // so the result is bit-identical to it - and to the dense factorisation, for the reason given at EnvMat.
+constexpr int kMaxEnvBlocks = 2048;      // poses the envelope table covers (beyond: dense, first = 0)
 constexpr int kMaxActiveRows = 512;      // active block rows of one step (each owns a stored block: the LDS budget holds < 490)
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -975,7 +989,330 @@ __device__ void chol_solve_wave(Mat A, double* Ld, int n, int* fail_flag, const 
   }
 }
 
-constexpr int kMaxEnvBlocks = 2048;      // poses the envelope table covers (beyond: dense, first = 0)
+// ---- ... and by FOUR waves in a look-ahead pipeline --------------------------------------------------------------------------
+// What bounds the two forms above is the serial chain  6 x 6 Cholesky of block (kb, kb) -> panel -> update of block column
+// kb + 1 -> next 6 x 6 Cholesky; the rest of a step's trailing update (all block columns beyond kb + 1) and the whole forward
+// substitution of the right-hand side are not on it.  Here wave 0 walks the chain and nothing else:
+//   wave 0    step kb: factor the diagonal block, panel; make sure the workers have finished step kb - 1; publish
+//             (`panel` = kb); update block column kb + 1 (the look-ahead); next step.
+//   wave 1    the right-hand side (its panel solve and its updates, all steps in order), then pair tasks
+//   waves 2-3 pair tasks of step kb for the block columns beyond kb + 1, as soon as `panel` >= kb; publish `done[w]` = kb.
+// Order of the operations an entry sees (= bit-identity with chol_solve_blocked): a worker starts step kb when `panel` >= kb,
+// which wave 0 publishes only after EVERY worker has finished step kb - 1 (two steps' updates of one entry may belong to two
+// different waves); wave 0's look-ahead of step kb comes after the same wait.  Waves of one workgroup are resident together,
+// so waiting on a flag in LDS cannot deadlock; LDS operations of a wave are performed in order, so data written before a flag
+// are visible to whoever sees the flag (the fences only pin the compiler and the wait counters).  Waits are bounded: a wave
+// that gives up sets `abort` and the solve reports failure instead of hanging the device.
+// Wave 0's step: the active rows of every step are listed ONCE, before the factorisation, by the whole workgroup (pipe_lists:
+// they depend on the envelope only); a step's lookups (list, row offsets) are made during the step before; the panel's
+// operand rows and the workers' flags are loaded BEFORE the 6 x 6 Cholesky; a lane keeps its panel row in registers for the
+// look-ahead update (it is that update's left operand).
+// Measured (tools/ba_solve_timeline.py, 63 free poses): 4.1 k cycles per block column against 6.7 k for one wave doing
+// everything.  A lone wave pays ~10-16 cycles of issue per LDS instruction and ~8 per fp64 operation, and ~150-200 per
+// dependent LDS round trip, so what is left is the 6 x 6 Cholesky (~1.0 k), the look-ahead (~1.5 k: 24 16-byte loads, 36
+// FMAs, 3 stores per lane) and the panel.  Tried on top of this and slower: the next diagonal block handed over through 42
+// v_readlane instead of LDS, and the factored block stored by six panel lanes instead of 27 stores of lane 0 (+5 %); the
+// look-ahead split into wave 0 (diagonal block, one entry per lane) and a worker (rest of the column, own flag) (+17 %: two
+// flag hand-overs on the chain cost more than the arithmetic they take off it).
+constexpr int kPipeSpinLimit = 1 << 20;
+constexpr int kPipeListMax = 2 * kMaxActiveRows;      // sub-diagonal blocks inside the envelope (every one is a stored block: < 494 in LDS)
+struct __attribute__((aligned(16))) PipeCtl { int panel; int done[3]; int abort; int total; };
+
+__device__ __forceinline__ int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void pipe_post(int* flag, int v) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool pipe_wait_panel(PipeCtl* ctl, int v) {
+  int spins = 0;
+  while (lds_peek(&ctl->panel) < v) {
+    if (lds_peek(&ctl->abort) || ++spins > kPipeSpinLimit) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+__device__ __forceinline__ int pipe_done_min(PipeCtl* ctl) {            // three reads in flight, one round trip
+  const int a = lds_peek(&ctl->done[0]), b = lds_peek(&ctl->done[1]), c = lds_peek(&ctl->done[2]);
+  return min(a, min(b, c));
+}
+__device__ __forceinline__ bool pipe_wait_done(PipeCtl* ctl, int seen, int v) {
+  int spins = 0;
+  while (seen < v) {
+    if (lds_peek(&ctl->abort) || ++spins > kPipeSpinLimit) return false;
+    __builtin_amdgcn_s_sleep(1);
+    seen = pipe_done_min(ctl);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+
+// Lists of every step's active block rows (ib > kb with first[ib] <= kb), ascending, in compressed-column form:
+// rowlist[colptr[kb] .. colptr[kb + 1]).  `reach` is consumed: on return it holds colptr (P + 1 entries; P < kMaxEnvBlocks).
+// Whole workgroup; returns false (everything untouched) when the lists do not fit.
+__device__ bool pipe_lists(const int* first, int* reach, int P, unsigned short* rowlist, PipeCtl* ctl) {
+  int hi_keep[kMaxEnvBlocks / 256], cnt_keep[kMaxEnvBlocks / 256];
+  int mine = 0;
+#pragma unroll
+  for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+    const int kb = q * 256 + threadIdx.x;
+    int cnt = 0, hi = -1;
+    if (kb < P) {
+      hi = reach[kb];
+      for (int ib = kb + 1; ib <= hi; ++ib) cnt += first[ib] <= kb ? 1 : 0;
+    }
+    hi_keep[q] = hi; cnt_keep[q] = cnt; mine += cnt;
+  }
+  if (threadIdx.x == 0) ctl->total = 0;
+  __syncthreads();
+  if (mine) atomicAdd(&ctl->total, mine);
+  __syncthreads();
+  if (ctl->total > kPipeListMax || P + 1 > kMaxEnvBlocks) return false;
+#pragma unroll
+  for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+    const int kb = q * 256 + threadIdx.x;
+    if (kb < P) reach[kb] = cnt_keep[q];
+  }
+  __syncthreads();
+  block_scan<false>(reach, P);                                            // inclusive
+#pragma unroll
+  for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+    const int kb = q * 256 + threadIdx.x;
+    if (kb >= P) continue;
+    int at = reach[kb] - cnt_keep[q];
+    for (int ib = kb + 1; ib <= hi_keep[q]; ++ib)
+      if (first[ib] <= kb) rowlist[at++] = static_cast<unsigned short>(ib);
+  }
+  __syncthreads();
+  // inclusive -> colptr: shift by one entry (through registers: in place)
+  int incl[kMaxEnvBlocks / 256];
+#pragma unroll
+  for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+    const int kb = q * 256 + threadIdx.x;
+    incl[q] = kb < P ? reach[kb] : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+    const int kb = q * 256 + threadIdx.x;
+    if (kb < P) reach[kb + 1] = incl[q];
+  }
+  if (threadIdx.x == 0) reach[0] = 0;
+  __syncthreads();
+  return true;
+}
+
+// acc (row r of block (ib, cb)) -= li (row r of L(ib, kb)) times L(cb, kb)^T, whose rows start at cprow0 and lie rstep apart;
+// entries beyond column cmax stay (diagonal blocks: lower triangle)
+__device__ __forceinline__ void pair_update(const double* cprow0, int rstep, const double (&li)[6], int cmax, double (&acc)[6]) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double cp[6];
+    ld6(cprow0 + c * rstep, cp);
+    double u = acc[c];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) u = fma(-li[q], cp[q], u);
+    acc[c] = (c <= cmax) ? u : acc[c];
+  }
+}
+template <class Mat>
+__device__ __forceinline__ void pair_task(const Mat& A, int kb, int ib, int r, int cb, int cmax) {
+  double li[6], acc[6];
+  ld6(A.brow(ib, r, kb), li);
+  double* dst = A.brow(ib, r, cb);
+  ld6(dst, acc);
+  pair_update(A.brow(cb, 0, kb), static_cast<int>(A.rowstep()), li, cmax, acc);
+  st6(dst, acc);
+}
+__device__ __forceinline__ void panel_row(const double (&v)[6], const double (&L)[21], const double (&rd)[6], double (&x)[6]) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double u = v[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) u = fma(-x[k], L[c * (c + 1) / 2 + k], u);
+    x[c] = u * rd[c];
+  }
+}
+
+template <class Mat>
+__device__ void chol_solve_pipe(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* colptr,
+                                const unsigned short* rowlist, PipeCtl* ctl) {
+  // executed by the four waves of the workgroup, after pipe_lists; on return (and after the caller's barrier) the rhs holds x
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int P = n / 6;
+  const int rstep = static_cast<int>(A.rowstep()), bstep = A.blockstep();
+#define PIPE_GIVE_UP() do { if (lane == 0) { *fail_flag = 1; __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } return; } while (0)
+  if (wave == 0) {
+    const int q0 = lane / 6, r0 = lane - 6 * q0;
+    int m = P > 0 ? colptr[1] - colptr[0] : 0;
+    const unsigned short* rows = rowlist + (P > 0 ? colptr[0] : 0);
+    bool one_trip = 6 * m <= 64, mine = one_trip && lane < 6 * m;
+    double* rp0 = A.brow(mine ? rows[q0] : 0, r0, 0);
+    double* dptr = A.brow(0, 0, 0);
+    bool ahead = m > 0 && rows[0] == 1;
+    for (int kb = 0; kb < P; ++kb) {
+      const bool more = kb + 1 < P;
+      BA_PROBE_STEP(8);
+      double D[21], L[21], rd[6], v0[6], x0[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double v[6];
+        ld6(dptr + r * rstep, v);
+#pragma unroll
+        for (int c = 0; c <= r; ++c) D[r * (r + 1) / 2 + c] = v[c];
+      }
+      if (one_trip) ld6(rp0, v0);                                          // (idle lanes read some valid row)
+      const int seen = kb >= 1 ? pipe_done_min(ctl) : 0;                   // the workers' progress, read early
+      const int nbeg = more ? colptr[kb + 1] : 0;                          // next step, first lookup
+      const int nm = more ? colptr[kb + 2] - nbeg : 0;
+      BA_PROBE_STEP(9);
+      const bool ok = chol6(D, L, rd);
+      if (!ok) PIPE_GIVE_UP();                                             // uniform: every lane saw the same block
+      BA_PROBE_STEP(10);
+      const unsigned short* nrows = rowlist + nbeg;                        // next step, second lookup
+      const bool n_one = 6 * nm <= 64, n_mine = n_one && lane < 6 * nm;
+      const int nib0 = n_mine ? nrows[q0] : (more ? kb + 1 : kb);
+      const bool nahead = nm > 0 && nrows[0] == kb + 2;
+      if (one_trip) {
+        panel_row(v0, L, rd, x0);
+        if (mine) st6(rp0, x0);
+      } else {
+        for (int t = lane; t < 6 * m; t += 64) {
+          const int q = t / 6;
+          double* rp = A.brow(rows[q], t - 6 * q, kb);
+          double v[6], x[6];
+          ld6(rp, v);
+          panel_row(v, L, rd, x);
+          st6(rp, x);
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 21; ++q) Ld[kb * 27 + q] = L[q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Ld[kb * 27 + 21 + q] = rd[q];
+      }
+      BA_PROBE_STEP(11);
+      double* nrp0 = A.brow(nib0, r0, more ? kb + 1 : kb);                 // next step, third lookup (the rows' offsets)
+      double* ndptr = more ? A.brow(kb + 1, 0, kb + 1) : dptr;
+      // nobody may start step kb before every worker has finished step kb - 1; the same wait covers the look-ahead below
+      // (block column kb + 1 must have seen the workers' step kb - 1 before this step's update and the next Cholesky)
+      if (kb >= 1 && !pipe_wait_done(ctl, seen, kb - 1)) PIPE_GIVE_UP();
+      BA_PROBE_STEP(12);
+      pipe_post(&ctl->panel, kb);
+      BA_PROBE_STEP(13);
+      if (ahead) {                                                         // look-ahead: pairs (a, 0) of the list; L(kb + 1, kb) sits left of the next diagonal block
+        if (one_trip) {
+          if (mine) {
+            double* dst = rp0 + bstep;
+            double acc[6];
+            ld6(dst, acc);
+            pair_update(ndptr - bstep, rstep, x0, q0 == 0 ? r0 : 5, acc);
+            st6(dst, acc);
+          }
+        } else {
+          for (int t = lane; t < 6 * m; t += 64) {
+            const int a = t / 6, r = t - 6 * a;
+            pair_task(A, kb, rows[a], r, kb + 1, a == 0 ? r : 5);
+          }
+        }
+      }
+      wave_lds_sync();
+      BA_PROBE_STEP(14);
+      m = nm; rows = nrows; one_trip = n_one; mine = n_mine; rp0 = nrp0; dptr = ndptr; ahead = nahead;
+    }
+    // the right-hand side's forward substitution is wave 1's: wait for its last step, then substitute back
+    if (!pipe_wait_done(ctl, pipe_done_min(ctl), P - 1)) PIPE_GIVE_UP();
+    BA_PROBE(2);
+    // Back substitution L^T x = y, block rows from the bottom, the arithmetic of chol_solve_blocked.  One wave, LDS
+    // operations in program order, so no fence inside: a step's operands that do not depend on x (this lane's column of
+    // L and its y entry, the next step's factored diagonal block) are in flight while the 6 x 6 triangular solve runs.
+    double Lc[27];
+    if (P > 0) {
+#pragma unroll
+      for (int q = 0; q < 27; ++q) Lc[q] = Ld[(P - 1) * 27 + q];
+    }
+    for (int kb = P - 1; kb >= 0; --kb) {
+      double* y = A.yrow(kb);
+      double yv[6], x[6], Ln[27];
+      ld6(y, yv);
+      const int ibeg = 6 * first[kb];
+      if (kb > 0) {
+#pragma unroll
+        for (int q = 0; q < 27; ++q) Ln[q] = Ld[(kb - 1) * 27 + q];
+      }
+#pragma unroll
+      for (int c = 5; c >= 0; --c) {
+        double v = yv[c];
+#pragma unroll
+        for (int k = c + 1; k < 6; ++k) v = fma(-Lc[k * (k + 1) / 2 + c], x[k], v);
+        x[c] = v * Lc[21 + c];                                             // reciprocal diagonal
+      }
+      asm volatile("" ::: "memory");
+      if (lane < 6) y[lane] = x[lane];
+      asm volatile("" ::: "memory");
+      for (int i = ibeg + lane; i < 6 * kb; i += 64) {                     // row block kb of L is zero left of its envelope
+        const int cbk = i / 6, c2 = i - 6 * cbk;
+        double* yp = A.yrow(cbk) + c2;
+        const double* lp = A.brow(kb, 0, cbk) + c2;
+        double v = *yp;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v = fma(-lp[c * rstep], x[c], v);
+        *yp = v;
+      }
+      asm volatile("" ::: "memory");                                       // (compiler only: the next step reads what other lanes wrote)
+      if (kb > 0) {
+#pragma unroll
+        for (int q = 0; q < 27; ++q) Lc[q] = Ln[q];
+      }
+    }
+    wave_lds_sync();
+    return;
+  }
+  // ---- workers
+  const int slot = wave == 1 ? 2 : wave - 2;                               // pair tasks go to waves 2, 3 first: wave 1 has the rhs
+  for (int kb = 0; kb < P; ++kb) {
+    const int beg = colptr[kb], m = colptr[kb + 1] - beg;
+    const unsigned short* rows = rowlist + beg;
+    if (!pipe_wait_panel(ctl, kb)) PIPE_GIVE_UP();
+    if (wave == 1) {
+      // rhs: y(kb) <- L(kb,kb)^-1 y(kb) (every lane redundantly, lane 0 stores), then y(cb) -= L(cb, kb) y(kb) per active row
+      const double* Lp = Ld + kb * 27;
+      double L[21], rd[6];
+#pragma unroll
+      for (int q = 0; q < 21; ++q) L[q] = Lp[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rd[q] = Lp[21 + q];
+      double* y = A.yrow(kb);
+      double v[6], x[6];
+      ld6(y, v);
+      panel_row(v, L, rd, x);
+      if (lane == 0) st6(y, x);
+      for (int a = lane; a < m; a += 64) {
+        const int cb = rows[a];
+        double* dst = A.yrow(cb);
+        double acc[6];
+        ld6(dst, acc);
+        pair_update(A.brow(cb, 0, kb), rstep, x, 5, acc);
+        st6(dst, acc);
+      }
+    }
+    const int b0 = (m > 0 && rows[0] == kb + 1) ? 1 : 0;                   // block column kb + 1 is wave 0's
+    const int mm = m - b0;
+    const int ntask = 6 * (mm * (mm + 1) / 2);
+    for (int t = slot * 64 + lane; t < ntask; t += 192) {
+      const int pr = t / 6, r = t - 6 * pr;
+      int a = static_cast<int>((sqrtf(8.0f * static_cast<float>(pr) + 1.0f) - 1.0f) * 0.5f);
+      while ((a + 1) * (a + 2) / 2 <= pr) ++a;
+      while (a * (a + 1) / 2 > pr) --a;
+      const int b = pr - a * (a + 1) / 2;
+      pair_task(A, kb, rows[a + b0], r, rows[b + b0], a == b ? r : 5);
+    }
+    pipe_post(&ctl->done[wave - 1], kb);
+  }
+#undef PIPE_GIVE_UP
+}
+
 
 // ---- systems beyond the dense LDS path (more than 22 free poses: the global bundle adjustment) --------------------------
 // Two multi-workgroup kernels prepare the one-workgroup solve (inside it, reading 1.1 MB of fixed point through a single CU
@@ -1068,17 +1405,21 @@ __global__ __launch_bounds__(256) void ba_prepare_kernel(long long* __restrict__
 __global__ __launch_bounds__(256) void ba_solve_kernel(
     long long* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
     float* __restrict__ dx_ws, float* __restrict__ dx_out, int* __restrict__ meta, int* __restrict__ status_out,
-    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget, int solver_wave) {
+    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget, int solver) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs | ...]
   int& fail = *reinterpret_cast<int*>(smem);
   const int n = 6 * P;
   __shared__ int first[kMaxEnvBlocks];                                           // envelope: first non-zero block column per block row
   __shared__ int reach[kMaxEnvBlocks];                                           // ... and last block row that reaches a block column
-  __shared__ unsigned short act_rows[kMaxActiveRows];                            // chol_solve_wave's list of active block rows
+  __shared__ unsigned short act_rows[2][kMaxActiveRows];                         // lists of a step's active block rows (wave / pipe solvers)
+  __shared__ PipeCtl pipe_ctl;
   __shared__ int blocks_s;
   BA_ACQ();
   BA_PROBE(0);
-  if (threadIdx.x == 0) fail = 0;
+  if (threadIdx.x == 0) {
+    fail = 0;
+    pipe_ctl.panel = -1; pipe_ctl.done[0] = pipe_ctl.done[1] = pipe_ctl.done[2] = -1; pipe_ctl.abort = 0; pipe_ctl.total = 0;
+  }
   double* xrow = nullptr;                                                        // where the solution ends up
   if (!use_lds) {
     // prepared by ba_env_kernel + ba_prepare_kernel
@@ -1106,17 +1447,18 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
       }
       __syncthreads();
       {
-        // 124 KB at 63 poses through one workgroup: eight 16-byte loads in flight per thread (one 8-byte load at a time
+        // 124 KB at 63 poses through one workgroup: sixteen 16-byte loads in flight per thread (one 8-byte load at a time
         // was 57 k cycles of latency)
         const int nd2 = (blocks + n) >> 1;                                          // blocks is a multiple of 36: pairs cover blocks + n but for an odd n
         const double2* src = reinterpret_cast<const double2*>(chol_global);
         double2* dst = reinterpret_cast<double2*>(blk);
-        for (int base = 0; base < nd2; base += 8 * blockDim.x) {
-          double2 v[8];
+        // (sixteen per thread, every load unconditional on a clamped index: a guarded `v[u] = src[i]` sends the array to scratch)
+        for (int base = 0; base < nd2; base += 16 * blockDim.x) {
+          double2 v[16];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = base + u * blockDim.x + threadIdx.x; if (i < nd2) v[u] = src[i]; }
+          for (int u = 0; u < 16; ++u) { const int i = base + u * blockDim.x + threadIdx.x; v[u] = src[i < nd2 ? i : nd2 - 1]; }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int i = base + u * blockDim.x + threadIdx.x; if (i < nd2) dst[i] = v[u]; }
+          for (int u = 0; u < 16; ++u) { const int i = base + u * blockDim.x + threadIdx.x; if (i < nd2) dst[i] = v[u]; }
         }
         if (((blocks + n) & 1) && threadIdx.x == 0) blk[blocks + n - 1] = chol_global[blocks + n - 1];
       }
@@ -1129,7 +1471,9 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
       __syncthreads();
       envelope_reach(first, reach, P);
       BA_PROBE(1);
-      if (solver_wave) { if (threadIdx.x < 64) chol_solve_wave(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach, act_rows); }
+      if (solver == 2 && pipe_lists(first, reach, P, act_rows[0], &pipe_ctl))
+        chol_solve_pipe(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach, act_rows[0], &pipe_ctl);
+      else if (solver >= 1) { if (threadIdx.x < 64) chol_solve_wave(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach, act_rows[0]); }
       else chol_solve_blocked(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach);
       xrow = rhs;
     } else {
@@ -1172,7 +1516,9 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(
     __syncthreads();
     envelope_reach(first, reach, P);
     BA_PROBE(1);
-    if (solver_wave) { if (threadIdx.x < 64) chol_solve_wave(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach, act_rows); }
+    if (solver == 2 && pipe_lists(first, reach, P, act_rows[0], &pipe_ctl))
+      chol_solve_pipe(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach, act_rows[0], &pipe_ctl);
+    else if (solver >= 1) { if (threadIdx.x < 64) chol_solve_wave(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach, act_rows[0]); }
     else chol_solve_blocked(DenseMat<int>{A, n}, A + n * n + n, n, &fail, first, reach);
     xrow = A + n * n;
   }
@@ -1358,7 +1704,7 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
   hipStream_t st = pvo_stream(stream);
   const int n6 = 6 * P;
   const int use_lds = n6 <= kLdsCholMax;
-  constexpr size_t kSolveLdsMax = 142000;      // dynamic LDS of the solve: the CU's 163840 B minus its 21520 B of static tables (envelope, reach, active rows, scan buffers)
+  constexpr size_t kSolveLdsMax = 142000;      // dynamic LDS of the solve: the CU's 163840 B minus its 20528 B of static tables (envelope, reach, active rows, scan buffers)
   const size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
   if (lds > 48 * 1024) {
     static bool attr_set = false;
@@ -1368,12 +1714,14 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
       attr_set = true;
     }
   }
-  // Two bit-identical factorisations of a system that lives in LDS (chol_solve_blocked: four waves and barriers;
-  // chol_solve_wave: one wave, none).  Measured with tools/ba_solve_timeline.py: 7 free poses 44.0 k cycles blocked / 47.6 k
-  // wave, 63 free poses 615 k / 537 k - the wave form wins once the envelope makes most of a step's candidate rows inactive.
-  // PVO_BA_SOLVER = blocked | wave overrides (tests compare the two bit for bit).
-  static const int solver_env = [] { const char* e = getenv("PVO_BA_SOLVER"); return !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'b' ? 2 : 0)); }();
-  const int solver_wave = solver_env == 1 ? 1 : (solver_env == 2 ? 0 : (P > 12 ? 1 : 0));
+  // Three bit-identical factorisations of a system that lives in LDS (chol_solve_blocked: four waves and barriers;
+  // chol_solve_wave: one wave, none; chol_solve_pipe: wave 0 on the critical chain, three worker waves behind it).  Measured
+  // with tools/ba_solve_timeline.py, cycles of the whole kernel: 7 free poses 44.8 k blocked / 48.0 k wave / 52.1 k pipe,
+  // 12: 87.5 k blocked / 86.0 k pipe, 21: 168 k / 157 k, 63: 578 k blocked / 485 k wave / 364 k pipe - the pipeline wins once the
+  // envelope makes most of a step's candidate rows inactive.  PVO_BA_SOLVER = blocked | wave | pipe overrides (tests compare
+  // the three bit for bit).
+  static const int solver_env = [] { const char* e = getenv("PVO_BA_SOLVER"); return !e ? -1 : (e[0] == 'b' ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'p' ? 2 : -1))); }();
+  const int solver_wave = solver_env >= 0 ? solver_env : (P > 12 ? 2 : 0);              // 0 blocked | 1 wave | 2 pipe
   if (!use_lds) {
     hipLaunchKernelGGL(ba_env_kernel, dim3((n6 * n6 + 2047) / 2048), dim3(256), 0, st, sys, w.plan.env, n6);
     PVO_CHECK_LAUNCH();

@@ -1193,9 +1193,10 @@ def clock_ghz(t):
     return c / (r * 10.0) if r else float("nan")
 
 
-def probe_arm(stage, capacity):
-    """record HIP events around `stage` ("lookup" | "gates" | "candidate" | "ba" | "update") of the next native updates"""
-    check(_lib.load().pvo_probe_arm(STAGES[stage], int(capacity)), "probe_arm")
+def probe_arm(stage, capacity, every=1):
+    """record HIP events around `stage` ("lookup" | "gates" | "candidate" | "ba" | "update") of the next native updates,
+    one occurrence in `every`"""
+    check(_lib.load().pvo_probe_arm_every(STAGES[stage], int(capacity), int(every)), "probe_arm")
 
 
 def probe_read(capacity):

@@ -233,9 +233,10 @@ def test_reproject_matches_reference_python_fixture(cuda):
 @pytest.mark.gpu
 @pytest.mark.parametrize("P,ht,wd,radius", [(8, 24, 32, 3), (22, 12, 16, 3), (40, 10, 12, 2), (64, 8, 12, 3)])
 def test_wave_and_blocked_cholesky_are_bit_identical(P, ht, wd, radius):
-    """the one-wave (barrier-free) and the four-wave blocked factorisation of the pose system perform the same operations
-    on every entry in the same order: poses and depths agree bit for bit (dense-in-LDS and compact-envelope storage,
-    with a loop closure in the long windows).  Each solver in its own process: the choice is read once per process."""
+    """the look-ahead pipeline (the default: wave 0 on the critical path, three worker waves behind it), the one-wave
+    (barrier-free) and the four-wave blocked factorisation of the pose system perform the same operations on every entry in
+    the same order: poses and depths agree bit for bit (dense-in-LDS and compact-envelope storage, with a loop closure in
+    the long windows).  Each solver in its own process: the choice is read once per process."""
     import subprocess
     import sys
     code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); from test_geom_ba_gpu import _scene; from pvo_amd import droid_backends as db; "
@@ -244,12 +245,13 @@ def test_wave_and_blocked_cholesky_are_bit_identical(P, ht, wd, radius):
             "torch.save((p.cpu(), q.cpu()), sys.argv[1])") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), P, ht, wd, radius)
     import tempfile
     outs = []
-    for solver in ("wave", "blocked"):
+    for solver in ("wave", "blocked", "pipe"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
             r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, PVO_BA_SOLVER=solver), stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=300)
             assert r.returncode == 0, r.stdout[-2000:]
             outs.append(torch.load(f.name))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
     from test_geom_ba_gpu import _scene as sc
     assert (outs[0][0] - sc(3, P, ht, wd, radius, 1)["poses"]).abs().max() > 1e-5

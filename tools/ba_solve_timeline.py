@@ -4,13 +4,13 @@ import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 PROBE_DIR = os.path.join(ROOT, "tools", "_probe")
-PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_ba.so")
+PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_ba%s.so" % os.environ.get("PROBE_TAG", ""))
 if "--build" in sys.argv:
     from pvo_amd import build
     build.build_hip()
     os.makedirs(PROBE_DIR, exist_ok=True)
-    obj = os.path.join(PROBE_DIR, "ba.o")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_BA_PROBE", "-c", os.path.join(build.CSRC, "ba.hip"), "-o", obj])
+    obj = os.path.join(PROBE_DIR, "ba%s.o" % os.environ.get("PROBE_TAG", ""))
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_BA_PROBE=%s" % os.environ.get("PROBE_LEVEL", "1")] + os.environ.get("PROBE_DEFS", "").split() + ["-c", os.path.join(build.CSRC, "ba.hip"), "-o", obj])
     objs = [obj if s == "ba.hip" else os.path.join(build.CSRC, s.replace(".hip", ".o")) for s in build.HIP_SOURCES]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_LIB] + objs)
     print(PROBE_LIB); sys.exit(0)
@@ -25,7 +25,7 @@ s = _scene(0, nf, 48, 64, 3, 1)
 d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()}
 lib = _lib.load()
 lib.pvo_debug_ba_probe.restype = ctypes.c_int; lib.pvo_debug_ba_probe.argtypes = [ctypes.c_void_p]
-buf = torch.zeros(8, dtype=torch.int64, device=dev)
+buf = torch.zeros(32, dtype=torch.int64, device=dev)
 run = lambda: db.ba(d["poses"].clone(), d["disps"].clone(), d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], 1, nf, 2, 1e-4, 0.1, False)
 for _ in range(3):
     run()
@@ -36,3 +36,6 @@ assert lib.pvo_debug_ba_probe(None) == 0
 t = buf.cpu().tolist()
 print("P = %d free poses: load + convert %.1f k cycles | factorisation %.1f | substitution %.1f | dx out + retraction %.1f | total %.1f"
       % (nf - 1, (t[1] - t[0]) / 1e3, (t[2] - t[1]) / 1e3, (t[4] - t[2]) / 1e3, (t[5] - t[4]) / 1e3, (t[5] - t[0]) / 1e3))
+if t[14]:
+    names = ["operand loads issued", "6x6 Cholesky", "panel + store of the factored block", "publish", "wait for the workers", "look-ahead update"]
+    print("   pipelined factorisation, wave 0, block column P/2: " + " | ".join("%s %d" % (nm, t[9 + i] - t[8 + i]) for i, nm in enumerate(names)) + " | step %d cycles" % (t[14] - t[8]))
