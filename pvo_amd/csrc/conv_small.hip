@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256) void gru_glo_mfma_kernel(const uint16_t* __res
         const unsigned char* row = tile + (g * 16 + lk * 4 + r) * kGloStride + (wave * 32 + li) * 2;
         const float n0 = Elem<T>::to_f32(*reinterpret_cast<const typename Elem<T>::store_t*>(row));
         const float n1 = Elem<T>::to_f32(*reinterpret_cast<const typename Elem<T>::store_t*>(row + 32));
-        s0 += n0 / (1.0f + __expf(-(d0[r] + b0)));        // padded pixels carry net = 0
-        s1 += n1 / (1.0f + __expf(-(d1[r] + b1)));
+        // (v_exp + v_rcp: an IEEE division here was a third of this kernel's 128 sigmoids x 72 cycles per lane; padded pixels carry net = 0)
+        s0 = fmaf(n0, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (d0[r] + b0))), s0);
+        s1 = fmaf(n1, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (d1[r] + b1))), s1);
       }
     }
   }

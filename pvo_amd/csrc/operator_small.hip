@@ -53,21 +53,26 @@ __global__ __launch_bounds__(384) void gate_context_kernel(const float* __restri
                                                            const float* __restrict__ gb, float* __restrict__ g, int chunks) {
   __shared__ float glo[128];
   const int e = blockIdx.x, t = threadIdx.x;
+  // L2 latency, not bandwidth, is the cost: all 128 weights of this output are requested before anything waits (four rounds of
+  // 32 were four round trips), the partial means in groups of 16
+  float wv[128];
+#pragma unroll
+  for (int q = 0; q < 128; ++q) wv[q] = wg_t[static_cast<size_t>(q) * 384 + t];
   if (t < 128) {
     float s = 0.0f;
-    for (int k = 0; k < chunks; ++k) s += part[(static_cast<size_t>(e) * chunks + k) * 128 + t];
+    for (int k0 = 0; k0 < chunks; k0 += 16) {
+      float pv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pv[k] = k0 + k < chunks ? part[(static_cast<size_t>(e) * chunks + k0 + k) * 128 + t] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += pv[k];                 // (same order as a serial sum: + 0.0f for the padding)
+    }
     glo[t] = s;
   }
   __syncthreads();
   float a[4] = {gb[t], 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-  for (int c0 = 0; c0 < 128; c0 += 32) {          // 32 weight loads in flight per thread (L2 latency, not bandwidth, is the cost)
-    float wv[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) wv[q] = wg_t[static_cast<size_t>(c0 + q) * 384 + t];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) a[q & 3] = fmaf(glo[c0 + q], wv[q], a[q & 3]);
-  }
+  for (int q = 0; q < 128; ++q) a[q & 3] = fmaf(glo[q], wv[q], a[q & 3]);
   g[static_cast<size_t>(e) * 384 + t] = (a[0] + a[1]) + (a[2] + a[3]);
 }
 
