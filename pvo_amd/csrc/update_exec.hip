@@ -338,7 +338,10 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // side stream idle.  (Letting the BA run beside the mask convolution hides those 17 us too, but one of ~290 repeated
   // two-update runs then differed in the last bits of the poses; starting the BA's edge-block assembly before `mid`, with
   // the wait in front of the Schur step only, made 13 of 13 differ - no buffer is shared (addresses checked), agent-scope
-  // loads of eta changed nothing; cause not found.  tools/update_poison_check.py, tests/...::test_native_updates_are_reproducible.)
+  // loads of eta changed nothing.  Round 3, tools/sched_bisect.py: not a race in this code - BA kernels co-resident with another
+  // hardware queue's kernel while cache write-back / invalidate operations are in flight read stale 64-byte sectors or lose
+  // 8-byte atomics on this platform; alone on the device 0 of 3000 runs differ.  DESIGN 7g, profiles/r03_sched_bisect.txt,
+  // tests/...::test_native_updates_are_reproducible.)
 #ifdef PVO_SCHED_DEBUG
   // mode 1: the mask convolution on the side stream behind the eta head, the BA beside it;  mode 2: additionally the first
   // assembly launched BEFORE the wait on `mid` (arranged below);  mode 3: as shipped but the mask convolution after the BA
@@ -404,7 +407,12 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
     hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, u->disps, n, u->disp_min);
     PVO_CHECK_LAUNCH();
   }
-  RUN(join(pending, stream));
+  // No second join here: the side stream's last work is the eta head, `mid` was recorded behind it, and this stream has waited
+  // for `mid` above (the branch's `join` event is recorded right behind `mid` with nothing in between).  A satisfied wait
+  // still costs the launch stream ~6 us (tools/update_timeline.sh).
+#ifdef PVO_SCHED_DEBUG
+  if (g_sched.mode == 1 || g_sched.mode == 2) RUN(join(pending, stream));      // (these put the mask convolution behind `mid`)
+#endif
   probe_mark(PVO_STAGE_UPDATE, 1, stream);
   return PVO_OK;
 }
