@@ -507,6 +507,20 @@ int pvo_ba_finish(float* poses, float* disps, void* sys,
                   float lm, float ep, int motion_only, int clamp_frames, float disp_min,
                   float* dx_out, float* dz_out, int dz_rows, int* status_out,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* pvo_ba_finish with a rider: the pose solve is one workgroup, the rest of the chip idles meanwhile, and no other queue may run
+ * beside the bundle adjustment - so an independent 1x1 convolution of a 128-channel channels-last tensor
+ * (cy[crows, cCout] = cx[crows, 128] cw^T + cbias, exactly pvo_conv1x1_c128 without ReLU; cCout a multiple of 192; 16-byte
+ * aligned pointers; cdtype PVO_F16 | PVO_BF16) is computed by additional workgroups of the SAME dispatch.  pvo_graph_update
+ * sends GraphAgg's upsampling mask (droid_net.py:76-77,93 - computed by the reference's update module and never read by its
+ * factor graph) this way.  cy == NULL: plain pvo_ba_finish.  The convolution must not alias any BA buffer. */
+int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys,
+                          const int64_t* ii, const int64_t* jj,
+                          int E, int nframes, int ht, int wd, int t0, int t1,
+                          float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                          float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                          void* workspace, size_t workspace_bytes,
+                          const void* cx, const void* cw, const float* cbias, void* cy, long long crows, int cCout, int cdtype,
+                          void* stream);
 
 #ifdef __cplusplus
 }

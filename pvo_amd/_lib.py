@@ -72,6 +72,8 @@ SIGNATURES = {
                           _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,
                            _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "pvo_ba_finish_conv1x1": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,
+                                   _vp, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),
 }
 
 

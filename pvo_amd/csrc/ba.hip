@@ -33,6 +33,7 @@
 // update when the factorisation fails, EvT6x1's skip of window pose 0 in the depth
 // back-substitution (:1084).  Deviation: expSE3 uses xi[5], not xi[45] (:154).
 #include "se3.h"
+#include "conv1x1_tile.h"
 #include <stdlib.h>
 
 namespace {
@@ -746,7 +747,7 @@ __device__ void envelope_reach(const int* first, int* reach, int P) {
 }
 
 template <class Mat>
-__device__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* reach) {
+__device__ __forceinline__ void chol_solve_blocked(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* reach) {
   // On return row n holds the solution x.
   const int tid = threadIdx.x, nt = blockDim.x;
   const int tx = tid & 15, ty = tid >> 4, nty = nt >> 4;
@@ -874,7 +875,7 @@ __device__ __forceinline__ void st6(double* p, const double (&v)[6]) {
 }
 
 template <class Mat>
-__device__ void chol_solve_wave(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* reach, unsigned short* rows) {
+__device__ __forceinline__ void chol_solve_wave(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* reach, unsigned short* rows) {
   // executed by the 64 lanes of ONE wave; on return the rhs holds the solution x
   const int lane = threadIdx.x & 63;
   const int P = n / 6;
@@ -1135,7 +1136,7 @@ __device__ __forceinline__ void panel_row(const double (&v)[6], const double (&L
 }
 
 template <class Mat>
-__device__ void chol_solve_pipe(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* colptr,
+__device__ __forceinline__ void chol_solve_pipe(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* colptr,
                                 const unsigned short* rowlist, PipeCtl* ctl) {
   // executed by the four waves of the workgroup, after pipe_lists; on return (and after the caller's barrier) the rhs holds x
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1402,11 +1403,30 @@ __global__ __launch_bounds__(256) void ba_prepare_kernel(long long* __restrict__
   }
 }
 
+// The pose solve is ONE workgroup for ~20 us (a window) to ~170 us (63 free poses) while the rest of the chip idles - and
+// nothing else may run beside the bundle adjustment on another queue.  Work that is independent of it can ride in
+// the SAME dispatch instead: workgroups 1 .. of this launch compute a 1x1 convolution of a 128-channel tensor (conv1x1_tile.h)
+// - GraphAgg's upsampling mask in pvo_graph_update, 17 us on the launch stream otherwise.  No buffer is shared with the solve.
+struct Conv1x1Rider { const uint16_t *x, *w; const float* bias; uint16_t* y; long long rows; int Cout, dtype, row_blocks; };
+
+__device__ __forceinline__ void ride_conv1x1(unsigned char* smem, const Conv1x1Rider rider, int b) {
+  const int cb = b / rider.row_blocks;
+  const long long rb = b - cb * rider.row_blocks;
+  if (rider.dtype == PVO_F16) c1t::conv1x1_c128_tile<pvo_half>(smem, rider.x, rider.w, rider.bias, rider.y, rider.rows, rider.Cout, 0, rb, cb);
+  else c1t::conv1x1_c128_tile<pvo_bf16>(smem, rider.x, rider.w, rider.bias, rider.y, rider.rows, rider.Cout, 0, rb, cb);
+}
+
 __global__ __launch_bounds__(256) void ba_solve_kernel(
     long long* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
     float* __restrict__ dx_ws, float* __restrict__ dx_out, int* __restrict__ meta, int* __restrict__ status_out,
-    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget, int solver) {
+    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget, int solver,
+    const uint16_t* __restrict__ rx, const uint16_t* __restrict__ rw, const float* __restrict__ rbias, uint16_t* __restrict__ ry,
+    long long rrows, int rCout, int rdtype, int rrow_blocks) {                  // (the rider's fields one by one: a struct argument cost a private segment)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs | ...]
+  if (blockIdx.x > 0) {                                                  // rider workgroups (launched only with a rider)
+    ride_conv1x1(smem, Conv1x1Rider{rx, rw, rbias, ry, rrows, rCout, rdtype, rrow_blocks}, blockIdx.x - 1);
+    return;
+  }
   int& fail = *reinterpret_cast<int*>(smem);
   const int n = 6 * P;
   __shared__ int first[kMaxEnvBlocks];                                           // envelope: first non-zero block column per block row
@@ -1692,6 +1712,29 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
                              float lm, float ep, int motion_only, int clamp_frames, float disp_min,
                              float* dx_out, float* dz_out, int dz_rows, int* status_out,
                              void* workspace, size_t workspace_bytes, void* stream) {
+  return pvo_ba_finish_conv1x1(poses, disps, sys_, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only, clamp_frames, disp_min,
+                               dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes,
+                               nullptr, nullptr, nullptr, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys_,
+                                     const int64_t* ii, const int64_t* jj,
+                                     int E, int nframes, int ht, int wd, int t0, int t1,
+                                     float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                                     float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                                     void* workspace, size_t workspace_bytes,
+                                     const void* cx, const void* cw, const float* cbias, void* cy, long long crows, int cCout, int cdtype,
+                                     void* stream) {
+  Conv1x1Rider rider{};
+  if (cy) {
+    if (!cx || !cw || crows < 0 || cCout <= 0 || cCout % 192) return PVO_EINVAL;
+    if (cdtype != PVO_F16 && cdtype != PVO_BF16) return PVO_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(cx) | reinterpret_cast<uintptr_t>(cw) | reinterpret_cast<uintptr_t>(cy)) & 15) return PVO_EINVAL;
+    if (crows > (1LL << 24)) return PVO_EUNSUPPORTED;
+    rider = Conv1x1Rider{static_cast<const uint16_t*>(cx), static_cast<const uint16_t*>(cw), cbias, static_cast<uint16_t*>(cy),
+                         crows, cCout, cdtype, static_cast<int>((crows + 63) / 64)};
+  }
+  const int rider_blocks = (cy && crows > 0) ? rider.row_blocks * (cCout / 192) : 0;
   int rc = check_common(E, nframes, ht, wd, t0, t1);
   if (rc != PVO_OK) return rc;
   if (clamp_frames < 0 || clamp_frames > nframes) return PVO_EINVAL;
@@ -1705,7 +1748,8 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
   const int n6 = 6 * P;
   const int use_lds = n6 <= kLdsCholMax;
   constexpr size_t kSolveLdsMax = 142000;      // dynamic LDS of the solve: the CU's 163840 B minus its 20528 B of static tables (envelope, reach, active rows, scan buffers)
-  const size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
+  size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
+  if (rider_blocks && lds < static_cast<size_t>(c1t::kTileBytes)) lds = c1t::kTileBytes;      // (the riders' tile lives in the dynamic segment)
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1729,8 +1773,9 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
                        static_cast<long long>(kSolveLdsMax));
     PVO_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
-                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax), solver_wave);
+  hipLaunchKernelGGL(ba_solve_kernel, dim3(1 + rider_blocks), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
+                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax), solver_wave,
+                     rider.x, rider.w, rider.bias, rider.y, rider.rows, rider.Cout, rider.dtype, rider.row_blocks);
   PVO_CHECK_LAUNCH();
   if (!motion_only && E + P > 0) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);

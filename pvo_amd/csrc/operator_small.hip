@@ -12,6 +12,7 @@
 //                      through pvo_corr_lookup_encode_tiled instead, where the 196 channels never reach HBM.
 //   pvo_segment_hist   per (edge, panoptic segment) pixel counts for the dynamic-segment vote (factor_graph.py:256-276)
 #include "common.h"
+#include "conv1x1_tile.h"
 
 namespace {
 
@@ -153,60 +154,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv1x1_c128_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                            const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                            long long rows, int Cout, int relu) {
-  __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 400];     // input tile (64 x 272 B), later the output slab (64 x 400 B)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lk = lane >> 4;
-  const long long r0 = static_cast<long long>(blockIdx.x) * 64;
-  const int c0 = blockIdx.y * 192 + wave * 48;
-  os_u32x4 bf[4][3];
-#pragma unroll
-  for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
-      bf[kc][nt] = *reinterpret_cast<const os_u32x4*>(wt + static_cast<size_t>(c0 + nt * 16 + li) * 128 + kc * 32 + lk * 8);
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int id = tid + 256 * it, px = id >> 4, c = id & 15;
-    os_u32x4 v = {0u, 0u, 0u, 0u};
-    if (r0 + px < rows) v = *reinterpret_cast<const os_u32x4*>(x + static_cast<size_t>(r0 + px) * 128 + c * 8);
-    *reinterpret_cast<os_u32x4*>(tile + px * kOsStride + c * 16) = v;
-  }
-  __syncthreads();
-  os_v4f d[4][3];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) d[g][nt] = os_v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      const os_u32x4 a = *reinterpret_cast<const os_u32x4*>(tile + (g * 16 + li) * kOsStride + kc * 64 + lk * 16);
-#pragma unroll
-      for (int nt = 0; nt < 3; ++nt) d[g][nt] = os_mfma<T>(a, bf[kc][nt], d[g][nt]);
-    }
-  __syncthreads();
-  float bb[3];
-#pragma unroll
-  for (int nt = 0; nt < 3; ++nt) bb[nt] = bias ? bias[c0 + nt * 16 + li] : 0.0f;
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {                        // D rows lk*4 + r = pixels, column li = channel
-        float v = d[g][nt][r] + bb[nt];
-        if (relu) v = fmaxf(v, 0.0f);
-        *reinterpret_cast<uint16_t*>(tile + (g * 16 + lk * 4 + r) * 400 + (wave * 48 + nt * 16 + li) * 2) = static_cast<uint16_t>(os_bits<T>(v));
-      }
-  __syncthreads();
-  for (int id = tid; id < 64 * 24; id += 256) {             // 24 chunks of 16 B per row
-    const int px = id / 24, c = id - px * 24;
-    if (r0 + px < rows)
-      *reinterpret_cast<os_u32x4*>(y + static_cast<size_t>(r0 + px) * Cout + blockIdx.y * 192 + c * 8) =
-          *reinterpret_cast<const os_u32x4*>(tile + px * 400 + c * 16);
-  }
+  __shared__ __attribute__((aligned(16))) unsigned char tile[c1t::kTileBytes];
+  c1t::conv1x1_c128_tile<T>(tile, x, wt, bias, y, rows, Cout, relu, blockIdx.x, blockIdx.y);      // (conv1x1_tile.h)
 }
 
 // ---------------------------------------------------------------------------

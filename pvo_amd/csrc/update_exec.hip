@@ -331,7 +331,15 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
                      u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW, u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW,
                      u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
                      S, u->vote_thresh, dt, stream));
-  // The aggregation branch ends at the eta head on the side stream (`mid`); the upsampling mask - which nothing here reads -
+  static const bool rider_off = [] { const char* e = getenv("PVO_UPMASK_RIDER"); return e && e[0] == '0'; }();
+  const bool mask_rides = u->itrs > 0 && a.K > 0 && a.upmask && !rider_off
+#ifdef PVO_SCHED_DEBUG
+                          && g_sched.mode == 0
+#endif
+      ;
+  // The upsampling mask - which nothing here reads - rides in the dispatch of the first pose solve (one workgroup solves, the
+  // mask convolution's workgroups fill the idle chip: pvo_ba_finish_conv1x1), unless there is no solve to ride.  Before round 3
+  // (and still without a BA iteration): The aggregation branch ends at the eta head on the side stream (`mid`); the mask
   // is computed on THIS stream between the mask / weight glue and the BA.  By then `mid` is long recorded (a satisfied wait
   // costs ~6 us on the stream, one that has to be woken ~19), the convolution takes 17 us alone instead of 27 beside the
   // glue kernels, and the BA starts ~20 us earlier than behind a join of the whole branch - while still running with the
@@ -357,7 +365,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
 #endif
   {
   if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
-  RUN(run_upmask(w, &a, b, stream));
+  if (!mask_rides) RUN(run_upmask(w, &a, b, stream));
   }
   // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
   const int Eb = u->n_in + E;
@@ -391,9 +399,12 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
     };
     RUN(tap());
 #endif
-    RUN(pvo_ba_finish(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
-                      u->motion_only, last && !u->motion_only ? u->clamp_frames : 0, u->disp_min,
-                      nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, stream));
+    const bool ride = mask_rides && it == 0;
+    RUN(pvo_ba_finish_conv1x1(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
+                              u->motion_only, last && !u->motion_only ? u->clamp_frames : 0, u->disp_min,
+                              nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes,
+                              ride ? b.a2 : nullptr, ride ? w->up_w : nullptr, ride ? w->up_b : nullptr, ride ? a.upmask : nullptr,
+                              ride ? static_cast<long long>(K) * HW : 0, ride ? 576 : 0, ride ? dt : 0, stream));
 #ifdef PVO_SCHED_DEBUG
     RUN(tap());
 #endif

@@ -587,11 +587,23 @@ def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, mo
 
 
 def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None, outputs=True,
-              clamp_frames=0, disp_min=0.001):
+              clamp_frames=0, disp_min=0.001, rider=None):
     """damp + solve the (all-reduced) system (left zeroed afterwards), retract poses, back-substitute this rank's depths -> [dx, dz]
     (outputs=False: poses / disps are updated in place and no dx / dz tensors are produced -> [None, None]).
-    clamp_frames > 0: disps[:clamp_frames].clamp_(min=disp_min) in the same launch."""
+    clamp_frames > 0: disps[:clamp_frames].clamp_(min=disp_min) in the same launch.
+    rider = (x, w, bias): an independent 1x1 convolution of x [N,128,H,W] (conv1x1_c128 without ReLU) computed by additional
+    workgroups of the pose solve's dispatch (pvo_ba_finish_conv1x1); its result is appended to the returned list."""
     dev = _dev(poses, disps, sys, ii, jj, workspace)
+    rx = rw = rb = ry = None
+    rrows = rC = rdt = 0
+    if rider is not None:
+        rx, rw, rb = rider
+        _cl(rx, "rider x", 128)
+        if rw.dim() != 2 or rw.shape[1] != 128 or rw.dtype != rx.dtype or not rw.is_contiguous():
+            raise PvoHipError("ba_finish: rider w must be a contiguous [Cout,128] tensor in x's dtype")
+        rC = rw.shape[0]
+        ry = _new_cl(rx.shape[0], rC, rx.shape[2], rx.shape[3], rx.dtype, dev)
+        rrows, rdt = rx.shape[0] * rx.shape[2] * rx.shape[3], _dtype_code(rx, "rider x")
     F, ht, wd = disps.shape
     P = int(t1) - int(t0)
     dx = torch.zeros(max(P, 0), 6, dtype=torch.float32, device=dev) if outputs else None
@@ -599,13 +611,15 @@ def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace,
     if not outputs:
         dz_rows = 0
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_ba_finish(_ptr(poses), _ptr(disps), _ptr(sys), _ptr(ii), _ptr(jj), ii.shape[0], F, ht, wd,
-                                        int(t0), int(t1), float(lm), float(ep), 1 if motion_only else 0,
-                                        int(clamp_frames), float(disp_min), _ptr(dx), _ptr(dz), int(dz_rows),
-                                        _ptr(status) if status is not None else ctypes.c_void_p(0),
-                                        ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(dev)),
-              "ba_finish")
-    return [dx, dz]
+        check(_lib.load().pvo_ba_finish_conv1x1(
+            _ptr(poses), _ptr(disps), _ptr(sys), _ptr(ii), _ptr(jj), ii.shape[0], F, ht, wd,
+            int(t0), int(t1), float(lm), float(ep), 1 if motion_only else 0,
+            int(clamp_frames), float(disp_min), _ptr(dx), _ptr(dz), int(dz_rows),
+            _ptr(status) if status is not None else ctypes.c_void_p(0),
+            ctypes.c_void_p(workspace.data_ptr()), workspace.numel(),
+            _ptr(rx), _ptr(rw), _bias(rb, rC, "rider bias") if rider is not None else ctypes.c_void_p(0), _ptr(ry),
+            int(rrows), int(rC), int(rdt), _stream(dev)), "ba_finish")
+    return [dx, dz] if rider is None else [dx, dz, ry]
 
 
 # --------------------------------------------------------------------------- update operator layers

@@ -207,3 +207,44 @@ def test_envelope_allreduce_path_is_bit_identical_on_the_hip_solver(cuda):
     assert (outs[0][0] - d(s["poses"])).abs().max() > 1e-4
     n6 = 6 * (s["t1"] - s["t0"])
     assert 0 < outs[1][2] < 0.2 * 8 * (n6 * n6 + n6)                      # 63 free poses, radius 3: ~12 % of the dense message
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nf,ht,wd", [(8, 48, 64), (30, 12, 16)])
+def test_pose_solve_with_a_convolution_riding_in_its_dispatch(cuda, nf, ht, wd):
+    """pvo_ba_finish_conv1x1: the one-workgroup pose solve and an independent 1x1 convolution (GraphAgg's upsampling mask in
+    pvo_graph_update) share a dispatch.  Poses and depths are bit-identical to the plain call over repeated runs, and the
+    convolution equals pvo_conv1x1_c128 bit for bit (window-sized system in LDS, and a 29-pose system on the envelope path)."""
+    from pvo_amd import droid_backends as db
+    from test_geom_ba_gpu import _scene
+    s = _scene(11, nf, ht, wd, 3, 1)
+    d = lambda t: t.to(cuda)
+    F = s["disps"].shape[0]
+    P = s["t1"] - s["t0"]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 128, 48, 64, generator=g).half().to(cuda).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(576, 128, generator=g) * 0.05).half().to(cuda)
+    b = torch.randn(576, generator=g).to(cuda)
+    want_y = db.conv1x1_c128(x, w, b)
+
+    def run(rider):
+        poses, disps = d(s["poses"].clone()), d(s["disps"].clone())
+        ws = db.ba_workspace(s["ii"].shape[0], P, F, ht * wd, cuda)
+        sys_buf = torch.zeros((6 * P) ** 2 + 6 * P, dtype=torch.int64, device=cuda)
+        db.ba_plan(d(s["ii"]), d(s["jj"]), F, ht * wd, s["eta"].shape[0], s["t0"], s["t1"], ws)
+        ys = []
+        for it in range(2):
+            db.ba_local(poses, disps, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]),
+                        s["t0"], s["t1"], False, sys_buf, ws, sys_is_zero=it > 0)
+            out = db.ba_finish(poses, disps, sys_buf, d(s["ii"]), d(s["jj"]), s["t0"], s["t1"], 1e-4, 0.1, False, ws,
+                               outputs=False, rider=(x, w, b) if rider and it == 0 else None)
+            if len(out) == 3:
+                ys.append(out[2])
+        return poses, disps, ys
+
+    p0, q0, _ = run(False)
+    assert (p0.cpu() - s["poses"]).abs().max() > 1e-5
+    for _ in range(6):
+        p1, q1, ys = run(True)
+        assert torch.equal(p0, p1) and torch.equal(q0, q1)
+        assert len(ys) == 1 and torch.equal(ys[0], want_y)
