@@ -351,6 +351,13 @@ typedef struct pvo_graph_update_args {
                                                                 zeroed once); planned with pvo_ba_plan(ii_ba, jj_ba, ..., K_eta = op.R) */
   int clamp_frames; float disp_min;                          /* disps[:clamp_frames].clamp_(min=disp_min) (depth_video.py:214) */
   int want_upmask;                                           /* compute agg.upmask_disp although FactorGraph.update discards it */
+  /* The ConvGRU's gate context is a function of the hidden state and the weights only.  context_ahead = 1: this call also
+   * computes the context of op.net_out - the NEXT update's input - inside its two pose solves' dispatches (needs itrs >= 2
+   * and a depth BA; ignored otherwise) and leaves it in the workspace.  context_ready = 1: the caller's promise that op.net
+   * has not been written since the previous pvo_graph_update of this device returned it as net_out; the library then uses
+   * the stored context if that call was made with context_ahead, the same workspace, weights, E, H, W and net_out == this
+   * op.net - and computes it as usual if not. */
+  int context_ahead, context_ready;
 } pvo_graph_update_args;
 
 size_t pvo_graph_update_workspace_bytes(int E, int K, int R, int H, int W, int max_segments);
@@ -424,6 +431,12 @@ int pvo_depth_filter(const float* poses, const float* disps, const float* intrin
 int pvo_reproject(const float* poses, const float* disps, const float* intrinsics,
                   const int64_t* ii, const int64_t* jj, float* coords, float* valid,
                   int E, int ht, int wd, void* stream);
+/* pvo_reproject + pvo_graph_motion (below: FactorGraph.update's motion features of the same edges, factor_graph.py:231-237) in
+ * one pass, bit-identical to the two calls; motn [E,ht,wd,8] in `dtype`, 16-byte aligned. */
+int pvo_reproject_motion(const float* poses, const float* disps, const float* intrinsics,
+                         const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                         const float* target, const float* delta_dy, const float* raw_mask, void* motn,
+                         int E, int ht, int wd, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* SE3 element-wise operations (lietorch subset)                              */
@@ -507,12 +520,29 @@ int pvo_ba_finish(float* poses, float* disps, void* sys,
                   float lm, float ep, int motion_only, int clamp_frames, float disp_min,
                   float* dx_out, float* dz_out, int dz_rows, int* status_out,
                   void* workspace, size_t workspace_bytes, void* stream);
-/* pvo_ba_finish with a rider: the pose solve is one workgroup, the rest of the chip idles meanwhile, and no other queue may run
- * beside the bundle adjustment - so an independent 1x1 convolution of a 128-channel channels-last tensor
- * (cy[crows, cCout] = cx[crows, 128] cw^T + cbias, exactly pvo_conv1x1_c128 without ReLU; cCout a multiple of 192; 16-byte
- * aligned pointers; cdtype PVO_F16 | PVO_BF16) is computed by additional workgroups of the SAME dispatch.  pvo_graph_update
- * sends GraphAgg's upsampling mask (droid_net.py:76-77,93 - computed by the reference's update module and never read by its
- * factor graph) this way.  cy == NULL: plain pvo_ba_finish.  The convolution must not alias any BA buffer. */
+/* pvo_ba_finish with riders: the pose solve is one workgroup, the rest of the chip idles meanwhile, and no other queue may run
+ * beside the bundle adjustment - so up to three independent jobs are computed by additional workgroups of the SAME dispatch
+ * (a job with a NULL output is absent; none of them may alias a BA buffer):
+ *   c*  cy[crows, cCout] = cx[crows, 128] cw^T + cbias, exactly pvo_conv1x1_c128 without ReLU (cCout a multiple of 192; 16-byte
+ *       aligned pointers; cdtype PVO_F16 | PVO_BF16).  pvo_graph_update sends GraphAgg's upsampling mask (droid_net.py:76-77,93
+ *       - computed by the reference's update module and never read by its factor graph) this way;
+ *   g*  gpart = pvo_gru_glo_fused(gnet [gE, gHW, 128], gw, gbias): the partial means of the ConvGRU's global context;
+ *   x*  xg = pvo_gate_context(xpart, xwt, xbias) for xE edges.  x* reads what g* wrote, so the two go into DIFFERENT solves:
+ *       pvo_graph_update computes the NEXT update's gate context (a function of the hidden state and the weights only) in
+ *       the first and second solve of this one (pvo_graph_update_args.context_ahead / context_ready). */
+typedef struct pvo_ba_riders {
+  const void* cx; const void* cw; const float* cbias; void* cy; long long crows; int cCout; int cdtype;
+  const void* gnet; const void* gw; const float* gbias; float* gpart; int gE; int gHW; int gdtype;
+  const float* xpart; const float* xwt; const float* xbias; float* xg; int xE; int xchunks;
+} pvo_ba_riders;
+int pvo_ba_finish_riders(float* poses, float* disps, void* sys,
+                         const int64_t* ii, const int64_t* jj,
+                         int E, int nframes, int ht, int wd, int t0, int t1,
+                         float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                         float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                         void* workspace, size_t workspace_bytes,
+                         const pvo_ba_riders* riders, void* stream);
+/* ... with the convolution job only */
 int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys,
                           const int64_t* ii, const int64_t* jj,
                           int E, int nframes, int ht, int wd, int t0, int t1,

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pvo_heads_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_segment_mean": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_graph_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_reproject_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_segment_hist": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "pvo_graph_post": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "pvo_operator_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -72,6 +73,8 @@ SIGNATURES = {
                           _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,
                            _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "pvo_ba_finish_riders": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,
+                                  _vp, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
     "pvo_ba_finish_conv1x1": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,
                                    _vp, _vp, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _vp]),
 }
@@ -103,7 +106,7 @@ class GraphUpdateArgs(_c.Structure):
                 ("n_in", _i), ("target_ba", _vp), ("weight_ba", _vp), ("ii_ba", _vp), ("jj_ba", _vp),
                 ("t0", _i), ("t1", _i), ("itrs", _i), ("motion_only", _i), ("lm", _f), ("ep", _f),
                 ("sys", _vp), ("ba_ws", _vp), ("ba_ws_bytes", _sz), ("clamp_frames", _i), ("disp_min", _f),
-                ("want_upmask", _i)]
+                ("want_upmask", _i), ("context_ahead", _i), ("context_ready", _i)]
 
 
 PVO_OP_CONV128_WIDE, PVO_OP_SINGLE_STREAM, PVO_OP_ENC_SIDE_STREAM = 1, 2, 4

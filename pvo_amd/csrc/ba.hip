@@ -34,6 +34,7 @@
 // back-substitution (:1084).  Deviation: expSE3 uses xi[5], not xi[45] (:154).
 #include "se3.h"
 #include "conv1x1_tile.h"
+#include "glo_tile.h"
 #include <stdlib.h>
 
 namespace {
@@ -702,7 +703,7 @@ __device__ __forceinline__ int* scan_scratch() {             // one copy for bot
   return scratch;
 }
 template <bool MAX>
-__device__ void block_scan(int* v, int P) {
+__device__ __forceinline__ void block_scan(int* v, int P) {
   int (*buf)[256] = reinterpret_cast<int (*)[256]>(scan_scratch());
   int& carry_s = scan_scratch()[512];
   const int tid = threadIdx.x;
@@ -733,7 +734,7 @@ __device__ void block_scan(int* v, int P) {
 // reach[kb] = last block row whose envelope reaches block column kb: the rows below it (except the rhs) take no part in
 // step kb, and scanning them - 23 loop trips per thread and step at 63 poses, each an LDS lookup to find out - cost more than
 // the arithmetic (tools/ba_solve_timeline.py: 14 k cycles per block column against 4.5 k at 7 poses)
-__device__ void envelope_reach(const int* first, int* reach, int P) {
+__device__ __forceinline__ void envelope_reach(const int* first, int* reach, int P) {
   if (P <= 12) {                                           // (nothing to skip in a window-sized system)
     for (int b = threadIdx.x; b < P; b += blockDim.x) reach[b] = P - 1;
     __syncthreads();
@@ -1051,7 +1052,7 @@ __device__ __forceinline__ bool pipe_wait_done(PipeCtl* ctl, int seen, int v) {
 // Lists of every step's active block rows (ib > kb with first[ib] <= kb), ascending, in compressed-column form:
 // rowlist[colptr[kb] .. colptr[kb + 1]).  `reach` is consumed: on return it holds colptr (P + 1 entries; P < kMaxEnvBlocks).
 // Whole workgroup; returns false (everything untouched) when the lists do not fit.
-__device__ bool pipe_lists(const int* first, int* reach, int P, unsigned short* rowlist, PipeCtl* ctl) {
+__device__ __forceinline__ bool pipe_lists(const int* first, int* reach, int P, unsigned short* rowlist, PipeCtl* ctl) {
   int hi_keep[kMaxEnvBlocks / 256], cnt_keep[kMaxEnvBlocks / 256];
   int mine = 0;
 #pragma unroll
@@ -1327,7 +1328,7 @@ __device__ __forceinline__ void chol_solve_pipe(Mat A, double* Ld, int n, int* f
 // blocks.  Executed by one thread.
 // first[] from the numeric envelope and the offsets of the compact layout (block row b = blocks first[b] .. b); returns the
 // number of doubles of all blocks, or INT_MAX when that does not fit an int.  Whole workgroup; valid after it returns.
-__device__ int env_layout(const int* __restrict__ env, int P, int* first, int* rowbase, int* total_s) {
+__device__ __forceinline__ int env_layout(const int* __restrict__ env, int P, int* first, int* rowbase, int* total_s) {
   for (int b = threadIdx.x; b < P; b += blockDim.x) {
     const int e = env[b];
     const int f = e < b ? e : b;
@@ -1405,26 +1406,47 @@ __global__ __launch_bounds__(256) void ba_prepare_kernel(long long* __restrict__
 
 // The pose solve is ONE workgroup for ~20 us (a window) to ~170 us (63 free poses) while the rest of the chip idles - and
 // nothing else may run beside the bundle adjustment on another queue.  Work that is independent of it can ride in
-// the SAME dispatch instead: workgroups 1 .. of this launch compute a 1x1 convolution of a 128-channel tensor (conv1x1_tile.h)
-// - GraphAgg's upsampling mask in pvo_graph_update, 17 us on the launch stream otherwise.  No buffer is shared with the solve.
-struct Conv1x1Rider { const uint16_t *x, *w; const float* bias; uint16_t* y; long long rows; int Cout, dtype, row_blocks; };
+// the SAME dispatch instead: workgroups 1 .. of this launch run up to three jobs that share no buffer with the solve -
+//   a 1x1 convolution of a 128-channel tensor (conv1x1_tile.h): GraphAgg's upsampling mask in pvo_graph_update, 17 us on the
+//   launch stream otherwise;
+//   the two halves of the ConvGRU's global context (glo_tile.h) of the NEXT update, which depend on the hidden state only:
+//   the partial means in the first solve's dispatch, the gate context in the second's (it reads what the first wrote - a
+//   kernel boundary in between, no fence inside a dispatch).
+struct Riders {
+  const uint16_t *cx, *cw; const float* cbias; uint16_t* cy; long long crows; int cCout, cdtype, crow_blocks, cblocks;
+  const uint16_t *gnet, *gw; const float* gbias; float* gpart; int gHW, gchunks, gdtype, gblocks;
+  const float *xpart, *xwt, *xbias; float* xg; int xchunks, xblocks;
+};
 
-__device__ __forceinline__ void ride_conv1x1(unsigned char* smem, const Conv1x1Rider rider, int b) {
-  const int cb = b / rider.row_blocks;
-  const long long rb = b - cb * rider.row_blocks;
-  if (rider.dtype == PVO_F16) c1t::conv1x1_c128_tile<pvo_half>(smem, rider.x, rider.w, rider.bias, rider.y, rider.rows, rider.Cout, 0, rb, cb);
-  else c1t::conv1x1_c128_tile<pvo_bf16>(smem, rider.x, rider.w, rider.bias, rider.y, rider.rows, rider.Cout, 0, rb, cb);
+__device__ __forceinline__ void ride(unsigned char* smem, const Riders r, int b) {
+  if (b < r.cblocks) {
+    const int cb = b / r.crow_blocks;
+    const long long rb = b - cb * r.crow_blocks;
+    if (r.cdtype == PVO_F16) c1t::conv1x1_c128_tile<pvo_half>(smem, r.cx, r.cw, r.cbias, r.cy, r.crows, r.cCout, 0, rb, cb);
+    else c1t::conv1x1_c128_tile<pvo_bf16>(smem, r.cx, r.cw, r.cbias, r.cy, r.crows, r.cCout, 0, rb, cb);
+    return;
+  }
+  b -= r.cblocks;
+  if (b < r.gblocks) {
+    const int e = b / r.gchunks, ci = b - e * r.gchunks;
+    if (r.gdtype == PVO_F16) glt::glo_partial_means<pvo_half>(smem, r.gnet, r.gw, r.gbias, r.gpart, r.gHW, 256, e, ci, r.gchunks);
+    else glt::glo_partial_means<pvo_bf16>(smem, r.gnet, r.gw, r.gbias, r.gpart, r.gHW, 256, e, ci, r.gchunks);
+    return;
+  }
+  b -= r.gblocks;
+  if (b < r.xblocks) glt::gate_context_256(reinterpret_cast<float*>(smem), r.xpart, r.xwt, r.xbias, r.xg, r.xchunks, b);
 }
 
-__global__ __launch_bounds__(256) void ba_solve_kernel(
+#ifndef PVO_SOLVE_ATTR
+#define PVO_SOLVE_ATTR
+#endif
+__global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
     long long* __restrict__ sys, double* __restrict__ chol_global, float* __restrict__ poses,
     float* __restrict__ dx_ws, float* __restrict__ dx_out, int* __restrict__ meta, int* __restrict__ status_out,
-    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget, int solver,
-    const uint16_t* __restrict__ rx, const uint16_t* __restrict__ rw, const float* __restrict__ rbias, uint16_t* __restrict__ ry,
-    long long rrows, int rCout, int rdtype, int rrow_blocks) {                  // (the rider's fields one by one: a struct argument cost a private segment)
+    int P, int t0, float lm, float ep, int use_lds, int* __restrict__ env, long long lds_budget, int solver, Riders riders) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | fp64 matrix + rhs | ...]
-  if (blockIdx.x > 0) {                                                  // rider workgroups (launched only with a rider)
-    ride_conv1x1(smem, Conv1x1Rider{rx, rw, rbias, ry, rrows, rCout, rdtype, rrow_blocks}, blockIdx.x - 1);
+  if (blockIdx.x > 0) {                                                  // rider workgroups (launched only with riders)
+    ride(smem, riders, blockIdx.x - 1);
     return;
   }
   int& fail = *reinterpret_cast<int*>(smem);
@@ -1712,9 +1734,8 @@ extern "C" int pvo_ba_finish(float* poses, float* disps, void* sys_,
                              float lm, float ep, int motion_only, int clamp_frames, float disp_min,
                              float* dx_out, float* dz_out, int dz_rows, int* status_out,
                              void* workspace, size_t workspace_bytes, void* stream) {
-  return pvo_ba_finish_conv1x1(poses, disps, sys_, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only, clamp_frames, disp_min,
-                               dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes,
-                               nullptr, nullptr, nullptr, nullptr, 0, 0, 0, stream);
+  return pvo_ba_finish_riders(poses, disps, sys_, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only, clamp_frames, disp_min,
+                              dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys_,
@@ -1725,16 +1746,48 @@ extern "C" int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys_,
                                      void* workspace, size_t workspace_bytes,
                                      const void* cx, const void* cw, const float* cbias, void* cy, long long crows, int cCout, int cdtype,
                                      void* stream) {
-  Conv1x1Rider rider{};
-  if (cy) {
-    if (!cx || !cw || crows < 0 || cCout <= 0 || cCout % 192) return PVO_EINVAL;
-    if (cdtype != PVO_F16 && cdtype != PVO_BF16) return PVO_EUNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(cx) | reinterpret_cast<uintptr_t>(cw) | reinterpret_cast<uintptr_t>(cy)) & 15) return PVO_EINVAL;
-    if (crows > (1LL << 24)) return PVO_EUNSUPPORTED;
-    rider = Conv1x1Rider{static_cast<const uint16_t*>(cx), static_cast<const uint16_t*>(cw), cbias, static_cast<uint16_t*>(cy),
-                         crows, cCout, cdtype, static_cast<int>((crows + 63) / 64)};
+  pvo_ba_riders r{};
+  r.cx = cx; r.cw = cw; r.cbias = cbias; r.cy = cy; r.crows = crows; r.cCout = cCout; r.cdtype = cdtype;
+  return pvo_ba_finish_riders(poses, disps, sys_, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only, clamp_frames, disp_min,
+                              dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes, cy ? &r : nullptr, stream);
+}
+
+extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
+                                    const int64_t* ii, const int64_t* jj,
+                                    int E, int nframes, int ht, int wd, int t0, int t1,
+                                    float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                                    float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                                    void* workspace, size_t workspace_bytes,
+                                    const pvo_ba_riders* jobs, void* stream) {
+  Riders rider{};
+  size_t rider_lds = 0;
+  if (jobs && jobs->cy && jobs->crows > 0) {
+    if (!jobs->cx || !jobs->cw || jobs->cCout <= 0 || jobs->cCout % 192) return PVO_EINVAL;
+    if (jobs->cdtype != PVO_F16 && jobs->cdtype != PVO_BF16) return PVO_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(jobs->cx) | reinterpret_cast<uintptr_t>(jobs->cw) | reinterpret_cast<uintptr_t>(jobs->cy)) & 15) return PVO_EINVAL;
+    if (jobs->crows > (1LL << 24)) return PVO_EUNSUPPORTED;
+    rider.cx = static_cast<const uint16_t*>(jobs->cx); rider.cw = static_cast<const uint16_t*>(jobs->cw); rider.cbias = jobs->cbias;
+    rider.cy = static_cast<uint16_t*>(jobs->cy); rider.crows = jobs->crows; rider.cCout = jobs->cCout; rider.cdtype = jobs->cdtype;
+    rider.crow_blocks = static_cast<int>((jobs->crows + 63) / 64);
+    rider.cblocks = rider.crow_blocks * (jobs->cCout / 192);
+    rider_lds = c1t::kTileBytes;
   }
-  const int rider_blocks = (cy && crows > 0) ? rider.row_blocks * (cCout / 192) : 0;
+  if (jobs && jobs->gpart && jobs->gE > 0 && jobs->gHW > 0) {
+    if (!jobs->gnet || !jobs->gw || jobs->gE > 65535) return PVO_EINVAL;
+    if (jobs->gdtype != PVO_F16 && jobs->gdtype != PVO_BF16) return PVO_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(jobs->gnet) | reinterpret_cast<uintptr_t>(jobs->gw)) & 15) return PVO_EINVAL;
+    rider.gnet = static_cast<const uint16_t*>(jobs->gnet); rider.gw = static_cast<const uint16_t*>(jobs->gw); rider.gbias = jobs->gbias;
+    rider.gpart = jobs->gpart; rider.gHW = jobs->gHW; rider.gchunks = (jobs->gHW + 255) / 256; rider.gdtype = jobs->gdtype;
+    rider.gblocks = jobs->gE * rider.gchunks;
+    if (rider_lds < static_cast<size_t>(glt::kTileBytes)) rider_lds = glt::kTileBytes;
+  }
+  if (jobs && jobs->xg && jobs->xE > 0) {
+    if (!jobs->xpart || !jobs->xwt || !jobs->xbias || jobs->xchunks <= 0) return PVO_EINVAL;
+    rider.xpart = jobs->xpart; rider.xwt = jobs->xwt; rider.xbias = jobs->xbias; rider.xg = jobs->xg;
+    rider.xchunks = jobs->xchunks; rider.xblocks = jobs->xE;
+    if (rider_lds < 512) rider_lds = 512;
+  }
+  const int rider_blocks = rider.cblocks + rider.gblocks + rider.xblocks;
   int rc = check_common(E, nframes, ht, wd, t0, t1);
   if (rc != PVO_OK) return rc;
   if (clamp_frames < 0 || clamp_frames > nframes) return PVO_EINVAL;
@@ -1749,7 +1802,7 @@ extern "C" int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys_,
   const int use_lds = n6 <= kLdsCholMax;
   constexpr size_t kSolveLdsMax = 142000;      // dynamic LDS of the solve: the CU's 163840 B minus its 20528 B of static tables (envelope, reach, active rows, scan buffers)
   size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
-  if (rider_blocks && lds < static_cast<size_t>(c1t::kTileBytes)) lds = c1t::kTileBytes;      // (the riders' tile lives in the dynamic segment)
+  if (lds < rider_lds) lds = rider_lds;                                   // (the riders' tiles live in the dynamic segment)
   if (lds > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1774,8 +1827,7 @@ extern "C" int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys_,
     PVO_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(ba_solve_kernel, dim3(1 + rider_blocks), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
-                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax), solver_wave,
-                     rider.x, rider.w, rider.bias, rider.y, rider.rows, rider.Cout, rider.dtype, rider.row_blocks);
+                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax), solver_wave, rider);
   PVO_CHECK_LAUNCH();
   if (!motion_only && E + P > 0) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);

@@ -11,6 +11,7 @@
 //   in LDS; wave w owns output channels [32w, 32w+32) and keeps its 26 weight fragments in registers for all 16 tile rows.
 //   Weights arrive pre-arranged as [52 taps (49 + 3 zero)][128 outputs][8 channels] 16-bit.
 #include "common.h"
+#include "glo_tile.h"
 #include <stdlib.h>
 
 namespace {
@@ -52,7 +53,10 @@ template <typename T> __device__ __forceinline__ cs_u32x4 cs_pack8(const float f
 }
 
 constexpr int kTH = 8, kTW = 16, kR = 3;
-constexpr int kTH7 = 16;                                      // the 7x7 kernel's tile is 16 rows high: weight fragments are
+#ifndef PVO_CONV7_ROWS
+#define PVO_CONV7_ROWS 16
+#endif
+constexpr int kTH7 = PVO_CONV7_ROWS;                          // the 7x7 kernel's tile is 16 rows high: weight fragments are
                                                               // fetched once per 256 pixels (they were 3x the output in L2 reads)
 constexpr int kHW_ = kTW + 2 * kR, kHH7 = kTH7 + 2 * kR;      // 22 x 22 halo
 constexpr int kTaps = 49, kSteps = 13;                        // 13 MFMAs x 4 taps
@@ -138,79 +142,12 @@ __global__ __launch_bounds__(256) void conv7x7_c8_kernel(const uint16_t* __restr
 //   accumulator layout (lane = channel), and each workgroup writes the partial means of its 256-pixel chunk: glo_part [E][chunks][128]; the
 //   consumer (a [E, chunks*128] x [chunks*128, 384] GEMM against row-tiled gate weights) sums the chunks for free.
 // ---------------------------------------------------------------------------
-constexpr int kGloTile = 64, kGloStride = 272;
-
 template <typename T>
 __global__ __launch_bounds__(256) void gru_glo_mfma_kernel(const uint16_t* __restrict__ net, const uint16_t* __restrict__ ww,
                                                            const float* __restrict__ bias, float* __restrict__ glo,
                                                            int HW, int chunk) {
-  __shared__ __attribute__((aligned(16))) unsigned char tile[kGloTile * kGloStride];
-  const int e = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lk = lane >> 4;
-  cs_u32x4 bf[4][2];
-#pragma unroll
-  for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-      bf[kc][nt] = *reinterpret_cast<const cs_u32x4*>(ww + static_cast<size_t>(wave * 32 + nt * 16 + li) * 128 + kc * 32 + lk * 8);
-  const float b0 = bias ? bias[wave * 32 + li] : 0.0f, b1 = bias ? bias[wave * 32 + 16 + li] : 0.0f;
-  float s0 = 0.0f, s1 = 0.0f;
-  const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, HW);
-  const uint16_t* ne = net + static_cast<size_t>(e) * HW * 128;
-  // software pipeline: the next tile's 16 KB are in flight (registers) while this tile is multiplied
-  cs_u32x4 pre[4];
-  auto fetch = [&](int p0) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {                      // 64 px x 16 chunks of 16 B
-      const int id = tid + 256 * it, px = id >> 4, c = id & 15;
-      pre[it] = cs_u32x4{0u, 0u, 0u, 0u};
-      if (p0 + px < p_end) pre[it] = *reinterpret_cast<const cs_u32x4*>(ne + static_cast<size_t>(p0 + px) * 128 + c * 8);
-    }
-  };
-  fetch(p_begin);
-  for (int p0 = p_begin; p0 < p_end; p0 += kGloTile) {
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int id = tid + 256 * it, px = id >> 4, c = id & 15;
-      *reinterpret_cast<cs_u32x4*>(tile + px * kGloStride + c * 16) = pre[it];
-    }
-    __syncthreads();
-    if (p0 + kGloTile < p_end) fetch(p0 + kGloTile);
-    cs_u32x4 afr[4][4];                                    // the tile's 16 A fragments, requested up front
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc)
-        afr[g][kc] = *reinterpret_cast<const cs_u32x4*>(tile + (g * 16 + li) * kGloStride + kc * 64 + lk * 16);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      cs_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
-        d0 = cs_mfma<T>(afr[g][kc], bf[kc][0], d0);
-        d1 = cs_mfma<T>(afr[g][kc], bf[kc][1], d1);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {                       // D rows lk*4 + r = pixels, column li = channel
-        const unsigned char* row = tile + (g * 16 + lk * 4 + r) * kGloStride + (wave * 32 + li) * 2;
-        const float n0 = Elem<T>::to_f32(*reinterpret_cast<const typename Elem<T>::store_t*>(row));
-        const float n1 = Elem<T>::to_f32(*reinterpret_cast<const typename Elem<T>::store_t*>(row + 32));
-        // (v_exp + v_rcp: an IEEE division here was a third of this kernel's 128 sigmoids x 72 cycles per lane; padded pixels carry net = 0)
-        s0 = fmaf(n0, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (d0[r] + b0))), s0);
-        s1 = fmaf(n1, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (d1[r] + b1))), s1);
-      }
-    }
-  }
-  s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-  s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-  if (lk == 0) {                                          // this workgroup's partial mean: no zero fill, no atomics
-    const float inv = 1.0f / static_cast<float>(HW);
-    float* o = glo + (static_cast<size_t>(e) * gridDim.x + blockIdx.x) * 128 + wave * 32;
-    o[li] = s0 * inv;
-    o[16 + li] = s1 * inv;
-  }
+  __shared__ __attribute__((aligned(16))) unsigned char tile[glt::kTileBytes];
+  glt::glo_partial_means<T>(tile, net, ww, bias, glo, HW, chunk, blockIdx.y, blockIdx.x, gridDim.x);      // (glo_tile.h)
 }
 
 // ---------------------------------------------------------------------------

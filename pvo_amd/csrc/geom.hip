@@ -265,6 +265,78 @@ extern "C" int pvo_depth_filter(const float* poses, const float* disps, const fl
   return PVO_OK;
 }
 
+template <typename T> __device__ __forceinline__ uint32_t bits16(float x);
+template <> __device__ __forceinline__ uint32_t bits16<pvo_half>(float x) {
+  union { _Float16 h; uint16_t u; } c; c.h = static_cast<_Float16>(x); return c.u;
+}
+template <> __device__ __forceinline__ uint32_t bits16<pvo_bf16>(float x) { return pvo_f32_to_bf16(x); }
+
+// reproject + FactorGraph.update's motion features (graph_glue.hip: graph_motion_kernel, the same arithmetic on the same
+// values) in one pass: alone at the head of a graph update this costs what the reprojection costs, while the separate motion
+// kernel ran for 20-24 us on the side stream beside the correlation lookup, which saturates the memory system's request rate.
+template <typename T>
+__global__ __launch_bounds__(256) void reproject_motion_kernel(
+    const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intrinsics,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+    float* __restrict__ coords, float* __restrict__ valid,
+    const float2* __restrict__ target, const float2* __restrict__ delta_dy, const float2* __restrict__ raw_mask,
+    uint16_t* __restrict__ motn, int HW, int wd) {
+  const int e = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= HW) return;
+  const long long idx = static_cast<long long>(e) * HW + k;
+  const float2 t = target[idx], dd = delta_dy[idx], m = raw_mask[idx];
+  const int ix = static_cast<int>(ii[e]), jx = static_cast<int>(jj[e]);
+  const Intr Ki = load_intr(intrinsics + 4 * static_cast<long long>(ix));
+  const Intr Kj = load_intr(intrinsics + 4 * static_cast<long long>(jx));
+  const Pose G = rel_pose(load_pose(poses + 7 * static_cast<long long>(ix)), load_pose(poses + 7 * static_cast<long long>(jx)));
+  const int i = k / wd, j = k - i * wd;
+  float X0[4] = {(static_cast<float>(j) - Ki.cx) / Ki.fx, (static_cast<float>(i) - Ki.cy) / Ki.fy, 1.0f,
+                 disps[static_cast<long long>(ix) * HW + k]};
+  float X1[4];
+  act4(G, X0, X1);
+  float Z = X1[2];
+  Z = (Z < 0.5f * kMinDepthPy) ? 1.0f : Z;   // projective_ops.py:48
+  const float d = 1.0f / Z;
+  float2 c;
+  c.x = Kj.fx * (X1[0] * d) + Kj.cx;
+  c.y = Kj.fy * (X1[1] * d) + Kj.cy;
+  *reinterpret_cast<float2*>(coords + idx * 2) = c;
+  valid[idx] = (X1[2] > kMinDepthPy && X0[2] > kMinDepthPy) ? 1.0f : 0.0f;
+  // factor_graph.py:233-237: motn = clamp(cat[target - coords0, target - coords0 + delta_dy, target - coords1, raw_mask], +-64)
+  const float x0 = static_cast<float>(j), y0 = static_cast<float>(i);
+  const float f[8] = {t.x - x0, t.y - y0, t.x - x0 + dd.x, t.y - y0 + dd.y, t.x - c.x, t.y - c.y, m.x, m.y};
+  uint32_t o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = fminf(fmaxf(f[2 * q], -64.0f), 64.0f), b = fminf(fmaxf(f[2 * q + 1], -64.0f), 64.0f);
+    o[q] = bits16<T>(a) | (bits16<T>(b) << 16);
+  }
+  *reinterpret_cast<uint4*>(motn + idx * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int pvo_reproject_motion(const float* poses, const float* disps, const float* intrinsics,
+                                    const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                                    const float* target, const float* delta_dy, const float* raw_mask, void* motn,
+                                    int E, int ht, int wd, int dtype, void* stream) {
+  PVO_REQ(E >= 0 && ht >= 0 && wd >= 0);
+  if (E == 0 || ht * wd == 0) return PVO_OK;
+  PVO_REQ(poses && disps && intrinsics && ii && jj && coords && valid && target && delta_dy && raw_mask && motn && E <= 65535);
+  PVO_REQ(!(reinterpret_cast<uintptr_t>(motn) & 15) && !((reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(delta_dy) |
+           reinterpret_cast<uintptr_t>(raw_mask) | reinterpret_cast<uintptr_t>(coords)) & 7));
+  const dim3 grid((ht * wd + 255) / 256, E);
+  auto f2 = [](const float* p) { return reinterpret_cast<const float2*>(p); };
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(reproject_motion_kernel<pvo_half>, grid, dim3(256), 0, pvo_stream(stream), poses, disps, intrinsics, ii, jj, coords, valid,
+                       f2(target), f2(delta_dy), f2(raw_mask), static_cast<uint16_t*>(motn), ht * wd, wd);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(reproject_motion_kernel<pvo_bf16>, grid, dim3(256), 0, pvo_stream(stream), poses, disps, intrinsics, ii, jj, coords, valid,
+                       f2(target), f2(delta_dy), f2(raw_mask), static_cast<uint16_t*>(motn), ht * wd, wd);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
 extern "C" int pvo_reproject(const float* poses, const float* disps, const float* intrinsics,
                              const int64_t* ii, const int64_t* jj, float* coords, float* valid,
                              int E, int ht, int wd, void* stream) {

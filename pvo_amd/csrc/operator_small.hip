@@ -13,6 +13,7 @@
 //   pvo_segment_hist   per (edge, panoptic segment) pixel counts for the dynamic-segment vote (factor_graph.py:256-276)
 #include "common.h"
 #include "conv1x1_tile.h"
+#include "glo_tile.h"
 
 namespace {
 
@@ -53,28 +54,7 @@ template <typename T> __device__ __forceinline__ void os_unpack8(os_u32x4 v, flo
 __global__ __launch_bounds__(384) void gate_context_kernel(const float* __restrict__ part, const float* __restrict__ wg_t,
                                                            const float* __restrict__ gb, float* __restrict__ g, int chunks) {
   __shared__ float glo[128];
-  const int e = blockIdx.x, t = threadIdx.x;
-  // L2 latency, not bandwidth, is the cost: all 128 weights of this output are requested before anything waits (four rounds of
-  // 32 were four round trips), the partial means in groups of 16
-  float wv[128];
-#pragma unroll
-  for (int q = 0; q < 128; ++q) wv[q] = wg_t[static_cast<size_t>(q) * 384 + t];
-  if (t < 128) {
-    float s = 0.0f;
-    for (int k0 = 0; k0 < chunks; k0 += 16) {
-      float pv[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) pv[k] = k0 + k < chunks ? part[(static_cast<size_t>(e) * chunks + k0 + k) * 128 + t] : 0.0f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) s += pv[k];                 // (same order as a serial sum: + 0.0f for the padding)
-    }
-    glo[t] = s;
-  }
-  __syncthreads();
-  float a[4] = {gb[t], 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int q = 0; q < 128; ++q) a[q & 3] = fmaf(glo[q], wv[q], a[q & 3]);
-  g[static_cast<size_t>(e) * 384 + t] = (a[0] + a[1]) + (a[2] + a[3]);
+  glt::gate_context_384(glo, part, wg_t, gb, g, chunks, blockIdx.x);      // (glo_tile.h)
 }
 
 // ---------------------------------------------------------------------------

@@ -53,6 +53,16 @@ SideCtx* side_ctx() {
 
 size_t al(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
+// The gate context of the NEXT update, computed ahead inside this update's pose solves (pvo_graph_update_args.context_ahead):
+// what it was computed for.  One record per device; any call that writes an operator workspace's context buffers drops it.
+struct ContextAhead { const void *ws, *weights, *glo_w, *gate_wt, *net; int E, H, W, dtype; bool valid; };
+ContextAhead g_ctx_ahead[64] = {};
+ContextAhead* ctx_ahead_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return &g_ctx_ahead[dev];
+}
+
 // Measurement hook (bench.py): HIP events around one stage of the update, recorded on the launch stream itself, so that a
 // kernel's duration INSIDE the timed steps can be read without a profiler.  Disarmed (stage -1) it costs one compare.
 // `every` > 1 samples one occurrence in `every` (the events cost the launch stream ~7 us per occurrence, 2 % of the bench's step).
@@ -143,7 +153,7 @@ struct MotionJob {           // pvo_graph_update's motion features: only the flo
 };
 
 int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, const void** P_zr, const void** P_q,
-              const MotionJob* mj) {
+              const MotionJob* mj, bool context_ready = false) {
   const int E = a->E, H = a->H, W = a->W, dt = w->dtype;
   const long long rows = static_cast<long long>(E) * H * W;
   hipStream_t st = pvo_stream(stream);
@@ -175,8 +185,10 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     RUN(pvo_conv3x3(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 128, 1, 192, 0, dt, stream));
   else
     RUN(pvo_conv3x3_c128(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 1, 192, 0, dt, stream));
-  RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s3));
-  RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s3));
+  if (!context_ready) {           // (else b.g already holds it: computed inside the previous update's pose solves)
+    RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s3));
+    RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s3));
+  }
   *P_zr = a->P_zr; *P_q = a->P_q;
   if (!a->P_zr || !a->P_q) {       // static-input term not cached by the caller: conv(W[:, inp], inp) for this call
     if (!a->inp) return PVO_EINVAL;
@@ -239,9 +251,9 @@ int check_op(const pvo_update_weights* w, const pvo_operator_args* a) {
 // leaves the join to the caller (pvo_graph_update joins only in front of the BA, so the K-frame kernels of the
 // aggregation branch, which occupy a fraction of the chip, also overlap the mask / weight glue).
 int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx** pending,
-                 const MotionJob* mj = nullptr, bool upmask_on_side = true) {
+                 const MotionJob* mj = nullptr, bool upmask_on_side = true, bool context_ready = false) {
   const void *P_zr, *P_q;
-  RUN(run_trunk(w, a, b, stream, &P_zr, &P_q, mj));
+  RUN(run_trunk(w, a, b, stream, &P_zr, &P_q, mj, context_ready));
   hipStream_t st = pvo_stream(stream);
   SideCtx* sc = (a->K > 0 && !(w->flags & PVO_OP_SINGLE_STREAM)) ? side_ctx() : nullptr;
   if (sc) {
@@ -283,6 +295,7 @@ extern "C" int pvo_update_operator(const pvo_update_weights* w, const pvo_operat
   if (!workspace || workspace_bytes < pvo_operator_workspace_bytes(a->E, a->K, a->H, a->W)) return PVO_EWORKSPACE;
   if (!a->motion) return PVO_EINVAL;
   OpWs b = carve_op(ws_base(workspace), a->E, a->K, a->H, a->W, pvo_gru_glo_chunks(a->H * a->W));
+  if (ContextAhead* ca = ctx_ahead_slot()) ca->valid = false;
   SideCtx* pending = nullptr;
   RUN(run_operator(w, a, b, stream, &pending));
   return join(pending, stream);
@@ -317,13 +330,21 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
 
   probe_mark(PVO_STAGE_UPDATE, 0, stream);
   // factor_graph.py:231-237: reprojection and motion features
-  RUN(pvo_reproject(u->poses, u->disps, u->intrinsics, u->ii, u->jj, s.coords, s.valid, E, H, W, stream));
-  const MotionJob mj{u->target, s.coords, u->delta_dy, u->raw_mask, s.motion};
+  // (the motion features ride on the reprojection: 20-24 us of the side chain beside the lookup otherwise)
+  RUN(pvo_reproject_motion(u->poses, u->disps, u->intrinsics, u->ii, u->jj, s.coords, s.valid, u->target, u->delta_dy, u->raw_mask,
+                           s.motion, E, H, W, dt, stream));
   a.coords = s.coords; a.corr = nullptr; a.motion = s.motion; a.heads = s.heads;
   a.eta = u->op.eta ? u->op.eta : s.eta;          // (a caller that runs the BA itself - edge sharding - supplies the buffer)
   if (u->want_upmask && !a.upmask) a.upmask = s.upmask;
+  // the gate context may already be in the workspace: computed ahead by the previous call, for exactly this input
+  static const bool ahead_off = [] { const char* e = getenv("PVO_CONTEXT_AHEAD"); return e && e[0] == '0'; }();
+  ContextAhead* ca = ctx_ahead_slot();
+  const bool ctx_ready = ca && ca->valid && u->context_ready && !ahead_off && ca->ws == workspace && ca->weights == w &&
+                         ca->glo_w == w->glo_w && ca->gate_wt == w->gate_wt && ca->net == a.net && ca->E == E && ca->H == H &&
+                         ca->W == W && ca->dtype == dt;
+  if (ca) ca->valid = false;
   SideCtx* pending = nullptr;
-  RUN(run_operator(w, &a, b, stream, &pending, &mj, false));
+  RUN(run_operator(w, &a, b, stream, &pending, nullptr, false, ctx_ready));
   // :249-306: mask update, (panoptic vote), weights, targets in the BA's layout, full flow
   if (u->segm)
     RUN(pvo_segment_hist(u->segm, u->raw_mask, s.heads, s.vote_tot, s.vote_dyn, E, HW, S, u->dy_thresh, dt, stream));
@@ -335,6 +356,13 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   const bool mask_rides = u->itrs > 0 && a.K > 0 && a.upmask && !rider_off
 #ifdef PVO_SCHED_DEBUG
                           && g_sched.mode == 0
+#endif
+      ;
+  // ... and so does the gate context of the NEXT update (a function of this update's net_out and the weights): its partial
+  // means in the first solve, the 1x1 context convolutions in the second
+  const bool context_ahead = u->context_ahead && u->itrs >= 2 && !u->motion_only && !ahead_off
+#ifdef PVO_SCHED_DEBUG
+                             && g_sched.mode == 0
 #endif
       ;
   // The upsampling mask - which nothing here reads - rides in the dispatch of the first pose solve (one workgroup solves, the
@@ -399,12 +427,20 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
     };
     RUN(tap());
 #endif
-    const bool ride = mask_rides && it == 0;
-    RUN(pvo_ba_finish_conv1x1(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
-                              u->motion_only, last && !u->motion_only ? u->clamp_frames : 0, u->disp_min,
-                              nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes,
-                              ride ? b.a2 : nullptr, ride ? w->up_w : nullptr, ride ? w->up_b : nullptr, ride ? a.upmask : nullptr,
-                              ride ? static_cast<long long>(K) * HW : 0, ride ? 576 : 0, ride ? dt : 0, stream));
+    pvo_ba_riders jobs{};
+    if (mask_rides && it == 0) {
+      jobs.cx = b.a2; jobs.cw = w->up_w; jobs.cbias = w->up_b; jobs.cy = a.upmask;
+      jobs.crows = static_cast<long long>(K) * HW; jobs.cCout = 576; jobs.cdtype = dt;
+    }
+    if (context_ahead && it == 0) {          // the next update's input is this update's net_out
+      jobs.gnet = a.net_out; jobs.gw = w->glo_w; jobs.gbias = w->glo_b; jobs.gpart = b.part; jobs.gE = E; jobs.gHW = HW; jobs.gdtype = dt;
+    }
+    if (context_ahead && it == 1) {
+      jobs.xpart = b.part; jobs.xwt = w->gate_wt; jobs.xbias = w->gate_b; jobs.xg = b.g; jobs.xE = E; jobs.xchunks = pvo_gru_glo_chunks(HW);
+    }
+    RUN(pvo_ba_finish_riders(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
+                             u->motion_only, last && !u->motion_only ? u->clamp_frames : 0, u->disp_min,
+                             nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, &jobs, stream));
 #ifdef PVO_SCHED_DEBUG
     RUN(tap());
 #endif
@@ -424,6 +460,8 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
 #ifdef PVO_SCHED_DEBUG
   if (g_sched.mode == 1 || g_sched.mode == 2) RUN(join(pending, stream));      // (these put the mask convolution behind `mid`)
 #endif
+  if (ca && context_ahead)
+    *ca = ContextAhead{workspace, w, w->glo_w, w->gate_wt, a.net_out, E, H, W, dt, true};
   probe_mark(PVO_STAGE_UPDATE, 1, stream);
   return PVO_OK;
 }

@@ -925,6 +925,26 @@ def graph_motion(target, coords1, delta_dy, raw_mask, dtype):
     return motn.permute(0, 3, 1, 2)[None]
 
 
+def reproject_motion(poses, disps, intrinsics, ii, jj, target, delta_dy, raw_mask, dtype):
+    """reproject + graph_motion in one pass (pvo_reproject_motion) -> coords [E,ht,wd,2], valid [E,ht,wd,1], motion [1,E,8,H,W]"""
+    for t, n in ((poses, "poses"), (disps, "disps"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj"), (target, "target"),
+                 (delta_dy, "delta_dy"), (raw_mask, "raw_mask")):
+        _contig(t, n)
+    for t, n in ((target, "target"), (delta_dy, "delta_dy"), (raw_mask, "raw_mask")):
+        _f32(t, n)
+    dev = _dev(poses, disps, intrinsics, ii, jj, target, delta_dy, raw_mask)
+    _long(ii, "ii"); _long(jj, "jj")
+    E, ht, wd = ii.shape[0], disps.shape[1], disps.shape[2]
+    coords = torch.empty(E, ht, wd, 2, dtype=torch.float32, device=dev)
+    valid = torch.empty(E, ht, wd, 1, dtype=torch.float32, device=dev)
+    motn = torch.empty(E, ht, wd, 8, dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_reproject_motion(_ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii), _ptr(jj), _ptr(coords), _ptr(valid),
+                                               _ptr(target), _ptr(delta_dy), _ptr(raw_mask), _ptr(motn), E, ht, wd, _DT[dtype],
+                                               _stream(dev)), "reproject_motion")
+    return coords, valid, motn.permute(0, 3, 1, 2)[None]
+
+
 def segment_hist(segm, raw_mask, heads, max_segments, dy_thresh=0.5):
     """counting half of the panoptic vote (factor_graph.py:256-261): segm int32 [E,H,W] dense labels in [0, max_segments),
     raw_mask [1,E,H,W,2] f32 (BEFORE the update), heads [E,8,H,W] channels-last -> (tot, dyn) int32 [E,max_segments]"""

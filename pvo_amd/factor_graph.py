@@ -16,6 +16,7 @@ What is different, because it is what costs time once the kernels are fast:
 """
 import contextlib
 
+import itertools
 import torch
 
 from .modules.corr import CorrBlock, CorrVolumePool
@@ -91,6 +92,9 @@ class _EdgeRows:
         b = self.buf[self.cur]
         fill(b[E:E + n])
         return b[:E + n]
+
+
+_CACHE_SERIAL = itertools.count(1)
 
 
 class FactorGraph:
@@ -746,7 +750,15 @@ class FactorGraph:
         a.weight, a.full_flow = self.weight.data_ptr(), self.full_flow.data_ptr()
         a.itrs = int(itrs) if sharded is None else 0
         a.clamp_frames = v.disps.shape[0] if sharded is None else 0
+        # The ConvGRU's gate context depends on the hidden state only: the library computes the NEXT update's inside this
+        # update's pose solves (context_ahead) and uses it if we can promise that nobody wrote `net` in between
+        # (context_ready): same tensor object state (torch's version counter: the native update writes through the raw
+        # pointer and does not move it) for the same edge-set cache entry.
+        token = (net.data_ptr(), net._version, st.setdefault("serial", next(_CACHE_SERIAL)))
+        a.context_ahead = 1
+        a.context_ready = 1 if getattr(self, "_ctx_token", None) == token else 0
         db.graph_update(self.update_op.packed_weights(dt), a, st["ws"])
+        self._ctx_token = token
         if sharded is not None:
             # edge sharding: assembly + Schur on this rank's edges, ONE integer all-reduce of the reduced pose system per
             # Gauss-Newton step, identical solve on every rank (pvo_amd/parallel.py)

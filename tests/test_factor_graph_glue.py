@@ -405,6 +405,59 @@ def test_native_updates_are_reproducible(cuda):
             assert torch.equal(a, b), r
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_reproject_with_motion_features_equals_the_two_kernels(cuda, dtype):
+    """pvo_reproject_motion (the head of pvo_graph_update) = pvo_reproject followed by pvo_graph_motion, bit for bit, on a map
+    whose size is not a multiple of the workgroup (30 x 101) and with out-of-range targets (the +-64 clamp)"""
+    from pvo_amd import droid_backends as db
+    from pvo_amd.geom.se3 import SE3
+    g = torch.Generator().manual_seed(5)
+    F, ht, wd = 6, 30, 101
+    poses = SE3.exp(0.05 * torch.randn(F, 6, generator=g)).data.to(cuda).contiguous()
+    disps = (0.2 + torch.rand(F, ht, wd, generator=g)).to(cuda)
+    intr = torch.tensor([90.0, 90.0, 50.5, 15.0]).repeat(F, 1).to(cuda)
+    ii = torch.tensor([0, 1, 2, 3, 4, 5, 2, 0], device=cuda)
+    jj = torch.tensor([1, 0, 4, 1, 2, 3, 5, 3], device=cuda)
+    E = ii.numel()
+    target = (200.0 * torch.randn(1, E, ht, wd, 2, generator=g)).to(cuda)
+    ddy = torch.randn(1, E, ht, wd, 2, generator=g).to(cuda)
+    raw = (40.0 * torch.randn(1, E, ht, wd, 2, generator=g)).to(cuda)
+    c0, v0 = db.reproject(poses, disps, intr, ii, jj)
+    m0 = db.graph_motion(target, c0[None].contiguous(), ddy, raw, dtype)
+    c1, v1, m1 = db.reproject_motion(poses, disps, intr, ii, jj, target, ddy, raw, dtype)
+    assert torch.equal(c0, c1) and torch.equal(v0, v1)
+    assert torch.equal(m0.view(torch.int16), m1.view(torch.int16))
+    assert (m1.float().abs() == 64).any()
+
+
+@pytest.mark.gpu
+def test_context_computed_ahead_inside_the_pose_solves_changes_nothing(cuda):
+    """pvo_graph_update computes the NEXT update's gate context (a function of the hidden state and the weights) inside this
+    update's two pose-solve dispatches and the next call uses it if nobody wrote `net` in between: two keyframe steps (12
+    updates, the first of every step recomputes - the step restores `net`) end in the same bits as with PVO_CONTEXT_AHEAD=0
+    and with the riders off altogether.  The choice is read once per process: one process per setting."""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r); import bench; dev = torch.device('cuda:0'); "
+            "video, graph = bench.make_window(dev, seed=0); snap = bench.Snapshot(video, graph); "
+            "snap.edge_list = list(zip(graph._ii_h, graph._jj_h)); "
+            "[bench.keyframe_update(video, graph, snap) for _ in range(4)]; torch.cuda.synchronize(); "
+            "torch.save([t.cpu() for t in (video.poses, video.disps, graph.damping, graph.net, graph.target_cam, graph.weight)], sys.argv[1])") % root
+    outs = []
+    for env in ({}, {"PVO_CONTEXT_AHEAD": "0"}, {"PVO_CONTEXT_AHEAD": "0", "PVO_UPMASK_RIDER": "0"}):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            outs.append(torch.load(f.name))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_packed_index_upload_keeps_parts_apart():
     """to_device_packed: several index tables in one staging buffer, each part its own dtype, 16-byte aligned, empty parts allowed
     (the CPU branch shares the packing arithmetic's contract: one tensor per part, same values)"""

@@ -5,7 +5,9 @@ TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/timeline_$TAG.txt
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/ut
-rocprofv3 --kernel-trace -f csv -d /tmp/ut -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /tmp/ut_bench.log 2>&1
+# (second argument: an experiment build of the library, tools/variant.py build <variant> ...)
+if [ -n "$2" ]; then BENCH="$GRAFT_REPO_ROOT/tools/variant.py bench $2"; else BENCH="$GRAFT_REPO_ROOT/bench.py"; fi
+rocprofv3 --kernel-trace -f csv -d /tmp/ut -- python $BENCH --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /tmp/ut_bench.log 2>&1
 python - > $OUT <<PY
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("/tmp/ut/*/*kernel_trace.csv")[0])))
@@ -13,8 +15,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     return n.split("(")[0][:52]
-# a graph update starts with reproject_kernel, the lookup among the next three dispatches; take the 30th update from the end
-starts = [i for i, r in enumerate(rows[:-4]) if "reproject_kernel" in r["Kernel_Name"]
+# a graph update starts with reproject_motion_kernel (reproject_kernel before round 3), the lookup among the next three dispatches; take the 30th update from the end
+starts = [i for i, r in enumerate(rows[:-4]) if ("reproject_motion_kernel" in r["Kernel_Name"] or "reproject_kernel" in r["Kernel_Name"])
           and any("corr_lookup" in rows[i + k]["Kernel_Name"] for k in (1, 2, 3))]
 i0, i1 = starts[-30], starts[-29]
 t0 = int(rows[i0]["Start_Timestamp"])
@@ -34,7 +36,7 @@ import collections
 ends = []
 for i in starts:
     j = i
-    while j + 1 < len(rows) and not ("reproject_kernel" in rows[j + 1]["Kernel_Name"] and j + 1 in set(starts)):
+    while j + 1 < len(rows) and not (("reproject_motion_kernel" in rows[j + 1]["Kernel_Name"] or "reproject_kernel" in rows[j + 1]["Kernel_Name"]) and j + 1 in set(starts)):
         if "ba_backsub_kernel" in rows[j]["Kernel_Name"] and j > i + 10 and "ba_backsub" not in rows[j + 1]["Kernel_Name"] and "ba_assemble" not in rows[j + 1]["Kernel_Name"]:
             break
         j += 1
