@@ -232,6 +232,12 @@ int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const floa
  * re-arranged to [52 taps (ky*7+kx; 49 real + 3 zero)][128 outputs][8 input channels] in `dtype`; bias f32 [128]. */
 int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y,
                    int E, int H, int W, int dtype, void* stream);
+/* The whole flow encoder (droid_net.py:176-180) in one kernel: y[E,H,W,ystride (channels yoff .. yoff+64)] =
+ * relu(conv3x3(relu(conv7x7(x[E,H,W,8]) + bias7), zero padding 1) + bias3); the 128-channel intermediate stays in LDS.
+ * Bit-identical to pvo_conv7x7_c8 followed by pvo_conv3x3_c128(Cout = 64, relu = 1).  w7_taps as pvo_conv7x7_c8's,
+ * w3_taps [9][64][128] as pvo_conv3x3_c128's; bias7 f32 [128], bias3 f32 [64] or NULL; ystride = 0: dense. */
+int pvo_flow_encoder(const void* x, const void* w7_taps, const float* bias7, const void* w3_taps, const float* bias3,
+                     void* y, int E, int H, int W, int ystride, int yoff, int dtype, void* stream);
 /* y[rows,128] = relu(W corr + b) for an already sampled correlation tensor corr [rows,196] (channels-last, 8-byte aligned):
  * corr_encoder[0:2] = Conv2d(196,128,1) + ReLU (droid_net.py:172-175) for callers without a resident volume pool (motion
  * filter, global BA with alt-corr).  enc_weight as in pvo_corr_lookup_encode_tiled: [128][224], zero padded. */

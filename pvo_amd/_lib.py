@@ -33,6 +33,7 @@ SIGNATURES = {
     "pvo_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv3x3_c128": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_conv7x7_c8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pvo_flow_encoder": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_encode": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _vp]),
     "pvo_eta_head": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
     "pvo_conv1x1_c128": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _i, _vp]),

@@ -650,6 +650,137 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
   CONV_PROBE(3);
 }
 
+// ---------------------------------------------------------------------------
+// pvo_flow_encoder: the update operator's flow encoder, Conv2d(8,128,7,padding=3) + ReLU -> Conv2d(128,64,3,padding=1) + ReLU
+// (droid_net.py:176-180), in ONE kernel: the 128-channel intermediate never leaves LDS.  As two launches
+// (conv7x7_c8_kernel, conv3x3_c128_kernel<.., 1>) the pair is the chain the gate convolution waits for once the ConvGRU's
+// context is computed ahead - 29 + 40 us alone, 52 + 53 us beside the correlation lookup - and the intermediate costs a
+// 28 MB write and a 40 MB halo read.  Workgroup = 8 x 14 output pixels: their 3x3 halo is 10 rows x 16 columns, exactly ten
+// 16-pixel MFMA rows of the 7x7 stage (22 x 16 input halo, 5.6 KB), whose bias + ReLU results go to the LDS tile the 3x3
+// stage reads (positions outside the image are the second convolution's zero padding: stored as zeros, not computed).  The
+// 3x3 stage is conv3x3_c128_kernel's with a 16-position row pitch: columns 14 and 15 of every MFMA row read past the tile row
+// and are discarded (12.5 % of its MFMAs).  The same MFMAs in the same order on the same 16-bit intermediate as the two
+// kernels: bit-identical output.
+// ---------------------------------------------------------------------------
+constexpr int kFeOW = 14;                                      // output columns per workgroup
+constexpr int kFeRows = kTH + 2;                               // rows of the intermediate tile
+constexpr int kFeM7W = 16 + 2 * kR;                            // 22: pitch of the 7x7 stage's input halo
+constexpr int kFeM7Pos = (kFeRows + 2 * kR) * kFeM7W;          // 16 x 22 positions
+constexpr int kFeF1Pos = kFeRows * 16 + 2;                     // + 2: what the discarded columns of the last row read
+constexpr int kFeLds = kFeF1Pos * kC3Stride + kFeM7Pos * 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void flow_encoder_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w7,
+                                                           const float* __restrict__ b7, const uint16_t* __restrict__ w3,
+                                                           const float* __restrict__ b3, uint16_t* __restrict__ y,
+                                                           int H, int W, int ystride, int yoff) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fes[];          // [f1 tile 162 x 272 B | input halo 352 x 16 B]
+  unsigned char* f1 = fes;
+  unsigned char* halo = fes + kFeF1Pos * kC3Stride;
+  const int e = blockIdx.z, y0 = blockIdx.y * kTH, x0 = blockIdx.x * kFeOW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+
+  // ---- stage 1: 7x7, 8 -> 128 channels, on the 10 x 16 positions (y0 - 1 .., x0 - 1 ..); wave w owns channels [32w, 32w + 32)
+  {
+    cs_u32x4 bf[kSteps][2];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        bf[s][nt] = *reinterpret_cast<const cs_u32x4*>(w7 + (static_cast<size_t>(4 * s + lk) * 128 + wave * 32 + nt * 16 + li) * 8);
+    const uint16_t* xe = x + static_cast<size_t>(e) * H * W * 8;
+    for (int pos = tid; pos < kFeM7Pos; pos += 256) {
+      const int hy = y0 - 1 - kR + pos / kFeM7W, hx = x0 - 1 - kR + pos % kFeM7W;
+      cs_u32x4 v = {0u, 0u, 0u, 0u};
+      if (hy >= 0 && hy < H && hx >= 0 && hx < W) v = *reinterpret_cast<const cs_u32x4*>(xe + (static_cast<size_t>(hy) * W + hx) * 8);
+      *reinterpret_cast<cs_u32x4*>(halo + pos * 16) = v;
+    }
+    if (tid < 2 * 17) *reinterpret_cast<cs_u32x4*>(f1 + kFeRows * 16 * kC3Stride + tid * 16) = cs_u32x4{0u, 0u, 0u, 0u};
+    int toff[kSteps];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+      const int tap = min(4 * s + lk, kTaps - 1);              // taps >= 49 have zero weights, any address does
+      toff[s] = ((tap / 7) * kFeM7W + (tap % 7) + li) * 16;
+    }
+    const float bb0 = b7[wave * 32 + li], bb1 = b7[wave * 32 + 16 + li];
+    __syncthreads();
+    for (int r = 0; r < kFeRows; ++r) {
+      const int gy = y0 - 1 + r;
+      cs_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      const bool row_in = gy >= 0 && gy < H;                   // (uniform)
+      if (row_in) {
+        const unsigned char* rowp = halo + r * kFeM7W * 16;
+        cs_u32x4 afr[kSteps];
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) afr[s] = *reinterpret_cast<const cs_u32x4*>(rowp + toff[s]);
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) {
+          d0 = cs_mfma<T>(afr[s], bf[s][0], d0);
+          d1 = cs_mfma<T>(afr[s], bf[s][1], d1);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                            // D: column li = channel, rows lk*4 + q = positions of the row
+        const int p = lk * 4 + q, gx = x0 - 1 + p;
+        const bool in = row_in && gx >= 0 && gx < W;
+        unsigned char* dst = f1 + (r * 16 + p) * kC3Stride + (wave * 32 + li) * 2;
+        *reinterpret_cast<uint16_t*>(dst) = in ? static_cast<uint16_t>(cs_bits<T>(fmaxf(d0[q] + bb0, 0.0f))) : static_cast<uint16_t>(0);
+        *reinterpret_cast<uint16_t*>(dst + 32) = in ? static_cast<uint16_t>(cs_bits<T>(fmaxf(d1[q] + bb1, 0.0f))) : static_cast<uint16_t>(0);
+      }
+    }
+  }
+  // ---- stage 2: 3x3, 128 -> 64 channels; wave w owns output channels [16w, 16w + 16)
+  const int co0 = wave * 16;
+  const uint16_t* wl = w3 + (static_cast<size_t>(co0 + li)) * 128 + lk * 8;
+  constexpr size_t tap_stride = static_cast<size_t>(64) * 128;
+  cs_u32x4 bcur[4], bnxt[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) bcur[kc] = *reinterpret_cast<const cs_u32x4*>(wl + kc * 32);
+  cs_v4f acc[kTH];
+#pragma unroll
+  for (int py = 0; py < kTH; ++py) acc[py] = cs_v4f{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {
+    if (t < 8) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) bnxt[kc] = *reinterpret_cast<const cs_u32x4*>(wl + (t + 1) * tap_stride + kc * 32);
+    }
+    const unsigned char* tp = f1 + ((t / 3) * 16 + (t % 3) + li) * kC3Stride + lk * 16;
+#pragma unroll
+    for (int py = 0; py < kTH; ++py) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const cs_u32x4 a = *reinterpret_cast<const cs_u32x4*>(tp + py * 16 * kC3Stride + kc * 64);
+        acc[py] = cs_mfma<T>(a, bcur[kc], acc[py]);
+      }
+    }
+    if (t < 8) {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) bcur[kc] = bnxt[kc];
+    }
+  }
+  __syncthreads();                                             // the intermediate is consumed: its LDS becomes the output slab
+  constexpr int kOutStride = 64 * 2 + 16;
+  const float bb = b3 ? b3[co0 + li] : 0.0f;
+#pragma unroll
+  for (int py = 0; py < kTH; ++py)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<uint16_t*>(f1 + (py * 16 + lk * 4 + q) * kOutStride + (co0 + li) * 2) =
+          static_cast<uint16_t>(cs_bits<T>(fmaxf(acc[py][q] + bb, 0.0f)));
+  __syncthreads();
+  for (int id = tid; id < kTH * 16 * 8; id += 256) {           // 8 chunks of 16 B per pixel
+    const int p = id >> 3, c = id & 7;
+    const int px = p & 15, gy = y0 + (p >> 4), gx = x0 + px;
+    if (px < kFeOW && gy < H && gx < W)
+      *reinterpret_cast<cs_u32x4*>(y + ((static_cast<size_t>(e) * H + gy) * W + gx) * ystride + yoff + c * 8) =
+          *reinterpret_cast<const cs_u32x4*>(f1 + p * kOutStride + c * 16);
+  }
+}
+
 }  // namespace
 
 #ifdef PVO_CONV_PROBE
@@ -672,6 +803,35 @@ extern "C" int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bi
   else if (dtype == PVO_BF16)
     hipLaunchKernelGGL(conv7x7_c8_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x),
                        static_cast<const uint16_t*>(w_taps), bias, static_cast<uint16_t*>(y), H, W);
+  else
+    return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_flow_encoder(const void* x, const void* w7_taps, const float* bias7, const void* w3_taps, const float* bias3,
+                                void* y, int E, int H, int W, int ystride, int yoff, int dtype, void* stream) {
+  if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
+  if (ystride == 0) ystride = 64;
+  if (ystride < yoff + 64 || yoff < 0 || (ystride & 7) || (yoff & 7)) return PVO_EINVAL;
+  if (E == 0 || H == 0 || W == 0) return PVO_OK;
+  if (!x || !w7_taps || !bias7 || !w3_taps || !y || E > 65535) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w7_taps) | reinterpret_cast<uintptr_t>(w3_taps) | reinterpret_cast<uintptr_t>(y)) & 15)
+    return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  const dim3 grid((W + kFeOW - 1) / kFeOW, (H + kTH - 1) / kTH, E);
+  const uint16_t *xp = static_cast<const uint16_t*>(x), *w7 = static_cast<const uint16_t*>(w7_taps), *w3 = static_cast<const uint16_t*>(w3_taps);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flow_encoder_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, kFeLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(flow_encoder_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, kFeLds) != hipSuccess)
+      return PVO_ELAUNCH;
+    attr_set = true;
+  }
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(flow_encoder_kernel<pvo_half>, grid, dim3(256), kFeLds, st, xp, w7, bias7, w3, bias3, static_cast<uint16_t*>(y), H, W, ystride, yoff);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(flow_encoder_kernel<pvo_bf16>, grid, dim3(256), kFeLds, st, xp, w7, bias7, w3, bias3, static_cast<uint16_t*>(y), H, W, ystride, yoff);
   else
     return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();

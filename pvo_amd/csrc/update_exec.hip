@@ -177,8 +177,17 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     RUN(pvo_corr_encode(a->corr, w->enc0_w, w->enc0_b, b.c1, rows, dt, stream));
   }
   if (mj) RUN(pvo_graph_motion(mj->target, mj->coords, mj->delta_dy, mj->raw_mask, mj->motion, E, H, W, dt, s2));
-  RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
-  RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
+  // The flow encoder as two kernels.  pvo_flow_encoder (one kernel, the 128-channel intermediate in LDS; PVO_FLOW_ENCODER_FUSED=1)
+  // is bit-identical and shorter alone, but this stretch of the update is throughput-bound: beside it corr_encoder[2] on the
+  // launch stream takes 74 instead of 41 us (its redundant 7x7 halo work occupies the matrix cores) and the gate convolution
+  // starts 8 us LATER (226.9 -> 225.2 keyframe updates/s).
+  static const bool fe_two = [] { const char* e = getenv("PVO_FLOW_ENCODER_FUSED"); return !(e && e[0] == '1'); }();
+  if (fe_two) {
+    RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
+    RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
+  } else {
+    RUN(pvo_flow_encoder(a->motion, w->fenc0_w, w->fenc0_b, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 192, 128, dt, s2));
+  }
   if (sc && hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
   // the encoders' second layers write relu(features + bias) side by side: CF = [corr features (128) | flow features (64)]
   if (w->flags & PVO_OP_CONV128_WIDE)

@@ -700,6 +700,23 @@ def conv7x7_c8(x, w_taps, bias):
     return y
 
 
+def flow_encoder(x, w7_taps, bias7, w3_taps, bias3, out=None, out_offset=0):
+    """relu(conv3x3(relu(conv7x7(x) + bias7)) + bias3) in one kernel (pvo_flow_encoder): x [E,8,H,W] channels-last 16-bit ->
+    [E,64,H,W] channels-last, or a channel slice of `out`"""
+    _cl(x, "x", 8)
+    dev = _dev(x, w7_taps, bias7, w3_taps, out)
+    E, _, H, W = x.shape
+    if w7_taps.dtype != x.dtype or tuple(w7_taps.shape) != (52, 128, 8) or not w7_taps.is_contiguous():
+        raise PvoHipError("flow_encoder: w7_taps must be the [52,128,8] tensor of conv7x7_c8_weights in x's dtype")
+    if tuple(w3_taps.shape) != (9, 64, 128) or w3_taps.dtype != x.dtype or not w3_taps.is_contiguous():
+        raise PvoHipError("flow_encoder: w3_taps must be the [9,64,128] tensor of conv3x3_c128_weights in x's dtype")
+    ret, y, ys, yo = _out_slice(out, out_offset, E, 64, H, W, x.dtype, dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_flow_encoder(_ptr(x), _ptr(w7_taps), _bias(bias7, 128, "bias7"), _ptr(w3_taps), _bias(bias3, 64, "bias3"),
+                                           _ptr(y), E, H, W, ys, yo, _dtype_code(x, "x"), _stream(dev)), "flow_encoder")
+    return ret
+
+
 def conv3x3_c128_weights(weight, dtype):
     """[Cout,128,3,3] conv filter -> the [9,Cout,128] tap-major layout pvo_conv3x3_c128 reads"""
     co, ci, kh, kw = weight.shape
