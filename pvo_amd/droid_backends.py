@@ -11,6 +11,7 @@ A maintainer of the reference replaces `import droid_backends` with
 `from pvo_amd import droid_backends`.
 """
 import ctypes
+import itertools
 
 import torch
 
@@ -1012,8 +1013,11 @@ class PackedWeights:
 
     FIELDS = [n for n, _ in _lib.UpdateWeights._fields_[2:]]
 
+    _serial = itertools.count(1)
+
     def __init__(self, dtype, tensors, flags=0):
         self.dtype, self.tensors, self.flags = dtype, dict(tensors), flags
+        self.serial = next(PackedWeights._serial)      # (identity that survives address reuse: FactorGraph's context token)
         st = _lib.UpdateWeights()
         st.dtype, st.flags = _DT[dtype], flags
         dev = None

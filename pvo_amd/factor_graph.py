@@ -754,10 +754,11 @@ class FactorGraph:
         # update's pose solves (context_ahead) and uses it if we can promise that nobody wrote `net` in between
         # (context_ready): same tensor object state (torch's version counter: the native update writes through the raw
         # pointer and does not move it) for the same edge-set cache entry.
-        token = (net.data_ptr(), net._version, st.setdefault("serial", next(_CACHE_SERIAL)))
+        weights = self.update_op.packed_weights(dt)
+        token = (net.data_ptr(), net._version, st.setdefault("serial", next(_CACHE_SERIAL)), weights.serial)
         a.context_ahead = 1
         a.context_ready = 1 if getattr(self, "_ctx_token", None) == token else 0
-        db.graph_update(self.update_op.packed_weights(dt), a, st["ws"])
+        db.graph_update(weights, a, st["ws"])
         self._ctx_token = token
         if sharded is not None:
             # edge sharding: assembly + Schur on this rank's edges, ONE integer all-reduce of the reduced pose system per
