@@ -359,10 +359,10 @@ typedef struct pvo_graph_update_args {
   int want_upmask;                                           /* compute agg.upmask_disp although FactorGraph.update discards it */
   /* The ConvGRU's gate context is a function of the hidden state and the weights only.  context_ahead = 1: this call also
    * computes the context of op.net_out - the NEXT update's input - inside its two pose solves' dispatches (needs itrs >= 2
-   * and a depth BA; ignored otherwise) and leaves it in the workspace.  context_ready = 1: the caller's promise that op.net
-   * has not been written since the previous pvo_graph_update of this device returned it as net_out; the library then uses
-   * the stored context if that call was made with context_ahead, the same workspace, weights, E, H, W and net_out == this
-   * op.net - and computes it as usual if not. */
+   * and a depth BA; ignored otherwise) and leaves it in the workspace.  context_ready = 1: the caller's promise that neither
+   * op.net nor the context weights (glo_w, glo_b, gate_wt, gate_b) have been written since the previous pvo_graph_update of
+   * this device returned op.net as net_out; the library then uses the stored context if that call was made with context_ahead,
+   * the same workspace, weight struct and weight pointers, E, H, W and net_out == this op.net - and computes it as usual if not. */
   int context_ahead, context_ready;
 } pvo_graph_update_args;
 
