@@ -18,7 +18,8 @@ so that K steps do identical work (8 device copies inside the timed step that a 
 N > 1: one process per GPU (torch.distributed, RCCL); every rank tracks its own window
 (independent sequences, no data-path collective), value = N*K / max-over-ranks time.
 
-Extra objects on the JSON line: "roofline" for the dominant hand-written HBM-bound kernel (the fused 4-level lookup),
+Extra objects on the JSON line: "roofline" for the dominant hand-written HBM-bound kernel (the fused 4-level lookup; its
+duration = HIP events around it inside the timed steps minus what an event pair around nothing reads at the same place),
 "roofline_wide_conv" (matrix-core roofline of the wide 3x3 convolution, the kernel with the largest share of the step,
 with the shader clock the chip sustains under it and inside a step: pvo_clock_probe), "stage_us_in_step", "host",
 "workload_S_A" (the reference driver's 30x101 maps), "workload_S_1" (configs[0]: one tools/test_vo2.py clip at 47x156 maps),
@@ -316,15 +317,20 @@ def scattered_ceiling(device, traffic_bytes, write_bytes, lookup_us):
             "note": "reads priced at the random-64-byte-line rate (an upper bound on the time: the rate is per line touched, and some of the 64-byte fetches share a line), writes at the streaming rate; `roofline.frac` stays priced on algorithmic bytes against the 8 TB/s peak"}
 
 
-def lookup_roofline(E, HW, in_step_ms, traffic=None):
+def lookup_roofline(E, HW, in_step_ms, traffic=None, event_pair_us=None):
+    """`achieved` is priced on the kernel's duration = the event reading minus what an event pair around NOTHING reads at the
+    same place of the stream (`event_pair_us`, PVO_STAGE_EMPTY, from two extra steps): that is the figure rocprofv3's
+    per-kernel average agrees with (profiles/); both readings are in the object.  Without the calibration (None): the raw one."""
     in_us = sorted(1e3 * v for v in in_step_ms)
-    us = sum(in_us) / max(len(in_us), 1)
+    raw = sum(in_us) / max(len(in_us), 1)
+    us = raw - event_pair_us if event_pair_us is not None and raw > event_pair_us else raw
     alg = E * HW * (4 * 64 * 2 + 8 + 128 * 2)      # SURVEY 8d: taps + coords + (encoded) output, fp16
     ach = alg / (us * 1e-6) / 1e9 if us > 0 else 0.0
     return {"kernel": "corr_lookup_r3_kernel<half, tiled, enc> (4-level lookup + 196->128 encoder layer, 8x8-tiled resident volumes)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": us, "launches_timed": len(in_us),
-            "timing": "HIP events around the kernel on its launch stream, inside the timed steps (every %dth launch)" % PROBE_EVERY,
+            "avg_event_reading_us": raw, "event_pair_around_nothing_us": event_pair_us,
+            "timing": "HIP events around the kernel on its launch stream, inside the timed steps (every %dth launch), minus the reading of an event pair around nothing at the same place" % PROBE_EVERY,
             "in_step_us_min_median_max": [in_us[0], in_us[len(in_us) // 2], in_us[-1]] if in_us else None}
 
 
@@ -649,7 +655,7 @@ def main():
 
     # per-stage durations inside the step, from a few extra untimed steps (one probe at a time)
     stage_us = {}
-    for stage in ("gates", "candidate", "ba", "update"):
+    for stage in ("gates", "candidate", "ba", "update", "empty"):
         db.probe_arm(stage, 2 * updates_per_step)
         for _ in range(2):
             keyframe_update(video, graph, snap)
@@ -750,7 +756,7 @@ def main():
             "graph_updates_per_s": world * args.steps * updates_per_step / elapsed,
             "host": {"issue_ms_per_step_median": 1e3 * hi[len(hi) // 2], "issue_ms_per_step_max": 1e3 * hi[-1],
                      "priming_blocks_of_8_steps": blocks},
-            "roofline": dict(lookup_roofline(E, HW, in_step_lookup, traffic), isolated_cold_us=lookup_cold_us,
+            "roofline": dict(lookup_roofline(E, HW, in_step_lookup, traffic, stage_us.pop("empty", None)), isolated_cold_us=lookup_cold_us,
                              isolated_cold="Infinity Cache evicted by a 600 MB read before each of 20 launches",
                              warm_back_to_back_us=lookup_b2b_us, traffic_source=traffic_src, scattered_lines=scat),
             "roofline_wide_conv": {

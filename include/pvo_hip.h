@@ -378,7 +378,8 @@ int pvo_side_stream(void** stream_out);
  * pvo_update_operator calls (at most `capacity` occurrences), so a benchmark can read a kernel's duration inside its timed
  * steps.  pvo_probe_read waits for the recorded events, writes their elapsed times in milliseconds to HOST memory,
  * disarms the probe and returns the number of samples (or -1). */
-enum { PVO_STAGE_LOOKUP = 0, PVO_STAGE_GATES = 1, PVO_STAGE_CANDIDATE = 2, PVO_STAGE_BA = 3, PVO_STAGE_UPDATE = 4 };
+enum { PVO_STAGE_LOOKUP = 0, PVO_STAGE_GATES = 1, PVO_STAGE_CANDIDATE = 2, PVO_STAGE_BA = 3, PVO_STAGE_UPDATE = 4,
+       PVO_STAGE_EMPTY = 5 /* an event pair around nothing in front of the lookup: what the pair itself adds to a reading */ };
 int pvo_probe_arm(int stage, int capacity);
 /* The same, sampling one occurrence in `every` (>= 1): the event pair costs the launch stream a few microseconds per occurrence. */
 int pvo_probe_arm_every(int stage, int capacity, int every);

@@ -169,6 +169,8 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
   }
   if (a->levels[0]) {
+    probe_mark(PVO_STAGE_EMPTY, 0, stream);      // (calibration: an event pair around nothing, at the lookup's place in the stream)
+    probe_mark(PVO_STAGE_EMPTY, 1, stream);
     probe_mark(PVO_STAGE_LOOKUP, 0, stream);
     RUN(pvo_corr_lookup_encode_tiled(a->levels, a->coords, w->enc0_w, w->enc0_b, b.c1, E, H, W, dt, a->slots, a->num_slots, stream));
     probe_mark(PVO_STAGE_LOOKUP, 1, stream);

@@ -1188,7 +1188,7 @@ def se3_binary(op, a, rep_a, b, rep_b, out_batch):
     return y
 
 
-STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4}
+STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4, "empty": 5}
 
 
 _side_streams = {}
