@@ -143,16 +143,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 
   // ---- epilogue: every level is formed in registers, transposed through a per-wave LDS
   // slab and leaves as 16-byte row segments (a 2-byte store per value is store-issue bound).
+  // Two passes of 16 source pixels each through a HALF-size slab: with slabs for all 32 rows (94 KB) the kernel ran one
+  // workgroup per CU; 47 KB (< the 70 KB fmap2 patch) lets two reside, and one can compute while the other drains its stores.
+  // The slabs are per wave: between fill and drain only the wave itself has to be ordered (no workgroup barrier).
   __syncthreads();                                   // the fmap2 patch is dead: its LDS is reused
   constexpr int RS0 = kPatchPix * 2 + 16, RS1 = 64 * 2 + 16, RS2 = 16 * 2 + 16, RS3 = 16;
-  unsigned char* slab0 = smem + wave * (32 * RS0);
-  unsigned char* slab1 = smem + 4 * (32 * RS0) + wave * (32 * RS1);
-  unsigned char* slab2 = smem + 4 * (32 * (RS0 + RS1)) + wave * (32 * RS2);
-  unsigned char* slab3 = smem + 4 * (32 * (RS0 + RS1 + RS2)) + wave * (32 * RS3);
+  constexpr int kHalfRows = 16;
+  unsigned char* slab0 = smem + wave * (kHalfRows * RS0);
+  unsigned char* slab1 = smem + 4 * (kHalfRows * RS0) + wave * (kHalfRows * RS1);
+  unsigned char* slab2 = smem + 4 * (kHalfRows * (RS0 + RS1)) + wave * (kHalfRows * RS2);
+  unsigned char* slab3 = smem + 4 * (kHalfRows * (RS0 + RS1 + RS2)) + wave * (kHalfRows * RS3);
   const int x2l = lane & 31;
+  const long long plane00 = static_cast<long long>(a.out_slots ? a.out_slots[n] : n) * HW + m0;   // plane of this wave's row 0
+  const int rows_all = min(32, HW - m0);                           // valid source pixels of this wave
+  // aligned: every level's row segments are 16-byte (level 3: 8-byte) aligned and complete
+  const bool aligned = ((W & 63) == 0) && ((H & 7) == 0) &&
+      (((reinterpret_cast<uintptr_t>(a.lv[0]) | reinterpret_cast<uintptr_t>(a.lv[1]) |
+         reinterpret_cast<uintptr_t>(a.lv[2]) | reinterpret_cast<uintptr_t>(a.lv[3])) & 15) == 0 || a.nlev < 4);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int mrow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int r = 8 * half + rr;
+    const int mrow = (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);       // row inside this half: (r & 3) + 8 (r >> 2) + 4 (lane >> 5) - 16 half
     float v0[8];                                     // rounded level-0 values, one per patch row
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -184,15 +197,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         *reinterpret_cast<uint16_t*>(slab3 + mrow * RS3 + (x2l >> 3) * 2) = static_cast<uint16_t>(Cvt16<T>::bits(v3));
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  const long long plane0 = static_cast<long long>(a.out_slots ? a.out_slots[n] : n) * HW + m0;   // plane of this wave's row 0
-  const int rows_ok = min(32, HW - m0);                            // valid source pixels of this wave
-  if (rows_ok <= 0) return;
-  // aligned: every level's row segments are 16-byte (level 3: 8-byte) aligned and complete
-  const bool aligned = ((W & 63) == 0) && ((H & 7) == 0) &&
-      (((reinterpret_cast<uintptr_t>(a.lv[0]) | reinterpret_cast<uintptr_t>(a.lv[1]) |
-         reinterpret_cast<uintptr_t>(a.lv[2]) | reinterpret_cast<uintptr_t>(a.lv[3])) & 15) == 0 || a.nlev < 4);
+  const long long plane0 = plane00 + kHalfRows * half;             // plane of this half's row 0
+  const int rows_ok = min(kHalfRows, rows_all - kHalfRows * half);   // valid source pixels of this half
+  if (rows_ok > 0) {
   if (a.nlev == 4 && a.tiled) {
     // 8x8-tiled planes, any map size: level l is [ceil(Hl/8)][ceil(Wl/8)] tiles of 8x8 (Hl = H >> l).  The patch is one
     // tile row high and 8-aligned, so its level-0 part is 4 whole tiles = 512 contiguous bytes per source pixel, and the
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                     pe2 = static_cast<long long>(th2) * tw2 * 64, pe3 = static_cast<long long>(th3) * tw3 * 64;
     uint16_t* L0 = reinterpret_cast<uint16_t*>(a.lv[0]);
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {                   // level 0: 32 rows x 4 tiles x 8 tile rows
+    for (int i = 0; i < 8; ++i) {                    // level 0: 16 rows x 4 tiles x 8 tile rows
       const int id = lane + 64 * i;
       const int mrow = id >> 5, c = (id >> 3) & 3, t = id & 7;
       if (mrow < rows_ok && (x2_0 >> 3) + c < tw0) {
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
     uint16_t* L1 = reinterpret_cast<uint16_t*>(a.lv[1]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                    // level 1: 32 rows x 2 tiles x 4 tile rows
+    for (int i = 0; i < 2; ++i) {                    // level 1: 16 rows x 2 tiles x 4 tile rows
       const int id = lane + 64 * i;
       const int mrow = id >> 3, c = (id >> 2) & 1, q = id & 3;
       if (mrow < rows_ok && (x2_0 >> 4) + c < tw1 && (y2_0 >> 4) < th1) {
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       }
     }
     uint16_t* L2 = reinterpret_cast<uint16_t*>(a.lv[2]);
-    {                                                // level 2: 32 rows x 2 tile rows of one tile
+    if (lane < 32) {                                 // level 2: 16 rows x 2 tile rows of one tile
       const int mrow = lane >> 1, q = lane & 1;
       if (mrow < rows_ok && (x2_0 >> 5) < tw2 && (y2_0 >> 5) < th2) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab2 + mrow * RS2 + q * 16);
@@ -233,17 +244,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       }
     }
     uint16_t* L3 = reinterpret_cast<uint16_t*>(a.lv[3]);
-    if (lane < 32 && lane < rows_ok && (x2_0 >> 6) < tw3 && (y2_0 >> 6) < th3) {      // level 3: 4 values = half a tile row
+    if (lane < kHalfRows && lane < rows_ok && (x2_0 >> 6) < tw3 && (y2_0 >> 6) < th3) {      // level 3: 4 values = half a tile row
       const uint2 v = *reinterpret_cast<const uint2*>(slab3 + lane * RS3);
       *reinterpret_cast<uint2*>(L3 + (plane0 + lane) * pe3 + (static_cast<long long>(y2_0 >> 6) * tw3 + (x2_0 >> 6)) * 64 +
                                 ((y2_0 >> 3) & 7) * 8 + ((x2_0 >> 3) & 7)) = v;
     }
-    return;
-  }
-  if (aligned && a.nlev == 4) {
+  } else if (aligned && a.nlev == 4) {
     uint16_t* L0 = reinterpret_cast<uint16_t*>(a.lv[0]);
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {                   // level 0: 32 rows x 8 patch rows x 4 chunks of 8
+    for (int i = 0; i < 8; ++i) {                    // level 0: 16 rows x 8 patch rows x 4 chunks of 8
       const int id = lane + 64 * i;
       const int mrow = id >> 5, t = (id >> 2) & 7, c = id & 3;
       if (mrow < rows_ok) {
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       uint16_t* L1 = reinterpret_cast<uint16_t*>(a.lv[1]);
       const int H1 = H >> 1, W1 = W >> 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                  // level 1: 32 rows x 4 rows x 2 chunks of 8
+      for (int i = 0; i < 2; ++i) {                  // level 1: 16 rows x 4 rows x 2 chunks of 8
         const int id = lane + 64 * i;
         const int mrow = id >> 3, q = (id >> 1) & 3, c = id & 1;
         if (mrow < rows_ok) {
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       }
       uint16_t* L2 = reinterpret_cast<uint16_t*>(a.lv[2]);
       const int H2 = H >> 2, W2 = W >> 2;
-      {                                              // level 2: 32 rows x 2 rows x 1 chunk of 8
+      if (lane < 32) {                               // level 2: 16 rows x 2 rows x 1 chunk of 8
         const int mrow = lane >> 1, q = lane & 1;
         if (mrow < rows_ok) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(slab2 + mrow * RS2 + q * 16);
@@ -274,15 +283,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       }
       uint16_t* L3 = reinterpret_cast<uint16_t*>(a.lv[3]);
       const int H3 = H >> 3, W3 = W >> 3;
-      if (lane < 32 && lane < rows_ok) {             // level 3: 32 rows x 4 values (8 bytes)
+      if (lane < kHalfRows && lane < rows_ok) {      // level 3: 16 rows x 4 values (8 bytes)
         const uint2 v = *reinterpret_cast<const uint2*>(slab3 + lane * RS3);
         *reinterpret_cast<uint2*>(L3 + ((plane0 + lane) * H3 + (y2_0 >> 3)) * W3 + (x2_0 >> 3)) = v;
       }
     }
-    return;
-  }
-  // ragged shapes: element stores, consecutive lanes along x
-  {
+  } else {
+    // ragged shapes: element stores, consecutive lanes along x
     const unsigned char* slabs[4] = {slab0, slab1, slab2, slab3};
     const int RS[4] = {RS0, RS1, RS2, RS3};
     for (int l = 0; l < a.nlev; ++l) {
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       const int Hl = H >> l, Wl = W >> l;
       const int ph = kPatchH >> l, pw = kPatchW >> l;          // patch extent at this level
       const int y0 = y2_0 >> l, x0 = x2_0 >> l;
-      for (int id = lane; id < 32 * ph * pw; id += 64) {
+      for (int id = lane; id < kHalfRows * ph * pw; id += 64) {
         const int mrow = id / (ph * pw);
         const int rem = id - mrow * (ph * pw);
         const int yy = rem / pw, xx = rem - yy * pw;
@@ -299,6 +306,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
               *reinterpret_cast<const uint16_t*>(slabs[l] + mrow * RS[l] + (yy * pw + xx) * 2);
       }
     }
+  }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the slab is free again once this wave has read it
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -408,7 +420,7 @@ template <typename T>
 int build_mfma(const BuildArgs& a, hipStream_t st) {
   const int HW = a.H * a.W;
   const size_t lds_in = static_cast<size_t>(kPatchPix) * (a.C * 2 + 16);
-  const size_t lds_out = 4 * 32 * static_cast<size_t>((kPatchPix * 2 + 16) + (64 * 2 + 16) + (16 * 2 + 16) + 16);
+  const size_t lds_out = 4 * 16 * static_cast<size_t>((kPatchPix * 2 + 16) + (64 * 2 + 16) + (16 * 2 + 16) + 16);      // half-size slabs: two passes
   const size_t lds = lds_in > lds_out ? lds_in : lds_out;
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_mfma_kernel<T>),
