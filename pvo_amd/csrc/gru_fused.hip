@@ -5,6 +5,7 @@
 //   heads_out   the second stage of the four output heads, 4 x (ReLU + Conv3x3(128 -> 2)) (droid_net.py:184-210)
 // Layout: channels-last fp16/bf16 rows ([E, H*W, C]); 8 channels (16 B) per thread per access; arithmetic in fp32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -304,15 +305,81 @@ __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restri
   *reinterpret_cast<uint32_t*>(y + p * 8 + 2 * head) = lo | (hi << 16);
 }
 
+// The same through LDS: a workgroup owns 8 x 16 pixels and stages their 10 x 18 halo of z rows (288 B each) with whole 16-byte
+// reads - consecutive lanes along a row: every byte of z is fetched once (1.4x with the halo) - where the kernel above sends nine
+// 8-byte reads per thread that each touch a different 72-byte segment of a row.  Same sums in the same order: bit-identical.
+constexpr int kHgTH = 8, kHgTW = 16, kHgPos = (kHgTH + 2) * (kHgTW + 2), kHgRow = 288 + 16;      // (+16: rows of one pixel column land on different banks)
+
+template <typename T>
+__global__ __launch_bounds__(256) void heads_gather_tiled_kernel(const float* __restrict__ z, const float* __restrict__ bias2,
+                                                                 uint16_t* __restrict__ y, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hgs[];
+  const int e = blockIdx.z, y0 = blockIdx.y * kHgTH, x0 = blockIdx.x * kHgTW, tid = threadIdx.x;
+  const float* ze = z + static_cast<size_t>(e) * H * W * 72;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int kChunks = kHgPos * 18, kIter = (kChunks + 255) / 256;              // 16-byte chunks of the halo: 18 per position
+  u32x4 stg[kIter];
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int id = tid + 256 * it, pos = id / 18, c = id - pos * 18;
+    const int hy = y0 - 1 + pos / (kHgTW + 2), hx = x0 - 1 + pos % (kHgTW + 2);
+    stg[it] = u32x4{0u, 0u, 0u, 0u};
+    if (id < kChunks && hy >= 0 && hy < H && hx >= 0 && hx < W)
+      stg[it] = *reinterpret_cast<const u32x4*>(ze + (static_cast<size_t>(hy) * W + hx) * 72 + c * 4);
+  }
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int id = tid + 256 * it, pos = id / 18, c = id - pos * 18;
+    if (id < kChunks) *reinterpret_cast<u32x4*>(hgs + pos * kHgRow + c * 16) = stg[it];
+  }
+  __syncthreads();
+  const int head = tid & 3;
+  const float b0 = bias2[2 * head], b1 = bias2[2 * head + 1];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int pl = (tid >> 2) + 64 * pass, ly = pl >> 4, lx = pl & 15;             // pixel of the tile
+    const int py = y0 + ly, px = x0 + lx;
+    if (py >= H || px >= W) continue;
+    float a0 = b0, a1 = b1;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int qy = py + t / 3 - 1, qx = px + t % 3 - 1;
+      if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+        const float2 v = *reinterpret_cast<const float2*>(hgs + ((ly + t / 3) * (kHgTW + 2) + lx + t % 3) * kHgRow + (head * 18 + 2 * t) * 4);
+        a0 += v.x; a1 += v.y;
+      }
+    }
+    const uint32_t lo = H8<T>::to_bits(Elem<T>::from_f32(a0)), hi = H8<T>::to_bits(Elem<T>::from_f32(a1));
+    *reinterpret_cast<uint32_t*>(y + ((static_cast<size_t>(e) * H + py) * W + px) * 8 + 2 * head) = lo | (hi << 16);
+  }
+}
+
 }  // namespace
 
 extern "C" int pvo_heads_gather(const float* z, const float* bias2, void* y, int E, int H, int W, int dtype, void* stream) {
   if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
   if (E == 0 || H == 0 || W == 0) return PVO_OK;
   if (!z || !bias2 || !y || (reinterpret_cast<uintptr_t>(z) & 7) || (reinterpret_cast<uintptr_t>(y) & 3)) return PVO_EINVAL;
+  hipStream_t st = pvo_stream(stream);
+  static const bool flat = [] { const char* e = getenv("PVO_HEADS_GATHER_TILED"); return e && e[0] == '0'; }();
+  if (!flat && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && E <= 65535) {
+    const dim3 grid((W + kHgTW - 1) / kHgTW, (H + kHgTH - 1) / kHgTH, E);
+    constexpr size_t lds = static_cast<size_t>(kHgPos) * kHgRow;                      // 54720 B
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+        return PVO_ELAUNCH;
+      attr_set = true;
+    }
+    if (dtype == PVO_F16) hipLaunchKernelGGL(heads_gather_tiled_kernel<pvo_half>, grid, dim3(256), lds, st, z, bias2, static_cast<uint16_t*>(y), H, W);
+    else if (dtype == PVO_BF16) hipLaunchKernelGGL(heads_gather_tiled_kernel<pvo_bf16>, grid, dim3(256), lds, st, z, bias2, static_cast<uint16_t*>(y), H, W);
+    else return PVO_EUNSUPPORTED;
+    PVO_CHECK_LAUNCH();
+    return PVO_OK;
+  }
   const long long total = static_cast<long long>(E) * H * W * 4;
   const dim3 grid(static_cast<unsigned>((total + 255) / 256));
-  hipStream_t st = pvo_stream(stream);
   if (dtype == PVO_F16) hipLaunchKernelGGL(heads_gather_kernel<pvo_half>, grid, dim3(256), 0, st, z, bias2, static_cast<uint16_t*>(y), H, W, total);
   else if (dtype == PVO_BF16) hipLaunchKernelGGL(heads_gather_kernel<pvo_bf16>, grid, dim3(256), 0, st, z, bias2, static_cast<uint16_t*>(y), H, W, total);
   else return PVO_EUNSUPPORTED;
