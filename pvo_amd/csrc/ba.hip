@@ -90,6 +90,7 @@ struct Ws {
   float *Ei;             // [P][6][HW]
   float *Q, *w;          // [F'][HW]   (F' = min(F, P+E) rows)
   float *dx;             // [P][6]
+  float *part;           // [E][assembly chunks][90]: per-chunk sums of an edge's pose blocks and gradients (depth BA)
   long long* sys;        // [(6P)^2 + 6P] fixed point
   double* chol;          // [(6P)^2 + 6P] scratch for the global-memory factorisation
   size_t bytes;
@@ -118,6 +119,7 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.Q = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(Kmax) * HW));
   w.w = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(Kmax) * HW));
   w.dx = reinterpret_cast<float*>(take(sizeof(float) * (n6 + 8)));
+  w.part = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * ((HW + kChunkA - 1) / kChunkA) * 90 + 16));
   w.sys = reinterpret_cast<long long*>(take(sizeof(double) * (n6 * n6 + n6 + 8)));
   w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + n6 + 27 * (n6 / 6) + 32 : 8)));
   w.bytes = off;
@@ -259,12 +261,49 @@ __device__ __forceinline__ void pixel_terms(const EdgeGeom& g, float u, float v,
   bzz += wv * rv * Jz;
 }
 
+// Entry t of an edge's 90 sums - upper triangle of [Ji Jj]^T W [Ji Jj] (78, droid_kernels.cu:309-315 ordering), vi (6), vj (6) -
+// added to the pose system in fixed point.
+__device__ __forceinline__ void pose_block_scatter(int t, double val, int pi, int pj, int P, long long* __restrict__ sys, int* __restrict__ meta) {
+  const bool iok = pi >= 0 && pi < P, jok = pj >= 0 && pj < P;
+  const int n6 = 6 * P;
+  if (t < 78) {
+    // invert l -> (n, m), m <= n
+    int n = 0, base = 0;
+    while (base + n + 1 <= t) { base += n + 1; ++n; }
+    const int m = t - base;
+    if (n < 6) {                                  // (ii,ii), symmetric
+      if (iok) {
+        fix_add(sys, static_cast<long long>(6 * pi + n) * n6 + 6 * pi + m, val, meta);
+        if (n != m) fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pi + n, val, meta);
+      }
+    } else if (m < 6) {                           // (ii,jj)[m][n-6] and (jj,ii)[n-6][m]
+      if (iok && jok) {
+        fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pj + (n - 6), val, meta);
+        fix_add(sys, static_cast<long long>(6 * pj + (n - 6)) * n6 + 6 * pi + m, val, meta);
+      }
+    } else {                                      // (jj,jj), symmetric
+      if (jok) {
+        fix_add(sys, static_cast<long long>(6 * pj + n - 6) * n6 + 6 * pj + m - 6, val, meta);
+        if (n != m) fix_add(sys, static_cast<long long>(6 * pj + m - 6) * n6 + 6 * pj + n - 6, val, meta);
+      }
+    }
+  } else if (t < 84) {
+    if (iok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pi + (t - 78), val, meta);
+  } else {
+    if (jok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pj + (t - 84), val, meta);
+  }
+}
+
 __global__ __launch_bounds__(256) void ba_assemble_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intr,
     const float* __restrict__ targets, const float* __restrict__ weights,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
     float* __restrict__ Eii, float* __restrict__ Eij, float* __restrict__ Cii, float* __restrict__ bz,
-    long long* __restrict__ sys, int* __restrict__ meta, int HW, int wd, int t0, int P, int motion_only) {
+    long long* __restrict__ sys, int* __restrict__ meta, int HW, int wd, int t0, int P, int motion_only, float* __restrict__ part) {
+  // Every (edge, pixel chunk) workgroup ends with 90 sums.  Added to `sys` right here they are 216 x 90 memory-side atomics on
+  // ~1800 addresses at S-B - each address serialises the ~30 workgroups that hit it, 5 of this kernel's 14 us (ablation build).
+  // In a depth BA (`part`) the chunk sums are stored instead and the Schur kernel, which follows anyway, adds them up per edge:
+  // a sixth of the atomics, issued while its own work starts.
   __shared__ float red[4][90];
   BA_ACQ();
   const int e = blockIdx.y;
@@ -315,36 +354,9 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   __syncthreads();
   const int t = threadIdx.x;
   if (t < 90) {
-    const double val = static_cast<double>((red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
-    const int pi = ix - t0, pj = jx - t0;
-    const bool iok = pi >= 0 && pi < P, jok = pj >= 0 && pj < P;
-    const int n6 = 6 * P;
-    if (t < 78) {
-      // invert l -> (n, m), m <= n   (droid_kernels.cu:309-315 ordering)
-      int n = 0, base = 0;
-      while (base + n + 1 <= t) { base += n + 1; ++n; }
-      const int m = t - base;
-      if (n < 6) {                                  // (ii,ii), symmetric
-        if (iok) {
-          fix_add(sys, static_cast<long long>(6 * pi + n) * n6 + 6 * pi + m, val, meta);
-          if (n != m) fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pi + n, val, meta);
-        }
-      } else if (m < 6) {                           // (ii,jj)[m][n-6] and (jj,ii)[n-6][m]
-        if (iok && jok) {
-          fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pj + (n - 6), val, meta);
-          fix_add(sys, static_cast<long long>(6 * pj + (n - 6)) * n6 + 6 * pi + m, val, meta);
-        }
-      } else {                                      // (jj,jj), symmetric
-        if (jok) {
-          fix_add(sys, static_cast<long long>(6 * pj + n - 6) * n6 + 6 * pj + m - 6, val, meta);
-          if (n != m) fix_add(sys, static_cast<long long>(6 * pj + m - 6) * n6 + 6 * pj + n - 6, val, meta);
-        }
-      }
-    } else if (t < 84) {
-      if (iok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pi + (t - 78), val, meta);
-    } else {
-      if (jok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pj + (t - 84), val, meta);
-    }
+    const float sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (part) part[(static_cast<long long>(e) * gridDim.x + blockIdx.x) * 90 + t] = sum;      // summed per edge by the Schur kernel
+    else pose_block_scatter(t, static_cast<double>(sum), ix - t0, jx - t0, P, sys, meta);
   }
   BA_REL();
 }
@@ -515,11 +527,20 @@ __device__ __forceinline__ void ba_schur_body(
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
-    int HW, int t0, int P) {
+    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA) {
   __shared__ gfloat* rowptr[kMaxRows];
   __shared__ int rowout[kMaxRows];        // 6*pose + comp for an M row, -2 for the w row, -1 padding
   __shared__ int nrows_s;
   __shared__ float red[4 * (kFastTiles * (kFastTiles + 1) / 2) * 256];   // 40 KB
+  // the assembly's chunk sums, per edge: edges are dealt over ALL workgroups of the launch (also those without a depth frame)
+  if (part && threadIdx.x < 90) {
+    const int nwg = gridDim.x * gridDim.y;
+    for (int e = blockIdx.y * gridDim.x + blockIdx.x; e < E; e += nwg) {
+      double val = 0.0;
+      for (int c = 0; c < chunksA; ++c) val += static_cast<double>(part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]);
+      pose_block_scatter(threadIdx.x, val, static_cast<int>(ii[e]) - t0, static_cast<int>(jj[e]) - t0, P, sys, pl.meta);
+    }
+  }
   const int k = blockIdx.y;
   if (k >= pl.meta[0]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -596,9 +617,9 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
-    int HW, int t0, int P) {
+    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA) {
   BA_ACQ();
-  ba_schur_body<VEC4>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P);
+  ba_schur_body<VEC4>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA);
   BA_REL();
 }
 
@@ -1711,18 +1732,23 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
   motion_only &= 1;
   if (!clean && !only_schur && hipMemsetAsync(sys, 0, sizeof(long long) * (n6 * n6 + n6), st) != hipSuccess) return PVO_ELAUNCH;
   if (E == 0) return PVO_OK;
+  static const bool direct = [] { const char* e = getenv("PVO_BA_POSE_ATOMICS"); return e && e[0] == 'd'; }();      // (A/B: "direct")
+  const bool two_stage = !motion_only && !direct;      // the chunk sums go through the Schur kernel (there is none in a motion-only BA)
+  const int chunksA = (HW + kChunkA - 1) / kChunkA;
   if (!only_schur)
   hipLaunchKernelGGL(ba_assemble_kernel, dim3((HW + kChunkA - 1) / kChunkA, E), dim3(256), 0, st,
                      poses, disps, intrinsics, targets, weights, ii, jj, w.Eii, w.Eij, w.Cii, w.bz,
-                     sys, w.plan.meta, HW, wd, t0, P, motion_only);
+                     sys, w.plan.meta, HW, wd, t0, P, motion_only, two_stage ? w.part : nullptr);
   PVO_CHECK_LAUNCH();
   if (!motion_only && !only_assemble) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);
     const dim3 sgrid((HW + kSchurPix - 1) / kSchurPix, Kmax);
     if ((HW & 3) == 0)
-      hipLaunchKernelGGL(ba_schur_mfma_kernel<true>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P);
+      hipLaunchKernelGGL(ba_schur_mfma_kernel<true>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P,
+                         two_stage ? w.part : nullptr, ii, E, chunksA);
     else
-      hipLaunchKernelGGL(ba_schur_mfma_kernel<false>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P);
+      hipLaunchKernelGGL(ba_schur_mfma_kernel<false>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P,
+                         two_stage ? w.part : nullptr, ii, E, chunksA);
     PVO_CHECK_LAUNCH();
   }
   return PVO_OK;
