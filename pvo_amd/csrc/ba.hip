@@ -1458,6 +1458,8 @@ __device__ __forceinline__ void ride(unsigned char* smem, const Riders r, int b)
   if (b < r.xblocks) glt::gate_context_256(reinterpret_cast<float*>(smem), r.xpart, r.xwt, r.xbias, r.xg, r.xchunks, b);
 }
 
+// (experiment hook, tools/variant.py: -DPVO_SOLVE_ATTR='__attribute__((amdgpu_waves_per_eu(3,4)))' caps the registers of the fused
+// solve + riders kernel for three workgroups per CU - measured within noise of the default)
 #ifndef PVO_SOLVE_ATTR
 #define PVO_SOLVE_ATTR
 #endif

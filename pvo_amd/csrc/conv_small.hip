@@ -53,7 +53,7 @@ template <typename T> __device__ __forceinline__ cs_u32x4 cs_pack8(const float f
 }
 
 constexpr int kTH = 8, kTW = 16, kR = 3;
-#ifndef PVO_CONV7_ROWS
+#ifndef PVO_CONV7_ROWS                                      // (experiment hook, tools/variant.py: 8 / 4 rows measured, no change in the update)
 #define PVO_CONV7_ROWS 16
 #endif
 constexpr int kTH7 = PVO_CONV7_ROWS;                          // the 7x7 kernel's tile is 16 rows high: weight fragments are
