@@ -21,7 +21,8 @@
  *   - threading / streams: as the reference (called from the single Python main thread with the GIL held,
  *     droid.cpp has no gil_scoped_release), the library is re-entrant PER DEVICE, not per thread: the
  *     composite calls (pvo_update_operator, pvo_graph_update) fork onto ONE library-owned side stream per device
- *     (pvo_side_stream) with one set of fork / join events, created lazily without a lock.  One host thread per device
+ *     (pvo_side_stream) with one set of fork / join events, created lazily without a lock, and keep one record per device of
+ *     the gate context computed ahead (pvo_graph_update_args.context_ahead).  One host thread per device
  *     issues them, on one launch stream at a time; two graphs may share a device as long as their calls are not
  *     issued concurrently from different threads or interleaved on different launch streams without the caller
  *     ordering those streams.  The plain kernels (lookup, build, ba, geometry) have no shared state and may be
