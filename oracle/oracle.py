@@ -174,6 +174,20 @@ def ba(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iteratio
     return out
 
 
+def ba_assemble(poses, disps, intrinsics, targets, weights, ii, jj):
+    """projective_transform_kernel alone (droid_kernels.cu:177-403): dict(Hs, vs [fp64 sums], Eii, Eij, Cii, bz [fp32])"""
+    poses, disps, intrinsics = _f32c(poses), _f32c(disps), _f32c(intrinsics)
+    targets, weights, ii, jj = _f32c(targets), _f32c(weights), _i64c(ii), _i64c(jj)
+    (_, ht, wd), E = disps.shape, ii.shape[0]
+    HW = ht * wd
+    Hs, vs = np.zeros((4, E, 6, 6), np.float64), np.zeros((2, E, 6), np.float64)
+    Eii, Eij = np.zeros((E, 6, HW), np.float32), np.zeros((E, 6, HW), np.float32)
+    Cii, bz = np.zeros((E, HW), np.float32), np.zeros((E, HW), np.float32)
+    lib().oracle_ba_assemble(_p(poses), _p(disps), _p(intrinsics), _p(targets), _p(weights), _p(ii), _p(jj), E, ht, wd,
+                             _p(Hs), _p(vs), _p(Eii), _p(Eij), _p(Cii), _p(bz))
+    return dict(Hs=Hs, vs=vs, Eii=Eii, Eij=Eij, Cii=Cii, bz=bz)
+
+
 def ba_apply(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, dx, motion_only=False):
     """one BA iteration on these edges with the pose update `dx` imposed (sharded-BA test harness)"""
     poses, disps = _f32c(poses).copy(), _f32c(disps).copy()

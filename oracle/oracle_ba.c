@@ -335,10 +335,14 @@ static void assemble_edge(const float* target, const float* weight, const float*
     actSE3(tij, qij, Xi, Xj);
     {
       const float x = Xj[0], y = Xj[1], hh = Xj[3];
-      const float d = (Xj[2] < MIN_DEPTH) ? 0.0f : 1.0f / Xj[2];
+      /* :287,290-291 are written with double literals (`1.0 / Xj[2]`, `.001 * weight`): the quotient and the products
+       * are formed in double and rounded to float once.  For the quotient that equals the float division (double
+       * rounding of a correctly rounded quotient is innocuous at 53 >= 2*24+2 bits); for the weights it does NOT
+       * (.001 and .001f are different numbers), so the text is followed literally. */
+      const float d = (Xj[2] < MIN_DEPTH) ? 0.0f : (float)(1.0 / (double)Xj[2]);
       const float d2 = d * d;
-      const float wu = (Xj[2] < MIN_DEPTH) ? 0.0f : .001f * weight[0 * HW + k];
-      const float wv = (Xj[2] < MIN_DEPTH) ? 0.0f : .001f * weight[1 * HW + k];
+      const float wu = (Xj[2] < MIN_DEPTH) ? 0.0f : (float)(.001 * (double)weight[0 * HW + k]);
+      const float wv = (Xj[2] < MIN_DEPTH) ? 0.0f : (float)(.001 * (double)weight[1 * HW + k]);
       const float ru = target[0 * HW + k] - (fx * d * x + cx);
       const float rv = target[1 * HW + k] - (fy * d * y + cy);
 
@@ -376,6 +380,30 @@ static void assemble_edge(const float* target, const float* weight, const float*
       Cii[k] += wv * Jz * Jz;
       bz[k] += wv * rv * Jz;
     }
+  }
+}
+
+/* The first launch of ba_cuda on its own (droid_kernels.cu:1346-1349): Hs [4,E,6,6] (ii, ij, ji, jj blocks as :386-398
+ * scatter them), vs [2,E,6], Eii/Eij [E,6,HW], Cii/bz [E,HW].  Per-pixel outputs are fp32 exactly as the kernel forms
+ * them; the 90 sums are fp64 here (the kernel: fp32 thread partials + a 256-leaf tree).  Pinned by
+ * tests/golden/ba_assemble_kernel.npz (the kernel's own text run on the host). */
+void oracle_ba_assemble(const float* poses, const float* disps, const float* intr, const float* targets,
+                        const float* weights, const int64_t* ii, const int64_t* jj, int E, int ht, int wd,
+                        double* Hs, double* vs, float* Eii, float* Eij, float* Cii, float* bz) {
+  const int HW = ht * wd;
+  for (int e = 0; e < E; e++) {
+    double h[78], vi[6], vj[6];
+    int l = 0;
+    assemble_edge(targets + (long long)e * 2 * HW, weights + (long long)e * 2 * HW, poses, disps, intr,
+                  (int)ii[e], (int)jj[e], ht, wd, h, vi, vj, Eii + (long long)e * 6 * HW, Eij + (long long)e * 6 * HW,
+                  Cii + (long long)e * HW, bz + (long long)e * HW);
+    for (int n = 0; n < 6; n++) { vs[(0 * E + e) * 6 + n] = vi[n]; vs[(1 * E + e) * 6 + n] = vj[n]; }
+    for (int n = 0; n < 12; n++)
+      for (int m = 0; m <= n; m++, l++) {
+        if (n < 6 && m < 6) { Hs[((0LL * E + e) * 6 + n) * 6 + m] = h[l]; Hs[((0LL * E + e) * 6 + m) * 6 + n] = h[l]; }
+        else if (n >= 6 && m < 6) { Hs[((1LL * E + e) * 6 + m) * 6 + (n - 6)] = h[l]; Hs[((2LL * E + e) * 6 + (n - 6)) * 6 + m] = h[l]; }
+        else { Hs[((3LL * E + e) * 6 + (n - 6)) * 6 + (m - 6)] = h[l]; Hs[((3LL * E + e) * 6 + (m - 6)) * 6 + (n - 6)] = h[l]; }
+      }
   }
 }
 

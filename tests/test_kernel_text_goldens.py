@@ -1,0 +1,197 @@
+"""Fixtures produced by the reference's KERNEL TEXT (tests/golden/gen_kernel_golden.py: line ranges of
+correlation_kernels.cu / droid_kernels.cu compiled on the host behind a shim, in the build container; data only is
+committed).  CPU: the oracle against them.  GPU: the HIP kernels, through the C ABI, against them.
+
+Integer / index / per-pixel work and the 16-bit lookup: bit for bit.  fp32 sums whose ORDER the reference fixes by its
+block reduction (256 strided partials + a tree) and the build fixes differently: relative 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+@pytest.fixture(scope="module")
+def corr():
+    return np.load(os.path.join(G, "corr_lookup_kernel.npz"))
+
+
+@pytest.fixture(scope="module")
+def geom():
+    return np.load(os.path.join(G, "geom_kernels.npz"))
+
+
+@pytest.fixture(scope="module")
+def bak():
+    return np.load(os.path.join(G, "ba_assemble_kernel.npz"))
+
+
+CASES = "abcd"
+
+
+# ---------------------------------------------------------------------------------------------------- lookup, CPU
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_lookup_forward_is_the_kernel_text_bit_for_bit(corr, case):
+    vol, co, r = corr[case + "_volume"], corr[case + "_coords"], int(corr[case + "_radius"])
+    for tag, contract in (("fma", True), ("nofma", False)):
+        got = O.corr_index_forward(vol, co, r, contract=contract)
+        assert np.array_equal(_bits(got), _bits(corr[case + "_fwd_f32_" + tag])), tag
+    got = O.corr_index_forward(vol.astype(np.float16), co, r)
+    assert got.dtype == np.float16 and np.array_equal(_bits(got), _bits(corr[case + "_fwd_f16"]))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_lookup_backward_is_the_kernel_text_bit_for_bit(corr, case):
+    vol, co, r, grad = corr[case + "_volume"], corr[case + "_coords"], int(corr[case + "_radius"]), corr[case + "_grad"]
+    for tag, contract in (("fma", True), ("nofma", False)):
+        got = O.corr_index_backward(vol.shape, co, grad, r, contract=contract)
+        assert np.array_equal(_bits(got), _bits(corr[case + "_bwd_f32_" + tag])), tag
+    got = O.corr_index_backward(vol.shape, co, grad.astype(np.float16), r)
+    assert np.array_equal(_bits(got), _bits(corr[case + "_bwd_f16"]))
+
+
+def test_lookup_fixture_exercises_what_it_claims(corr):
+    # borders: some windows entirely outside (all-zero outputs), some partly; FMA contraction visible in fp32
+    assert (corr["c_fwd_f32_fma"] == 0).mean() > 0.5 and (corr["a_fwd_f32_fma"] != 0).mean() > 0.5
+    assert (corr["a_fwd_f32_fma"] != corr["a_fwd_f32_nofma"]).any()
+    assert int(corr["c_radius"]) == 2 and int(corr["a_radius"]) == 3
+
+
+# ---------------------------------------------------------------------------------------------------- geometry, CPU
+@pytest.mark.parametrize("case", "ab")
+def test_oracle_geometry_kernels_against_the_kernel_text(geom, case):
+    poses, disps, intr, ii, jj = (geom[case + "_" + k] for k in ("poses", "disps", "intr", "ii", "jj"))
+    co, va = O.projmap(poses, disps, intr, ii, jj)
+    assert np.array_equal(_bits(co), _bits(geom[case + "_projmap_coords"]))
+    assert np.array_equal(va, geom[case + "_projmap_valid"])
+    assert np.array_equal(_bits(O.iproj(poses, disps, intr)), _bits(geom[case + "_iproj"]))
+    for t in (0.005, 0.05):
+        th = np.full(len(poses), t, np.float32)
+        got = O.depth_filter(poses, disps, intr, np.arange(len(poses)), th)
+        ref = geom[case + "_depth_filter_t%g" % t]
+        assert np.array_equal(got, ref) and ref.max() >= 1      # integer counts: exact
+    for beta in (0.3, 1.0, 0.0):
+        got, ref = O.frame_distance(poses, disps, intr, ii, jj, beta), geom[case + "_frame_distance_beta%g" % beta]
+        assert np.array_equal(got >= 1000, ref >= 1000)          # the valid / total < 0.75 rule (droid_kernels.cu:634)
+        np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-6)   # the oracle sums in fp64, the kernel in an fp32 tree
+    if case == "b":
+        assert (geom["b_frame_distance_beta0.3"] >= 1000).sum() >= 2
+
+
+# ---------------------------------------------------------------------------------------------------- BA, CPU
+@pytest.mark.parametrize("case", "ab")
+def test_oracle_ba_assembly_per_pixel_rows_are_the_kernel_text(bak, case):
+    a = {k: bak[case + "_" + k] for k in ("poses", "disps", "intr", "targets", "weights", "ii", "jj")}
+    r = O.ba_assemble(a["poses"], a["disps"], a["intr"], a["targets"], a["weights"], a["ii"], a["jj"])
+    for k in ("Eii", "Eij", "Cii", "bz"):
+        assert np.array_equal(_bits(r[k]), _bits(bak[case + "_" + k])), k     # fp32 per pixel: bit for bit
+    for k in ("Hs", "vs"):
+        ref = bak[case + "_" + k]
+        assert np.abs(r[k] - ref).max() <= 1e-6 * np.abs(ref).max(), k         # 90 sums: fp64 here, fp32 tree there
+    if case == "b":
+        assert (bak["b_Cii"] == 0).any()                                     # pixels behind MIN_DEPTH took part
+
+
+@pytest.mark.parametrize("case", "ab")
+def test_oracle_ba_step_against_the_kernel_text_chain(bak, case):
+    """one Gauss-Newton step: reduced system, dx, dz (every kernel of ba_cuda is the reference's text; the host code
+    between them restated in the generator; solve = dense fp64 Cholesky)"""
+    a = {k: bak[case + "_" + k] for k in ("poses", "disps", "intr", "targets", "weights", "ii", "jj", "eta")}
+    P = len(a["poses"])
+    r = O.ba(a["poses"], a["disps"], a["intr"], a["targets"], a["weights"], a["eta"], a["ii"], a["jj"], 1, P, 1, 1e-4, 0.1,
+             want_sys=True)
+    n6 = 6 * (P - 1)
+    A, b = r["sys"][:n6 * n6].reshape(n6, n6), r["sys"][n6 * n6:]
+    assert np.abs(A - bak[case + "_step_sysA"]).max() <= 2e-6 * np.abs(A).max()
+    assert np.abs(b - bak[case + "_step_sysb"]).max() <= 2e-6 * np.abs(b).max()
+    dx, dz = bak[case + "_step_dx"], bak[case + "_step_dz"]
+    # case b is ill-conditioned on purpose (a blob at disparity 14: cond(A - S) = 5e4), the fp32 sums' 5e-7 shows in dx
+    tol_dx, tol_dz = (1e-6, 1e-6) if case == "a" else (1e-3, 2e-3)
+    assert np.abs(r["dx"] - dx).max() <= tol_dx * np.abs(dx).max()
+    assert np.abs(r["dz"] - dz).max() <= tol_dz * np.abs(dz).max()
+    assert r["K"] == len(bak[case + "_step_kx"]) and not r["failed"]
+
+
+# ==================================================================================================== GPU (C ABI)
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_hip_lookup_forward_and_backward_are_the_kernel_text_bit_for_bit(cuda, corr, case):
+    from pvo_amd import droid_backends as db
+    vol, co, r = corr[case + "_volume"], corr[case + "_coords"], int(corr[case + "_radius"])
+    grad = corr[case + "_grad"]
+    v, c, g = (torch.from_numpy(x).to(cuda) for x in (vol, co, grad))
+    out = db.corr_index_forward(v, c, r)[0]
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(corr[case + "_fwd_f32_fma"]))       # nvcc contracts: fma
+    out = db.corr_index_forward(v.half(), c, r)[0]
+    assert out.dtype == torch.float16 and np.array_equal(_bits(out.cpu().numpy()), _bits(corr[case + "_fwd_f16"]))
+    out = db.corr_index_backward(v, c, g, r)[0]
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(corr[case + "_bwd_f32_fma"]))
+    out = db.corr_index_backward(v.half(), c, g.half(), r)[0]
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(corr[case + "_bwd_f16"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", "ab")
+def test_hip_fused_pyramid_lookup_equals_the_kernel_text_per_level(cuda, corr, case):
+    """the one-launch pyramid lookup (what the product runs) on a pyramid whose level 0 is the fixture volume: its
+    first 49 channels are the reference kernel's output for that level"""
+    from pvo_amd import droid_backends as db
+    if int(corr[case + "_radius"]) != 3:
+        pytest.skip("fused form is radius 3")
+    vol, co = corr[case + "_volume"], corr[case + "_coords"]
+    N, h1, w1, h2, w2 = vol.shape
+    g = np.random.default_rng(5)
+    pyr = [vol.astype(np.float16)] + [g.standard_normal((N, h1, w1, h2 >> l, w2 >> l)).astype(np.float16)
+                                      for l in (1, 2, 3)]
+    c_nhw2 = np.ascontiguousarray(np.transpose(co, (0, 2, 3, 1)))
+    got = db.corr_pyramid_lookup([torch.from_numpy(p).to(cuda) for p in pyr], torch.from_numpy(c_nhw2).to(cuda), 3)
+    got = got.cpu().numpy().reshape(N, 4, 7, 7, h1, w1)[:, 0]
+    assert np.array_equal(_bits(got), _bits(corr[case + "_fwd_f16"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", "ab")
+def test_hip_geometry_kernels_against_the_kernel_text(cuda, geom, case):
+    from pvo_amd import droid_backends as db
+    poses, disps, intr, ii, jj = (torch.from_numpy(geom[case + "_" + k]).to(cuda) for k in ("poses", "disps", "intr", "ii", "jj"))
+    co, va = db.projmap(poses, disps, intr, ii, jj)
+    np.testing.assert_allclose(co.cpu().numpy(), geom[case + "_projmap_coords"], rtol=2e-6, atol=2e-5)   # hipcc contracts FMAs
+    assert np.array_equal(va.cpu().numpy(), geom[case + "_projmap_valid"])
+    np.testing.assert_allclose(db.iproj(poses, disps, intr).cpu().numpy(), geom[case + "_iproj"], rtol=2e-6, atol=1e-5)
+    P = poses.shape[0]
+    for t in (0.005, 0.05):
+        th = torch.full((P,), t, device=cuda)
+        got = db.depth_filter(poses, disps, intr, torch.arange(P, device=cuda), th).cpu().numpy()
+        ref = geom[case + "_depth_filter_t%g" % t]
+        # a count can differ only where |1/dj - 1/d| sits within rounding of the threshold: allow 0.5 % of the pixels
+        assert (got != ref).mean() <= 0.005 and np.abs(got - ref).max() <= 1
+    for beta in (0.3, 1.0, 0.0):
+        got = db.frame_distance(poses, disps, intr, ii, jj, beta).cpu().numpy()
+        ref = geom[case + "_frame_distance_beta%g" % beta]
+        assert np.array_equal(got >= 1000, ref >= 1000)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", "ab")
+def test_hip_ba_step_against_the_kernel_text_chain(cuda, bak, case):
+    from pvo_amd import droid_backends as db
+    a = {k: torch.from_numpy(bak[case + "_" + k]).to(cuda) for k in ("poses", "disps", "intr", "targets", "weights", "ii", "jj", "eta")}
+    P = a["poses"].shape[0]
+    status = torch.zeros(4, dtype=torch.int32, device=cuda)
+    dx, dz = db.ba(a["poses"], a["disps"], a["intr"], a["targets"], a["weights"], a["eta"], a["ii"], a["jj"], 1, P, 1, 1e-4, 0.1,
+                   False, status=status)
+    rdx, rdz = bak[case + "_step_dx"], bak[case + "_step_dz"]
+    tol_dx, tol_dz = (1e-4, 1e-4) if case == "a" else (2e-3, 4e-3)     # b: cond 5e4, see the CPU test
+    assert np.abs(dx.cpu().numpy() - rdx).max() <= tol_dx * max(np.abs(rdx).max(), 1e-3)
+    assert np.abs(dz.cpu().numpy() - rdz).max() <= tol_dz * max(np.abs(rdz).max(), 1e-3)
+    assert status.cpu().numpy()[0] == 0
