@@ -45,15 +45,31 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 
 
+def s3_segments(H8, W8, frame):
+    """S-3: 8 rectangular panoptic instances (ids 1..8; 0 = no segment) on a 2 x 4 grid with a
+    background margin; instances 3 and 6 move one pixel per frame"""
+    seg = torch.zeros(H8, W8, dtype=torch.int32)
+    bh, bw = H8 // 2, W8 // 4
+    for n in range(8):
+        r, c = divmod(n, 4)
+        shift = frame if n + 1 in (3, 6) else 0
+        y0, x0 = r * bh + 2, c * bw + 2 + shift
+        seg[y0:y0 + bh - 4, max(x0, 0):min(x0 + bw - 4, W8)] = n + 1
+    return seg
+
+
 def make_window(device, seed=0, H8=H8, W8=W8, NKF=NKF, buffer=16, corr_impl="volume", intr=(40.0, 40.0, 32.0, 24.0),
-                add_edges=True, max_factors=48):
-    """synthetic keyframe window: S-B by default (8 keyframes, 48x64 maps, edges |i-j| <= 3)"""
+                add_edges=True, max_factors=48, segments=False, thresh=0.8):
+    """synthetic keyframe window (SURVEY.md 8d): S-B by default (8 keyframes, 48x64 maps, edges |i-j| <= 3);
+    segments=True: S-3 = S-B + panoptic segments with the vote of factor_graph.py:256-276 switched on"""
     from pvo_amd.depth_video import DepthVideo
     from pvo_amd.factor_graph import FactorGraph
     from pvo_amd.geom.se3 import SE3
     from pvo_amd.modules.update import DynamicUpdateModule
     g = torch.Generator().manual_seed(seed)
-    video = DepthVideo(image_size=(H8 * 8, W8 * 8), buffer=buffer, device=device)
+    video = DepthVideo(image_size=(H8 * 8, W8 * 8), buffer=buffer, device=device, segm_filter=bool(segments), thresh=thresh)
+    if segments:
+        video.max_segments = 16
     xi = torch.tensor([0.05, 0.0, 0.02, 0.0, 0.01, 0.0])
     low = torch.rand(1, 1, 6, 8, generator=g) * 0.8 + 0.2
     disp_gt = torch.nn.functional.interpolate(low, size=(H8, W8), mode="bilinear", align_corners=True)[0, 0]
@@ -62,7 +78,8 @@ def make_window(device, seed=0, H8=H8, W8=W8, NKF=NKF, buffer=16, corr_impl="vol
         video.append(float(k), SE3.exp(max(k - 1, 0) * xi).data.to(device), torch.ones(H8, W8, device=device),
                      intr.to(device), torch.randn(H8, W8, 128, generator=g).half().to(device),
                      torch.tanh(torch.randn(128, H8, W8, generator=g)).half().to(device),
-                     torch.relu(torch.randn(128, H8, W8, generator=g)).half().to(device))
+                     torch.relu(torch.randn(128, H8, W8, generator=g)).half().to(device),
+                     **(dict(segm=s3_segments(H8, W8, k).to(device)[None]) if segments else {}))
     video.disps[:NKF] = 1.0
     torch.manual_seed(seed)
     update = DynamicUpdateModule().to(device).eval().half()   # fp16 inference weights (the reference runs this module under fp16 autocast)

@@ -24,7 +24,7 @@ class OracleVideo:
         self.intrinsics = torch.zeros(buffer, 4)
         self.tstamp = torch.zeros(buffer); self.dirty = torch.zeros(buffer, dtype=torch.bool)
         self.segms = torch.zeros(buffer, 1, ht8, wd8, dtype=torch.int)
-        self.segm_filter, self.thresh = False, 0.8
+        self.segm_filter, self.thresh, self.max_segments = False, 0.8, 1024
         self.nets = self.inps = self.fmaps = None
 
     def reproject(self, ii, jj):
@@ -66,6 +66,9 @@ def cpu_twin(video, graph, n_frames):
     ov.counter = n_frames
     ov.poses.copy_(video.poses.cpu()); ov.disps.copy_(video.disps.cpu()); ov.intrinsics.copy_(video.intrinsics.cpu())
     ov.fmaps, ov.nets, ov.inps = video.fmaps.float().cpu(), video.nets.float().cpu(), video.inps.float().cpu()
+    # panoptic vote (factor_graph.py:256-276): the twin votes with the same dense labels, threshold and histogram width
+    ov.segms.copy_(video.segms.cpu())
+    ov.segm_filter, ov.thresh, ov.max_segments = bool(video.segm_filter), float(video.thresh), int(video.max_segments)
     op = copy.deepcopy(graph.update_op).float().cpu().eval()
     old = FG.CorrBlock
     FG.CorrBlock = OracleCorr

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpvo_hip.so")
 
 PVO_F32, PVO_F16, PVO_BF16, PVO_F64 = 0, 1, 2, 3
+PVO_ABI_VERSION = 101          # include/pvo_hip.h
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
@@ -18,6 +19,7 @@ _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 SIGNATURES = {
     "pvo_strerror": (_c.c_char_p, [_i]),
     "pvo_version": (_i, []),
+    "pvo_graph_update_args_size": (_sz, []),
     "pvo_last_hip_error": (_c.c_char_p, []),
     "pvo_corr_index_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_index_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -137,6 +139,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.pvo_version() != PVO_ABI_VERSION or lib.pvo_graph_update_args_size() != ctypes.sizeof(GraphUpdateArgs):
+        raise PvoHipError("libpvo_hip.so is ABI version %d with a %d-byte pvo_graph_update_args; this binding is written for version %d / %d bytes - "
+                          "rebuild with `python -m pvo_amd.build`" % (lib.pvo_version(), lib.pvo_graph_update_args_size(), PVO_ABI_VERSION,
+                                                                     ctypes.sizeof(GraphUpdateArgs)))
     _lib = lib
     return lib
 

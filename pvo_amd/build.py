@@ -29,8 +29,16 @@ HIP_SOURCES = [
     "se3_ops.hip",
     "ba.hip",
 ]
+# -target-feature -packed-fp32-ops: NO v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 in the device code.  On MI355X
+# (ROCm 7.0.2) a wave that executes packed-FP32 VALU instructions gets wrong results in single registers of single lanes while
+# a kernel of ANOTHER stream that issues MFMA instructions is resident on the same compute unit - the cause of the bundle
+# adjustment's run-to-run differences beside the side stream's convolutions (rounds 2-3).  Found in round 4
+# (profiles/r04_coresidency.md, tools/sched_bisect.py): arrangements that differed in 200 of 200 runs are bit-identical in 2100 of
+# 2100 with this flag; the step time does not change (bench: 229.8 vs 227.5 keyframe updates/s).  The host half of the
+# compilation prints "not a recognized feature for this target" for it: expected, the flag is for the gfx950 half.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-               "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+               "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + NO_PACKED_FP32
 
 
 def _newer(target, deps):

@@ -74,6 +74,26 @@ constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system live
 #define BA_REL()
 #endif
 
+// Hand-off experiment (tools/sched_bisect.py --variant coh1|coh2): the rows one BA kernel stores and a later
+// one loads (level 1: Eii / Eij / Cii / bz / part; level 2: also Ei / Q / w / dx and the pose system's read + re-zero; level 3: also the assembly's per-pixel INPUTS) go
+// through agent-scope relaxed atomic stores / loads - `sc1` accesses that write through to, and read from, the device's
+// coherence point instead of relying on the L2 write-back / invalidate at the kernel boundary.
+#ifndef PVO_BA_COHERENT
+#define PVO_BA_COHERENT 0
+#endif
+#ifdef PVO_BA_COHERENT_ONLY_INPUTS
+#define PVO_BA_COH_ON(level) ((level) == 3)
+#else
+#define PVO_BA_COH_ON(level) (PVO_BA_COHERENT >= (level))
+#endif
+template <int LEVEL, typename T> __device__ __forceinline__ void st_h(T* p, T v) {
+  if (PVO_BA_COH_ON(LEVEL)) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <int LEVEL, typename T> __device__ __forceinline__ T ld_h(const T* p) {
+  if (PVO_BA_COH_ON(LEVEL)) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
 struct Plan {            // int region of the workspace
   int* kidx;             // [F]   frame -> depth index, -1 if none
   int* kx;               // [F]   depth index -> frame
@@ -203,8 +223,11 @@ __device__ __forceinline__ void pixel_terms(const EdgeGeom& g, float u, float v,
   const bool ok = !(Xj[2] < kMinDepth);
   const float d = ok ? 1.0f / Xj[2] : 0.0f;
   const float d2 = d * d;
-  const float wu = ok ? 0.001f * wgu : 0.0f;
-  const float wv = ok ? 0.001f * wgv : 0.0f;
+  // droid_kernels.cu:290-291 write `.001 * weight`: a DOUBLE literal, so the product is formed in double and rounded to
+  // float once - not the same number as 0.001f * w (0.001f != 0.001).  Followed literally; `1.0 / Xj[2]` (:287) equals the
+  // correctly rounded float division (double rounding of a quotient is innocuous at 53 >= 2 * 24 + 2 bits).
+  const float wu = ok ? static_cast<float>(0.001 * static_cast<double>(wgu)) : 0.0f;
+  const float wv = ok ? static_cast<float>(0.001 * static_cast<double>(wgv)) : 0.0f;
   const float ru = tu - (g.fx * d * x + g.cx);
   const float rv = tv - (g.fy * d * y + g.cy);
   float J[12];   // [Ji | Jj]
@@ -294,6 +317,10 @@ __device__ __forceinline__ void pose_block_scatter(int t, double val, int pi, in
   }
 }
 
+#ifdef PVO_SCHED_DEBUG
+__device__ unsigned long long* g_dbg_log_ba = nullptr;       // see graph_glue.hip
+__device__ float* g_dbg_partials = nullptr;                   // [E][chunks][4 waves][90]: every wave's sums BEFORE they cross LDS
+#endif
 __global__ __launch_bounds__(256) void ba_assemble_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intr,
     const float* __restrict__ targets, const float* __restrict__ weights,
@@ -306,6 +333,12 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   // a sixth of the atomics, issued while its own work starts.
   __shared__ float red[4][90];
   BA_ACQ();
+#ifdef PVO_SCHED_DEBUG
+  if (g_dbg_log_ba && threadIdx.x == 0) {
+    const unsigned long long i_ = atomicAdd(&g_dbg_log_ba[0], 1ull);
+    if (i_ < 16000ull) g_dbg_log_ba[1 + i_] = (2ull << 62) | (wall_clock64() & ((1ull << 62) - 1));
+  }
+#endif
   const int e = blockIdx.y;
   const int ix = static_cast<int>(ii[e]), jx = static_cast<int>(jj[e]);
   EdgeGeom g;
@@ -327,14 +360,14 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
     if (k < HW) {
       const int i = k / wd, j = k - i * wd;
       float eii[6], eij[6], cii, bzz;
-      pixel_terms(g, static_cast<float>(j), static_cast<float>(i), d_i[k], tg[k], tg[HW + k], wg[k], wg[HW + k],
+      pixel_terms(g, static_cast<float>(j), static_cast<float>(i), ld_h<3>(&d_i[k]), ld_h<3>(&tg[k]), ld_h<3>(&tg[HW + k]), ld_h<3>(&wg[k]), ld_h<3>(&wg[HW + k]),
                   h, vi, vj, eii, eij, cii, bzz);
       if (!motion_only) {
         const long long eb = static_cast<long long>(e) * 6 * HW + k;
 #pragma unroll
-        for (int n = 0; n < 6; ++n) { Eii[eb + static_cast<long long>(n) * HW] = eii[n]; Eij[eb + static_cast<long long>(n) * HW] = eij[n]; }
-        Cii[static_cast<long long>(e) * HW + k] = cii;
-        bz[static_cast<long long>(e) * HW + k] = bzz;
+        for (int n = 0; n < 6; ++n) { st_h<1>(&Eii[eb + static_cast<long long>(n) * HW], eii[n]); st_h<1>(&Eij[eb + static_cast<long long>(n) * HW], eij[n]); }
+        st_h<1>(&Cii[static_cast<long long>(e) * HW + k], cii);
+        st_h<1>(&bz[static_cast<long long>(e) * HW + k], bzz);
       }
     }
   }
@@ -344,18 +377,30 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
 #ifdef PVO_ABL_NOREDUCE      // ablation build: what do the 90 wave reductions cost?  (results are wrong)
   for (int l = 0; l < 78; ++l) { if (lane == 0) red[wave][l] = h[l]; }
 #else
-  for (int l = 0; l < 78; ++l) { const float s = pvo_wave_sum(h[l]); if (lane == 0) red[wave][l] = s; }
+  for (int l = 0; l < 78; ++l) {
+    const float s = pvo_wave_sum(h[l]);
+    if (lane == 0) red[wave][l] = s;
+#ifdef PVO_SCHED_DEBUG
+    if (g_dbg_partials && lane == 0) g_dbg_partials[((static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 90 + l] = s;
+#endif
+  }
 #endif
 #pragma unroll
   for (int n = 0; n < 6; ++n) {
     const float a = pvo_wave_sum(vi[n]), b = pvo_wave_sum(vj[n]);
     if (lane == 0) { red[wave][78 + n] = a; red[wave][84 + n] = b; }
+#ifdef PVO_SCHED_DEBUG
+    if (g_dbg_partials && lane == 0) {
+      g_dbg_partials[((static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 90 + 78 + n] = a;
+      g_dbg_partials[((static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 90 + 84 + n] = b;
+    }
+#endif
   }
   __syncthreads();
   const int t = threadIdx.x;
   if (t < 90) {
     const float sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    if (part) part[(static_cast<long long>(e) * gridDim.x + blockIdx.x) * 90 + t] = sum;      // summed per edge by the Schur kernel
+    if (part) st_h<1>(&part[(static_cast<long long>(e) * gridDim.x + blockIdx.x) * 90 + t], sum);      // summed per edge by the Schur kernel
     else pose_block_scatter(t, static_cast<double>(sum), ix - t0, jx - t0, P, sys, meta);
   }
   BA_REL();
@@ -396,20 +441,20 @@ __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const 
   float C = 0.0f, ww = 0.0f, ei[6] = {0, 0, 0, 0, 0, 0};
   for (int o = e0; o < e1; ++o) {
     const int e = pl.eidx[o];
-    C += Cii[static_cast<long long>(e) * HW + x];
-    ww += bz[static_cast<long long>(e) * HW + x];
+    C += ld_h<1>(&Cii[static_cast<long long>(e) * HW + x]);
+    ww += ld_h<1>(&bz[static_cast<long long>(e) * HW + x]);
     if (self_in) {
 #pragma unroll
-      for (int n = 0; n < 6; ++n) ei[n] += Eii[(static_cast<long long>(e) * 6 + n) * HW + x];
+      for (int n = 0; n < 6; ++n) ei[n] += ld_h<1>(&Eii[(static_cast<long long>(e) * 6 + n) * HW + x]);
     }
   }
   // K_eta == 1 broadcasts; a row-count mismatch is flagged in meta[2] and clamped here
   const float et = eta[static_cast<long long>(k < K_eta ? k : K_eta - 1) * HW + x];
-  Q[static_cast<long long>(k) * HW + x] = 1.0f / (C + et);           // droid_kernels.cu:1376
-  w[static_cast<long long>(k) * HW + x] = ww;
+  st_h<2>(&Q[static_cast<long long>(k) * HW + x], 1.0f / (C + et));           // droid_kernels.cu:1376
+  st_h<2>(&w[static_cast<long long>(k) * HW + x], ww);
   if (self_in) {
 #pragma unroll
-    for (int n = 0; n < 6; ++n) Ei[(static_cast<long long>(pself) * 6 + n) * HW + x] = ei[n];
+    for (int n = 0; n < 6; ++n) st_h<2>(&Ei[(static_cast<long long>(pself) * 6 + n) * HW + x], ei[n]);
   }
 }
 
@@ -442,6 +487,13 @@ template <bool VEC4>
 __device__ __forceinline__ f32x4 load4(gfloat* __restrict__ row, int p, int HW) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (row == nullptr) return v;
+  if (PVO_BA_COH_ON(1)) {
+    if (p < HW) v.x = __hip_atomic_load(row + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p + 1 < HW) v.y = __hip_atomic_load(row + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p + 2 < HW) v.z = __hip_atomic_load(row + p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p + 3 < HW) v.w = __hip_atomic_load(row + p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  }
   if (VEC4) {
     if (p + 3 < HW) return *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(row + p);
   }
@@ -537,7 +589,7 @@ __device__ __forceinline__ void ba_schur_body(
     const int nwg = gridDim.x * gridDim.y;
     for (int e = blockIdx.y * gridDim.x + blockIdx.x; e < E; e += nwg) {
       double val = 0.0;
-      for (int c = 0; c < chunksA; ++c) val += static_cast<double>(part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]);
+      for (int c = 0; c < chunksA; ++c) val += static_cast<double>(ld_h<1>(&part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]));
       pose_block_scatter(threadIdx.x, val, static_cast<int>(ii[e]) - t0, static_cast<int>(jj[e]) - t0, P, sys, pl.meta);
     }
   }
@@ -1562,14 +1614,14 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = base + u * blockDim.x + threadIdx.x;
-        raw[u] = idx < N ? sys[idx] : 0;
+        raw[u] = idx < N ? ld_h<2>(&sys[idx]) : 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = base + u * blockDim.x + threadIdx.x;
         if (idx >= N) continue;
         double v = static_cast<double>(raw[u]) * kInvFix;       // fixed point -> fp64
-        sys[idx] = 0;                                           // ready for the next Gauss-Newton step's accumulation
+        st_h<2>(&sys[idx], 0LL);                                // ready for the next Gauss-Newton step's accumulation
         if (idx < n * n) {
           const int r = idx / n, c = idx - r * n;
           if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
@@ -1592,7 +1644,7 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
   const int failed = fail | meta[4];
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
     const float v = failed ? 0.0f : static_cast<float>(xrow[idx]);    // zeros on failure (:1186-1189)
-    dx_ws[idx] = v;
+    st_h<2>(&dx_ws[idx], v);
     if (dx_out) dx_out[idx] = v;
   }
   __syncthreads();
@@ -1642,10 +1694,10 @@ __device__ __forceinline__ void ba_backsub_body(
     if (R.pose < lo) continue;
     float s = 0.0f;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) s += R.base[static_cast<long long>(n) * HW + x] * dx[6 * R.pose + n];
+    for (int n = 0; n < 6; ++n) s += ld_h<2>(&R.base[static_cast<long long>(n) * HW + x]) * ld_h<2>(&dx[6 * R.pose + n]);
     acc += s;
   }
-  const float dz = Q[static_cast<long long>(k) * HW + x] * (w[static_cast<long long>(k) * HW + x] - acc);
+  const float dz = ld_h<2>(&Q[static_cast<long long>(k) * HW + x]) * (ld_h<2>(&w[static_cast<long long>(k) * HW + x]) - acc);
   float d = disps[static_cast<long long>(pl.kx[k]) * HW + x] + dz;  // disp_retr_kernel (:912-925)
   if (pl.kx[k] < clamp_frames && d < disp_min) d = disp_min;
   disps[static_cast<long long>(pl.kx[k]) * HW + x] = d;
@@ -1684,6 +1736,15 @@ extern "C" int pvo_debug_ba_layout(int E, int P, int nframes, int HW, size_t* ou
   out[14] = static_cast<size_t>(reinterpret_cast<char*>(w.sys) - base);
   out[15] = w.bytes;
   return 0;
+}
+#endif
+
+#ifdef PVO_SCHED_DEBUG
+extern "C" int pvo_debug_partials(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_partials), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+extern "C" int pvo_debug_log_ba(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_log_ba), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
 }
 #endif
 

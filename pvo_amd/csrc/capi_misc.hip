@@ -12,7 +12,10 @@ extern "C" const char* pvo_strerror(int code) {
   }
 }
 
-extern "C" int pvo_version(void) { return 100; }
+// 101: pvo_graph_update_args grew by context_ahead / context_ready (round 3) - a caller built against a 100 header passes a
+// shorter struct; pvo_graph_update_args_size() lets any caller compare its sizeof with the library's before the first call
+extern "C" int pvo_version(void) { return PVO_ABI_VERSION; }
+extern "C" size_t pvo_graph_update_args_size(void) { return sizeof(pvo_graph_update_args); }
 
 static thread_local int g_last_hip_error = 0;
 extern "C" void pvo_note_hip_error(int code) { g_last_hip_error = code; }

@@ -42,6 +42,9 @@ SideCtx* side_ctx() {
     if (const char* e = getenv("PVO_EVENT_SYSTEM_FENCE"))       // A/B switch for the measurement in DESIGN.md section 5
       g_event_flags = (e[0] == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
+#ifdef PVO_SCHED_DEBUG
+    if (const char* e = getenv("PVO_SIDE_PRIO")) { if (e[0] == 'n') greatest = 0; else if (e[0] == 'l') greatest = least; }   // experiment: normal / low priority
+#endif
     if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.fork, g_event_flags) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.join, g_event_flags) != hipSuccess) return nullptr;
@@ -245,6 +248,9 @@ int run_agg(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, vo
   if (a->eta)
     RUN(pvo_eta_head(b.a2, w->eta_w, w->eta_b, a->eta_frame, a->eta_pos, a->damping, a->eta, a->eta_frame ? a->R : K, H, W, a->EP, a->eta_scale, dt, stream));
   if (mark && hipEventRecord(mark->mid, pvo_stream(stream)) != hipSuccess) return PVO_ELAUNCH;
+  // INVARIANT pvo_graph_update relies on (it waits for `mid` and has no second join): with with_upmask == false NOTHING is
+  // enqueued on this stream behind `mid`.  Whatever is added below this line must be waited for by the callers that pass a
+  // `mark` (run_operator's `pending` users), or go in front of the record.
   if (with_upmask) RUN(run_upmask(w, a, b, stream));
   return PVO_OK;
 }
@@ -364,7 +370,11 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
                      u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
                      S, u->vote_thresh, dt, stream));
   static const bool rider_off = [] { const char* e = getenv("PVO_UPMASK_RIDER"); return e && e[0] == '0'; }();
-  const bool mask_rides = u->itrs > 0 && a.K > 0 && a.upmask && !rider_off
+  // (the rider has preconditions the stand-alone convolution does not: at most 2^24 rows and 16-byte aligned operands,
+  // pvo_ba_finish_riders - beyond them the mask is computed the old way, on this stream, instead of failing the update)
+  const bool rider_fits = static_cast<long long>(K) * HW <= (1LL << 24) &&
+                          !((reinterpret_cast<uintptr_t>(b.a2) | reinterpret_cast<uintptr_t>(w->up_w) | reinterpret_cast<uintptr_t>(a.upmask)) & 15);
+  const bool mask_rides = u->itrs > 0 && a.K > 0 && a.upmask && !rider_off && rider_fits
 #ifdef PVO_SCHED_DEBUG
                           && g_sched.mode == 0
 #endif
@@ -392,12 +402,32 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
 #ifdef PVO_SCHED_DEBUG
   // mode 1: the mask convolution on the side stream behind the eta head, the BA beside it;  mode 2: additionally the first
   // assembly launched BEFORE the wait on `mid` (arranged below);  mode 3: as shipped but the mask convolution after the BA
-  if (g_sched.mode == 1 || g_sched.mode == 2) {
+  // round 4: mode 4 = mode 1 with a FILL of the mask buffer (a blit kernel, none of ours) in place of the mask convolution;
+  // mode 5 = mode 1 + an empty kernel on the launch stream between the wait and the first BA kernel;  mode 6 = mode 1 with the
+  // BA waiting for the side stream's mask convolution as well (nothing of another queue resident beside the BA: control)
+  if (g_sched.mode == 1 || g_sched.mode == 2 || (g_sched.mode >= 4 && g_sched.mode <= 9)) {
     if (pending) {
-      RUN(run_upmask(w, &a, b, pending->side));
+      // mode 7: another MFMA + LDS kernel of ours (the 3x3 convolution of the aggregation branch, over the K frames) instead of the
+      // mask convolution;  mode 8: three plain streaming passes (no LDS, no matrix cores) over the mask buffer;  mode 9: the mask
+      // convolution over 64 rows only (one workgroup per channel block)
+      if (g_sched.mode == 4) {
+        if (a.upmask && hipMemsetAsync(a.upmask, 0, static_cast<size_t>(K) * HW * 576 * 2, pending->side) != hipSuccess) return PVO_ELAUNCH;
+      } else if (g_sched.mode == 7) {
+        RUN(pvo_conv3x3_c128(b.am, w->agg2_w, w->agg2_b, a.upmask, K, H, W, 128, 1, 0, 0, dt, pending->side));
+      } else if (g_sched.mode == 8) {
+        const long long nf = static_cast<long long>(K) * HW * 288;
+        for (int rep = 0; rep < 3; ++rep) {
+          hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((nf + 255) / 256)), dim3(256), 0, pending->side, reinterpret_cast<float*>(a.upmask), nf, -3.0e38f);
+          PVO_CHECK_LAUNCH();
+        }
+      } else if (g_sched.mode == 9) {
+        RUN(pvo_conv1x1_c128(b.a2, w->up_w, w->up_b, a.upmask, 64, 576, 0, w->dtype, pending->side));
+      } else RUN(run_upmask(w, &a, b, pending->side));
       if (!g_sched.no_marker && hipEventRecord(pending->join, pending->side) != hipSuccess) return PVO_ELAUNCH;
     } else RUN(run_upmask(w, &a, b, stream));
-    if (g_sched.mode == 1 && pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
+    if (g_sched.mode != 2 && pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
+    if (g_sched.mode == 6 && pending && hipStreamWaitEvent(st, pending->join, 0) != hipSuccess) return PVO_ELAUNCH;
+    if (g_sched.mode == 5) { hipLaunchKernelGGL(clamp_min_kernel, dim3(1), dim3(64), 0, st, u->disps, 0LL, 0.0f); PVO_CHECK_LAUNCH(); }
   } else if (g_sched.mode == 3) {
     if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
   } else
@@ -469,7 +499,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // for `mid` above (the branch's `join` event is recorded right behind `mid` with nothing in between).  A satisfied wait
   // still costs the launch stream ~6 us (tools/update_timeline.sh).
 #ifdef PVO_SCHED_DEBUG
-  if (g_sched.mode == 1 || g_sched.mode == 2) RUN(join(pending, stream));      // (these put the mask convolution behind `mid`)
+  if (g_sched.mode == 1 || g_sched.mode == 2 || (g_sched.mode >= 4 && g_sched.mode <= 9)) RUN(join(pending, stream));      // (these put the mask convolution behind `mid`)
 #endif
   if (ca && context_ahead)
     *ca = ContextAhead{workspace, w, w->glo_w, w->gate_wt, a.net_out, E, H, W, dt, true};

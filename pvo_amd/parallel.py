@@ -68,14 +68,18 @@ def envelope_index(first, device):
     1.15 MB)."""
     P = len(first)
     n6 = 6 * P
-    idx = []
-    for b in range(P):
-        for cb in range(first[b], b + 1):
-            for r in range(6):
-                base = (6 * b + r) * n6 + 6 * cb
-                idx.extend(range(base, base + 6))
-    idx.extend(range(n6 * n6, n6 * n6 + n6))
-    return torch.tensor(idx, dtype=torch.long, device=device)
+    if P == 0:
+        return torch.zeros(0, dtype=torch.long, device=device)
+    # (tensor arithmetic, not Python loops: a global BA over several hundred free poses has tens of millions of entries)
+    fb = torch.as_tensor(list(first), dtype=torch.long)
+    b = torch.arange(P, dtype=torch.long)
+    ncols = 6 * (b - fb + 1)                                   # scalar columns of block row b inside the envelope
+    rows = torch.arange(n6, dtype=torch.long)                  # every scalar row 6 b + r ...
+    cnt = ncols.repeat_interleave(6)                           # ... holds ncols[b] consecutive entries starting at column 6 first[b]
+    start = rows * n6 + (6 * fb).repeat_interleave(6)
+    offs = torch.arange(int(cnt.sum()), dtype=torch.long) - (torch.cumsum(cnt, 0) - cnt).repeat_interleave(cnt)
+    idx = torch.cat([start.repeat_interleave(cnt) + offs, torch.arange(n6 * n6, n6 * n6 + n6, dtype=torch.long)])
+    return idx.to(device)
 
 
 class ShardedBA:

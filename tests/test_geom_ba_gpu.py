@@ -115,6 +115,20 @@ def test_ba_matches_oracle_at_SA_size(cuda):
     assert np.abs(dx - want["dx"]).max() < 1e-4 and np.abs(dz - want["dz"]).max() < 1e-4
 
 
+def test_ba_matches_oracle_at_S20_size(cuda):
+    """S-20 (BASELINE.json configs[3]) at its full size: 64 keyframes, the 372 edges |i - j| <= 3, 48x64 maps, 63 free
+    poses (the envelope solve in LDS) - the device BA against the oracle's dense fp64 solve"""
+    P, ht, wd = 64, 48, 64
+    s = _scene(2020, P, ht, wd, 3, 1)
+    assert s["ii"].shape[0] == 372
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
+    assert status[0] == 0 and status[1] == want["K"] == 64
+    assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
+    assert np.abs(dx - want["dx"]).max() < 1e-4 and np.abs(dz - want["dz"]).max() < 1e-4
+
+
 def test_ba_matches_reference_python_fixture_poses(cuda):
     """Poses after a native BA step equal the reference geom/ba.py result (the pose update is
     unaffected by EvT6x1's pose-0 skip); fixtures generated from /root/reference."""

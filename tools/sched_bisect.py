@@ -12,20 +12,29 @@ state and compared bit for bit with the first run of the same arrangement: final
 the first differing tap the named parts of the workspace (Eii, Eij, Cii, bz | Ei, Q, w | dx ...) and the BA's inputs.
 """
 import ctypes, os, subprocess, sys
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROBE_DIR = os.path.join(ROOT, "tools", "_probe")
 FENCES = "--build-fences" in sys.argv or os.environ.get("PVO_BA_FENCES") == "1"
-PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_sched_fences.so" if FENCES else "libpvo_hip_sched.so")
+# --variant coh1 | coh2 (or PVO_SCHED_VARIANT): the BA's hand-off rows through agent-scope (sc1) stores / loads (ba.hip, PVO_BA_COHERENT)
+VARIANT = os.environ.get("PVO_SCHED_VARIANT", "")
+for k, a_ in enumerate(sys.argv):
+    if a_ == "--variant":
+        VARIANT = sys.argv[k + 1]
+        del sys.argv[k:k + 2]
+        break
+VDEF = {"": [], "coh1": ["-DPVO_BA_COHERENT=1"], "coh2": ["-DPVO_BA_COHERENT=2"], "coh3": ["-DPVO_BA_COHERENT=3"], "shfl": ["-DPVO_WAVE_SUM_SHFL"], "nopk": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"], "in3": ["-DPVO_BA_COHERENT=3", "-DPVO_BA_COHERENT_ONLY_INPUTS"]}[VARIANT]
+PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_sched_fences.so" if FENCES else "libpvo_hip_sched%s.so" % (("_" + VARIANT) if VARIANT else ""))
 if "--build" in sys.argv or "--build-fences" in sys.argv:
     from pvo_amd import build
     build.build_hip()
     os.makedirs(PROBE_DIR, exist_ok=True)
     objs = []
     for s in build.HIP_SOURCES:
-        if s in ("update_exec.hip", "ba.hip"):
-            obj = os.path.join(PROBE_DIR, ("schedf_" if FENCES else "sched_") + s.replace(".hip", ".o"))
-            subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_SCHED_DEBUG"] + (["-DPVO_BA_FENCES"] if FENCES else []) +
+        if s in ("update_exec.hip", "ba.hip", "graph_glue.hip"):
+            obj = os.path.join(PROBE_DIR, ("schedf_" if FENCES else "sched%s_" % VARIANT) + s.replace(".hip", ".o"))
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_SCHED_DEBUG"] + VDEF + (["-DPVO_BA_FENCES"] if FENCES else []) +
                                   ["-c", os.path.join(build.CSRC, s), "-o", obj])
         else:
             obj = os.path.join(build.CSRC, s.replace(".hip", ".o"))
@@ -40,6 +49,7 @@ import bench                                           # noqa: E402
 sys.argv = [sys.argv[0]] + [a for a in sys.argv[1:] if not a.startswith("--")]
 RUNS = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 N_UPD = int(os.environ.get("PVO_CHECK_UPDATES", "2"))
+ITRS = int(os.environ.get("PVO_CHECK_ITRS", "2"))
 # mode[:flags]  flags: s = events without the system-scope fence (hipEventDisableSystemFence), d = device-scope release
 # (hipEventReleaseToDevice), n = mode 1/2 without the event record on the side stream behind the mask convolution
 # h = "fence hammer": while the updates run, a third stream executes a train of default-flag event records (each a marker with a
@@ -98,7 +108,7 @@ def run(mode, with_tap=True):
         for e in evs:
             e.record(hammer_stream)
     for _ in range(N_UPD):
-        graph.update(None, None, use_inactive=True)
+        graph.update(None, None, itrs=ITRS, use_inactive=True)
     torch.cuda.synchronize()
     out = dict(net=graph.net.clone(), target=graph.target_cam.clone(), weight=graph.weight.clone(), raw_mask=graph.raw_mask.clone(),
                damping=graph.damping.clone(), poses=video.poses.clone(), disps=video.disps.clone(),
@@ -130,6 +140,133 @@ def first_diff(ref_tap, got_tap):
         return "update %d, iteration %d, after %s: %s" % (upd, it, STAGE[stage], "; ".join(what) or "padding only")
     return None
 
+
+TIMES = os.environ.get("PVO_SCHED_TIMES") == "1"
+if TIMES:
+    # per run: a log of constant-rate clock stamps (100 MHz) - graph_post workgroups when their stores are acknowledged (tag 1),
+    # assembly workgroups when they start (tag 2).  In stream order every assembly of an update starts after the LAST graph_post
+    # workgroup of that update has finished; the first assembly of an update is the first kernel behind the wait on `mid`.
+    lib.pvo_debug_log_graph.argtypes = [ctypes.c_void_p]; lib.pvo_debug_log_ba.argtypes = [ctypes.c_void_p]
+    tlog = torch.zeros(16002, dtype=torch.int64, device=dev)
+    assert lib.pvo_debug_log_graph(tlog.data_ptr()) == 0 and lib.pvo_debug_log_ba(tlog.data_ptr()) == 0
+    for spec in MODES:
+        mode, _, fl = spec.partition(":")
+        assert lib.pvo_debug_event_flags(EVF[fl]) == 0
+        run(int(mode), False)
+        ref, _ = run(int(mode), False)
+        early_runs = bad = 0; worst = 0.0; gaps = []
+        for r in range(RUNS):
+            tlog.zero_(); torch.cuda.synchronize()
+            out, _ = run(int(mode), False)
+            differs = any(not torch.equal(bits(out[k]), bits(ref[k])) for k in ref)
+            n = int(tlog[0]); ent = tlog[1:1 + n].cpu().numpy()
+            tag, t = (ent >> 62) & 3, ent & ((1 << 62) - 1)
+            order = t.argsort(kind="stable"); tag, t = tag[order], t[order]
+            early = 0.0
+            # per update (by counts, in clock order): graph_post's workgroups, then the two assemblies'
+            posts, asms = t[tag == 1], t[tag == 2]
+            npost = posts.size // N_UPD; nasm = asms.size // N_UPD
+            for u in range(N_UPD):
+                p_u = np.sort(posts)[u * npost:(u + 1) * npost]; a_u = np.sort(asms)[u * nasm:(u + 1) * nasm]
+                gap = (a_u.min() - p_u.max()) * 0.01          # us: first assembly start minus last graph_post end
+                gaps.append(gap); early = min(early, gap)
+            early_runs += early < 0; bad += differs; worst = min(worst, early)
+            if (early < 0 or differs) and early_runs + bad <= 8:
+                print("mode %s run %d: result %s; first assembly start - last graph_post end = %.2f us (negative = the assembly STARTED BEFORE graph_post FINISHED)" % (spec, r, "DIFFERS" if differs else "equal", early), flush=True)
+        g = np.array(gaps)
+        print("mode %s: %d of %d runs differ; %d runs with an assembly workgroup that started before the last graph_post workgroup finished (worst %.2f us); gap median %.2f us, min %.2f us" % (
+            spec, bad, RUNS, early_runs, worst, float(np.median(g)), float(g.min())), flush=True)
+    sys.exit(0)
+
+if os.environ.get("PVO_SCHED_PARTIALS") == "1":
+    # The assembly's chunk sums: every wave's 90 sums before they cross LDS (debug copy) and the workgroup's sums after (`part`).
+    # One update with ONE BA iteration per run (PVO_CHECK_UPDATES=1 PVO_CHECK_ITRS=1), so that the first tap and the debug copy
+    # belong to the assembly that runs beside the side stream's kernel; the clean reference is the shipped arrangement (mode 0).
+    assert N_UPD == 1 and ITRS == 1
+    lib.pvo_debug_partials.argtypes = [ctypes.c_void_p]
+    chunks = (HW + 511) // 512
+    pbuf = torch.zeros(E_ba * chunks * 4 * 90, dtype=torch.float32, device=dev)
+    assert lib.pvo_debug_partials(pbuf.data_ptr()) == 0
+    part_lo = offs[PARTS.index("dx")] // 4 + ((4 * (6 * P + 8) + 255) // 256) * 64           # `part` follows dx (256-byte aligned)
+    def one(mode):
+        pbuf.zero_(); torch.cuda.synchronize()
+        out, t = run(mode)
+        ws = t[0:slot][sys_pad + ws_skew:sys_pad + ws_bytes].view(torch.float32)
+        return out, pbuf.clone().view(E_ba, chunks, 4, 90), ws[part_lo:part_lo + E_ba * chunks * 90].clone().view(E_ba, chunks, 90)
+    assert lib.pvo_debug_event_flags(EVF[""]) == 0
+    one(0); ref_out, ref_pw, ref_part = one(0)
+    _, pw2, part2 = one(0)
+    summed = lambda pw: (pw[:, :, 0] + pw[:, :, 1]) + (pw[:, :, 2] + pw[:, :, 3])
+    print("mode 0 twice: partials equal %s, part equal %s; part == (w0 + w1) + (w2 + w3) of the partials: %s" % (
+        torch.equal(pw2, ref_pw), torch.equal(part2, ref_part), torch.equal(bits(summed(ref_pw)), bits(ref_part))))
+    mode = int(MODES[-1].split(":")[0])
+    nbad = 0
+    for r in range(RUNS):
+        out, pw, part = one(mode)
+        dpart = (bits(part) != bits(ref_part)).nonzero()
+        dpw = (bits(pw) != bits(ref_pw)).nonzero()
+        lds = (bits(summed(pw)) != bits(part)).nonzero()
+        if dpart.numel() == 0 and dpw.numel() == 0:
+            continue
+        nbad += 1
+        if nbad > 10:
+            continue
+        print("mode %d run %d: %d of %d chunk sums differ from the clean run; %d of %d WAVE partials differ from the clean run; %d chunk sums are not the sum of this run's own four partials" % (
+            mode, r, dpart.shape[0], ref_part.numel(), dpw.shape[0], ref_pw.numel(), lds.shape[0]), flush=True)
+        for e_, c_, w_, l_ in dpw[:10].tolist():
+            print("      edge %d chunk %d wave %d sum %d: partial %.9g (clean %.9g)" % (e_, c_, w_, l_, float(pw[e_, c_, w_, l_]), float(ref_pw[e_, c_, w_, l_])))
+        waves = sorted(set((e_, c_, w_) for e_, c_, w_, l_ in dpw.tolist()))
+        print("      waves hit: %s" % ", ".join("(edge %d chunk %d wave %d: sums %s)" % (e_, c_, w_, [l for a1, a2, a3, l in dpw.tolist() if (a1, a2, a3) == (e_, c_, w_)]) for e_, c_, w_ in waves[:8]))
+    print("mode %d: %d of %d runs differ" % (mode, nbad, RUNS))
+    sys.exit(0)
+
+if os.environ.get("PVO_SCHED_DETAIL") == "1":
+    # where exactly do the first differing taps differ?  decode every differing word of Eii / Eij / Cii / bz / part into (edge, row,
+    # pixel) and test it against the SAME word one tap earlier in this run and in the reference run (is it an old value?)
+    spec = MODES[-1]
+    mode, _, fl = spec.partition(":")
+    assert lib.pvo_debug_event_flags(EVF[fl]) == 0
+    run(int(mode)); ref, ref_tap = run(int(mode))
+    shown = 0
+    for r in range(RUNS):
+        out, t = run(int(mode))
+        for k in range(n_slots):
+            rs, gs = ref_tap[k * slot:(k + 1) * slot], t[k * slot:(k + 1) * slot]
+            if torch.equal(rs, gs) or k % 2 == 1:
+                continue
+            wr, wg = rs[sys_pad + ws_skew:sys_pad + ws_bytes], gs[sys_pad + ws_skew:sys_pad + ws_bytes]
+            msgs = []
+            for i, name in enumerate(PARTS):
+                lo, hi = offs[i], offs[i + 1]
+                if name not in ("Eii", "Eij", "Cii", "bz", "Ei", "Q", "w", "dx") or hi > wr.numel() or torch.equal(wr[lo:hi], wg[lo:hi]):
+                    continue
+                a_, b_ = wr[lo:hi].view(torch.int32), wg[lo:hi].view(torch.int32)
+                d = (a_ != b_).nonzero().flatten().cpu().numpy()
+                old = None
+                if k >= 2:        # the same words after the previous assemble+schur of THIS run
+                    prev = t[(k - 2) * slot:(k - 1) * slot][sys_pad + ws_skew:sys_pad + ws_bytes][lo:hi].view(torch.int32)
+                    old = int((prev[torch.from_numpy(d).to(dev)] == b_[torch.from_numpy(d).to(dev)]).sum())
+                sect = np.unique(d // 16)
+                if name in ("Eii", "Eij"):
+                    where = sorted(set((int(x) // (6 * HW), (int(x) // HW) % 6, (int(x) % HW) // 16 * 16) for x in d))
+                    by_px = {}
+                    for e_, n_, p_ in where:
+                        by_px.setdefault((e_, p_), []).append(n_)
+                    desc = "; ".join("edge %d px %d..%d rows %s" % (e_, p_, p_ + 15, rows) for (e_, p_), rows in sorted(by_px.items())[:6])
+                elif name in ("Cii", "bz"):
+                    desc = "; ".join("edge %d px %d" % (int(x) // HW, int(x) % HW) for x in d[:6])
+                elif name == "dx":
+                    dd = d[d >= 6 * P + 8] - (6 * P + 8)
+                    desc = "part: " + "; ".join("edge %d chunk %d sum %d" % (int(x) // 540, (int(x) // 90) % 6, int(x) % 90) for x in dd[:24]) + (" | dx itself: %d words" % int((d < 6 * P + 8).sum()))
+                else:
+                    desc = "words %s" % d[:8].tolist()
+                msgs.append("%s: %d words in %d 64-byte sectors (%s of them equal this run's previous assemble+schur tap) [%s]" % (name, d.size, sect.size, old, desc))
+            print("run %d tap %d (update %d iteration %d):\n    %s" % (r, k, k // 4, (k // 2) % 2, "\n    ".join(msgs) or "other parts only"), flush=True)
+            shown += 1
+            break
+        if shown >= 12:
+            break
+    sys.exit(0)
 
 for spec in MODES:
     mode, _, fl = spec.partition(":")

@@ -25,26 +25,39 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def str2bool(v):
+    """the reference declares its switches with argparse `type=bool` (train.py:317-393): any non-empty string, 'False' included, is
+    True there, so its defaults can only be switched ON from the command line.  Same option names and defaults here, but the value
+    is parsed: --ssim False turns SSIM off."""
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("1", "true", "t", "yes", "y", "on"):
+        return True
+    if v.lower() in ("0", "false", "f", "no", "n", "off", ""):
+        return False
+    raise argparse.ArgumentTypeError("expected a boolean, got %r" % v)
+
+
 def parse_args(argv=None):
     p = argparse.ArgumentParser()
     # (defaults are train.py:279-343's)
     p.add_argument("--name", default="vkitti2_dy_train")
     p.add_argument("--datapath", default="synthetic")
-    p.add_argument("--need_inv", type=bool, default=False)
+    p.add_argument("--need_inv", type=str2bool, default=False)
     p.add_argument("--gpus", type=str, default="0")
     p.add_argument("--mode", type=str, default="semisup", help="sup, semisup, unsup")
     p.add_argument("--lr", type=float, default=0.0005)
     p.add_argument("--steps", type=int, default=20000)
-    p.add_argument("--occ_ph", type=bool, default=False)
+    p.add_argument("--occ_ph", type=str2bool, default=False)
     p.add_argument("--ckpt")
-    p.add_argument("--flow_label", type=bool, default=False)
-    p.add_argument("--aug_graph", type=bool, default=True)
-    p.add_argument("--use_aff_bri", type=bool, default=False)
-    p.add_argument("--downsample", type=bool, default=True)
-    p.add_argument("--ssim", type=bool, default=True)
-    p.add_argument("--ce_reg", type=bool, default=False)
-    p.add_argument("--con_loss", type=bool, default=False)
-    p.add_argument("--ph_loss", type=bool, default=True)
+    p.add_argument("--flow_label", type=str2bool, default=False)
+    p.add_argument("--aug_graph", type=str2bool, default=True)
+    p.add_argument("--use_aff_bri", type=str2bool, default=False)
+    p.add_argument("--downsample", type=str2bool, default=True)
+    p.add_argument("--ssim", type=str2bool, default=True)
+    p.add_argument("--ce_reg", type=str2bool, default=False)
+    p.add_argument("--con_loss", type=str2bool, default=False)
+    p.add_argument("--ph_loss", type=str2bool, default=True)
     p.add_argument("--batch", type=int, default=1)
     p.add_argument("--iters", type=int, default=15)
     p.add_argument("--clip", type=float, default=2.5)
@@ -94,6 +107,8 @@ def objective(args, L, out, batch, graph, ssim, step):
     metrics, loss = {}, 0.0
     res_loss, m = L.residual_loss(residuals); metrics.update(m)
     loss = loss + args.w2 * res_loss
+    # (`late` is keyed on the GLOBAL step here; the reference keys it on i_batch, the index inside the current pass over its data
+    # loader, train.py:196 - with synthetic clips there is no epoch boundary to restart it at)
     late = args.occ_ph and step > args.steps * 0.75
     if args.mode == "sup":
         geo, m = L.geodesic_loss(Ps, poses_est, graph, do_scale=False); metrics.update(m)
