@@ -588,6 +588,57 @@ def edge_sharded_leg(device, rank, world, steps=3):
     P = nkf - 1
     dense_bytes = 8 * ((6 * P) ** 2 + 6 * P)
     ar_us = None
+    one_rank = None
+    if world == 1 and os.environ.get("PVO_BENCH_RCCL_ONE_RANK", "1") == "1":
+        # No second GPU here: the collective of the edge-sharded BA still runs through RCCL on a ONE-rank group - the int64
+        # envelope message, on the BA's stream, between pvo_ba_local and pvo_ba_finish (ShardedBA.collective_at_one) - so that the
+        # path the 8-GPU run takes is executed (ordering, dtype, message size) and its latency floor is on record.
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            try:
+                video, graph = make_window(device, seed=7, NKF=nkf, buffer=80, corr_impl=corr_impl, add_edges=False, max_factors=-1)
+                video.counter = nkf
+                graph.add_factors(ii, jj)
+                H_, W_ = graph.ht, graph.wd
+                g = torch.Generator().manual_seed(3)
+                target = (graph.target_cam + 0.5 * torch.randn(len(ii), H_, W_, 2, generator=g).to(device)[None]).view(-1, H_, W_, 2).permute(0, 3, 1, 2).contiguous()
+                weight = torch.rand(len(ii), H_, W_, 2, generator=g).to(device).permute(0, 3, 1, 2).contiguous()
+                eta = torch.full((nkf, H_, W_), 1e-4, device=device)
+                bi, bj = graph.ii.contiguous(), graph.jj.contiguous()
+                res = {}
+                for name, on in (("plain", False), ("rccl", True)):
+                    sb = ShardedBA(structure=(ii, jj))
+                    sb.always_pack, sb.collective_at_one = True, on
+                    p_, d_ = video.poses.clone(), video.disps.clone()
+                    run_ba = lambda: sb.ba(p_, d_, video.intrinsics[0], target, weight, eta, bi, bj, 1, nkf, itrs=2, lm=1e-5, ep=1e-2, plan_key=("one", name))
+                    run_ba(); torch.cuda.synchronize()
+                    p_.copy_(video.poses); d_.copy_(video.disps)
+                    run_ba(); torch.cuda.synchronize()
+                    first = p_.clone()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        run_ba()
+                    torch.cuda.synchronize()
+                    res[name] = ((time.perf_counter() - t0) / 10 * 1e3, first, sb.last_message_bytes)
+                msg = torch.zeros(max(res["rccl"][2] // 8, 1), dtype=torch.int64, device=device)
+                for _ in range(5):
+                    dist.all_reduce(msg)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    dist.all_reduce(msg)
+                torch.cuda.synchronize()
+                one_rank = {"backend": dist.get_backend(), "world_size": 1, "allreduce_us": (time.perf_counter() - t0) / 50 * 1e6,
+                            "allreduce_bytes": int(res["rccl"][2]), "ba_2_steps_ms_with_the_collective": res["rccl"][0],
+                            "ba_2_steps_ms_pack_unpack_only": res["plain"][0],
+                            "poses_bitwise_equal_with_and_without_the_collective": bool(torch.equal(res["rccl"][1], res["plain"][1]))}
+                del graph, video
+                torch.cuda.empty_cache()
+            finally:
+                dist.destroy_process_group()
+        except Exception as e:                                       # noqa: BLE001
+            one_rank = {"error": repr(e)}
     if world > 1:
         msg = torch.zeros(max(msg_bytes // 8, 1), dtype=torch.int64, device=device)
         for _ in range(5):
@@ -614,6 +665,8 @@ def edge_sharded_leg(device, rank, world, steps=3):
            "ba_2_steps_ms": ba_ms, "allreduce_us": ar_us, "allreduce_bytes": int(msg_bytes) if world > 1 else None,
            "allreduce_bytes_dense": dense_bytes, "allreduce_message": "envelope blocks of the lower triangle + rhs, int64 fixed point",
            "backend": dist.get_backend() if world > 1 else None, "world_size": world, "poses_bitwise_equal_across_ranks": same}
+    if one_rank is not None:
+        out["rccl_one_rank"] = one_rank
     if world > 1:
         tt = torch.tensor([el, ba_ms, whole[0], whole[1]], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

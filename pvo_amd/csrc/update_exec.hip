@@ -187,11 +187,12 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   // launch stream takes 74 instead of 41 us (its redundant 7x7 halo work occupies the matrix cores) and the gate convolution
   // starts 8 us LATER (226.9 -> 225.2 keyframe updates/s).
   static const bool fe_two = [] { const char* e = getenv("PVO_FLOW_ENCODER_FUSED"); return !(e && e[0] == '1'); }();
-  // Round 4: the two chains in front of the gates were unequal (timeline r03n: launch stream done at 99 us, side stream at
-  // 120, and a wait that has to be WOKEN costs ~11 us more than one that is already satisfied): the last `E_main` edges of
-  // flow_encoder[2] run on the launch stream behind corr_encoder[2] (the 7x7 output of ALL edges is needed first: one more
-  // event).  PVO_TRUNK_SPLIT=<percent of the edges that move> (default 33; 0 = the round-3 arrangement).
-  static const int split_pct = [] { const char* e = getenv("PVO_TRUNK_SPLIT"); const int v = e ? atoi(e) : 33; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
+  // Round 4 experiment, kept behind a switch: the two chains in front of the gates are unequal (timeline r03n: launch stream
+  // done at 99 us, side stream at 120, then a wait that has to be WOKEN), so PVO_TRUNK_SPLIT=<percent> moves the last edges of
+  // flow_encoder[2] onto the launch stream behind corr_encoder[2] (one more event: the 7x7 output of all edges).  Measured at
+  // 0 / 20 / 33 / 45 %: 193.8 / 193.7 / 192.7 / 192.8 keyframe updates/s on one (slow) box - no gain, the stretch is bound by the
+  // sum of the work, not by the longer chain.  Default 0 = the round-3 arrangement.
+  static const int split_pct = [] { const char* e = getenv("PVO_TRUNK_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
   const int E_main = (sc && fe_two) ? (E * split_pct) / 100 : 0, E_side = E - E_main;
   const size_t px = static_cast<size_t>(H) * W;
   if (fe_two) {
@@ -209,8 +210,8 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     RUN(pvo_conv3x3_c128(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 1, 192, 0, dt, stream));
   if (E_main > 0) {
     if (hipStreamWaitEvent(st, sc->mid, 0) != hipSuccess) return PVO_ELAUNCH;
-    RUN(pvo_conv3x3_c128(static_cast<const uint16_t*>(b.f1) + static_cast<size_t>(E_side) * px * 128, w->fenc2_w, w->fenc2_b,
-                         static_cast<uint16_t*>(b.CF) + static_cast<size_t>(E_side) * px * 192, E_main, H, W, 64, 1, 192, 128, dt, stream));
+    RUN(pvo_conv3x3_c128(b.f1 + static_cast<size_t>(E_side) * px * 128 * 2, w->fenc2_w, w->fenc2_b,
+                         b.CF + static_cast<size_t>(E_side) * px * 192 * 2, E_main, H, W, 64, 1, 192, 128, dt, stream));
   }
   if (!context_ready) {           // (else b.g already holds it: computed inside the previous update's pose solves)
     RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s3));

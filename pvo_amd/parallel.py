@@ -98,6 +98,7 @@ class ShardedBA:
         self._plan_key = None
         self._env_idx = None
         self.always_pack = False        # tests: run the pack / unpack pair on a single rank too
+        self.collective_at_one = False  # run the all-reduce through the process group even when it has ONE rank (the RCCL path on a 1-GPU box)
         self.last_message_bytes = 0
 
     # the two places that touch the process group (tests substitute an in-process exchange)
@@ -135,7 +136,7 @@ class ShardedBA:
             self.db.ba_plan(ii_local, jj_local, F, ht * wd, K_eta, t0, t1, ws)
             self._plan_key, self._plan_edges = key, (ii_local, jj_local)
             self._env_idx = None
-        multi = self._world() > 1
+        multi = self._world() > 1 or (self.collective_at_one and self.communicate and dist.is_available() and dist.is_initialized())
         if structure is not None and self._env_idx is None and (multi or self.always_pack):
             self._env_idx = envelope_index(envelope_structure(structure[0], structure[1], t0, t1), disps.device)
         sys_buf = self._sys

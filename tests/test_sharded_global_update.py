@@ -223,3 +223,51 @@ def test_hip_sharded_global_update_two_virtual_ranks_bit_identical_to_whole_grap
     assert torch.equal(out[0][0], whole_p)                    # ... with the whole graph, bit for bit
     merged = d0 + (out[0][1] - d0) + (out[1][1] - d0)
     assert (merged - whole_d).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_sharded_ba_through_a_one_rank_rccl_group(cuda):
+    """The collective of the edge-sharded BA on the path an 8-GPU run takes - `dist.all_reduce` of the int64 ENVELOPE message on an
+    RCCL ("nccl") process group, between pvo_ba_local and pvo_ba_finish - executed with the one rank a 1-GPU box has: the sum over
+    one rank is the identity, so poses and depths must equal, bit for bit, the same BA without communication; and the message
+    must be the envelope (not the dense system)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_geom_ba_gpu import _scene
+    from pvo_amd.parallel import ShardedBA, envelope_structure
+    P, ht, wd = 24, 16, 24
+    s = _scene(31, P, ht, wd, 3, 1)
+    args = lambda: (s["poses"].clone().to(cuda), s["disps"].clone().to(cuda))
+    dev = lambda k: s[k].to(cuda)
+    calls = []
+
+    class Counting(ShardedBA):
+        def _allreduce(self, t):
+            calls.append((t.dtype, t.numel(), t.device.type))
+            super()._allreduce(t)
+
+    def run(sb):
+        poses, disps = args()
+        sb.ba(poses, disps, dev("intr"), dev("target"), dev("weight"), dev("eta"), dev("ii"), dev("jj"), 1, P, itrs=2, lm=1e-4, ep=0.1)
+        torch.cuda.synchronize()
+        return poses.cpu(), disps.cpu()
+    structure = (s["ii"].tolist(), s["jj"].tolist())
+    plain = run(ShardedBA(structure=structure, communicate=False))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29541"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        assert dist.get_backend() == "nccl"
+        sb = Counting(structure=structure)
+        sb.always_pack, sb.collective_at_one = True, True
+        got = run(sb)
+    finally:
+        dist.destroy_process_group()
+    assert len(calls) == 2                                              # one collective per Gauss-Newton step
+    first = envelope_structure(structure[0], structure[1], 1, P)
+    n_env = sum(36 * (b - first[b] + 1) for b in range(P - 1)) + 6 * (P - 1)
+    assert all(c == (torch.int64, n_env, "cuda") for c in calls), (calls, n_env)
+    assert n_env < (6 * (P - 1)) ** 2 // 2
+    assert torch.equal(got[0], plain[0]) and torch.equal(got[1], plain[1])
+    assert (plain[0] - s["poses"]).abs().max() > 1e-4                 # the BA did move the poses
