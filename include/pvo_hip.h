@@ -231,6 +231,8 @@ int pvo_gru_conv_candidate(const void* RN, const void* cf, int cf_channels, cons
 int pvo_conv3x3_heads(const void* x, const void* w1_taps, const float* bias1, const void* w2_frags, float* z,
                       int E, int H, int W, int dtype, void* stream);
 int pvo_heads_gather(const float* z, const float* bias2, void* y, int E, int H, int W, int dtype, void* stream);
+/* pvo_heads_out: SUPERSEDED by the pair above (round 2); not called by pvo_update_operator / pvo_graph_update.  Kept as a
+ * single-layer entry point for tests/test_update_operator.py, which checks the pair against it. */
 int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const float* bias2, void* y,
                   int E, int H, int W, int dtype, void* stream);
 /* y[E,H,W,128] = relu(conv7x7(x[E,H,W,8], zero padding 3) + bias): the first layer of the update operator's
@@ -242,6 +244,8 @@ int pvo_conv7x7_c8(const void* x, const void* w_taps, const float* bias, void* y
  * relu(conv3x3(relu(conv7x7(x[E,H,W,8]) + bias7), zero padding 1) + bias3); the 128-channel intermediate stays in LDS.
  * Bit-identical to pvo_conv7x7_c8 followed by pvo_conv3x3_c128(Cout = 64, relu = 1).  w7_taps as pvo_conv7x7_c8's,
  * w3_taps [9][64][128] as pvo_conv3x3_c128's; bias7 f32 [128], bias3 f32 [64] or NULL; ystride = 0: dense. */
+/* (pvo_flow_encoder: not the default inside the update - two kernels are faster there, PVO_FLOW_ENCODER_FUSED=1 selects it;
+ * an entry point of its own for callers that run the flow encoder alone, and for tests) */
 int pvo_flow_encoder(const void* x, const void* w7_taps, const float* bias7, const void* w3_taps, const float* bias3,
                      void* y, int E, int H, int W, int ystride, int yoff, int dtype, void* stream);
 /* y[rows,128] = relu(W corr + b) for an already sampled correlation tensor corr [rows,196] (channels-last, 8-byte aligned):
@@ -283,6 +287,8 @@ int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, l
  *                     10 (1-bin)); full_flow = coords1 + delta_dy - coords0; target_ba / weight_ba [E,2,H,W] are the
  *                     layouts pvo_ba reads                                                (:249-306)
  * target / delta_dy may alias the tensors pvo_graph_motion read. */
+/* (pvo_graph_motion: inside pvo_graph_update the motion features are written by pvo_reproject_motion since round 3; this
+ * entry point serves pvo_update_operator callers that reproject themselves, and tests) */
 int pvo_graph_motion(const float* target, const float* coords1, const float* delta_dy, const float* raw_mask,
                      void* motn, int E, int H, int W, int dtype, void* stream);
 int pvo_segment_hist(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
@@ -390,17 +396,6 @@ int pvo_probe_arm(int stage, int capacity);
 /* The same, sampling one occurrence in `every` (>= 1): the event pair costs the launch stream a few microseconds per occurrence. */
 int pvo_probe_arm_every(int stage, int capacity, int every);
 int pvo_probe_read(float* ms_host, int max_n);
-/* Shader-clock probe: one wave runs iters x 64 dependent v_fma_f32 and writes {s_memtime cycles, s_memrealtime ticks of
- * 10 ns, (unused)} to out3_u64 (device, 3 x uint64).  Launched on a second stream beside a kernel, cycles / (10 ns x
- * ticks) is the clock the chip sustains under that kernel's load (the MFMA-bound convolutions run at ~1.35 GHz on random
- * data, 2.1 GHz on zero-filled operands, 2.4 GHz idle: DESIGN.md section 5). */
-int pvo_clock_probe(void* out3_u64, int iters, void* stream);
-/* Memory-request probe (measurement): one launch of `blocks` x 256 lanes, each lane 8 x iters independent 16-byte loads from
- * `buf` (device, 128-byte aligned, `bytes` long; use >= 1 GiB so that neither L2 nor the Infinity Cache holds it) -
- * mode 0: consecutive 128-byte lines (streaming), 1: one RANDOM 128-byte line per 8 lanes, 2: one random 64-byte half line per
- * 4 lanes.  Returns the number of bytes the launch fetches (lines x line size), or -1; the caller times it.  The rate of mode 2
- * is the ceiling of the correlation lookup, whose traffic is scattered partial lines.  sink: >= 4 bytes. */
-long long pvo_mem_probe(const void* buf, size_t bytes, int mode, int iters, int blocks, void* sink, void* stream);
 int pvo_graph_update(const pvo_update_weights* weights, const pvo_graph_update_args* args,
                      void* workspace, size_t workspace_bytes, void* stream);
 

@@ -67,8 +67,6 @@ SIGNATURES = {
     "pvo_depth_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_reproject": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "pvo_ba_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "pvo_clock_probe": (_i, [_vp, _i, _vp]),
-    "pvo_mem_probe": (_c.c_longlong, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "pvo_ba": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                     _f, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -145,6 +143,29 @@ def load():
                                                                      ctypes.sizeof(GraphUpdateArgs)))
     _lib = lib
     return lib
+
+
+PROBE_LIB_PATH = os.path.join(_HERE, "libpvo_probe.so")
+PROBE_SIGNATURES = {                       # include/pvo_probe.h
+    "pvo_clock_probe": (_i, [_vp, _i, _vp]),
+    "pvo_mem_probe": (_c.c_longlong, [_vp, _sz, _i, _i, _i, _vp, _vp]),
+}
+_probe_lib = None
+
+
+def load_probe():
+    """libpvo_probe.so: the measurement kernels of bench.py / tools (not part of the product library)"""
+    global _probe_lib
+    if _probe_lib is None:
+        load()                                            # (torch's HIP runtime first, as above)
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise PvoHipError("libpvo_probe.so not found at %s - build it with `python -m pvo_amd.build`" % PROBE_LIB_PATH)
+        lib = ctypes.CDLL(PROBE_LIB_PATH)
+        for name, (res, args) in PROBE_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _probe_lib = lib
+    return _probe_lib
 
 
 def check(status, what):

@@ -12,6 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pvo_amd", "csrc")
 LIB = os.path.join(ROOT, "pvo_amd", "libpvo_hip.so")
+PROBE_LIB = os.path.join(ROOT, "pvo_amd", "libpvo_probe.so")      # measurement kernels (bench.py, tools/): csrc/probe_tools.hip
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libpvo_oracle.so")
 
@@ -113,6 +114,17 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+def build_probe(force=False):
+    """libpvo_probe.so: the shader-clock and memory-request probes, kept out of the product library"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, "probe_tools.hip")
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "pvo_probe.h"), os.path.join(ROOT, "include", "pvo_hip.h")]
+    if force or _stale(PROBE_LIB, deps, HIPCC_FLAGS):
+        _run([hipcc] + HIPCC_FLAGS + ["-shared", "-o", PROBE_LIB, src])
+        _stamp(PROBE_LIB, deps, HIPCC_FLAGS)
+    return PROBE_LIB
+
+
 def build_oracle(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in sorted(os.listdir(ORACLE_DIR)) if f.endswith(".c")]
     hdrs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".h")]
@@ -127,7 +139,9 @@ def build_oracle(force=False):
 
 
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_oracle(force)
+    lib = build_hip(force, verbose)
+    build_probe(force)
+    return lib, build_oracle(force)
 
 
 if __name__ == "__main__":

@@ -50,49 +50,13 @@ constexpr float kMinDepth = 0.25f;
 constexpr double kFix = 268435456.0, kInvFix = 1.0 / 268435456.0;
 __device__ __forceinline__ void fix_add(long long* sys, long long idx, double v, int* meta) {
   if (!(fabs(v) < 3.0e10)) { meta[4] = 1; return; }
-#ifdef PVO_ABL_NOATOMIC      // ablation build (tools/ba_ablate.sh): what do the atomics cost?  (results are wrong)
-  sys[idx] = __double2ll_rn(v * kFix);
-  return;
-#endif
   atomicAdd(reinterpret_cast<unsigned long long*>(sys + idx), static_cast<unsigned long long>(__double2ll_rn(v * kFix)));
 }
-#ifndef PVO_ASM_PPT
-#define PVO_ASM_PPT 2
-#endif
-constexpr int kPPT = PVO_ASM_PPT;       // pixels per thread in assemble
+constexpr int kPPT = 2;                 // pixels per thread in assemble (1: 432 workgroups, measured slower - profiles/r03_ba_ablation.txt)
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
 constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system lives DENSE in LDS (126*127*8 + 21*27*8 + 208 = 132.7 KB of the 143 KB the
                                         // solve kernel's static tables leave); beyond, the compact envelope form
 
-// tools/sched_bisect.py --build-fences: explicit agent-scope acquire at the start and release at the end of every BA kernel
-// (buffer_inv sc1 / buffer_wbl2 sc1), an experiment on where the cross-queue irreproducibility comes from
-#ifdef PVO_BA_FENCES
-#define BA_ACQ() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
-#define BA_REL() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
-#else
-#define BA_ACQ()
-#define BA_REL()
-#endif
-
-// Hand-off experiment (tools/sched_bisect.py --variant coh1|coh2): the rows one BA kernel stores and a later
-// one loads (level 1: Eii / Eij / Cii / bz / part; level 2: also Ei / Q / w / dx and the pose system's read + re-zero; level 3: also the assembly's per-pixel INPUTS) go
-// through agent-scope relaxed atomic stores / loads - `sc1` accesses that write through to, and read from, the device's
-// coherence point instead of relying on the L2 write-back / invalidate at the kernel boundary.
-#ifndef PVO_BA_COHERENT
-#define PVO_BA_COHERENT 0
-#endif
-#ifdef PVO_BA_COHERENT_ONLY_INPUTS
-#define PVO_BA_COH_ON(level) ((level) == 3)
-#else
-#define PVO_BA_COH_ON(level) (PVO_BA_COHERENT >= (level))
-#endif
-template <int LEVEL, typename T> __device__ __forceinline__ void st_h(T* p, T v) {
-  if (PVO_BA_COH_ON(LEVEL)) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
-template <int LEVEL, typename T> __device__ __forceinline__ T ld_h(const T* p) {
-  if (PVO_BA_COH_ON(LEVEL)) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
-}
 
 struct Plan {            // int region of the workspace
   int* kidx;             // [F]   frame -> depth index, -1 if none
@@ -332,7 +296,6 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   // In a depth BA (`part`) the chunk sums are stored instead and the Schur kernel, which follows anyway, adds them up per edge:
   // a sixth of the atomics, issued while its own work starts.
   __shared__ float red[4][90];
-  BA_ACQ();
 #ifdef PVO_SCHED_DEBUG
   if (g_dbg_log_ba && threadIdx.x == 0) {
     const unsigned long long i_ = atomicAdd(&g_dbg_log_ba[0], 1ull);
@@ -360,23 +323,20 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
     if (k < HW) {
       const int i = k / wd, j = k - i * wd;
       float eii[6], eij[6], cii, bzz;
-      pixel_terms(g, static_cast<float>(j), static_cast<float>(i), ld_h<3>(&d_i[k]), ld_h<3>(&tg[k]), ld_h<3>(&tg[HW + k]), ld_h<3>(&wg[k]), ld_h<3>(&wg[HW + k]),
+      pixel_terms(g, static_cast<float>(j), static_cast<float>(i), d_i[k], tg[k], tg[HW + k], wg[k], wg[HW + k],
                   h, vi, vj, eii, eij, cii, bzz);
       if (!motion_only) {
         const long long eb = static_cast<long long>(e) * 6 * HW + k;
 #pragma unroll
-        for (int n = 0; n < 6; ++n) { st_h<1>(&Eii[eb + static_cast<long long>(n) * HW], eii[n]); st_h<1>(&Eij[eb + static_cast<long long>(n) * HW], eij[n]); }
-        st_h<1>(&Cii[static_cast<long long>(e) * HW + k], cii);
-        st_h<1>(&bz[static_cast<long long>(e) * HW + k], bzz);
+        for (int n = 0; n < 6; ++n) { Eii[eb + static_cast<long long>(n) * HW] = eii[n]; Eij[eb + static_cast<long long>(n) * HW] = eij[n]; }
+        Cii[static_cast<long long>(e) * HW + k] = cii;
+        bz[static_cast<long long>(e) * HW + k] = bzz;
       }
     }
   }
   // 90 sums: wave shuffle reduce, 4 partials through LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-#ifdef PVO_ABL_NOREDUCE      // ablation build: what do the 90 wave reductions cost?  (results are wrong)
-  for (int l = 0; l < 78; ++l) { if (lane == 0) red[wave][l] = h[l]; }
-#else
   for (int l = 0; l < 78; ++l) {
     const float s = pvo_wave_sum(h[l]);
     if (lane == 0) red[wave][l] = s;
@@ -384,7 +344,6 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
     if (g_dbg_partials && lane == 0) g_dbg_partials[((static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 90 + l] = s;
 #endif
   }
-#endif
 #pragma unroll
   for (int n = 0; n < 6; ++n) {
     const float a = pvo_wave_sum(vi[n]), b = pvo_wave_sum(vj[n]);
@@ -400,10 +359,9 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   const int t = threadIdx.x;
   if (t < 90) {
     const float sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    if (part) st_h<1>(&part[(static_cast<long long>(e) * gridDim.x + blockIdx.x) * 90 + t], sum);      // summed per edge by the Schur kernel
+    if (part) part[(static_cast<long long>(e) * gridDim.x + blockIdx.x) * 90 + t] = sum;      // summed per edge by the Schur kernel
     else pose_block_scatter(t, static_cast<double>(sum), ix - t0, jx - t0, P, sys, meta);
   }
-  BA_REL();
 }
 
 // ---------------------------------------------------------------------------
@@ -441,20 +399,20 @@ __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const 
   float C = 0.0f, ww = 0.0f, ei[6] = {0, 0, 0, 0, 0, 0};
   for (int o = e0; o < e1; ++o) {
     const int e = pl.eidx[o];
-    C += ld_h<1>(&Cii[static_cast<long long>(e) * HW + x]);
-    ww += ld_h<1>(&bz[static_cast<long long>(e) * HW + x]);
+    C += Cii[static_cast<long long>(e) * HW + x];
+    ww += bz[static_cast<long long>(e) * HW + x];
     if (self_in) {
 #pragma unroll
-      for (int n = 0; n < 6; ++n) ei[n] += ld_h<1>(&Eii[(static_cast<long long>(e) * 6 + n) * HW + x]);
+      for (int n = 0; n < 6; ++n) ei[n] += Eii[(static_cast<long long>(e) * 6 + n) * HW + x];
     }
   }
   // K_eta == 1 broadcasts; a row-count mismatch is flagged in meta[2] and clamped here
   const float et = eta[static_cast<long long>(k < K_eta ? k : K_eta - 1) * HW + x];
-  st_h<2>(&Q[static_cast<long long>(k) * HW + x], 1.0f / (C + et));           // droid_kernels.cu:1376
-  st_h<2>(&w[static_cast<long long>(k) * HW + x], ww);
+  Q[static_cast<long long>(k) * HW + x] = 1.0f / (C + et);           // droid_kernels.cu:1376
+  w[static_cast<long long>(k) * HW + x] = ww;
   if (self_in) {
 #pragma unroll
-    for (int n = 0; n < 6; ++n) st_h<2>(&Ei[(static_cast<long long>(pself) * 6 + n) * HW + x], ei[n]);
+    for (int n = 0; n < 6; ++n) Ei[(static_cast<long long>(pself) * 6 + n) * HW + x] = ei[n];
   }
 }
 
@@ -470,10 +428,7 @@ __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const 
 // The reference enumerates (a,b,k) triples on the host and launches one 256-thread block per
 // triple with 36 LDS tree reductions each (schur_block :1201-1290, EEt6x6 :980-1035).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef PVO_SCHUR_PIX
-#define PVO_SCHUR_PIX 256      // 512: 48 workgroups at S-B, 19.9 us; 256: 96 workgroups, 18.1 us (tools/ba_ablate.sh)
-#endif
-constexpr int kSchurPix = PVO_SCHUR_PIX; // pixels per workgroup (a quarter per wave)
+constexpr int kSchurPix = 256;           // pixels per workgroup (a quarter per wave); 512: 48 workgroups at S-B, 19.9 us; 256: 96, 18.1 us
 constexpr int kSchurSteps = kSchurPix / 4 / 16;
 constexpr int kMaxRows = 1024;           // rows of M the LDS row table can describe
 constexpr int kFastTiles = 4;            // up to 4 row tiles (63 rows + w) accumulate in one pass
@@ -487,13 +442,6 @@ template <bool VEC4>
 __device__ __forceinline__ f32x4 load4(gfloat* __restrict__ row, int p, int HW) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (row == nullptr) return v;
-  if (PVO_BA_COH_ON(1)) {
-    if (p < HW) v.x = __hip_atomic_load(row + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p + 1 < HW) v.y = __hip_atomic_load(row + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p + 2 < HW) v.z = __hip_atomic_load(row + p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p + 3 < HW) v.w = __hip_atomic_load(row + p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
-  }
   if (VEC4) {
     if (p + 3 < HW) return *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(row + p);
   }
@@ -589,7 +537,7 @@ __device__ __forceinline__ void ba_schur_body(
     const int nwg = gridDim.x * gridDim.y;
     for (int e = blockIdx.y * gridDim.x + blockIdx.x; e < E; e += nwg) {
       double val = 0.0;
-      for (int c = 0; c < chunksA; ++c) val += static_cast<double>(ld_h<1>(&part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]));
+      for (int c = 0; c < chunksA; ++c) val += static_cast<double>(part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]);
       pose_block_scatter(threadIdx.x, val, static_cast<int>(ii[e]) - t0, static_cast<int>(jj[e]) - t0, P, sys, pl.meta);
     }
   }
@@ -670,9 +618,7 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
     int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA) {
-  BA_ACQ();
   ba_schur_body<VEC4>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA);
-  BA_REL();
 }
 
 // ---------------------------------------------------------------------------
@@ -1531,7 +1477,6 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
   __shared__ unsigned short act_rows[2][kMaxActiveRows];                         // lists of a step's active block rows (wave / pipe solvers)
   __shared__ PipeCtl pipe_ctl;
   __shared__ int blocks_s;
-  BA_ACQ();
   BA_PROBE(0);
   if (threadIdx.x == 0) {
     fail = 0;
@@ -1614,14 +1559,14 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = base + u * blockDim.x + threadIdx.x;
-        raw[u] = idx < N ? ld_h<2>(&sys[idx]) : 0;
+        raw[u] = idx < N ? sys[idx] : 0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = base + u * blockDim.x + threadIdx.x;
         if (idx >= N) continue;
         double v = static_cast<double>(raw[u]) * kInvFix;       // fixed point -> fp64
-        st_h<2>(&sys[idx], 0LL);                                // ready for the next Gauss-Newton step's accumulation
+        sys[idx] = 0LL;                                // ready for the next Gauss-Newton step's accumulation
         if (idx < n * n) {
           const int r = idx / n, c = idx - r * n;
           if (r == c) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
@@ -1644,7 +1589,7 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
   const int failed = fail | meta[4];
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
     const float v = failed ? 0.0f : static_cast<float>(xrow[idx]);    // zeros on failure (:1186-1189)
-    st_h<2>(&dx_ws[idx], v);
+    dx_ws[idx] = v;
     if (dx_out) dx_out[idx] = v;
   }
   __syncthreads();
@@ -1664,7 +1609,6 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
     if (failed) meta[1] = 1;
     if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
   }
-  BA_REL();
 }
 
 // ---------------------------------------------------------------------------
@@ -1694,10 +1638,10 @@ __device__ __forceinline__ void ba_backsub_body(
     if (R.pose < lo) continue;
     float s = 0.0f;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) s += ld_h<2>(&R.base[static_cast<long long>(n) * HW + x]) * ld_h<2>(&dx[6 * R.pose + n]);
+    for (int n = 0; n < 6; ++n) s += R.base[static_cast<long long>(n) * HW + x] * dx[6 * R.pose + n];
     acc += s;
   }
-  const float dz = ld_h<2>(&Q[static_cast<long long>(k) * HW + x]) * (ld_h<2>(&w[static_cast<long long>(k) * HW + x]) - acc);
+  const float dz = Q[static_cast<long long>(k) * HW + x] * (w[static_cast<long long>(k) * HW + x] - acc);
   float d = disps[static_cast<long long>(pl.kx[k]) * HW + x] + dz;  // disp_retr_kernel (:912-925)
   if (pl.kx[k] < clamp_frames && d < disp_min) d = disp_min;
   disps[static_cast<long long>(pl.kx[k]) * HW + x] = d;
@@ -1709,9 +1653,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(
     const float* __restrict__ Q, const float* __restrict__ w, const float* __restrict__ dx,
     float* __restrict__ disps, float* __restrict__ dz_out, int dz_rows, int HW, int t0, int P, int flags,
     int clamp_frames, float disp_min) {
-  BA_ACQ();
   ba_backsub_body(pl, jj, Ei, Eij, Q, w, dx, disps, dz_out, dz_rows, HW, t0, P, flags, clamp_frames, disp_min);
-  BA_REL();
 }
 
 int check_common(int E, int F, int ht, int wd, int t0, int t1) {

@@ -69,10 +69,6 @@ __device__ __forceinline__ float pvo_dpp_step(float v) {
   return v + __int_as_float(moved);
 }
 __device__ __forceinline__ float pvo_wave_sum(float v) {
-#ifdef PVO_WAVE_SUM_SHFL        // experiment (tools/sched_bisect.py --variant shfl): the same sum through ds_bpermute, no DPP / v_readlane
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-  return v;
-#endif
   v = pvo_dpp_step<0xB1>(v);    // quad_perm [1,0,3,2]
   v = pvo_dpp_step<0x4E>(v);    // quad_perm [2,3,0,1]
   v = pvo_dpp_step<0x141>(v);   // row_half_mirror

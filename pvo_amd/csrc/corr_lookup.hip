@@ -209,11 +209,7 @@ __device__ unsigned long long* g_lk_probe = nullptr;
 #define LK_PROBE(slot)
 #endif
 
-#if defined(PVO_LK_ABL) && PVO_LK_ABL == 3      // ablation: no workgroup barriers in the fused path (wrong results): how much do they couple the waves?
-#define LK_SYNC() do { } while (0)
-#else
 #define LK_SYNC() __syncthreads()
-#endif
 
 template <typename T, bool TILED, bool ENC>
 __device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
@@ -263,11 +259,7 @@ __device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
         if (l < a.nlev) {
           const LookupLevel L = a.lv[l];
           const int ixp = pvo_floor_to_int(x0 * L.scale) - 3, iyp = pvo_floor_to_int(y0 * L.scale) - 3 + row;
-#if defined(PVO_LK_ABL) && PVO_LK_ABL == 2      // ablation (tools/lookup_ablate.py): no volume loads - what do arithmetic + encoder + stores cost?
-          RA[l] = lk_u32x4{static_cast<uint32_t>(tid) * 0x3c003c00u, 0x3c003800u, 0x38003c00u, 0x3c003c00u}; RB[l] = RA[l];
-#else
           tiled_issue(reinterpret_cast<const uint16_t*>(L.vol), plane * L.plane_elems, L.tw, L.h2, iyp, ixp, RA[l], RB[l]);
-#endif
         }
       }
     }
@@ -306,11 +298,6 @@ __device__ __forceinline__ void corr_lookup_r3_body(const LookupArgs& a) {
           tiled_finish(RA[l], RB[l], ix, u);
         else
           fetch_row8_16(reinterpret_cast<const uint16_t*>(L.vol), g, L.total, mask, u);
-#if defined(PVO_LK_ABL) && PVO_LK_ABL == 1      // ablation: loads only - the bilinear arithmetic and its LDS stores replaced by one store per lane
-        if (row < 7) reinterpret_cast<uint16_t*>(stage)[(ENC || a.out_channels_last) ? p * cl_stride + l * 49 + row : (l * 49 + row) * kStripPad + p] =
-            static_cast<uint16_t>((u[0] ^ u[1] ^ u[2] ^ u[3]) & 0x3fffu);
-        continue;
-#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) un[k] = next_lane(u[k]);
         u[4] = 0u; un[4] = 0u;

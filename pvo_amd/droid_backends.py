@@ -1216,7 +1216,7 @@ def clock_probe(stream, iters=20000):
         # (allocated ON `stream`: a block the caching allocator recycles for the current stream may still be in use by
         # kernels queued there, which is only safe for work ordered behind them)
         out = torch.zeros(3, dtype=torch.int64, device=dev)
-        check(_lib.load().pvo_clock_probe(_ptr(out), int(iters), ctypes.c_void_p(stream.cuda_stream)), "clock_probe")
+        check(_lib.load_probe().pvo_clock_probe(_ptr(out), int(iters), ctypes.c_void_p(stream.cuda_stream)), "clock_probe")
     return out
 
 
@@ -1226,7 +1226,7 @@ def mem_probe_gbps(device, nbytes=1 << 30, iters=16, blocks=8192, reps=5):
     dev = torch.device(device)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
-    lib, out = _lib.load(), {}
+    lib, out = _lib.load_probe(), {}
     with torch.cuda.device(dev):
         for name, mode in (("streaming_128B", 0), ("random_128B", 1), ("random_64B", 2)):
             run = lambda: lib.pvo_mem_probe(_ptr(buf), nbytes, mode, iters, blocks, _ptr(sink), _stream(dev))

@@ -27,6 +27,22 @@ def test_library_exports_every_declared_function():
     assert not missing, missing
 
 
+def test_probe_library_exports_its_header_and_the_product_library_has_no_measurement_kernels():
+    """include/pvo_probe.h <-> libpvo_probe.so <-> _lib.PROBE_SIGNATURES; and libpvo_hip.so exports none of them"""
+    import ctypes
+    from pvo_amd import _lib, build
+    text = open(os.path.join(ROOT, "include", "pvo_probe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(pvo_\w+)\s*\(", text))
+    assert declared == set(_lib.PROBE_SIGNATURES) == {"pvo_clock_probe", "pvo_mem_probe"}
+    build.build_probe()
+    probe = ctypes.CDLL(build.PROBE_LIB)
+    product = ctypes.CDLL(build.LIB)
+    for name in declared:
+        getattr(probe, name)
+        assert not hasattr(product, name), name
+
+
 def test_ctypes_mirror_covers_the_header():
     from pvo_amd import _lib
     declared = set(_declared())
@@ -81,7 +97,8 @@ def test_built_library_has_no_packed_fp32_instructions(tmp_path):
     blob = fat.read_bytes()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
-    assert len(starts) == len(build.HIP_SOURCES), (len(starts), len(build.HIP_SOURCES))      # one bundle per translation unit
+    with_kernels = [f for f in build.HIP_SOURCES if "__global__" in open(os.path.join(build.CSRC, f)).read()]
+    assert len(starts) == len(with_kernels), (len(starts), len(with_kernels))                 # one bundle per translation unit that has device code
     seen_mfma = 0
     for k, lo in enumerate(starts):
         hi = starts[k + 1] if k + 1 < len(starts) else len(blob)

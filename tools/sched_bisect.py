@@ -16,26 +16,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROBE_DIR = os.path.join(ROOT, "tools", "_probe")
-FENCES = "--build-fences" in sys.argv or os.environ.get("PVO_BA_FENCES") == "1"
-# --variant coh1 | coh2 (or PVO_SCHED_VARIANT): the BA's hand-off rows through agent-scope (sc1) stores / loads (ba.hip, PVO_BA_COHERENT)
+# --variant pk (or PVO_SCHED_VARIANT=pk): the library built WITH packed-FP32 VALU instructions, i.e. as it was before round 4 -
+# the build in which arrangements 1 / 2 / 7 / 9 differ from run to run (profiles/r04_coresidency.md).  Default: the shipped flags.
+# (Round 4 also had variants with agent-scope loads / stores of the BA's buffers, explicit fences and a ds_bpermute wave sum; their
+# switches are gone from the sources, their results are in that file.)
 VARIANT = os.environ.get("PVO_SCHED_VARIANT", "")
 for k, a_ in enumerate(sys.argv):
     if a_ == "--variant":
         VARIANT = sys.argv[k + 1]
         del sys.argv[k:k + 2]
         break
-VDEF = {"": [], "coh1": ["-DPVO_BA_COHERENT=1"], "coh2": ["-DPVO_BA_COHERENT=2"], "coh3": ["-DPVO_BA_COHERENT=3"], "shfl": ["-DPVO_WAVE_SUM_SHFL"], "nopk": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"], "in3": ["-DPVO_BA_COHERENT=3", "-DPVO_BA_COHERENT_ONLY_INPUTS"]}[VARIANT]
-PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_sched_fences.so" if FENCES else "libpvo_hip_sched%s.so" % (("_" + VARIANT) if VARIANT else ""))
-if "--build" in sys.argv or "--build-fences" in sys.argv:
+assert VARIANT in ("", "pk")
+PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_sched%s.so" % (("_" + VARIANT) if VARIANT else ""))
+if "--build" in sys.argv:
     from pvo_amd import build
     build.build_hip()
     os.makedirs(PROBE_DIR, exist_ok=True)
+    flags = [f for f in build.HIPCC_FLAGS]
+    if VARIANT == "pk":
+        k = flags.index(build.NO_PACKED_FP32[0])
+        del flags[k:k + len(build.NO_PACKED_FP32)]
     objs = []
     for s in build.HIP_SOURCES:
-        if s in ("update_exec.hip", "ba.hip", "graph_glue.hip"):
-            obj = os.path.join(PROBE_DIR, ("schedf_" if FENCES else "sched%s_" % VARIANT) + s.replace(".hip", ".o"))
-            subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_SCHED_DEBUG"] + VDEF + (["-DPVO_BA_FENCES"] if FENCES else []) +
-                                  ["-c", os.path.join(build.CSRC, s), "-o", obj])
+        if s in ("update_exec.hip", "ba.hip", "graph_glue.hip") or VARIANT == "pk":
+            obj = os.path.join(PROBE_DIR, "sched%s_" % VARIANT + s.replace(".hip", ".o"))
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + (["-DPVO_SCHED_DEBUG"] if s in ("update_exec.hip", "ba.hip", "graph_glue.hip") else []) +
+                                  ["-c", os.path.join(build.CSRC, s), "-o", obj], stderr=subprocess.DEVNULL)
         else:
             obj = os.path.join(build.CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
