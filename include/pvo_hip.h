@@ -462,6 +462,14 @@ int pvo_reproject_motion(const float* poses, const float* disps, const float* in
 int pvo_se3_unary(int op, const void* x, void* y, long long n, int dtype, void* stream);
 int pvo_se3_binary(int op, const void* a, long long rep_a, const void* b, long long rep_b, void* y, long long n,
                    int dtype, void* stream);
+/* Backward of the two (round 4; lietorch's counterpart: the *_backward kernels of lietorch_gpu.cu): vector-Jacobian products in the
+ * operands' own coordinates, i.e. what autograd gives for the formulas - se3_ops.hip evaluates its forward templates on dual numbers.
+ *   pvo_se3_unary_vjp : gx [n, in] from gy [n, out] (in / out as pvo_se3_unary)
+ *   pvo_se3_binary_vjp: ga [n,7] and gb [n, size of b's element] PER OUTPUT ELEMENT i (which read a[i / rep_a], b[i / rep_b]); either
+ *                       may be NULL; the caller sums them over the repeats of a broadcast operand. */
+int pvo_se3_unary_vjp(int op, const void* x, const void* gy, void* gx, long long n, int dtype, void* stream);
+int pvo_se3_binary_vjp(int op, const void* a, long long rep_a, const void* b, long long rep_b, const void* gy,
+                       void* ga, void* gb, long long n, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Dense bundle adjustment                                                    */

@@ -4,9 +4,16 @@
 // group maths lietorch/include/se3.h:36-56,84-86,124-142, so3.h:55-60,115-208, EPS = 1e-6 common.h:7): one thread per group
 // element, fp32 and fp64.  lietorch broadcasts by MATERIALISING the pose once per pixel (`broadcast_inputs` -> .repeat,
 // broadcasting.py:27-29); here an operand with fewer elements is indexed i / rep (a pose per edge acting on H*W points),
-// so nothing is copied.  Forward only: autograd goes through the PyTorch formulation in pvo_amd/geom/se3.py.
+// so nothing is copied.
+// Backward (round 4; lietorch: hand-written backward kernels, lietorch_gpu.cu:21-296 / groups.py:141-178): pvo_se3_vjp, the
+// vector-Jacobian product of every operation in AMBIENT coordinates (the 7 / 6 / 4 / 3 numbers of each operand) - what
+// torch.autograd computes for the PyTorch formulation of the same formulas in pvo_amd/geom/se3.py, which stays the reference
+// the kernels are tested against.  Not derived by hand: the forward templates below are instantiated with a forward-mode dual
+// number and evaluated once per input component (at most 14 evaluations of a few dozen flops; the operations are launch- and
+// memory-bound), so a derivative can only be wrong if the forward formula is.
 //   data layout [n,7] = (tx,ty,tz, qx,qy,qz,qw); tangent (tau, phi).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -28,6 +35,33 @@ template <typename F> __device__ __forceinline__ Q4<F> qmul(Q4<F> a, Q4<F> b) {
           a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
 }
 template <typename F> __device__ __forceinline__ Q4<F> qconj(Q4<F> q) { return {-q.x, -q.y, -q.z, q.w}; }
+
+// forward-mode dual number over F (value, derivative along ONE seeded input direction)
+template <typename F> struct Dual {
+  F v, d;
+  __device__ __forceinline__ Dual() : v(0), d(0) {}
+  __device__ __forceinline__ Dual(F v_) : v(v_), d(0) {}
+  __device__ __forceinline__ Dual(F v_, F d_) : v(v_), d(d_) {}
+  template <typename C, typename = typename std::enable_if<std::is_arithmetic<C>::value && !std::is_same<C, F>::value>::type>
+  __device__ __forceinline__ explicit Dual(C c) : v(static_cast<F>(c)), d(0) {}      // literals: F(2), F(0.5), F(kEps)
+};
+template <typename F> struct ScalarOf { using type = F; };
+template <typename F> struct ScalarOf<Dual<F>> { using type = F; };
+using ::sqrt; using ::sin; using ::cos; using ::atan; using ::fabs;      // (the overloads below must not hide the float / double ones)
+#define DU __device__ __forceinline__
+template <typename F> DU Dual<F> operator+(Dual<F> a, Dual<F> b) { return {a.v + b.v, a.d + b.d}; }
+template <typename F> DU Dual<F> operator-(Dual<F> a, Dual<F> b) { return {a.v - b.v, a.d - b.d}; }
+template <typename F> DU Dual<F> operator-(Dual<F> a) { return {-a.v, -a.d}; }
+template <typename F> DU Dual<F> operator*(Dual<F> a, Dual<F> b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+template <typename F> DU Dual<F> operator/(Dual<F> a, Dual<F> b) { const F q = a.v / b.v; return {q, (a.d - q * b.d) / b.v}; }
+template <typename F> DU bool operator<(Dual<F> a, Dual<F> b) { return a.v < b.v; }
+template <typename F> DU bool operator>(Dual<F> a, Dual<F> b) { return a.v > b.v; }
+template <typename F> DU Dual<F> sqrt(Dual<F> a) { const F r = sqrt(a.v); return {r, a.d / (F(2) * r)}; }
+template <typename F> DU Dual<F> sin(Dual<F> a) { return {sin(a.v), cos(a.v) * a.d}; }
+template <typename F> DU Dual<F> cos(Dual<F> a) { return {cos(a.v), -sin(a.v) * a.d}; }
+template <typename F> DU Dual<F> atan(Dual<F> a) { return {atan(a.v), a.d / (F(1) + a.v * a.v)}; }
+template <typename F> DU Dual<F> fabs(Dual<F> a) { return a.v < F(0) ? Dual<F>{-a.v, -a.d} : a; }
+#undef DU
 
 constexpr double kEps = 1e-6;
 enum { OP_EXP = 0, OP_LOG = 1, OP_INV = 2, OP_MUL = 3, OP_ACT4 = 4, OP_ACT3 = 5, OP_ADJ = 6, OP_ADJT = 7 };
@@ -67,6 +101,83 @@ template <typename F> __device__ __forceinline__ void se3_log(const F* g, F* out
   out[3] = phi.x; out[4] = phi.y; out[5] = phi.z;
 }
 
+// ---- the remaining operations as templates over the scalar (F or Dual<F>): inputs / outputs as small arrays ----------------
+template <typename F> __device__ __forceinline__ void se3_inv(const F* g, F* out) {
+  const V3<F> t = {g[0], g[1], g[2]};
+  const Q4<F> qi = qconj(Q4<F>{g[3], g[4], g[5], g[6]});
+  const V3<F> r = qrot(qi, t);
+  out[0] = -r.x; out[1] = -r.y; out[2] = -r.z; out[3] = qi.x; out[4] = qi.y; out[5] = qi.z; out[6] = qi.w;
+}
+// op in {MUL, ACT4, ACT3, ADJ, ADJT}: g [7] group element, x the second operand ([7] / [4] / [3] / [6]), out [7] / [4] / [3] / [6]
+template <typename F> __device__ __forceinline__ void se3_bin(int op, const F* g, const F* x, F* out) {
+  const V3<F> t = {g[0], g[1], g[2]};
+  const Q4<F> q = {g[3], g[4], g[5], g[6]};
+  if (op == OP_MUL) {
+    const V3<F> r = qrot(q, V3<F>{x[0], x[1], x[2]});
+    const Q4<F> qq = qmul(q, Q4<F>{x[3], x[4], x[5], x[6]});
+    out[0] = t.x + r.x; out[1] = t.y + r.y; out[2] = t.z + r.z; out[3] = qq.x; out[4] = qq.y; out[5] = qq.z; out[6] = qq.w;
+  } else if (op == OP_ACT4) {
+    const V3<F> r = qrot(q, V3<F>{x[0], x[1], x[2]});
+    out[0] = r.x + t.x * x[3]; out[1] = r.y + t.y * x[3]; out[2] = r.z + t.z * x[3]; out[3] = x[3];
+  } else if (op == OP_ACT3) {
+    const V3<F> r = qrot(q, V3<F>{x[0], x[1], x[2]});
+    out[0] = r.x + t.x; out[1] = r.y + t.y; out[2] = r.z + t.z;
+  } else if (op == OP_ADJ) {
+    const V3<F> rphi = qrot(q, V3<F>{x[3], x[4], x[5]}), rt = qrot(q, V3<F>{x[0], x[1], x[2]}), c = cross(t, rphi);
+    out[0] = rt.x + c.x; out[1] = rt.y + c.y; out[2] = rt.z + c.z; out[3] = rphi.x; out[4] = rphi.y; out[5] = rphi.z;
+  } else {                                         // adjT
+    const Q4<F> qi = qconj(q);
+    const V3<F> at = {x[0], x[1], x[2]};
+    const V3<F> r0 = qrot(qi, at), r1 = qrot(qi, V3<F>{x[3], x[4], x[5]}), r2 = qrot(qi, cross(at, t));
+    out[0] = r0.x; out[1] = r0.y; out[2] = r0.z; out[3] = r1.x + r2.x; out[4] = r1.y + r2.y; out[5] = r1.z + r2.z;
+  }
+}
+__host__ __device__ __forceinline__ int se3_nb(int op) { return op == OP_MUL ? 7 : (op == OP_ACT4 ? 4 : (op == OP_ACT3 ? 3 : 6)); }      // second operand = output size
+__host__ __device__ __forceinline__ int se3_nin(int op) { return op == OP_EXP ? 6 : 7; }
+__host__ __device__ __forceinline__ int se3_nout(int op) { return op == OP_EXP ? 7 : (op == OP_LOG ? 6 : 7); }
+
+// Vector-Jacobian products.  Unary: gx[i, :] = gy[i, :] . d op(x[i]) / dx.  Binary: the per-ELEMENT products ga [n,7] and gb [n,nb]
+// (element i reads a[i / rep_a], b[i / rep_b] as in the forward kernel); the caller sums ga / gb over the repeats of a broadcast
+// operand.  One forward evaluation on dual numbers per input component.
+template <typename F>
+__global__ __launch_bounds__(256) void se3_unary_vjp_kernel(int op, const F* __restrict__ x, const F* __restrict__ gy, F* __restrict__ gx, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int ni = se3_nin(op), no = se3_nout(op);
+  F xv[7], g[7];
+  for (int k = 0; k < ni; ++k) xv[k] = x[i * ni + k];
+  for (int k = 0; k < no; ++k) g[k] = gy[i * no + k];
+#pragma unroll 1
+  for (int j = 0; j < ni; ++j) {
+    Dual<F> in[7], out[7];
+    for (int k = 0; k < 7; ++k) in[k] = Dual<F>(k < ni ? xv[k] : F(0), k == j ? F(1) : F(0));
+    if (op == OP_EXP) se3_exp(in, out); else if (op == OP_LOG) se3_log(in, out); else se3_inv(in, out);
+    F acc = 0;
+    for (int k = 0; k < no; ++k) acc += g[k] * out[k].d;
+    gx[i * ni + j] = acc;
+  }
+}
+template <typename F>
+__global__ __launch_bounds__(256) void se3_binary_vjp_kernel(int op, const F* __restrict__ a, long long rep_a, const F* __restrict__ b, long long rep_b,
+                                                             const F* __restrict__ gy, F* __restrict__ ga, F* __restrict__ gb, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int nb = se3_nb(op);
+  F av[7], bv[7], g[7];
+  for (int k = 0; k < 7; ++k) av[k] = a[(i / rep_a) * 7 + k];
+  for (int k = 0; k < nb; ++k) { bv[k] = b[(i / rep_b) * nb + k]; g[k] = gy[i * nb + k]; }
+#pragma unroll 1
+  for (int j = 0; j < 7 + nb; ++j) {
+    Dual<F> A[7], B[7], out[7];
+    for (int k = 0; k < 7; ++k) A[k] = Dual<F>(av[k], k == j ? F(1) : F(0));
+    for (int k = 0; k < 7; ++k) B[k] = Dual<F>(k < nb ? bv[k] : F(0), k + 7 == j ? F(1) : F(0));
+    se3_bin(op, A, B, out);
+    F acc = 0;
+    for (int k = 0; k < nb; ++k) acc += g[k] * out[k].d;
+    if (j < 7) { if (ga) ga[i * 7 + j] = acc; } else if (gb) gb[i * nb + (j - 7)] = acc;
+  }
+}
+
 template <typename F>
 __global__ __launch_bounds__(256) void se3_unary_kernel(int op, const F* __restrict__ x, F* __restrict__ y, long long n) {
   const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
@@ -86,11 +197,12 @@ __global__ __launch_bounds__(256) void se3_unary_kernel(int op, const F* __restr
 #pragma unroll
     for (int k = 0; k < 6; ++k) y[i * 6 + k] = o[k];
   } else {                                         // inverse
-    const V3<F> t = {x[i * 7], x[i * 7 + 1], x[i * 7 + 2]};
-    const Q4<F> qi = qconj(Q4<F>{x[i * 7 + 3], x[i * 7 + 4], x[i * 7 + 5], x[i * 7 + 6]});
-    const V3<F> r = qrot(qi, t);
-    y[i * 7] = -r.x; y[i * 7 + 1] = -r.y; y[i * 7 + 2] = -r.z;
-    y[i * 7 + 3] = qi.x; y[i * 7 + 4] = qi.y; y[i * 7 + 5] = qi.z; y[i * 7 + 6] = qi.w;
+    F g[7], o[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) g[k] = x[i * 7 + k];
+    se3_inv(g, o);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) y[i * 7 + k] = o[k];
   }
 }
 
@@ -100,37 +212,12 @@ __global__ __launch_bounds__(256) void se3_binary_kernel(int op, const F* __rest
                                                          long long rep_b, F* __restrict__ y, long long n) {
   const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
-  const F* g = a + (i / rep_a) * 7;
-  const V3<F> t = {g[0], g[1], g[2]};
-  const Q4<F> q = {g[3], g[4], g[5], g[6]};
-  const long long ib = i / rep_b;
-  if (op == OP_MUL) {
-    const F* h = b + ib * 7;
-    const V3<F> r = qrot(q, V3<F>{h[0], h[1], h[2]});
-    const Q4<F> qq = qmul(q, Q4<F>{h[3], h[4], h[5], h[6]});
-    y[i * 7] = t.x + r.x; y[i * 7 + 1] = t.y + r.y; y[i * 7 + 2] = t.z + r.z;
-    y[i * 7 + 3] = qq.x; y[i * 7 + 4] = qq.y; y[i * 7 + 5] = qq.z; y[i * 7 + 6] = qq.w;
-  } else if (op == OP_ACT4) {
-    const F* p = b + ib * 4;
-    const V3<F> r = qrot(q, V3<F>{p[0], p[1], p[2]});
-    y[i * 4] = r.x + t.x * p[3]; y[i * 4 + 1] = r.y + t.y * p[3]; y[i * 4 + 2] = r.z + t.z * p[3]; y[i * 4 + 3] = p[3];
-  } else if (op == OP_ACT3) {
-    const F* p = b + ib * 3;
-    const V3<F> r = qrot(q, V3<F>{p[0], p[1], p[2]});
-    y[i * 3] = r.x + t.x; y[i * 3 + 1] = r.y + t.y; y[i * 3 + 2] = r.z + t.z;
-  } else if (op == OP_ADJ) {
-    const F* x = b + ib * 6;
-    const V3<F> rphi = qrot(q, V3<F>{x[3], x[4], x[5]}), rt = qrot(q, V3<F>{x[0], x[1], x[2]}), c = cross(t, rphi);
-    y[i * 6] = rt.x + c.x; y[i * 6 + 1] = rt.y + c.y; y[i * 6 + 2] = rt.z + c.z;
-    y[i * 6 + 3] = rphi.x; y[i * 6 + 4] = rphi.y; y[i * 6 + 5] = rphi.z;
-  } else {                                         // adjT
-    const F* x = b + ib * 6;
-    const Q4<F> qi = qconj(q);
-    const V3<F> at = {x[0], x[1], x[2]};
-    const V3<F> r0 = qrot(qi, at), r1 = qrot(qi, V3<F>{x[3], x[4], x[5]}), r2 = qrot(qi, cross(at, t));
-    y[i * 6] = r0.x; y[i * 6 + 1] = r0.y; y[i * 6 + 2] = r0.z;
-    y[i * 6 + 3] = r1.x + r2.x; y[i * 6 + 4] = r1.y + r2.y; y[i * 6 + 5] = r1.z + r2.z;
-  }
+  const int nb = se3_nb(op);
+  F g[7], x[7], o[7];
+  for (int k = 0; k < 7; ++k) g[k] = a[(i / rep_a) * 7 + k];
+  for (int k = 0; k < nb; ++k) x[k] = b[(i / rep_b) * nb + k];
+  se3_bin(op, g, x, o);
+  for (int k = 0; k < nb; ++k) y[i * nb + k] = o[k];
 }
 
 }  // namespace
@@ -161,6 +248,40 @@ extern "C" int pvo_se3_binary(int op, const void* a, long long rep_a, const void
   else if (dtype == PVO_F64)
     hipLaunchKernelGGL(se3_binary_kernel<double>, grid, dim3(256), 0, pvo_stream(stream), op, static_cast<const double*>(a), rep_a,
                        static_cast<const double*>(b), rep_b, static_cast<double*>(y), n);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+// Backward of pvo_se3_unary / pvo_se3_binary (ambient-coordinate vector-Jacobian products; see the head of this file).
+//   unary : gx [n, in] = gy [n, out] . J          binary: ga [n,7], gb [n,nb] PER OUTPUT ELEMENT (either may be NULL); the caller sums
+//   them over the `rep` repeats of a broadcast operand (element i belongs to a[i / rep_a], b[i / rep_b]).
+extern "C" int pvo_se3_unary_vjp(int op, const void* x, const void* gy, void* gx, long long n, int dtype, void* stream) {
+  if (n < 0 || op < OP_EXP || op > OP_INV) return PVO_EINVAL;
+  if (n == 0) return PVO_OK;
+  if (!x || !gy || !gx) return PVO_EINVAL;
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256));
+  if (dtype == PVO_F32)
+    hipLaunchKernelGGL(se3_unary_vjp_kernel<float>, grid, dim3(256), 0, pvo_stream(stream), op, static_cast<const float*>(x), static_cast<const float*>(gy), static_cast<float*>(gx), n);
+  else if (dtype == PVO_F64)
+    hipLaunchKernelGGL(se3_unary_vjp_kernel<double>, grid, dim3(256), 0, pvo_stream(stream), op, static_cast<const double*>(x), static_cast<const double*>(gy), static_cast<double*>(gx), n);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_se3_binary_vjp(int op, const void* a, long long rep_a, const void* b, long long rep_b, const void* gy,
+                                  void* ga, void* gb, long long n, int dtype, void* stream) {
+  if (n < 0 || op < OP_MUL || op > OP_ADJT || rep_a <= 0 || rep_b <= 0) return PVO_EINVAL;
+  if (n == 0) return PVO_OK;
+  if (!a || !b || !gy || (!ga && !gb)) return PVO_EINVAL;
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256));
+  if (dtype == PVO_F32)
+    hipLaunchKernelGGL(se3_binary_vjp_kernel<float>, grid, dim3(256), 0, pvo_stream(stream), op, static_cast<const float*>(a), rep_a, static_cast<const float*>(b), rep_b,
+                       static_cast<const float*>(gy), static_cast<float*>(ga), static_cast<float*>(gb), n);
+  else if (dtype == PVO_F64)
+    hipLaunchKernelGGL(se3_binary_vjp_kernel<double>, grid, dim3(256), 0, pvo_stream(stream), op, static_cast<const double*>(a), rep_a, static_cast<const double*>(b), rep_b,
+                       static_cast<const double*>(gy), static_cast<double*>(ga), static_cast<double*>(gb), n);
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;

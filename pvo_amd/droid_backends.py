@@ -1188,6 +1188,35 @@ def se3_binary(op, a, rep_a, b, rep_b, out_batch):
     return y
 
 
+def se3_unary_vjp(op, x, gy):
+    """gx of se3_unary(op, x) for the output gradient gy (ambient coordinates)"""
+    dev = _dev(x, gy)
+    _contig(x, "x"); _contig(gy, "gy")
+    n = x.numel() // x.shape[-1]
+    gx = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_se3_unary_vjp(SE3_OPS[op], _ptr(x), _ptr(gy), _ptr(gx), n, _DT[x.dtype], _stream(dev)), "se3_%s_vjp" % op)
+    return gx
+
+
+def se3_binary_vjp(op, a, rep_a, b, rep_b, gy, need_a=True, need_b=True):
+    """(ga, gb) of se3_binary for the output gradient gy, summed over the repeats of a broadcast operand"""
+    dev = _dev(a, b, gy)
+    _contig(a, "a"); _contig(b, "b"); _contig(gy, "gy")
+    nb = _SE3_OUT[op]
+    n = gy.numel() // nb
+    ga = torch.empty((n, 7), dtype=a.dtype, device=dev) if need_a else None
+    gb = torch.empty((n, nb), dtype=a.dtype, device=dev) if need_b else None
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_se3_binary_vjp(SE3_OPS[op], _ptr(a), int(rep_a), _ptr(b), int(rep_b), _ptr(gy), _vp(ga), _vp(gb), n,
+                                             _DT[a.dtype], _stream(dev)), "se3_%s_vjp" % op)
+    if ga is not None:
+        ga = (ga.view(-1, int(rep_a), 7).sum(1) if rep_a > 1 else ga).view(a.shape)
+    if gb is not None:
+        gb = (gb.view(-1, int(rep_b), nb).sum(1) if rep_b > 1 else gb).view(b.shape)
+    return ga, gb
+
+
 STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4, "empty": 5}
 
 

@@ -7,10 +7,13 @@ acts on homogeneous points [..., 4]; `inv`, `adjT`, `exp`, `log`, `retr`.
 
 True broadcasting is used (lietorch materialises the pose once per pixel with
 `.repeat`, broadcasting.py:27-29).  Two implementations of the same formulas:
-  * on the GPU, when no operand needs a gradient: ONE fused HIP kernel per operation
-    (pvo_amd/csrc/se3_ops.hip, `pvo_se3_unary/_binary`; lietorch's counterpart is its CUDA
-    element-wise kernel set, lietorch_gpu.cu:21-296), a smaller operand indexed i // rep;
-  * otherwise the torch ops below, whose autograd gives the backward passes (CPU, training).
+  * on the GPU: ONE fused HIP kernel per operation (pvo_amd/csrc/se3_ops.hip, `pvo_se3_unary/_binary`; lietorch's
+    counterpart is its CUDA element-wise kernel set, lietorch_gpu.cu:21-296), a smaller operand indexed i // rep - and,
+    since round 4, ONE kernel for its backward pass (`pvo_se3_*_vjp` behind torch.autograd.Function: lietorch's backward
+    kernels), where the torch formulation costs ~25 element-wise launches forward and ~50 backward per operation - 46 % of the
+    operators a training step dispatches (profiles/r04_train_step_stats.txt);
+  * otherwise (CPU, general broadcasting, PVO_SE3_TORCH=1) the torch ops below, whose autograd is also the reference the
+    backward kernels are tested against (tests/test_se3.py).
 The native BA / reprojection kernels do not go through this class; it serves the
 differentiable Python path (geom/ba.py, DroidNet.forward) and host-side bookkeeping.
 """
@@ -19,15 +22,66 @@ import torch
 EPS = 1e-6  # lietorch include/common.h:7
 
 
+import os
+
+FORCE_TORCH = os.environ.get("PVO_SE3_TORCH") == "1"      # tests: the torch formulation everywhere
+
+
 def _native(*ts):
-    """the fused HIP kernels apply: device tensors of one fp32 / fp64 dtype and no gradient to record"""
+    """the fused HIP kernels apply: device tensors of one fp32 / fp64 dtype"""
     t0 = ts[0]
-    if not t0.is_cuda or t0.dtype not in (torch.float32, torch.float64):
+    if FORCE_TORCH or not t0.is_cuda or t0.dtype not in (torch.float32, torch.float64):
         return False
     for t in ts:
         if not t.is_cuda or t.dtype != t0.dtype or t.device != t0.device:
             return False
-    return not (torch.is_grad_enabled() and any(t.requires_grad for t in ts))
+    return True
+
+
+def _grad(*ts):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+
+
+class _Unary(torch.autograd.Function):
+    """exp / log / inv: forward and backward one HIP kernel each"""
+
+    @staticmethod
+    def forward(ctx, op, x):
+        from .. import droid_backends as db
+        x = x.contiguous()
+        ctx.op = op
+        ctx.save_for_backward(x)
+        return db.se3_unary(op, x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import droid_backends as db
+        (x,) = ctx.saved_tensors
+        return None, db.se3_unary_vjp(ctx.op, x, gy.contiguous())
+
+
+class _Binary(torch.autograd.Function):
+    """mul / act / adj / adjT with index broadcasting; the gradient of a broadcast operand is summed over its repeats"""
+
+    @staticmethod
+    def forward(ctx, op, a, rep_a, b, rep_b, out_shape):
+        from .. import droid_backends as db
+        a, b = a.contiguous(), b.contiguous()
+        ctx.op, ctx.rep_a, ctx.rep_b = op, rep_a, rep_b
+        ctx.save_for_backward(a, b)
+        return db.se3_binary(op, a, rep_a, b, rep_b, out_shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import droid_backends as db
+        a, b = ctx.saved_tensors
+        ga, gb = db.se3_binary_vjp(ctx.op, a, ctx.rep_a, b, ctx.rep_b, gy.contiguous(), ctx.needs_input_grad[1], ctx.needs_input_grad[3])
+        return None, ga, None, gb, None, None
+
+
+def _unary(op, x):
+    from .. import droid_backends as db
+    return _Unary.apply(op, x) if _grad(x) else db.se3_unary(op, x.contiguous())
 
 
 def _bcast(sa, sb):
@@ -57,6 +111,8 @@ def _binary(op, g, b):
     if bc is None:
         return None
     out, rep_a, rep_b = bc
+    if _grad(g, b):
+        return _Binary.apply(op, g, rep_a, b, rep_b, out)
     return db.se3_binary(op, g.contiguous(), rep_a, b.contiguous(), rep_b, out)
 
 
@@ -179,8 +235,7 @@ class SE3:
     @classmethod
     def exp(cls, x):
         if _native(x):
-            from .. import droid_backends as db
-            return cls(db.se3_unary("exp", x.contiguous()))
+            return cls(_unary("exp", x))
         tau, phi = x[..., :3], x[..., 3:]
         q = _so3_exp(phi)
         c1, c2 = _left_jacobian_coefs(phi)
@@ -190,8 +245,7 @@ class SE3:
 
     def log(self):
         if _native(self.data):
-            from .. import droid_backends as db
-            return db.se3_unary("log", self.data.contiguous())
+            return _unary("log", self.data)
         t, q = self.data[..., :3], self.data[..., 3:]
         phi = _so3_log(q)
         th2 = (phi * phi).sum(-1, keepdim=True)
@@ -207,8 +261,7 @@ class SE3:
 
     def inv(self):
         if _native(self.data):
-            from .. import droid_backends as db
-            return SE3(db.se3_unary("inv", self.data.contiguous()))
+            return SE3(_unary("inv", self.data))
         t, q = self.data[..., :3], self.data[..., 3:]
         qi = _qconj(q)
         return SE3(torch.cat([-_qrot(qi, t), qi], dim=-1))

@@ -173,38 +173,96 @@ def test_se3_property_tests_on_the_gpu(cuda):
     assert torch.allclose(X.act(p), (X.matrix() @ p[..., None])[..., 0], atol=1e-10)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def torch_formulation():
+    """the SE3 class on its PyTorch formulas (what CPU tensors always use): the reference of the HIP kernels, forward and backward"""
+    from pvo_amd.geom import se3 as S
+    old = S.FORCE_TORCH
+    S.FORCE_TORCH = True
+    try:
+        yield
+    finally:
+        S.FORCE_TORCH = old
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,atol", [(torch.float64, 1e-12), (torch.float32, 2e-6)])
 def test_native_se3_kernels_equal_the_torch_formulation(cuda, dtype, atol):
-    """pvo_se3_unary / pvo_se3_binary (one fused kernel per operation, index broadcasting) against the differentiable torch
-    formulation of the same class - reached by making an operand require a gradient - for every operation and for the
-    broadcasting patterns the VO path uses (a pose per edge acting on H x W points, equal shapes, scalar pose)"""
+    """pvo_se3_unary / pvo_se3_binary (one fused kernel per operation, index broadcasting) against the torch formulation of
+    the same class for every operation and for the broadcasting patterns the VO path uses (a pose per edge acting on H x W
+    points, equal shapes, scalar pose)"""
     torch.manual_seed(3)
     B, N, H, W = 2, 5, 6, 7
     xi = torch.randn(B, N, 6, dtype=dtype, device=cuda) * 0.7
     xi[0, 0, 3:] *= 1e-8                                                       # small-angle branches
-    Xn = SE3.exp(xi)                                                           # native
-    xg = xi.clone().requires_grad_(True)
-    Xt = SE3.exp(xg)                                                           # torch ops (autograd)
-    assert Xt.data.requires_grad and not Xn.data.requires_grad
-    assert torch.allclose(Xn.data, Xt.data.detach(), atol=atol)
-    Xt = SE3(Xt.data.detach().requires_grad_(True))
-    Yn = SE3.exp(torch.flip(xi, [1]))
-    assert torch.allclose(Xn.log(), Xt.log().detach(), atol=atol)
-    assert torch.allclose(Xn.inv().data, Xt.inv().data.detach(), atol=atol)
-    assert torch.allclose((Xn * Yn).data, (Xt * Yn).data.detach(), atol=atol)
     p4 = torch.randn(B, N, H, W, 4, dtype=dtype, device=cuda)
-    got = Xn[:, :, None, None] * p4                                            # one pose per edge, H x W points: index broadcast
-    assert got.shape == p4.shape and torch.allclose(got, (Xt[:, :, None, None] * p4).detach(), atol=atol)
     p3 = torch.randn(B, N, 3, dtype=dtype, device=cuda)
-    assert torch.allclose(Xn.act(p3), Xt.act(p3).detach(), atol=atol)
     a = torch.randn(B, N, H, W, 2, 6, dtype=dtype, device=cuda)
-    assert torch.allclose(Xn[:, :, None, None, None].adjT(a), Xt[:, :, None, None, None].adjT(a).detach(), atol=atol)
-    assert torch.allclose(Xn.adj(a[:, :, 0, 0, 0]), Xt.adj(a[:, :, 0, 0, 0]).detach(), atol=atol)
-    one = SE3(Xn.data[0, 0])                                                   # a single pose against a batch
-    assert torch.allclose((one * Yn).data, (SE3(Xt.data[0, 0]) * Yn).data.detach(), atol=atol)
-    assert torch.allclose(Yn.retr(xi).data, SE3.exp(xi).mul(Yn).data, atol=atol)
+
+    def everything():
+        X, Y = SE3.exp(xi), SE3.exp(torch.flip(xi, [1]))
+        one = SE3(X.data[0, 0])                                                # a single pose against a batch
+        return [X.data, X.log(), X.inv().data, (X * Y).data, X[:, :, None, None] * p4, X.act(p3), X[:, :, None, None, None].adjT(a),
+                X.adj(a[:, :, 0, 0, 0]), (one * Y).data, Y.retr(xi).data]
+    native = everything()
+    with torch_formulation():
+        ref = everything()
+    for k, (g, r) in enumerate(zip(native, ref)):
+        assert g.shape == r.shape and torch.allclose(g, r, atol=atol), k
     # a broadcast that is not an index broadcast falls back to the torch formulation
     q = torch.randn(1, N, H, 1, 4, dtype=dtype, device=cuda)
-    out = SE3(Xn.data[:, :1, None, None]) * q
+    out = SE3(native[0][:, :1, None, None]) * q
     assert out.shape == (B, N, H, 1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,rtol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+def test_native_se3_backward_kernels_equal_autograd_of_the_torch_formulation(cuda, dtype, rtol):
+    """pvo_se3_unary_vjp / pvo_se3_binary_vjp (forward templates on dual numbers, one kernel per backward pass) against
+    torch.autograd of the PyTorch formulation: every operation, both operands, index broadcasting (the gradient of a pose
+    that acts on H x W points is the sum over them), the small-angle branches, and a composite expression of the kind the
+    differentiable BA builds (Gj * Gi^-1 acting on points, retraction)."""
+    torch.manual_seed(11)
+    B, N, H, W = 2, 4, 5, 6
+    leaves = dict(
+        xi=torch.randn(B, N, 6, dtype=dtype, device=cuda) * 0.6,
+        yi=torch.randn(B, N, 6, dtype=dtype, device=cuda) * 0.6,
+        p4=torch.randn(B, N, H, W, 4, dtype=dtype, device=cuda),
+        p3=torch.randn(B, N, 3, dtype=dtype, device=cuda),
+        a=torch.randn(B, N, H, W, 2, 6, dtype=dtype, device=cuda),
+        d=torch.randn(B, N, 6, dtype=dtype, device=cuda) * 0.1)
+    leaves["xi"][0, 0, 3:] *= 1e-9                                             # (exp / log on their series branches)
+
+    def run():
+        L = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+        X, Y = SE3.exp(L["xi"]), SE3.exp(L["yi"])
+        outs = [X.log(), X.inv().data, (X * Y).data, X[:, :, None, None] * L["p4"], X.act(L["p3"]),
+                X[:, :, None, None, None].adjT(L["a"]), Y.adj(L["a"][:, :, 0, 0, 0]),
+                ((Y * X.inv())[:, :, None, None] * L["p4"])[..., :3] / (1.0 + L["p4"][..., 3:] ** 2),      # relative pose acting on points
+                Y.retr(L["d"]).data, (SE3(X.data[0, 0]) * Y).data]
+        torch.manual_seed(5)
+        loss = sum((o * torch.randn(o.shape, dtype=dtype, device=cuda)).sum() for o in outs)
+        grads = torch.autograd.grad(loss, list(L.values()))
+        return [o.detach() for o in outs], dict(zip(L.keys(), grads))
+    outs_n, g_n = run()
+    with torch_formulation():
+        outs_t, g_t = run()
+    for k, (x, y) in enumerate(zip(outs_n, outs_t)):
+        assert torch.allclose(x, y, atol=1e-12 if dtype == torch.float64 else 2e-6), k
+    for k in g_n:
+        scale = g_t[k].abs().max().item()
+        assert scale > 0 and (g_n[k] - g_t[k]).abs().max().item() <= rtol * scale, (k, (g_n[k] - g_t[k]).abs().max().item(), scale)
+
+
+@pytest.mark.gpu
+def test_native_se3_autograd_functions_are_used_when_a_gradient_is_recorded(cuda):
+    x = (0.3 * torch.randn(7, 6, device=cuda)).requires_grad_(True)
+    X = SE3.exp(x)
+    assert X.data.requires_grad and "Unary" in type(X.data.grad_fn).__name__
+    Y = X * X.inv()
+    assert "Binary" in type(Y.data.grad_fn).__name__
+    Y.data.sum().backward()
+    assert torch.isfinite(x.grad).all()
