@@ -496,7 +496,7 @@ def lookup_traffic():
     of the kernel (it records the sha256 of corr_lookup.hip); otherwise None: a counter value is not carried over a code change"""
     import hashlib
     sha = hashlib.sha256(open(os.path.join(ROOT, "pvo_amd", "csrc", "corr_lookup.hip"), "rb").read()).hexdigest()
-    for name in ("r03_lookup_pmc.json", "r02_lookup_pmc.json"):
+    for name in ("r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -686,6 +686,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the S-A workload and the edge-sharded leg")
+    ap.add_argument("--steps-only", action="store_true", help="priming, warm-up and the timed steps ONLY (for profilers: no stage probes, no "
+                    "isolated kernel loops, no measurement kernels); prints a reduced line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -723,6 +725,13 @@ def main():
     updates_per_step = 6
     elapsed, host_issue, in_step_lookup = timed_steps(video, graph, snap, args.steps, world)
 
+    if args.steps_only:
+        if rank == 0:
+            print(json.dumps({"metric": "VO keyframe updates/sec (steps only: profiler run)", "value": world * args.steps / elapsed,
+                              "unit": "keyframe updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                              "note": "bench.py --steps-only: the timed loop of the default run and nothing behind it"}))
+        return
     # per-stage durations inside the step, from a few extra untimed steps (one probe at a time)
     stage_us = {}
     for stage in ("gates", "candidate", "ba", "update", "empty"):

@@ -27,6 +27,13 @@
  *     issued concurrently from different threads or interleaved on different launch streams without the caller
  *     ordering those streams.  The plain kernels (lookup, build, ba, geometry) have no shared state and may be
  *     called from any thread on any stream.
+ *   - kernels side by side on one device: every kernel of this library may be resident beside kernels of other streams,
+ *     pvo_ba included.  That was NOT so before round 4: on MI355X (ROCm 7.0.2) packed-FP32 VALU instructions returned wrong
+ *     values while an MFMA kernel of another stream was resident on the compute unit, which made pvo_ba irreproducible
+ *     beside the library's own convolutions; the library is therefore built WITHOUT packed-FP32 instructions
+ *     (-target-feature -packed-fp32-ops: pvo_amd/build.py, DESIGN.md section 5, profiles/r04_coresidency.md) - keep the
+ *     flag when building it by other means.  The converse is untested: a CALLER's kernels that use packed-FP32 arithmetic,
+ *     run on another stream, beside this library's matrix-core kernels.
  *
  * Limits (PVO_EUNSUPPORTED beyond them)
  *   - edges / images per call: 65535 (they index a grid's y or z dimension)
@@ -492,7 +499,9 @@ size_t pvo_ba_workspace_bytes(int E, int P, int nframes, int HW);
  * The depth back-substitution reproduces EvT6x1_kernel's skip of window pose 0
  * (droid_kernels.cu:1084).  expSE3 uses xi[5] where the reference reads xi[45] (:154).
  * No host synchronisation: the factor-graph index structures are built on the
- * device, the (6P)^2 system is factorised in fp64 by one workgroup. */
+ * device, the (6P)^2 system is factorised in fp64 by one workgroup.
+ * Bitwise reproducible run to run, alone on the device or beside kernels of other streams (see "kernels side by side"
+ * at the head of this file: true for a library built with pvo_amd/build.py's flags). */
 int pvo_ba(float* poses, float* disps, const float* intrinsics,
            const float* targets, const float* weights, const float* eta,
            const int64_t* ii, const int64_t* jj,

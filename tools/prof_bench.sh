@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/pb
-rocprofv3 --kernel-trace --stats -f csv -d /tmp/pb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline ${PROF_ARGS---no-extras} > /tmp/pb_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/pb -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline ${PROF_ARGS---steps-only} > /tmp/pb_bench.log 2>&1
 mkdir -p $OUT
 cp /tmp/pb/*/*kernel_stats.csv $OUT/kernel_stats_full_run.csv
 grep "^{\"metric\"" /tmp/pb_bench.log | tail -1 > $OUT/bench_line.json

@@ -7,7 +7,7 @@ cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/ut
 # (second argument: an experiment build of the library, tools/variant.py build <variant> ...)
 if [ -n "$2" ]; then BENCH="$GRAFT_REPO_ROOT/tools/variant.py bench $2"; else BENCH="$GRAFT_REPO_ROOT/bench.py"; fi
-rocprofv3 --kernel-trace -f csv -d /tmp/ut -- python $BENCH --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /tmp/ut_bench.log 2>&1
+rocprofv3 --kernel-trace -f csv -d /tmp/ut -- python $BENCH --steps 10 --warmup 3 --steps-only > /tmp/ut_bench.log 2>&1
 python - > $OUT <<PY
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("/tmp/ut/*/*kernel_trace.csv")[0])))
