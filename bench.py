@@ -679,7 +679,28 @@ def edge_sharded_leg(device, rank, world, steps=3):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def _own_stdout():
+    """Everything that any library writes to file descriptor 1 during the run goes to stderr instead (RCCL prints a five-line version
+    banner to stdout when a process group comes up, from C, flushed at exit - i.e. AFTER the result line); the ONE JSON line of the
+    contract is written to the original descriptor by emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
+
+
 def main():
+    _own_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -727,7 +748,7 @@ def main():
 
     if args.steps_only:
         if rank == 0:
-            print(json.dumps({"metric": "VO keyframe updates/sec (steps only: profiler run)", "value": world * args.steps / elapsed,
+            emit(({"metric": "VO keyframe updates/sec (steps only: profiler run)", "value": world * args.steps / elapsed,
                               "unit": "keyframe updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                               "note": "bench.py --steps-only: the timed loop of the default run and nothing behind it"}))
@@ -878,7 +899,7 @@ def main():
                 out["chained_update_drift"] = chained_drift_leg(device)
             except Exception as e:
                 out["chained_update_drift"] = {"error": repr(e)}
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

@@ -392,13 +392,15 @@ __device__ __forceinline__ RowRef row_of(int r, int k, const Plan& pl, const flo
 // kernel: every workgroup prepares Q, w and Ei for exactly the pixels it is about to reduce.
 __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const float* __restrict__ eta, int K_eta,
                                             const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
-                                            float* __restrict__ Ei, float* __restrict__ Q, float* __restrict__ w, int HW, int t0, int P) {
-  const int e0 = pl.eptr[k], e1 = pl.eptr[k + 1];
-  const int pself = pl.kx[k] - t0;
+                                            float* __restrict__ Ei, float* __restrict__ Q, float* __restrict__ w, int HW, int t0, int P,
+                                            const int* __restrict__ edges, int deg, int pself) {
+  // `edges` = this depth frame's out-edges in LDS (round 4): read from the plan in global memory inside this loop, every
+  // iteration was two dependent round trips (eidx[o], then the rows of edge e) - 6 x 2 of them in front of the first product
   const bool self_in = pself >= 0 && pself < P;
   float C = 0.0f, ww = 0.0f, ei[6] = {0, 0, 0, 0, 0, 0};
-  for (int o = e0; o < e1; ++o) {
-    const int e = pl.eidx[o];
+#pragma unroll 2
+  for (int o = 0; o < deg; ++o) {
+    const int e = edges[o];
     C += Cii[static_cast<long long>(e) * HW + x];
     ww += bz[static_cast<long long>(e) * HW + x];
     if (self_in) {
@@ -416,7 +418,6 @@ __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const 
   }
 }
 
-// ---- schur: S_k = (M Q) M^T and M (Q w) on the matrix cores -----------------------------
 // For depth frame k, M stacks the 6-row blocks that couple it to window poses: Ei[k] (its own
 // pose) and Eij[e] for every outgoing edge whose target pose is free, plus one extra row w_k,
 // so that the rhs correction M (Q w) falls out of the same product.  One workgroup owns
@@ -545,21 +546,32 @@ __device__ __forceinline__ void ba_schur_body(
   if (k >= pl.meta[0]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n6 = 6 * P;
+  // this depth frame's out-edges and their target poses, fetched ONCE and in parallel into LDS: eptr -> eidx -> jj is a chain
+  // of three dependent loads that the depth phase and the row table used to walk per edge (12 + 12 serial round trips at S-B)
+  __shared__ int s_edge[256], s_pose[256];
+  const int e0 = pl.eptr[k], deg_all = pl.eptr[k + 1] - e0;
+  const int pself = pl.kx[k] - t0;
+  const bool in_lds = deg_all <= 256;
+  if (in_lds && tid < deg_all) {
+    const int e = pl.eidx[e0 + tid];
+    s_edge[tid] = e;
+    s_pose[tid] = static_cast<int>(jj[e]) - t0;
+  }
+  __syncthreads();
 #pragma unroll
   for (int h = 0; h < kSchurPix / 256; ++h) {          // depth phase for this workgroup's pixels
     const int x = blockIdx.x * kSchurPix + h * 256 + tid;
-    if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P);
+    if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
   }
 
   if (tid == 0) {                         // row table (a handful of rows: sequential is fine)
     int r = 0;
-    const int pself = pl.kx[k] - t0;
     if (pself >= 0 && pself < P) {
       for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Ei + (static_cast<long long>(pself) * 6 + n) * HW); rowout[r] = 6 * pself + n; ++r; }
     }
-    for (int o = pl.eptr[k]; o < pl.eptr[k + 1]; ++o) {
-      const int e = pl.eidx[o];
-      const int p = static_cast<int>(jj[e]) - t0;
+    for (int o = 0; o < deg_all; ++o) {
+      const int e = in_lds ? s_edge[o] : pl.eidx[e0 + o];
+      const int p = in_lds ? s_pose[o] : static_cast<int>(jj[e]) - t0;
       if (p < 0 || p >= P) continue;      // fixed target pose: drops out (:1125, :1227)
       if (r + 7 > kMaxRows) { pl.meta[3] = 1; break; }   // > 169 free neighbours of one frame: flagged
       for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Eij + (static_cast<long long>(e) * 6 + n) * HW); rowout[r] = 6 * p + n; ++r; }
@@ -1621,6 +1633,25 @@ __device__ __forceinline__ void ba_backsub_body(
     int clamp_frames, float disp_min) {
   const int k = blockIdx.y;
   const int x = blockIdx.x * 256 + threadIdx.x;
+  // (round 4) the depth frame's out-edges, their target poses and the pose updates those rows multiply, once per workgroup in LDS:
+  // row_of() walked eptr -> eidx -> jj per row and pixel, three dependent loads in front of every row's six products
+  __shared__ int s_edge[256], s_pose[256];
+  __shared__ float s_dx[256][6];
+  const bool live = k < pl.meta[0];                       // (uniform)
+  const int e0 = live ? pl.eptr[k] : 0, deg = live ? pl.eptr[k + 1] - e0 : 0;
+  const bool in_lds = deg <= 255;
+  const int lo = (flags & 1) ? 0 : 1;                     // EvT6x1_kernel returns early for pose index <= 0 (:1084): window pose 0 never reaches dz
+  if (live && in_lds && static_cast<int>(threadIdx.x) <= deg) {
+    const int r = static_cast<int>(threadIdx.x) - 1;      // row -1 = the frame's own pose row (Ei), rows 0.. = its out-edges (Eij)
+    int e = 0, p;
+    if (r < 0) p = pl.kx[k] - t0;
+    else { e = pl.eidx[e0 + r]; p = static_cast<int>(jj[e]) - t0; }
+    const bool ok = p >= 0 && p < P && p >= lo;
+    s_edge[threadIdx.x] = e; s_pose[threadIdx.x] = ok ? p : -1;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) s_dx[threadIdx.x][n] = ok ? dx[6 * p + n] : 0.0f;
+  }
+  __syncthreads();
   if (x >= HW) return;
   // clamp_frames > 0: disps[:clamp_frames].clamp_(min=disp_min) in the same launch (depth_video.py:214) - frames this BA
   // does not optimise here, by frame index; optimised ones below, after their update
@@ -1628,18 +1659,27 @@ __device__ __forceinline__ void ba_backsub_body(
     const float v = disps[static_cast<long long>(k) * HW + x];
     if (v < disp_min) disps[static_cast<long long>(k) * HW + x] = disp_min;            // NaN stays NaN, as in torch.clamp
   }
-  if (k >= pl.meta[0]) return;
-  const int e0 = pl.eptr[k], e1 = pl.eptr[k + 1];
-  // EvT6x1_kernel returns early for pose index <= 0 (:1084): window pose 0 never reaches dz.
-  const int lo = (flags & 1) ? 0 : 1;
+  if (!live) return;
   float acc = 0.0f;
-  for (int r = -1; r < e1 - e0; ++r) {
-    const RowRef R = row_of(r, k, pl, Ei, Eij, jj, HW, t0, P);
-    if (R.pose < lo) continue;
-    float s = 0.0f;
+  if (in_lds) {
+    for (int q = 0; q <= deg; ++q) {
+      const int p = s_pose[q];
+      if (p < 0) continue;
+      const float* base = (q == 0) ? Ei + static_cast<long long>(p) * 6 * HW : Eij + static_cast<long long>(s_edge[q]) * 6 * HW;
+      float sacc = 0.0f;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) s += R.base[static_cast<long long>(n) * HW + x] * dx[6 * R.pose + n];
-    acc += s;
+      for (int n = 0; n < 6; ++n) sacc += base[static_cast<long long>(n) * HW + x] * s_dx[q][n];
+      acc += sacc;
+    }
+  } else {
+    for (int r = -1; r < deg; ++r) {
+      const RowRef R = row_of(r, k, pl, Ei, Eij, jj, HW, t0, P);
+      if (R.pose < lo) continue;
+      float sacc = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 6; ++n) sacc += R.base[static_cast<long long>(n) * HW + x] * dx[6 * R.pose + n];
+      acc += sacc;
+    }
   }
   const float dz = Q[static_cast<long long>(k) * HW + x] * (w[static_cast<long long>(k) * HW + x] - acc);
   float d = disps[static_cast<long long>(pl.kx[k]) * HW + x] + dz;  // disp_retr_kernel (:912-925)
