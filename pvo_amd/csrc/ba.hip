@@ -58,6 +58,21 @@ constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system live
                                         // solve kernel's static tables leave); beyond, the compact envelope form
 
 
+// tools/ba_kernel_timeline.py builds this file with -DPVO_BA_PROBE=3: every workgroup of the assembly / Schur / back-substitution
+// kernels stamps the constant-rate clock (10 ns) at its phases: g_ba_wg_probe[(kernel * 4096 + workgroup) * 8 + slot]
+#if defined(PVO_BA_PROBE) && PVO_BA_PROBE == 3
+__device__ unsigned long long* g_ba_wg_probe = nullptr;
+#define BA_WG_PROBE(kern, slot)                                                                                         \
+  do {                                                                                                                  \
+    if (g_ba_wg_probe && threadIdx.x == 0) {                                                                            \
+      const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
+      if (wg_ < 4096u) g_ba_wg_probe[((kern) * 4096u + wg_) * 8u + (slot)] = wall_clock64();                            \
+    }                                                                                                                   \
+  } while (0)
+#else
+#define BA_WG_PROBE(kern, slot)
+#endif
+
 struct Plan {            // int region of the workspace
   int* kidx;             // [F]   frame -> depth index, -1 if none
   int* kx;               // [F]   depth index -> frame
@@ -296,6 +311,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   // In a depth BA (`part`) the chunk sums are stored instead and the Schur kernel, which follows anyway, adds them up per edge:
   // a sixth of the atomics, issued while its own work starts.
   __shared__ float red[4][90];
+  BA_WG_PROBE(0, 0);
 #ifdef PVO_SCHED_DEBUG
   if (g_dbg_log_ba && threadIdx.x == 0) {
     const unsigned long long i_ = atomicAdd(&g_dbg_log_ba[0], 1ull);
@@ -334,6 +350,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
       }
     }
   }
+  BA_WG_PROBE(0, 1);                     // pixel terms done (stores issued)
   // 90 sums: wave shuffle reduce, 4 partials through LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -356,12 +373,14 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
 #endif
   }
   __syncthreads();
+  BA_WG_PROBE(0, 2);                     // wave reductions done
   const int t = threadIdx.x;
   if (t < 90) {
     const float sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
     if (part) part[(static_cast<long long>(e) * gridDim.x + blockIdx.x) * 90 + t] = sum;      // summed per edge by the Schur kernel
     else pose_block_scatter(t, static_cast<double>(sum), ix - t0, jx - t0, P, sys, meta);
   }
+  BA_WG_PROBE(0, 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -503,12 +522,14 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
         ++n;
       }
   }
+  BA_WG_PROBE(1, 5);                     // products done (wave 0)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float* r = red + (static_cast<size_t>(wave) * NT + t) * 256;
     r[lane] = acc[t].x; r[64 + lane] = acc[t].y; r[128 + lane] = acc[t].z; r[192 + lane] = acc[t].w;
   }
   __syncthreads();
+  BA_WG_PROBE(1, 6);                     // all four waves' products in LDS
   int n = 0;
 #pragma unroll
   for (int ti = 0; ti < T; ++ti)
@@ -543,7 +564,9 @@ __device__ __forceinline__ void ba_schur_body(
     }
   }
   const int k = blockIdx.y;
+  BA_WG_PROBE(1, 0);
   if (k >= pl.meta[0]) return;
+  BA_WG_PROBE(1, 1);                     // chunk sums of the assembly added, meta read
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n6 = 6 * P;
   // this depth frame's out-edges and their target poses, fetched ONCE and in parallel into LDS: eptr -> eidx -> jj is a chain
@@ -558,12 +581,14 @@ __device__ __forceinline__ void ba_schur_body(
     s_pose[tid] = static_cast<int>(jj[e]) - t0;
   }
   __syncthreads();
+  BA_WG_PROBE(1, 2);                     // edge list in LDS
 #pragma unroll
   for (int h = 0; h < kSchurPix / 256; ++h) {          // depth phase for this workgroup's pixels
     const int x = blockIdx.x * kSchurPix + h * 256 + tid;
     if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
   }
 
+  BA_WG_PROBE(1, 3);                     // depth phase issued
   if (tid == 0) {                         // row table (a handful of rows: sequential is fine)
     int r = 0;
     if (pself >= 0 && pself < P) {
@@ -582,6 +607,7 @@ __device__ __forceinline__ void ba_schur_body(
     nrows_s = r;
   }
   __syncthreads();
+  BA_WG_PROBE(1, 4);                     // row table built, depth rows stored
   const int nrows = nrows_s;
   if (nrows == 0) return;
   const int T = (nrows + 15) >> 4;
@@ -589,10 +615,10 @@ __device__ __forceinline__ void ba_schur_body(
   const int pix_base = blockIdx.x * kSchurPix + wave * (kSchurPix / 4);
 
   switch (T) {
-    case 1: schur_pass<1, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
-    case 2: schur_pass<2, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
-    case 3: schur_pass<3, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
-    case 4: schur_pass<4, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); return;
+    case 1: schur_pass<1, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 2: schur_pass<2, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 3: schur_pass<3, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 4: schur_pass<4, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
     default: break;
   }
   // any degree: one tile pair at a time, row tiles re-read from L2
@@ -1651,7 +1677,9 @@ __device__ __forceinline__ void ba_backsub_body(
 #pragma unroll
     for (int n = 0; n < 6; ++n) s_dx[threadIdx.x][n] = ok ? dx[6 * p + n] : 0.0f;
   }
+  BA_WG_PROBE(2, 0);
   __syncthreads();
+  BA_WG_PROBE(2, 1);
   if (x >= HW) return;
   // clamp_frames > 0: disps[:clamp_frames].clamp_(min=disp_min) in the same launch (depth_video.py:214) - frames this BA
   // does not optimise here, by frame index; optimised ones below, after their update
@@ -1686,6 +1714,7 @@ __device__ __forceinline__ void ba_backsub_body(
   if (pl.kx[k] < clamp_frames && d < disp_min) d = disp_min;
   disps[static_cast<long long>(pl.kx[k]) * HW + x] = d;
   if (dz_out && k < dz_rows) dz_out[static_cast<long long>(k) * HW + x] = dz;
+  BA_WG_PROBE(2, 2);
 }
 
 __global__ __launch_bounds__(256) void ba_backsub_kernel(
@@ -1704,6 +1733,9 @@ int check_common(int E, int F, int ht, int wd, int t0, int t1) {
 
 }  // namespace
 
+#if defined(PVO_BA_PROBE) && PVO_BA_PROBE == 3
+extern "C" int pvo_debug_ba_wg_probe(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ba_wg_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#endif
 #ifdef PVO_BA_PROBE
 extern "C" int pvo_debug_ba_probe(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ba_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
 #endif

@@ -1,0 +1,56 @@
+"""Where the BA's three data-parallel kernels spend their time: per-workgroup stamps of the constant-rate clock (10 ns) at the phases
+of ba_assemble_kernel / ba_schur_mfma_kernel / ba_backsub_kernel at S-B (8 keyframes, 36 edges, 48x64).
+    python tools/ba_kernel_timeline.py --build       (here: -DPVO_BA_PROBE=3 -> tools/_probe/libpvo_hip_bawg.so)
+    python tools/ba_kernel_timeline.py               (GPU box)"""
+import ctypes, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+PROBE_DIR = os.path.join(ROOT, "tools", "_probe")
+PROBE_LIB = os.path.join(PROBE_DIR, "libpvo_hip_bawg.so")
+if "--build" in sys.argv:
+    from pvo_amd import build
+    build.build_hip()
+    os.makedirs(PROBE_DIR, exist_ok=True)
+    obj = os.path.join(PROBE_DIR, "bawg.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_BA_PROBE=3", "-c", os.path.join(build.CSRC, "ba.hip"), "-o", obj], stderr=subprocess.DEVNULL)
+    objs = [obj if s == "ba.hip" else os.path.join(build.CSRC, s.replace(".hip", ".o")) for s in build.HIP_SOURCES]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_LIB] + objs)
+    print(PROBE_LIB); sys.exit(0)
+import torch
+from pvo_amd import _lib
+_lib.LIB_PATH = PROBE_LIB
+from pvo_amd import droid_backends as db
+from test_geom_ba_gpu import _scene
+dev = torch.device("cuda:0")
+nf = int(os.environ.get("NF", "8"))
+s = _scene(0, nf, 48, 64, 3, 1)
+d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()}
+lib = _lib.load()
+lib.pvo_debug_ba_wg_probe.restype = ctypes.c_int; lib.pvo_debug_ba_wg_probe.argtypes = [ctypes.c_void_p]
+buf = torch.zeros(3 * 4096 * 8, dtype=torch.int64, device=dev)
+run = lambda it: db.ba(d["poses"].clone(), d["disps"].clone(), d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], 1, nf, it, 1e-4, 0.1, False)
+for _ in range(5):
+    run(2)
+torch.cuda.synchronize()
+assert lib.pvo_debug_ba_wg_probe(buf.data_ptr()) == 0
+run(1); torch.cuda.synchronize()
+assert lib.pvo_debug_ba_wg_probe(None) == 0
+t = buf.cpu().numpy().reshape(3, 4096, 8).astype(np.int64)
+def show(name, k, labels, last):
+    a = t[k]; live = a[:, 0] > 0
+    a = a[live]
+    if not len(a):
+        print(name, "no stamps"); return
+    t0 = a[:, 0].min()
+    print("%s: %d workgroups; entries spread over %.2f us; kernel (first entry -> last exit) %.2f us" % (name, len(a), (a[:, 0].max() - t0) * 0.01, (a[:, last][a[:, last] > 0].max() - t0) * 0.01))
+    for (i, j, lab) in labels:
+        ok = (a[:, i] > 0) & (a[:, j] > 0)
+        if ok.any():
+            dtt = (a[ok, j] - a[ok, i]) * 0.01
+            print("    %-58s median %6.2f us   max %6.2f   (%d workgroups)" % (lab, np.median(dtt), dtt.max(), ok.sum()))
+show("ba_assemble_kernel", 0, [(0, 1, "entry -> pixel terms computed, rows stored"), (1, 2, "90 wave reductions + barrier"), (2, 3, "chunk sums stored / atomics issued"), (0, 3, "whole workgroup")], 3)
+show("ba_schur_mfma_kernel", 1, [(0, 1, "entry -> assembly's chunk sums added (edge-dealing), meta read"), (1, 2, "edge list -> LDS"), (2, 3, "depth phase (C, w, Q, Ei) issued"),
+                                 (3, 4, "row table + barrier (depth rows visible)"), (4, 5, "16 steps of row loads + MFMA (wave 0)"), (5, 6, "products -> LDS + barrier"),
+                                 (6, 7, "4-wave sums + fixed-point atomics"), (0, 7, "whole workgroup")], 7)
+show("ba_backsub_kernel", 2, [(0, 1, "rows / dx -> LDS + barrier"), (1, 2, "rows x dx, depth update"), (0, 2, "whole workgroup")], 2)
