@@ -320,10 +320,14 @@ int oracle_altcorr_forward(const float* f1, const float* f2, const float* coords
                   const float* q = f2 + (((long long)b * H2 + h2) * W2 + w2) * C;
                   for (int k = c0; k < c0 + 32 && k < C; k++) s = fmaf(a[k], q[k], s);
                 }
-                if (iy > 0 && ix > 0) out[(long long)((iy - 1) + rd * (ix - 1)) * HW] += s * (dy * dx);
-                if (iy > 0 && ix < rd) out[(long long)((iy - 1) + rd * ix) * HW] += s * (dy * (1 - dx));
-                if (iy < rd && ix > 0) out[(long long)(iy + rd * (ix - 1)) * HW] += s * ((1 - dy) * dx);
-                if (iy < rd && ix < rd) out[(long long)(iy + rd * ix) * HW] += s * ((1 - dy) * (1 - dx));
+                /* `nw = s * w; corr += nw` (:113-135) is one fused multiply-add under nvcc's default -fmad=true, like the dot
+                 * product above: tests/golden/altcorr_kernel.npz (the kernel text run on the host with and without
+                 * contraction) pins this form bit for bit */
+                float* o;
+                if (iy > 0 && ix > 0) { o = out + (long long)((iy - 1) + rd * (ix - 1)) * HW; *o = fmaf(s, dy * dx, *o); }
+                if (iy > 0 && ix < rd) { o = out + (long long)((iy - 1) + rd * ix) * HW; *o = fmaf(s, dy * (1 - dx), *o); }
+                if (iy < rd && ix > 0) { o = out + (long long)(iy + rd * (ix - 1)) * HW; *o = fmaf(s, (1 - dy) * dx, *o); }
+                if (iy < rd && ix < rd) { o = out + (long long)(iy + rd * ix) * HW; *o = fmaf(s, (1 - dy) * (1 - dx), *o); }
               }
           }
   return 0;

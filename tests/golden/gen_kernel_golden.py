@@ -24,6 +24,8 @@ order, c10::Half arithmetic - not from a restatement of them.
       :406-495 projmap_kernel, :497-636 frame_distance_kernel, :640-754 depth_filter_kernel, :758-829 iproj_kernel
                                   -> geom_kernels.npz
       :177-403 projective_transform_kernel   -> ba_assemble_kernel.npz  (Hs, vs, Eii, Eij, Cii, bz of one BA step)
+  altcorr_kernel.cu:16-286        altcorr_forward_kernel / altcorr_backward_kernel (one warp per block; see _ALTCORR_SHIM)
+                                  -> altcorr_kernel.npz
 
 blockReduce (droid_kernels.cu:36-55) relies on the lock-step execution of a warp (`warpReduce` on volatile shared
 memory, no barrier): OS threads are not in lock step, so the shim supplies a reduction that performs the SAME additions
@@ -472,11 +474,134 @@ def gen_geom_kernels():
     print("ba_assemble_kernel.npz:", {k: v.shape for k, v in outb.items() if k.startswith("b_") and k[2:] in ("Hs", "vs", "Eii", "Cii")})
 
 
+# ------------------------------------------------------------------------------------------------------------
+# altcorr_kernel.cu: one 4 x 8 thread block = ONE WARP that hands data between its threads through shared memory with
+# fewer barriers than OS threads need
+# ------------------------------------------------------------------------------------------------------------
+_ALTCORR_SHIM = r"""
+#define __shared__ static
+#define __syncthreads() shim_barrier()
+struct ShimBarrier {
+  std::mutex m; std::condition_variable cv; int count = 0, gen = 0, n = 1;
+  void wait() { std::unique_lock<std::mutex> l(m); int g = gen; if (++count == n) { gen++; count = 0; cv.notify_all(); }
+                else cv.wait(l, [&]{ return g != gen; }); }
+};
+static ShimBarrier shim_bar;
+static inline void shim_barrier() { shim_bar.wait(); }
+// The 32 threads of a block are one warp, and the text leans on its lock step in four places: (1) the f2 tile of the next
+// tap is stored right after the dot products of this one (one __syncthreads per tap, none behind the reads); (2) the f1 tile
+// of the next channel slab likewise; (3) x2s / y2s are read by all threads right after each thread stored its own entry;
+// (4) backward: f2_grad is accumulated by columns, read by rows and zeroed again without a barrier.  OS threads are not in
+// lock step, so the emulation adds rendezvous where EVERY thread of the block passes the same number of times whatever its
+// pixel: every call of floor() (each of the four hand-overs is followed by one before the next access), and every
+// ASSIGNMENT to a scalar_t lvalue (the tile stores; the initialisations `scalar_t s = 0.0` are constructions, the
+// accumulations are +=, neither waits).  scalar_t is therefore not float but a struct around one: same arithmetic, float
+// operations on float values.
+static inline float shim_floor(float x) { shim_barrier(); return std::floor(x); }
+struct Sh {
+  float v;
+  Sh() = default;
+  Sh(const Sh&) = default;
+  Sh(float x) : v(x) {}
+  Sh(double x) : v(static_cast<float>(x)) {}
+  Sh(int x) : v(static_cast<float>(x)) {}
+  Sh& operator=(const Sh& o) { shim_barrier(); v = o.v; return *this; }
+  Sh& operator+=(const Sh& o) { v += o.v; return *this; }
+  explicit operator int() const { return static_cast<int>(v); }
+};
+static inline Sh operator*(const Sh& a, const Sh& b) { return Sh(a.v * b.v); }
+static inline Sh operator-(const Sh& a, const Sh& b) { return Sh(a.v - b.v); }
+static inline Sh shim_floor_any(const Sh& a) { return Sh(shim_floor(a.v)); }
+static inline float shim_floor_any(float x) { return shim_floor(x); }
+#define floor(x) shim_floor_any(x)
+static std::mutex shim_atomic_mutex;     // threads of one block do add to the same address (two pixels, one target)
+static inline void atomicAdd(Sh* p, const Sh& x) { std::lock_guard<std::mutex> l(shim_atomic_mutex); p->v += x.v; }
+template <typename F> static void shim_launch_4x8(int gx, int gy, int gz, F body) {
+  shim_bar.n = 32;
+  for (int bx = 0; bx < gx; bx++) for (int by = 0; by < gy; by++) for (int bz = 0; bz < gz; bz++) {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < 32; t++) pool.emplace_back([=]() {
+      blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz; blockDim.x = 4; blockDim.y = 8; threadIdx.x = t / 8; threadIdx.y = t % 8;
+      body();
+    });
+    for (auto &th : pool) th.join();
+    shim_bar.count = 0;
+  }
+}
+template <int N> static torch::PackedTensorAccessor32<Sh, N, torch::DefaultPtrTraits> sh_acc(torch::Tensor t) {
+  TORCH_CHECK(t.scalar_type() == torch::kFloat && t.dim() == N);
+  return torch::PackedTensorAccessor32<Sh, N, torch::DefaultPtrTraits>(reinterpret_cast<Sh*>(t.data_ptr<float>()), t.sizes().data(), t.strides().data());
+}
+"""
+
+
+def _altcorr_module(tag, cflags):
+    text = _lines(os.path.join(SRC, "altcorr_kernel.cu"), 16, 286)      # the four #defines, within_bounds, both kernels
+    cpp = _COMMON + _ALTCORR_SHIM + text + r"""
+// host wrappers restated from altcorr_kernel.cu:288-356 (allocation + launch geometry)
+torch::Tensor forward(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords, int64_t radius) {
+  const int B = coords.size(0), N = coords.size(1), H = coords.size(2), W = coords.size(3), rd = 2 * radius + 1;
+  auto corr = torch::zeros({B, N, rd * rd, H, W}, fmap1.options());
+  auto a1 = sh_acc<4>(fmap1), a2 = sh_acc<4>(fmap2);
+  auto co = coords.packed_accessor32<float,5,torch::DefaultPtrTraits>();
+  auto out = sh_acc<5>(corr);
+  shim_launch_4x8(B, (H + BLOCK_H - 1) / BLOCK_H, (W + BLOCK_W - 1) / BLOCK_W, [&]() { altcorr_forward_kernel<Sh>(a1, a2, co, out, (int)radius); });
+  return corr;
+}
+std::vector<torch::Tensor> backward(torch::Tensor fmap1, torch::Tensor fmap2, torch::Tensor coords, torch::Tensor corr_grad, int64_t radius) {
+  const int B = coords.size(0), N = coords.size(1), H1 = fmap1.size(1), W1 = fmap1.size(2);
+  // the text reads coords[b][n][h1][w1] for EVERY thread of a block, pixels beyond the image included (:207-208)
+  TORCH_CHECK(H1 % BLOCK_H == 0 && W1 % BLOCK_W == 0, "backward: whole blocks only");
+  auto g1 = torch::zeros_like(fmap1), g2 = torch::zeros_like(fmap2);
+  auto gc = torch::zeros({B, N, H1, W1, 2}, fmap1.options());
+  auto a1 = sh_acc<4>(fmap1), a2 = sh_acc<4>(fmap2), o1 = sh_acc<4>(g1), o2 = sh_acc<4>(g2);
+  auto co = sh_acc<5>(coords), cg = sh_acc<5>(corr_grad), og = sh_acc<5>(gc);
+  shim_launch_4x8(B, (H1 + BLOCK_H - 1) / BLOCK_H, (W1 + BLOCK_W - 1) / BLOCK_W, [&]() { altcorr_backward_kernel<Sh>(a1, a2, co, cg, o1, o2, og, (int)radius); });
+  return {g1, g2, gc};
+}
+"""
+    return _load("pvo_ref_altcorr_" + tag, cpp, ["forward", "backward"], list(cflags) + ["-pthread"])
+
+
+def gen_altcorr_kernel():
+    plain = _altcorr_module("plain", ["-ffp-contract=off"])
+    fused = _altcorr_module("fma", ["-mfma", "-ffp-contract=fast"])
+    g = np.random.default_rng(61)
+    out = {}
+    #        name B  S  H1 W1 H2 W2  C  r  spread
+    cases = (("a", 1, 2, 5, 9, 6, 7, 64, 3, 2.5),      # ragged: 2 x 2 blocks, three of them partly outside the image
+             ("b", 2, 1, 4, 8, 3, 5, 32, 3, 6.0),      # window larger than the plane; one channel slab
+             ("c", 1, 2, 4, 8, 7, 9, 96, 2, 1.5))      # radius 2, three slabs
+    for name, B, S, H1, W1, H2, W2, C, r, spread in cases:
+        f1 = g.standard_normal((B, H1, W1, C)).astype(np.float32)
+        f2 = g.standard_normal((B, H2, W2, C)).astype(np.float32)
+        base = np.stack(np.meshgrid(np.arange(W1), np.arange(H1)), -1).astype(np.float32)          # [H1,W1,2] (x, y)
+        co = base[None, None] * np.array([W2 / W1, H2 / H1], np.float32) + g.uniform(-spread, spread, (B, S, H1, W1, 2)).astype(np.float32)
+        co = co.astype(np.float32)
+        co[0, 0, 0, 0] = (1.0, 2.0)                    # integer coordinates: dx = dy = 0
+        co[0, 0, 0, 1] = (-20.0, 3.5)                  # whole window outside
+        rd = 2 * r + 1
+        t = torch.from_numpy
+        out[name + "_fmap1"], out[name + "_fmap2"], out[name + "_coords"], out[name + "_radius"] = f1, f2, co, np.int64(r)
+        out[name + "_fwd_fma"] = fused.forward(t(f1), t(f2), t(co), r).numpy()
+        out[name + "_fwd_nofma"] = plain.forward(t(f1), t(f2), t(co), r).numpy()
+        if H1 % 4 == 0 and W1 % 8 == 0:
+            cg = g.standard_normal((B, S, rd * rd, H1, W1)).astype(np.float32)
+            g1, g2, gc = fused.backward(t(f1), t(f2), t(co), t(cg), r)
+            assert not gc.any()                          # coords_grad is allocated and never written (altcorr_kernel.cu:340)
+            out[name + "_grad"], out[name + "_bwd_fmap1_fma"], out[name + "_bwd_fmap2_fma"] = cg, g1.numpy(), g2.numpy()
+    np.savez_compressed(os.path.join(HERE, "altcorr_kernel.npz"), **out)
+    print("altcorr_kernel.npz:", sorted(k for k in out if k.endswith("_fmap1")),
+          "fma changes %d of %d forward values (case a)" % (int((out["a_fwd_fma"] != out["a_fwd_nofma"]).sum()), out["a_fwd_fma"].size))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(SRC):
         raise SystemExit("reference tree not present; fixtures can only be generated in the build container")
-    which = sys.argv[1:] or ["corr", "geom"]
+    which = sys.argv[1:] or ["corr", "geom", "altcorr"]
     if "corr" in which:
         gen_corr_lookup_kernel()
     if "geom" in which:
         gen_geom_kernels()
+    if "altcorr" in which:
+        gen_altcorr_kernel()

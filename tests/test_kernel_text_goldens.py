@@ -31,6 +31,11 @@ def geom():
 
 
 @pytest.fixture(scope="module")
+def alt():
+    return np.load(os.path.join(G, "altcorr_kernel.npz"))
+
+
+@pytest.fixture(scope="module")
 def bak():
     return np.load(os.path.join(G, "ba_assemble_kernel.npz"))
 
@@ -122,6 +127,29 @@ def test_oracle_ba_step_against_the_kernel_text_chain(bak, case):
 
 
 # ==================================================================================================== GPU (C ABI)
+
+
+# ---------------------------------------------------------------------------------------------------- altcorr, CPU
+@pytest.mark.parametrize("case", "abc")
+def test_oracle_altcorr_forward_is_the_kernel_text_bit_for_bit(alt, case):
+    """altcorr_kernel.cu:27-149 with the contraction nvcc applies by default (dot product AND the bilinear scatter are
+    fused multiply-adds); the uncontracted run of the same text differs by rounding only"""
+    f1, f2, co, r = alt[case + "_fmap1"], alt[case + "_fmap2"], alt[case + "_coords"], int(alt[case + "_radius"])
+    got = O.altcorr_forward(f1, f2, co, r)
+    assert np.array_equal(_bits(got), _bits(alt[case + "_fwd_fma"]))
+    assert np.abs(got - alt[case + "_fwd_nofma"]).max() <= 4e-6 * np.abs(got).max()
+    assert (alt[case + "_fwd_fma"] != alt[case + "_fwd_nofma"]).any()
+
+
+@pytest.mark.parametrize("case", "bc")
+def test_oracle_altcorr_backward_against_the_kernel_text(alt, case):
+    """:152-286; fmap2's gradient is summed by atomicAdd in an order the text does not fix (the oracle sums in fp64)"""
+    f1, f2, co, r = alt[case + "_fmap1"], alt[case + "_fmap2"], alt[case + "_coords"], int(alt[case + "_radius"])
+    g1, g2 = O.altcorr_backward(f1, f2, co, alt[case + "_grad"], r)
+    for got, want in ((g1, alt[case + "_bwd_fmap1_fma"]), (g2, alt[case + "_bwd_fmap2_fma"])):
+        assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES)
 def test_hip_lookup_forward_and_backward_are_the_kernel_text_bit_for_bit(cuda, corr, case):
@@ -195,3 +223,20 @@ def test_hip_ba_step_against_the_kernel_text_chain(cuda, bak, case):
     assert np.abs(dx.cpu().numpy() - rdx).max() <= tol_dx * max(np.abs(rdx).max(), 1e-3)
     assert np.abs(dz.cpu().numpy() - rdz).max() <= tol_dz * max(np.abs(rdz).max(), 1e-3)
     assert status.cpu().numpy()[0] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", "abc")
+def test_hip_altcorr_against_the_kernel_text(cuda, alt, case):
+    """the HIP kernels sum the 128 channels in another order (lanes of a wave, not 32-channel slabs): fp32 rounding"""
+    from pvo_amd import droid_backends as db
+    f1, f2, co, r = alt[case + "_fmap1"], alt[case + "_fmap2"], alt[case + "_coords"], int(alt[case + "_radius"])
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    got, = db.altcorr_forward(t(f1), t(f2), t(co), r)
+    want = alt[case + "_fwd_fma"]
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-6 * np.abs(want).max()
+    if case + "_grad" in alt:
+        g1, g2, gc = db.altcorr_backward(t(f1), t(f2), t(co), t(alt[case + "_grad"]), r)
+        for g, w in ((g1, alt[case + "_bwd_fmap1_fma"]), (g2, alt[case + "_bwd_fmap2_fma"])):
+            assert np.abs(g.cpu().numpy() - w).max() <= 2e-6 * np.abs(w).max()
+        assert not gc.any()
