@@ -533,6 +533,14 @@ int pvo_ba(float* poses, float* disps, const float* intrinsics,
 int pvo_ba_plan(const int64_t* ii, const int64_t* jj, int E, int nframes, int HW,
                 int K_eta, int t0, int t1, void* workspace, size_t workspace_bytes,
                 void* stream);
+/* The pose solve beyond 21 free poses (the global bundle adjustment; the reference: Eigen's sparse LLT on the host,
+ * droid_kernels.cu:1160-1198) is PARTITIONED when the system is block-banded: two workgroups eliminate the pose chain from
+ * both ends at once, the separator - the poses that couple the two parts - last (ba.hip, ba_solve_twin_kernel).  Same
+ * result on every rank of an edge-sharded run (same integer system, same partition); against the one-chain solve it agrees
+ * to fp64 rounding.  Diagnostic: out[0] = m, out[1] = s of the last pvo_ba_finish on this workspace - poses [0, m) and
+ * [s, P) were the two parts, [m, s) the separator; 0, 0 = one chain (loop closures that widen the separator beyond 12
+ * poses, or a chain that would not get a quarter shorter).  Synchronises the stream. */
+int pvo_ba_last_partition(void* workspace, size_t workspace_bytes, int E, int P, int nframes, int HW, int* out, void* stream);
 int pvo_ba_local(const float* poses, const float* disps, const float* intrinsics,
                  const float* targets, const float* weights, const float* eta,
                  const int64_t* ii, const int64_t* jj,

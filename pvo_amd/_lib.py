@@ -72,6 +72,7 @@ SIGNATURES = {
     "pvo_ba": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                     _f, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "pvo_ba_last_partition": (_i, [_vp, _sz, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _vp]),
     "pvo_ba_local": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                           _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,

@@ -54,6 +54,8 @@ __device__ __forceinline__ void fix_add(long long* sys, long long idx, double v,
 }
 constexpr int kPPT = 2;                 // pixels per thread in assemble (1: 432 workgroups, measured slower - profiles/r03_ba_ablation.txt)
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
+constexpr int kMaxSep = 12;                                      // separator poses of the partitioned solve (beyond: not partitioned)
+constexpr int kXchgDoubles = 2 + 36 * kMaxSep * kMaxSep + 12 * kMaxSep;
 constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system lives DENSE in LDS (126*127*8 + 21*27*8 + 208 = 132.7 KB of the 143 KB the
                                         // solve kernel's static tables leave); beyond, the compact envelope form
 
@@ -92,6 +94,7 @@ struct Ws {
   float *part;           // [E][assembly chunks][90]: per-chunk sums of an edge's pose blocks and gradients (depth BA)
   long long* sys;        // [(6P)^2 + 6P] fixed point
   double* chol;          // [(6P)^2 + 6P] scratch for the global-memory factorisation
+  double* xchg;          // partitioned pose solve: [2 doubles = 4 ints: flags, split | separator terms | separator solution] (kXchgDoubles)
   size_t bytes;
 };
 
@@ -121,6 +124,7 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.part = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * ((HW + kChunkA - 1) / kChunkA) * 90 + 16));
   w.sys = reinterpret_cast<long long*>(take(sizeof(double) * (n6 * n6 + n6 + 8)));
   w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + n6 + 27 * (n6 / 6) + 32 : 8)));
+  w.xchg = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? kXchgDoubles : 2)));
   w.bytes = off;
   return w;
 }
@@ -279,9 +283,12 @@ __device__ __forceinline__ void pose_block_scatter(int t, double val, int pi, in
         if (n != m) fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pi + n, val, meta);
       }
     } else if (m < 6) {                           // (ii,jj)[m][n-6] and (jj,ii)[n-6][m]
+      // only the LOWER block triangle of the system is ever read (the solve factorises it; an edge-sharded run all-reduces
+      // exactly those blocks): of the two mirrored off-diagonal blocks the one above the diagonal is not written.  Nothing at
+      // window size; a global bundle adjustment's Schur kernel is bound by these atomics (round 4)
       if (iok && jok) {
-        fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pj + (n - 6), val, meta);
-        fix_add(sys, static_cast<long long>(6 * pj + (n - 6)) * n6 + 6 * pi + m, val, meta);
+        if (pi > pj) fix_add(sys, static_cast<long long>(6 * pi + m) * n6 + 6 * pj + (n - 6), val, meta);
+        else fix_add(sys, static_cast<long long>(6 * pj + (n - 6)) * n6 + 6 * pi + m, val, meta);
       }
     } else {                                      // (jj,jj), symmetric
       if (jok) {
@@ -481,8 +488,11 @@ __device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, in
   if (oi < 0) return;
   const double val = -static_cast<double>(v);
   if (oj >= 0) {
-    fix_add(sys, static_cast<long long>(oi) * n6 + oj, val, meta);
-    if (ti != tj) fix_add(sys, static_cast<long long>(oj) * n6 + oi, val, meta);   // mirrored tile
+    // lower block triangle only (see pose_block_scatter): entry (oi, oj) if its block row is not above its block column, and
+    // the mirrored entry of an off-diagonal tile pair under the same rule - inside a diagonal 6 x 6 block both are kept
+    const int bi = oi / 6, bj = oj / 6;
+    if (bi >= bj) fix_add(sys, static_cast<long long>(oi) * n6 + oj, val, meta);
+    if (ti != tj && bj >= bi) fix_add(sys, static_cast<long long>(oj) * n6 + oi, val, meta);   // mirrored tile
   } else if (oj == -2) {
     fix_add(sys, static_cast<long long>(n6) * n6 + oi, val, meta);                 // rhs: - E (Q w)
   }
@@ -1193,23 +1203,26 @@ __device__ __forceinline__ void panel_row(const double (&v)[6], const double (&L
   }
 }
 
+// Block columns [kb0, kb1) of the factorisation (and of the right-hand side's forward substitution): the whole of it is
+// (0, P); the partitioned solve (ba_solve_twin_kernel) stops in between, and continues with the flags where they stand -
+// `panel` and `done[]` hold kb0 - 1 when a range ends at kb0.  Executed by the four waves of the workgroup, after pipe_lists;
+// the caller puts a barrier behind it.
 template <class Mat>
-__device__ __forceinline__ void chol_solve_pipe(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* colptr,
-                                const unsigned short* rowlist, PipeCtl* ctl) {
-  // executed by the four waves of the workgroup, after pipe_lists; on return (and after the caller's barrier) the rhs holds x
+__device__ __forceinline__ void chol_pipe_range(Mat A, double* Ld, int P, int* fail_flag, const int* colptr,
+                                const unsigned short* rowlist, PipeCtl* ctl, int kb0, int kb1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int P = n / 6;
   const int rstep = static_cast<int>(A.rowstep()), bstep = A.blockstep();
 #define PIPE_GIVE_UP() do { if (lane == 0) { *fail_flag = 1; __hip_atomic_store(&ctl->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } return; } while (0)
+  if (kb0 >= kb1) return;
   if (wave == 0) {
     const int q0 = lane / 6, r0 = lane - 6 * q0;
-    int m = P > 0 ? colptr[1] - colptr[0] : 0;
-    const unsigned short* rows = rowlist + (P > 0 ? colptr[0] : 0);
+    int m = colptr[kb0 + 1] - colptr[kb0];
+    const unsigned short* rows = rowlist + colptr[kb0];
     bool one_trip = 6 * m <= 64, mine = one_trip && lane < 6 * m;
-    double* rp0 = A.brow(mine ? rows[q0] : 0, r0, 0);
-    double* dptr = A.brow(0, 0, 0);
-    bool ahead = m > 0 && rows[0] == 1;
-    for (int kb = 0; kb < P; ++kb) {
+    double* rp0 = A.brow(mine ? rows[q0] : kb0, r0, kb0);
+    double* dptr = A.brow(kb0, 0, kb0);
+    bool ahead = m > 0 && rows[0] == kb0 + 1;
+    for (int kb = kb0; kb < kb1; ++kb) {
       const bool more = kb + 1 < P;
       BA_PROBE_STEP(8);
       double D[21], L[21], rd[6], v0[6], x0[6];
@@ -1280,57 +1293,14 @@ __device__ __forceinline__ void chol_solve_pipe(Mat A, double* Ld, int n, int* f
       BA_PROBE_STEP(14);
       m = nm; rows = nrows; one_trip = n_one; mine = n_mine; rp0 = nrp0; dptr = ndptr; ahead = nahead;
     }
-    // the right-hand side's forward substitution is wave 1's: wait for its last step, then substitute back
-    if (!pipe_wait_done(ctl, pipe_done_min(ctl), P - 1)) PIPE_GIVE_UP();
-    BA_PROBE(2);
-    // Back substitution L^T x = y, block rows from the bottom, the arithmetic of chol_solve_blocked.  One wave, LDS
-    // operations in program order, so no fence inside: a step's operands that do not depend on x (this lane's column of
-    // L and its y entry, the next step's factored diagonal block) are in flight while the 6 x 6 triangular solve runs.
-    double Lc[27];
-    if (P > 0) {
-#pragma unroll
-      for (int q = 0; q < 27; ++q) Lc[q] = Ld[(P - 1) * 27 + q];
-    }
-    for (int kb = P - 1; kb >= 0; --kb) {
-      double* y = A.yrow(kb);
-      double yv[6], x[6], Ln[27];
-      ld6(y, yv);
-      const int ibeg = 6 * first[kb];
-      if (kb > 0) {
-#pragma unroll
-        for (int q = 0; q < 27; ++q) Ln[q] = Ld[(kb - 1) * 27 + q];
-      }
-#pragma unroll
-      for (int c = 5; c >= 0; --c) {
-        double v = yv[c];
-#pragma unroll
-        for (int k = c + 1; k < 6; ++k) v = fma(-Lc[k * (k + 1) / 2 + c], x[k], v);
-        x[c] = v * Lc[21 + c];                                             // reciprocal diagonal
-      }
-      asm volatile("" ::: "memory");
-      if (lane < 6) y[lane] = x[lane];
-      asm volatile("" ::: "memory");
-      for (int i = ibeg + lane; i < 6 * kb; i += 64) {                     // row block kb of L is zero left of its envelope
-        const int cbk = i / 6, c2 = i - 6 * cbk;
-        double* yp = A.yrow(cbk) + c2;
-        const double* lp = A.brow(kb, 0, cbk) + c2;
-        double v = *yp;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v = fma(-lp[c * rstep], x[c], v);
-        *yp = v;
-      }
-      asm volatile("" ::: "memory");                                       // (compiler only: the next step reads what other lanes wrote)
-      if (kb > 0) {
-#pragma unroll
-        for (int q = 0; q < 27; ++q) Lc[q] = Ln[q];
-      }
-    }
+    // the right-hand side's forward substitution is wave 1's: wait for its last step
+    if (!pipe_wait_done(ctl, pipe_done_min(ctl), kb1 - 1)) PIPE_GIVE_UP();
     wave_lds_sync();
     return;
   }
   // ---- workers
   const int slot = wave == 1 ? 2 : wave - 2;                               // pair tasks go to waves 2, 3 first: wave 1 has the rhs
-  for (int kb = 0; kb < P; ++kb) {
+  for (int kb = kb0; kb < kb1; ++kb) {
     const int beg = colptr[kb], m = colptr[kb + 1] - beg;
     const unsigned short* rows = rowlist + beg;
     if (!pipe_wait_panel(ctl, kb)) PIPE_GIVE_UP();
@@ -1372,6 +1342,71 @@ __device__ __forceinline__ void chol_solve_pipe(Mat A, double* Ld, int n, int* f
 #undef PIPE_GIVE_UP
 }
 
+// Back substitution L^T x = y by wave 0, block rows kb_top .. 0, the arithmetic of chol_solve_blocked.  One wave, LDS
+// operations in program order, so no fence inside: a step's operands that do not depend on x (this lane's column of
+// L and its y entry, the next step's factored diagonal block) are in flight while the 6 x 6 triangular solve runs.
+// Block rows >= given_from hold their solution already (the partitioned solve: the separator's unknowns arrive from the
+// other workgroup); they only update the rows below given_from.  given_from > kb_top: the ordinary substitution.
+// Stops after block row kb_bot (every row above it has then received all its updates from the rows processed).
+template <class Mat>
+__device__ __forceinline__ void pipe_backsub(Mat A, const double* Ld, const int* first, int kb_top, int given_from, int kb_bot = 0) {
+  if (threadIdx.x >= 64 || kb_top < kb_bot) return;
+  const int lane = threadIdx.x & 63;
+  const int rstep = static_cast<int>(A.rowstep());
+  double Lc[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) Lc[q] = Ld[kb_top * 27 + q];
+  for (int kb = kb_top; kb >= kb_bot; --kb) {
+    double* y = A.yrow(kb);
+    double yv[6], x[6], Ln[27];
+    ld6(y, yv);
+    const int ibeg = 6 * first[kb];
+    const bool given = kb >= given_from;
+    const int iend = 6 * (given ? given_from : kb);
+    if (kb > 0) {
+#pragma unroll
+      for (int q = 0; q < 27; ++q) Ln[q] = Ld[(kb - 1) * 27 + q];
+    }
+#pragma unroll
+    for (int c = 5; c >= 0; --c) {
+      double v = yv[c];
+#pragma unroll
+      for (int k = c + 1; k < 6; ++k) v = fma(-Lc[k * (k + 1) / 2 + c], x[k], v);
+      x[c] = given ? yv[c] : v * Lc[21 + c];                               // reciprocal diagonal
+    }
+    asm volatile("" ::: "memory");
+    if (lane < 6 && !given) y[lane] = x[lane];
+    asm volatile("" ::: "memory");
+    for (int i = ibeg + lane; i < iend; i += 64) {                         // row block kb of L is zero left of its envelope
+      const int cbk = i / 6, c2 = i - 6 * cbk;
+      double* yp = A.yrow(cbk) + c2;
+      const double* lp = A.brow(kb, 0, cbk) + c2;
+      double v = *yp;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v = fma(-lp[c * rstep], x[c], v);
+      *yp = v;
+    }
+    asm volatile("" ::: "memory");                                         // (compiler only: the next step reads what other lanes wrote)
+    if (kb > 0) {
+#pragma unroll
+      for (int q = 0; q < 27; ++q) Lc[q] = Ln[q];
+    }
+  }
+  wave_lds_sync();
+}
+
+template <class Mat>
+__device__ __forceinline__ void chol_solve_pipe(Mat A, double* Ld, int n, int* fail_flag, const int* first, const int* colptr,
+                                const unsigned short* rowlist, PipeCtl* ctl) {
+  // executed by the four waves of the workgroup, after pipe_lists; on return (and after the caller's barrier) the rhs holds x
+  const int P = n / 6;
+  chol_pipe_range(A, Ld, P, fail_flag, colptr, rowlist, ctl, 0, P);
+  if (threadIdx.x < 64 && !lds_peek(&ctl->abort)) {
+    BA_PROBE(2);
+    pipe_backsub(A, Ld, first, P - 1, P);
+  }
+}
+
 
 // ---- systems beyond the dense LDS path (more than 22 free poses: the global bundle adjustment) --------------------------
 // Two multi-workgroup kernels prepare the one-workgroup solve (inside it, reading 1.1 MB of fixed point through a single CU
@@ -1410,8 +1445,15 @@ __device__ __host__ __forceinline__ long long env_lds_bytes(long long blocks, in
 }
 
 __global__ __launch_bounds__(256) void ba_env_kernel(const long long* __restrict__ sys, int* __restrict__ env, int n) {
+  // the minima of the few block rows a workgroup's 2048 entries span are formed in LDS first: one atomic per entry on ~P
+  // global addresses was 69 us of a 64-keyframe step (15 k non-zeros below the diagonal, ~250 per address)
+  constexpr int kSlots = 64;
+  __shared__ int smin[kSlots];
   const int NN = n * n;
   const int base = blockIdx.x * 2048;
+  const int br0 = (base / n) / 6;
+  if (threadIdx.x < kSlots) smin[threadIdx.x] = 0x7fffffff;
+  __syncthreads();
   long long raw[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
@@ -1423,17 +1465,68 @@ __global__ __launch_bounds__(256) void ba_env_kernel(const long long* __restrict
     const int idx = base + u * 256 + threadIdx.x;
     if (idx >= NN || raw[u] == 0) continue;
     const int r = idx / n, c = idx - r * n;
-    if (c < r) atomicMin(&env[r / 6], c / 6);
+    if (c >= r) continue;
+    const int slot = r / 6 - br0, cb = c / 6;
+    if (slot < kSlots) { if (cb < smin[slot]) atomicMin(&smin[slot], cb); }      // (the plain read only skips atomics that cannot lower the minimum)
+    else atomicMin(&env[r / 6], cb);
   }
+  __syncthreads();
+  if (threadIdx.x < kSlots && smin[threadIdx.x] != 0x7fffffff) atomicMin(&env[br0 + threadIdx.x], smin[threadIdx.x]);
+}
+
+// The partition of the pose chain (ba_solve_twin_kernel): poses [0, m) are eliminated by one workgroup, poses [s, P) - in
+// reverse order - by another, at the same time; the separator [m, s) = every pose that couples with one below m (s =
+// reach[m - 1] + 1) comes last.  Chosen to make the longer chain + the separator shortest; 0 / 0 = not partitioned: separator
+// wider than kMaxSep (loop closures), a chain less than a quarter shorter, or an image that does not fit the LDS budget.
+// One workgroup, after env_layout (first, exclusive row offsets) and envelope_reach.
+__device__ __forceinline__ void choose_partition(const int* first, const int* reach, const int* rowbase, int P, int blocks,
+                                                 long long lds_budget, int* xchg_i) {
+  __shared__ int best_s, colsum_s;
+  if (threadIdx.x == 0) { best_s = 0x7fffffff; colsum_s = 0; }
+  __syncthreads();
+  for (int m = 1 + threadIdx.x; m < P; m += blockDim.x) {
+    const int sp = reach[m - 1] + 1, w = sp - m;
+    if (w < 1 || w > kMaxSep || P - sp < 2 || m < 2) continue;
+    const int cost = (m > P - sp ? m : P - sp) + w;
+    atomicMin(&best_s, cost * 4096 + m);
+  }
+  __syncthreads();
+  int m = 0, sp = 0;
+  if (best_s != 0x7fffffff && P < 4096) {
+    m = best_s & 4095; sp = reach[m - 1] + 1;
+    if (4 * (best_s >> 12) > 3 * P) m = 0;
+  }
+  if (m) {                                                 // sizes of the two images (bounds: the separator rows are stored dense)
+    int mine = 0;
+    for (int g = m + threadIdx.x; g < P; g += blockDim.x) mine += reach[g] - g + 1;
+    if (mine) atomicAdd(&colsum_s, mine);
+    __syncthreads();
+    const int w = sp - m;
+    const long long b0 = rowbase[sp] + 36LL * w * w, b1 = 36LL * (colsum_s + w * w);
+    const long long tail = 16LL * (P + 2);                 // the global tables the loaders keep beside the image
+    const bool fits = env_lds_bytes(b0, 6 * sp, sp) + tail <= lds_budget && env_lds_bytes(b1, 6 * (P - m), P - m) + tail <= lds_budget &&
+                      b0 / 36 - sp <= kPipeListMax && b1 / 36 - (P - m) <= kPipeListMax && blocks > 0;
+    if (!fits) m = 0;
+  }
+  if (threadIdx.x == 0) { xchg_i[0] = 0; xchg_i[1] = 0; xchg_i[2] = m; xchg_i[3] = m ? sp : 0; }
 }
 
 __global__ __launch_bounds__(256) void ba_prepare_kernel(long long* __restrict__ sys, double* __restrict__ out, const int* __restrict__ env,
-                                                         int n, float lm, float ep, long long lds_budget) {
+                                                         int n, float lm, float ep, long long lds_budget, int* __restrict__ xchg_i) {
   __shared__ int first[kMaxEnvBlocks], rowbase[kMaxEnvBlocks + 1];
   __shared__ int blocks_s;
   const int P = n / 6;
   const int blocks = env_layout(env, P, first, rowbase, &blocks_s);
   const bool compact = env_lds_bytes(blocks, n, P) <= lds_budget;
+  if (xchg_i && blockIdx.x == 0) {                         // (block-uniform)
+    __shared__ int reach[kMaxEnvBlocks];
+    if (compact && P > 12) {
+      envelope_reach(first, reach, P);
+      choose_partition(first, reach, rowbase, P, blocks, lds_budget, xchg_i);
+    } else if (threadIdx.x == 0) {
+      xchg_i[0] = 0; xchg_i[1] = 0; xchg_i[2] = 0; xchg_i[3] = 0;
+    }
+  }
   const int N = n * n + n;
   const int base = blockIdx.x * 2048;
   long long raw[8];
@@ -1643,6 +1736,338 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
   __syncthreads();
   BA_PROBE(5);
   if (threadIdx.x == 0) {
+    meta[4] = 0;
+    if (failed) meta[1] = 1;
+    if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
+  }
+}
+
+// ---- the PARTITIONED pose solve (systems in the compact envelope form: the global bundle adjustment) ----------------------
+// The factorisation is a serial chain of P block columns (chol_solve_pipe: ~4 k cycles each), replicated on every rank of an
+// edge-sharded run.  A keyframe graph's pose system is block-banded away from its loop closures, and a banded chain can be
+// eliminated from BOTH ends at once (a "twisted" factorisation, the two-way case of nested dissection): ba_prepare_kernel
+// picks poses m <= s (choose_partition) such that nothing below m couples with anything from s on; then
+//   workgroup 0   loads block rows [0, s), eliminates [0, m), waits for workgroup 1's terms on the separator [m, s), adds them,
+//                 eliminates the separator, substitutes back, hands the separator's solution over, retracts poses [0, s);
+//   workgroup 1   loads block rows [m, P) REVERSED (local row l = pose P - 1 - l, blocks transposed: eliminating from the far
+//                 end is the ordinary factorisation of the reversed matrix, whose envelope is the column envelope `reach`),
+//                 with the separator x separator blocks and the separator's right-hand side ZERO, eliminates its interior
+//                 [s, P) - what is left in the separator's blocks is exactly its Schur-complement term -, writes that to
+//                 global memory, waits for the separator's solution, substitutes back, retracts poses [s, P).
+// Both run chol_pipe_range / pipe_backsub, i.e. the pipelined factorisation of the whole chain on their part; the order
+// of elimination differs from the one-chain solve, so the result agrees with it to fp64 rounding, not bit for bit - and it
+// is the same on every rank, because every rank factorises the same (all-reduced, integer) system with the same partition.
+// Hand-over through global memory: data, agent-scope release fence, flag; the reader spins on the flag (bounded), acquires.
+// Workgroups 0 and 1 of a dispatch are resident together (the first two to be placed), so the wait cannot deadlock; if a
+// limit is hit anyway the solve reports failure (zero update) instead of hanging.
+// (-DPVO_BA_PROBE, tools/ba_solve_timeline.py: the constant-rate 100 MHz clock - the two workgroups sit on different CUs -
+// at the phases of either part, slots 32 + 16 * part + k)
+#ifdef PVO_BA_PROBE
+#define TWIN_PROBE(k) do { if (g_ba_probe && threadIdx.x == 0) g_ba_probe[32 + 16 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TWIN_PROBE(k)
+#endif
+constexpr int kTwinSpinLimit = 1 << 18;
+__device__ __forceinline__ int twin_wait(int* flag) {                      // thread 0: 1 = data ready, 2 = the other side failed / timeout
+  int v = 0, spins = 0;
+  while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+    if (++spins > kTwinSpinLimit) return 2;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ba_solve_twin_kernel(
+    double* __restrict__ chol_global, float* __restrict__ poses, float* __restrict__ dx_ws, float* __restrict__ dx_out,
+    int* __restrict__ meta, int* __restrict__ status_out, int P, int t0, int* __restrict__ env, long long lds_budget,
+    double* __restrict__ xchg, Riders riders) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (blockIdx.x > 1) {
+    ride(smem, riders, blockIdx.x - 2);
+    return;
+  }
+  int* xi = reinterpret_cast<int*>(xchg);                                  // 0: terms ready  1: solution ready  2: m  3: s
+  const int m = xi[2], s = xi[3];
+  const bool split = m > 0, bottom = blockIdx.x == 1;
+  if (bottom && !split) return;
+  int& fail = *reinterpret_cast<int*>(smem);
+  __shared__ int first[kMaxEnvBlocks];
+  __shared__ int reach[kMaxEnvBlocks];
+  __shared__ unsigned short act_rows[2][kMaxActiveRows];
+  __shared__ PipeCtl pipe_ctl;
+  __shared__ int blocks_s, got_s;
+  const int meta4 = meta[4];
+  if (threadIdx.x == 0) {
+    fail = 0;
+    pipe_ctl.panel = -1; pipe_ctl.done[0] = pipe_ctl.done[1] = pipe_ctl.done[2] = -1; pipe_ctl.abort = 0; pipe_ctl.total = 0;
+  }
+  const int n = 6 * P;
+  TWIN_PROBE(0);
+  // the global tables: first[] and the offsets of the compact layout ba_prepare_kernel wrote, the column envelope
+  int* tmp = reinterpret_cast<int*>(smem + 16);
+  env_layout(env, P, first, tmp, &blocks_s);
+  const int blocks = blocks_s;
+  if (!split) {
+    // one chain (what ba_solve_kernel does with a compact system)
+    double* blk = reinterpret_cast<double*>(smem + 16);
+    double* rhs = blk + blocks;
+    double* Ld = rhs + n;
+    int* rowbase = reinterpret_cast<int*>(Ld + 27 * P + 24);
+    const bool compact = env_lds_bytes(blocks, n, P) <= lds_budget;
+    double* xrow;
+    if (compact) {
+      int rb_keep[kMaxEnvBlocks / 256];
+#pragma unroll
+      for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+        const int b = q * 256 + threadIdx.x;
+        rb_keep[q] = b < P ? tmp[b] : 0;
+      }
+      __syncthreads();
+      const int nd2 = (blocks + n) >> 1;
+      const double2* src = reinterpret_cast<const double2*>(chol_global);
+      double2* dst = reinterpret_cast<double2*>(blk);
+      for (int base = 0; base < nd2; base += 16 * blockDim.x) {
+        double2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = base + u * blockDim.x + threadIdx.x; v[u] = src[i < nd2 ? i : nd2 - 1]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = base + u * blockDim.x + threadIdx.x; if (i < nd2) dst[i] = v[u]; }
+      }
+      if (((blocks + n) & 1) && threadIdx.x == 0) blk[blocks + n - 1] = chol_global[blocks + n - 1];
+#pragma unroll
+      for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+        const int b = q * 256 + threadIdx.x;
+        if (b < P) rowbase[b] = rb_keep[q] - 36 * first[b];
+      }
+      for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
+      __syncthreads();
+      envelope_reach(first, reach, P);
+      if (pipe_lists(first, reach, P, act_rows[0], &pipe_ctl))
+        chol_solve_pipe(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach, act_rows[0], &pipe_ctl);
+      else if (threadIdx.x < 64) chol_solve_wave(EnvMat{blk, rhs, rowbase, n}, Ld, n, &fail, first, reach, act_rows[0]);
+      xrow = rhs;
+    } else {
+      for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
+      double* A = chol_global;
+      __syncthreads();
+      envelope_reach(first, reach, P);
+      chol_solve_blocked(DenseMat<long long>{A, n}, A + static_cast<long long>(n) * n + n, n, &fail, first, reach);
+      xrow = A + static_cast<long long>(n) * n;
+    }
+    __syncthreads();
+    const int failed = fail | meta4;
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+      const float v = failed ? 0.0f : static_cast<float>(xrow[idx]);
+      dx_ws[idx] = v;
+      if (dx_out) dx_out[idx] = v;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      float xi6[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) xi6[c] = dx_ws[6 * p + c];
+      float* ps = poses + 7 * static_cast<long long>(t0 + p);
+      const Pose T = retract(xi6, load_pose(ps));
+      ps[0] = T.t.x; ps[1] = T.t.y; ps[2] = T.t.z;
+      ps[3] = T.q.x; ps[4] = T.q.y; ps[5] = T.q.z; ps[6] = T.q.w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      meta[4] = 0;
+      if (failed) meta[1] = 1;
+      if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
+    }
+    return;
+  }
+
+  // ---- partitioned
+  envelope_reach(first, reach, P);                                         // column envelope of the whole system
+  const int w = s - m, Pl = bottom ? P - m : s, nl = 6 * Pl;
+  // the global tables move to the end of the dynamic segment (the image grows from its start; choose_partition left room)
+  int* tail = reinterpret_cast<int*>(smem + ((lds_budget - 16LL * (P + 2)) & ~15LL));
+  int* gfirst = tail, *grow = tail + (P + 2), *lrow = tail + 2 * (P + 2), *greach = tail + 3 * (P + 2);
+  {
+    int keep[4][kMaxEnvBlocks / 256];
+#pragma unroll
+    for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+      const int b = q * 256 + threadIdx.x;
+      keep[0][q] = b < P ? first[b] : 0; keep[1][q] = b < P ? tmp[b] : 0; keep[2][q] = b < P ? reach[b] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kMaxEnvBlocks / 256; ++q) {
+      const int b = q * 256 + threadIdx.x;
+      if (b < P) { gfirst[b] = keep[0][q]; grow[b] = keep[1][q]; greach[b] = keep[2][q]; }
+    }
+    if (threadIdx.x == 0) grow[P] = blocks;
+    __syncthreads();
+  }
+  // this part's envelope: the separator's rows are dense inside the separator (the other part's elimination fills them)
+  for (int l = threadIdx.x; l < Pl; l += blockDim.x) {
+    int f;
+    if (!bottom) f = l < m ? gfirst[l] : min(gfirst[l], m);
+    else { const int g = P - 1 - l; f = P - 1 - greach[g]; if (l >= P - s) f = min(f, P - s); }
+    first[l] = f;
+  }
+  __syncthreads();
+  const int lblocks = env_layout(first, Pl, first, lrow, &blocks_s);       // (reads first[b] as the envelope, writes min(first[b], b) back)
+  double* blk = reinterpret_cast<double*>(smem + 16);
+  double* rhs = blk + lblocks;
+  double* Ld = rhs + nl;
+  int* rowoff = reinterpret_cast<int*>(Ld + 27 * Pl + 24);
+  const bool room = reinterpret_cast<unsigned char*>(rowoff + Pl + 2) <= reinterpret_cast<unsigned char*>(tail);
+  if (!room) {                                                             // (choose_partition checked a bound of this: not reached)
+    if (threadIdx.x == 0) fail = 1;
+  } else {
+    for (int i = threadIdx.x; i < lblocks + nl; i += blockDim.x) blk[i] = 0.0;
+    for (int l = threadIdx.x; l < Pl; l += blockDim.x) rowoff[l] = lrow[l] - 36 * first[l];
+  }
+  __syncthreads();
+  TWIN_PROBE(1);
+  if (room) {
+    // source: whole block rows of the compact image, [0, s) for the top part, [s, P) for the bottom part.  Rows [0, m) keep
+    // their layout: a straight copy.  Everything else is placed pair by pair (offsets are multiples of 36, so a 16-byte pair
+    // never straddles a block): sixteen loads in flight per thread, the row search and the index arithmetic behind them.
+    const double2* src2 = reinterpret_cast<const double2*>(chol_global);
+    if (!bottom) {
+      const int nd2 = grow[m] >> 1;
+      double2* dst2 = reinterpret_cast<double2*>(blk);
+      for (int base = 0; base < nd2; base += 16 * blockDim.x) {
+        double2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = base + u * blockDim.x + threadIdx.x; v[u] = src2[i < nd2 ? i : nd2 - 1]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = base + u * blockDim.x + threadIdx.x; if (i < nd2) dst2[i] = v[u]; }
+      }
+    }
+    const int p0 = (bottom ? grow[s] : grow[m]) >> 1, p1 = (bottom ? blocks : grow[s]) >> 1;
+    for (int base = p0; base < p1; base += 16 * blockDim.x) {
+      double2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int i = base + u * blockDim.x + threadIdx.x; v[u] = src2[i < p1 ? i : p1 - 1]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i2 = base + u * blockDim.x + threadIdx.x;
+        if (i2 >= p1) continue;
+        const int i = 2 * i2;
+        int lo = bottom ? s : m, hi = bottom ? P : s;                      // row rb with grow[rb] <= i < grow[rb + 1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (grow[mid] <= i) lo = mid; else hi = mid; }
+        const int rb = lo, k = i - grow[rb], kb36 = k / 36, e = k - 36 * kb36, cb = gfirst[rb] + kb36;
+        if (!bottom) {
+          *reinterpret_cast<double2*>(blk + rowoff[rb] + 36 * cb + e) = v[u];
+        } else {
+          const int ri = e / 6, ci = e - 6 * ri;                           // (e even: ci and ci + 1 lie in one row)
+          const int l = P - 1 - cb, lp = P - 1 - rb;                       // block (rb, cb) -> block (l, lp), transposed
+          double* dst = blk + rowoff[l] + 36 * lp + 6 * ci + ri;
+          dst[0] = v[u].x; dst[6] = v[u].y;
+        }
+      }
+    }
+    if (!bottom) { for (int i = threadIdx.x; i < 6 * s; i += blockDim.x) rhs[i] = chol_global[blocks + i]; }
+    else { for (int i = threadIdx.x; i < 6 * (P - s); i += blockDim.x) { const int l = i / 6; rhs[i] = chol_global[blocks + 6 * (P - 1 - l) + (i - 6 * l)]; } }
+  }
+  __syncthreads();
+  TWIN_PROBE(2);
+  bool lists = false;
+  if (room) {
+    envelope_reach(first, reach, Pl);
+    lists = pipe_lists(first, reach, Pl, act_rows[0], &pipe_ctl);
+    if (!lists && threadIdx.x == 0) fail = 1;
+  }
+  __syncthreads();
+  const EnvMat A{blk, rhs, rowoff, nl};
+  TWIN_PROBE(3);
+  double* cterm = xchg + 2;                                                // [w][w][36] rows a >= c, then the rhs [6 w], then x [6 w]
+  double* crhs = cterm + 36 * kMaxSep * kMaxSep;
+  double* xsep = crhs + 6 * kMaxSep;
+  if (!bottom) {
+    if (!fail) chol_pipe_range(A, Ld, Pl, &fail, reach, act_rows[0], &pipe_ctl, 0, m);
+    __syncthreads();
+    TWIN_PROBE(4);
+    if (threadIdx.x == 0) got_s = twin_wait(&xi[0]);                       // (always: workgroup 1 reads `env`, reset below)
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (got_s != 1 && threadIdx.x == 0) fail = 1;
+    TWIN_PROBE(5);
+    for (int b = threadIdx.x; b < P; b += blockDim.x) env[b] = 0x7fffffff;
+    __syncthreads();
+    if (!fail) {
+      for (int t = threadIdx.x; t < 36 * w * w; t += blockDim.x) {
+        const int pr = t / 36, e = t - 36 * pr, a = pr / w, c = pr - a * w;
+        if (c > a) continue;
+        blk[rowoff[m + a] + 36 * (m + c) + e] += cterm[(a * kMaxSep + c) * 36 + e];
+      }
+      for (int t = threadIdx.x; t < 6 * w; t += blockDim.x) rhs[6 * m + t] += crhs[t];
+    }
+    __syncthreads();
+    TWIN_PROBE(6);
+    if (!fail) chol_pipe_range(A, Ld, Pl, &fail, reach, act_rows[0], &pipe_ctl, m, s);
+    __syncthreads();
+    TWIN_PROBE(7);
+    if (!fail) pipe_backsub(A, Ld, first, Pl - 1, Pl, m);                   // the separator's unknowns first: the other part waits for them
+    __syncthreads();
+    TWIN_PROBE(8);
+    if (threadIdx.x < 6 * w) xsep[threadIdx.x] = fail ? 0.0 : rhs[6 * m + threadIdx.x];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&xi[1], fail ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    TWIN_PROBE(9);
+    if (!fail) pipe_backsub(A, Ld, first, m - 1, Pl);
+  } else {
+    if (!fail) chol_pipe_range(A, Ld, Pl, &fail, reach, act_rows[0], &pipe_ctl, 0, P - s);
+    __syncthreads();
+    TWIN_PROBE(4);
+    if (!fail) {
+      for (int t = threadIdx.x; t < 36 * w * w; t += blockDim.x) {
+        const int pr = t / 36, e = t - 36 * pr, a = pr / w, c = pr - a * w;
+        if (c > a) continue;
+        const int ri = e / 6, ci = e - 6 * ri;
+        const int l = P - 1 - (m + c), lp = P - 1 - (m + a);               // global block (m + a, m + c), a >= c  <-  local (l, lp), l >= lp
+        cterm[(a * kMaxSep + c) * 36 + e] = blk[rowoff[l] + 36 * lp + (a == c ? 6 * ri + ci : 6 * ci + ri)];
+      }
+      for (int t = threadIdx.x; t < 6 * w; t += blockDim.x) { const int a = t / 6; crhs[t] = rhs[6 * (P - 1 - (m + a)) + (t - 6 * a)]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&xi[0], fail ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      TWIN_PROBE(5);
+      got_s = twin_wait(&xi[1]);
+    }
+    __syncthreads();
+    TWIN_PROBE(6);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (got_s != 1 && threadIdx.x == 0) fail = 1;
+    __syncthreads();
+    if (!fail) {
+      for (int t = threadIdx.x; t < 6 * w; t += blockDim.x) { const int a = t / 6; rhs[6 * (P - 1 - (m + a)) + (t - 6 * a)] = xsep[t]; }
+    }
+    __syncthreads();
+    if (!fail) pipe_backsub(A, Ld, first, Pl - 1, P - s);
+  }
+  __syncthreads();
+  TWIN_PROBE(10);
+  const int failed = fail | meta4;
+  const int g0 = bottom ? s : 0, g1 = bottom ? P : s;                      // the poses this part owns
+  for (int idx = 6 * g0 + threadIdx.x; idx < 6 * g1; idx += blockDim.x) {
+    const int g = idx / 6, c = idx - 6 * g;
+    const float v = failed ? 0.0f : static_cast<float>(rhs[bottom ? 6 * (P - 1 - g) + c : idx]);
+    dx_ws[idx] = v;
+    if (dx_out) dx_out[idx] = v;
+  }
+  __syncthreads();
+  for (int p = g0 + threadIdx.x; p < g1; p += blockDim.x) {               // pose_retr_kernel (:877-910)
+    float xi6[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xi6[c] = dx_ws[6 * p + c];
+    float* ps = poses + 7 * static_cast<long long>(t0 + p);
+    const Pose T = retract(xi6, load_pose(ps));
+    ps[0] = T.t.x; ps[1] = T.t.y; ps[2] = T.t.z;
+    ps[3] = T.q.x; ps[4] = T.q.y; ps[5] = T.q.z; ps[6] = T.q.w;
+  }
+  __syncthreads();
+  TWIN_PROBE(11);
+  if (threadIdx.x == 0 && !bottom) {
     meta[4] = 0;
     if (failed) meta[1] = 1;
     if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
@@ -1920,17 +2345,32 @@ extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
   // 12: 87.5 k blocked / 86.0 k pipe, 21: 168 k / 157 k, 63: 578 k blocked / 485 k wave / 364 k pipe - the pipeline wins once the
   // envelope makes most of a step's candidate rows inactive.  PVO_BA_SOLVER = blocked | wave | pipe overrides (tests compare
   // the three bit for bit).
-  static const int solver_env = [] { const char* e = getenv("PVO_BA_SOLVER"); return !e ? -1 : (e[0] == 'b' ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'p' ? 2 : -1))); }();
-  const int solver_wave = solver_env >= 0 ? solver_env : (P > 12 ? 2 : 0);              // 0 blocked | 1 wave | 2 pipe
+  // Beyond the dense LDS path a fourth form, the PARTITIONED solve (ba_solve_twin_kernel: two workgroups eliminate the pose
+  // chain from both ends, tools/ba_solve_timeline.py), is the default; its result equals the others' to fp64 rounding.
+  static const int solver_env = [] { const char* e = getenv("PVO_BA_SOLVER"); return !e ? -1 : (e[0] == 'b' ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 't' ? 3 : -1)))); }();
+  const int solver_pick = solver_env >= 0 ? solver_env : (use_lds ? (P > 12 ? 2 : 0) : 3);      // 0 blocked | 1 wave | 2 pipe | 3 partitioned
+  const bool twin = solver_pick == 3 && !use_lds;
+  const int solver_wave = solver_pick == 3 ? 2 : solver_pick;
   if (!use_lds) {
     hipLaunchKernelGGL(ba_env_kernel, dim3((n6 * n6 + 2047) / 2048), dim3(256), 0, st, sys, w.plan.env, n6);
     PVO_CHECK_LAUNCH();
     hipLaunchKernelGGL(ba_prepare_kernel, dim3((n6 * n6 + n6 + 2047) / 2048), dim3(256), 0, st, sys, w.chol, w.plan.env, n6, lm, ep,
-                       static_cast<long long>(kSolveLdsMax));
+                       static_cast<long long>(kSolveLdsMax), twin ? reinterpret_cast<int*>(w.xchg) : nullptr);
     PVO_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(ba_solve_kernel, dim3(1 + rider_blocks), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
-                     w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax), solver_wave, rider);
+  if (twin) {
+    static bool twin_attr_set = false;
+    if (!twin_attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_twin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(kSolveLdsMax)) != hipSuccess) return PVO_ELAUNCH;
+      twin_attr_set = true;
+    }
+    hipLaunchKernelGGL(ba_solve_twin_kernel, dim3(2 + rider_blocks), dim3(256), lds, st, w.chol, poses, w.dx, dx_out,
+                       w.plan.meta, status_out, P, t0, w.plan.env, static_cast<long long>(kSolveLdsMax), w.xchg, rider);
+  } else {
+    hipLaunchKernelGGL(ba_solve_kernel, dim3(1 + rider_blocks), dim3(256), lds, st, sys, w.chol, poses, w.dx, dx_out,
+                       w.plan.meta, status_out, P, t0, lm, ep, use_lds, w.plan.env, static_cast<long long>(kSolveLdsMax), solver_wave, rider);
+  }
   PVO_CHECK_LAUNCH();
   if (!motion_only && E + P > 0) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);
@@ -1939,6 +2379,21 @@ extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
                        w.plan, jj, w.Ei, w.Eij, w.Q, w.w, w.dx, disps, dz_out, dz_rows, HW, t0, P, flags, clamp_frames, disp_min);
     PVO_CHECK_LAUNCH();
   }
+  return PVO_OK;
+}
+
+// diagnostic (tests, tools): the partition the last pvo_ba_finish on this workspace chose - out[0] = m, out[1] = s, both 0 when the
+// pose chain was solved in one piece.  Synchronises the stream.
+extern "C" int pvo_ba_last_partition(void* workspace, size_t workspace_bytes, int E, int P, int nframes, int HW, int* out, void* stream) {
+  if (!workspace || !out || E < 0 || P < 0) return PVO_EINVAL;
+  if (workspace_bytes < pvo_ba_workspace_bytes(E, P, nframes, HW)) return PVO_EWORKSPACE;
+  out[0] = out[1] = 0;
+  if (6 * P <= kLdsCholMax) return PVO_OK;
+  Ws w = carve(ws_base(workspace), E, P, nframes, HW);
+  int host[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(host, w.xchg, sizeof(host), hipMemcpyDeviceToHost, pvo_stream(stream)) != hipSuccess) return PVO_ELAUNCH;
+  if (hipStreamSynchronize(pvo_stream(stream)) != hipSuccess) return PVO_ELAUNCH;
+  out[0] = host[2]; out[1] = host[3];
   return PVO_OK;
 }
 

@@ -557,6 +557,20 @@ def ba_workspace(E, P, nframes, HW, device):
     return torch.empty(int(n), dtype=torch.uint8, device=device)
 
 
+def ba_last_partition(E, P, nframes, HW, device, workspace=None):
+    """diagnostic: (m, s) of the partitioned pose solve the last BA of this size ran with on `device` - poses [0, m) and
+    [s, P) were eliminated by two workgroups at once, the separator [m, s) last; (0, 0) = one chain.  `workspace`: the
+    private workspace of the split entry points, default the one `ba` uses.  Synchronises."""
+    dev = torch.device(device)
+    lib = _lib.load()
+    ws = workspace if workspace is not None else _workspace(dev, lib.pvo_ba_workspace_bytes(int(E), int(P), int(nframes), int(HW)))
+    out = (ctypes.c_int * 2)()
+    with torch.cuda.device(dev):
+        check(lib.pvo_ba_last_partition(ctypes.c_void_p(ws.data_ptr()), ws.numel(), int(E), int(P), int(nframes), int(HW), out, _stream(dev)),
+              "ba_last_partition")
+    return int(out[0]), int(out[1])
+
+
 def ba_plan(ii, jj, nframes, HW, K_eta, t0, t1, workspace):
     dev = _dev(ii, jj, workspace)
     _long(ii, "ii"); _long(jj, "jj")

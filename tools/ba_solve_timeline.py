@@ -25,7 +25,7 @@ s = _scene(0, nf, 48, 64, 3, 1)
 d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()}
 lib = _lib.load()
 lib.pvo_debug_ba_probe.restype = ctypes.c_int; lib.pvo_debug_ba_probe.argtypes = [ctypes.c_void_p]
-buf = torch.zeros(32, dtype=torch.int64, device=dev)
+buf = torch.zeros(64, dtype=torch.int64, device=dev)
 run = lambda: db.ba(d["poses"].clone(), d["disps"].clone(), d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], 1, nf, 2, 1e-4, 0.1, False)
 for _ in range(3):
     run()
@@ -39,3 +39,16 @@ print("P = %d free poses: load + convert %.1f k cycles | factorisation %.1f | su
 if t[14]:
     names = ["operand loads issued", "6x6 Cholesky", "panel + store of the factored block", "publish", "wait for the workers", "look-ahead update"]
     print("   pipelined factorisation, wave 0, block column P/2: " + " | ".join("%s %d" % (nm, t[9 + i] - t[8 + i]) for i, nm in enumerate(names)) + " | step %d cycles" % (t[14] - t[8]))
+if t[32]:
+    part = db.ba_last_partition(d["ii"].shape[0], nf - 1, nf, 48 * 64, dev)
+    names = ["", "tables, local layout, zero fill", "load", "active-row lists", "own columns", "top: wait for the terms | bottom: terms written", "top: terms added | bottom: wait for x",
+             "top: separator columns | bottom: (none)", "top: back substitution", "top: x handed over", "back substitution (bottom) / idle", "dx out + retraction"]
+    base = min(t[32], t[48])
+    print("   partitioned solve, (m, s) = %s; 100 MHz clock, us since the first workgroup entered:" % (part,))
+    for w, nm in ((0, "workgroup 0 (poses [0, s))"), (1, "workgroup 1 (poses [s, P) reversed)")):
+        st = [t[32 + 16 * w + k] for k in range(12)]
+        print("     %s: entered at %.2f" % (nm, (st[0] - base) / 100.0))
+        prev = st[0]
+        for k in range(1, 12):
+            if st[k]:
+                print("        %-62s %7.2f us  (at %.2f)" % (names[k], (st[k] - prev) / 100.0, (st[k] - base) / 100.0)); prev = st[k]
