@@ -456,7 +456,6 @@ __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const 
 // triple with 36 LDS tree reductions each (schur_block :1201-1290, EEt6x6 :980-1035).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSchurPix = 256;           // pixels per workgroup (a quarter per wave); 512: 48 workgroups at S-B, 19.9 us; 256: 96, 18.1 us
-constexpr int kSchurSteps = kSchurPix / 4 / 16;
 constexpr int kMaxRows = 1024;           // rows of M the LDS row table can describe
 constexpr int kFastTiles = 4;            // up to 4 row tiles (63 rows + w) accumulate in one pass
 
@@ -499,7 +498,7 @@ __device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, in
 }
 
 // all T(T+1)/2 tile pairs in ONE pass over the pixels (rows read once, accumulators static)
-template <int T, bool VEC4>
+template <int T, bool VEC4, int PIX>
 __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* rowout,
                                            gfloat* __restrict__ qrow, float* red /*[4][NT*4][64]*/,
                                            long long* __restrict__ sys, int HW, int n6, int pix_base, int* meta) {
@@ -513,7 +512,7 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
-  for (int s = 0; s < kSchurSteps; ++s) {
+  for (int s = 0; s < PIX / 64; ++s) {
     const int p = pix_base + s * 16 + 4 * kq;
     const f32x4 q = load4<VEC4>(qrow, p, HW);
     f32x4 b[T], a[T];
@@ -553,7 +552,7 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
     }
 }
 
-template <bool VEC4>
+template <bool VEC4, int PIX>
 __device__ __forceinline__ void ba_schur_body(
     const Plan& pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
@@ -593,8 +592,8 @@ __device__ __forceinline__ void ba_schur_body(
   __syncthreads();
   BA_WG_PROBE(1, 2);                     // edge list in LDS
 #pragma unroll
-  for (int h = 0; h < kSchurPix / 256; ++h) {          // depth phase for this workgroup's pixels
-    const int x = blockIdx.x * kSchurPix + h * 256 + tid;
+  for (int h = 0; h < PIX / 256; ++h) {                // depth phase for this workgroup's pixels
+    const int x = blockIdx.x * PIX + h * 256 + tid;
     if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
   }
 
@@ -622,13 +621,13 @@ __device__ __forceinline__ void ba_schur_body(
   if (nrows == 0) return;
   const int T = (nrows + 15) >> 4;
   gfloat* __restrict__ qrow = (gfloat*)(Q + static_cast<long long>(k) * HW);
-  const int pix_base = blockIdx.x * kSchurPix + wave * (kSchurPix / 4);
+  const int pix_base = blockIdx.x * PIX + wave * (PIX / 4);
 
   switch (T) {
-    case 1: schur_pass<1, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
-    case 2: schur_pass<2, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
-    case 3: schur_pass<3, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
-    case 4: schur_pass<4, VEC4>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 1: schur_pass<1, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 2: schur_pass<2, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 3: schur_pass<3, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 4: schur_pass<4, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
     default: break;
   }
   // any degree: one tile pair at a time, row tiles re-read from L2
@@ -639,7 +638,7 @@ __device__ __forceinline__ void ba_schur_body(
       gfloat* __restrict__ rb = rowptr[tj * 16 + idx];
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-      for (int s = 0; s < kSchurSteps; ++s) {
+      for (int s = 0; s < PIX / 64; ++s) {
         const int p = pix_base + s * 16 + 4 * kq;
         const f32x4 a = load4<VEC4>(ra, p, HW);
         const f32x4 b = (ti == tj) ? a : load4<VEC4>(rb, p, HW);
@@ -659,14 +658,14 @@ __device__ __forceinline__ void ba_schur_body(
   }
 }
 
-template <bool VEC4>
+template <bool VEC4, int PIX>
 __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     Plan pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
     int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA) {
-  ba_schur_body<VEC4>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA);
+  ba_schur_body<VEC4, PIX>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA);
 }
 
 // ---------------------------------------------------------------------------
@@ -2244,13 +2243,20 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
   PVO_CHECK_LAUNCH();
   if (!motion_only && !only_assemble) {
     const int Kmax = (nframes < P + E) ? nframes : (P + E);
-    const dim3 sgrid((HW + kSchurPix - 1) / kSchurPix, Kmax);
-    if ((HW & 3) == 0)
-      hipLaunchKernelGGL(ba_schur_mfma_kernel<true>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P,
-                         two_stage ? w.part : nullptr, ii, E, chunksA);
-    else
-      hipLaunchKernelGGL(ba_schur_mfma_kernel<false>, sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Eij, w.Q, w.w, sys, HW, t0, P,
-                         two_stage ? w.part : nullptr, ii, E, chunksA);
+    // pixels per workgroup: 256 while the grid fits the chip's resident slots (two 55 KB workgroups per CU); a global bundle
+    // adjustment (64 keyframes x 12 chunks: 768 workgroups in two rounds, every one issuing ~1000 atomics into the same 63 x 63
+    // blocks) takes bigger chunks - fewer, longer workgroups, a fraction of the atomics
+    static const int pix_env = [] { const char* e = getenv("PVO_SCHUR_PIX"); return e ? atoi(e) : 0; }();
+    // (a function of the map size and the buffer length only - not of this rank's edge count: the chunking fixes the fp32
+    // partial sums, and an edge-sharded run must form the same ones as the whole graph)
+    const long long wg256 = static_cast<long long>((HW + 255) / 256) * nframes;
+    const int pix = (pix_env == 256 || pix_env == 512 || pix_env == 1024) ? pix_env : (wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024));
+    const dim3 sgrid((HW + pix - 1) / pix, Kmax);
+#define PVO_SCHUR_LAUNCH(V, PX) hipLaunchKernelGGL((ba_schur_mfma_kernel<V, PX>), sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, \
+                                                   w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA)
+    if ((HW & 3) == 0) { if (pix == 256) PVO_SCHUR_LAUNCH(true, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(true, 512); else PVO_SCHUR_LAUNCH(true, 1024); }
+    else { if (pix == 256) PVO_SCHUR_LAUNCH(false, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(false, 512); else PVO_SCHUR_LAUNCH(false, 1024); }
+#undef PVO_SCHUR_LAUNCH
     PVO_CHECK_LAUNCH();
   }
   return PVO_OK;
