@@ -2364,6 +2364,7 @@ extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
                        static_cast<long long>(kSolveLdsMax), twin ? reinterpret_cast<int*>(w.xchg) : nullptr);
     PVO_CHECK_LAUNCH();
   }
+  if (!use_lds && !twin && hipMemsetAsync(w.xchg, 0, 16, st) != hipSuccess) return PVO_ELAUNCH;      // (pvo_ba_last_partition: one chain)
   if (twin) {
     static bool twin_attr_set = false;
     if (!twin_attr_set) {

@@ -172,6 +172,82 @@ def test_ba_fixed_source_frame_and_broadcast_eta(cuda):
     assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("P,radius", [(64, 3), (40, 2), (23, 3)])
+def test_partitioned_pose_solve_partitions_a_chain_and_matches_the_oracle(cuda, P, radius):
+    """the pose solve beyond the dense LDS path (ba_solve_twin_kernel): a keyframe chain is eliminated from both ends by two
+    workgroups, the separator last - the partition is reported, balanced, and the result is the oracle's (dense fp64 solve)"""
+    from pvo_amd import droid_backends as db
+    ht, wd = 8, 10
+    s = _scene(P + radius, P, ht, wd, radius, 1)
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 1, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 1)
+    m, sp = db.ba_last_partition(s["ii"].shape[0], P - 1, P, ht * wd, cuda)
+    free = P - 1
+    assert 2 <= m < sp <= free - 2 and sp - m == 2 * radius, (m, sp)            # separator: the 2 * radius poses coupled across the cut
+    assert abs(m - (free - sp)) <= 1                                             # the two chains are as long as each other
+    assert status[0] == 0 and status[1] == want["K"]
+    assert np.abs(dx - want["dx"]).max() < 2e-6 * max(1.0, np.abs(want["dx"]).max() / 1e-2)
+    assert np.abs(poses - want["poses"]).max() < 1e-5 and np.abs(disps - want["disps"]).max() < 1e-4
+
+
+def test_partitioned_pose_solve_declines_a_wide_separator(cuda):
+    """loop closures from the far end back to the first poses couple everything below the cut with the end of the chain: the
+    separator would be wider than the exchange buffer allows, the solve stays one chain (and is still the oracle's)"""
+    from pvo_amd import droid_backends as db
+    P, ht, wd = 30, 8, 10
+    s = _scene(77, P, ht, wd, 2, 1)
+    far = list(range(P - 14, P - 1))
+    extra_i, extra_j = torch.tensor([1] * len(far) + far), torch.tensor(far + [1] * len(far))
+    c, _ = O.reproject(s["poses_gt"].numpy(), s["disps_gt"].numpy(), s["intr"][None].repeat(P, 1).numpy(), extra_i.numpy(), extra_j.numpy())
+    g = torch.Generator().manual_seed(5)
+    ne = extra_i.shape[0]
+    t_extra = (torch.from_numpy(c) + 0.1 * torch.randn(ne, ht, wd, 2, generator=g)).permute(0, 3, 1, 2)
+    s = dict(s, ii=torch.cat([s["ii"], extra_i]), jj=torch.cat([s["jj"], extra_j]), target=torch.cat([s["target"], t_extra]).contiguous(),
+             weight=torch.cat([s["weight"], 0.2 * torch.rand(ne, 2, ht, wd, generator=g)]).contiguous())
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 1, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 1)
+    assert db.ba_last_partition(s["ii"].shape[0], P - 1, P, ht * wd, cuda) == (0, 0)
+    assert status[0] == 0 and np.abs(poses - want["poses"]).max() < 1e-5
+
+
+def test_partitioned_pose_solve_reports_a_non_spd_system(cuda):
+    """a pivot fails in one of the two parts: both write a zero update, the status says so (no hang: the hand-over carries
+    the failure)"""
+    P = 40
+    s = _scene(11, P, 8, 10, 2, 1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 1, lm=0.0, ep=-1e9)
+    assert status[0] == 1 and not dx.any()
+    assert np.array_equal(poses, s["poses"].numpy())
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 1)                           # the workspace is usable afterwards
+    assert dx.any()
+
+
+def test_partitioned_and_one_chain_solves_agree(cuda):
+    """the same system through ba_solve_twin_kernel and through the one-chain pipeline (PVO_BA_SOLVER, read once per process):
+    fp64 rounding apart (the order of elimination differs), far inside fp32"""
+    import subprocess
+    import sys
+    import tempfile
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); from test_geom_ba_gpu import _scene; from pvo_amd import droid_backends as db; "
+            "s = _scene(3, 50, 8, 10, 3, 1); d = lambda t: t.cuda(); p, q = d(s['poses'].clone()), d(s['disps'].clone()); "
+            "dx, dz = db.ba(p, q, d(s['intr']), d(s['target']), d(s['weight']), d(s['eta']), d(s['ii']), d(s['jj']), s['t0'], s['t1'], 1, 1e-4, 0.1, False); "
+            "torch.save((dx.cpu(), dz.cpu(), db.ba_last_partition(s['ii'].shape[0], 49, 50, 80, 'cuda')), sys.argv[1])") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for solver in ("pipe", "twin"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, PVO_BA_SOLVER=solver), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout[-2000:]
+            outs[solver] = torch.load(f.name)
+    assert outs["pipe"][2] == (0, 0) and outs["twin"][2][0] > 0
+    scale = outs["pipe"][0].abs().max().item()
+    assert (outs["pipe"][0] - outs["twin"][0]).abs().max().item() <= 4e-7 * scale
+    assert (outs["pipe"][1] - outs["twin"][1]).abs().max().item() <= 1e-6 * max(1.0, outs["pipe"][1].abs().max().item())
+
+
 def test_ba_non_spd_gives_zero_update(cuda):
     s = _scene(10, 4, 6, 8, 2, 1)
     s["weight"] = torch.zeros_like(s["weight"])
