@@ -553,6 +553,27 @@ int pvo_ba_finish(float* poses, float* disps, void* sys,
                   float lm, float ep, int motion_only, int clamp_frames, float disp_min,
                   float* dx_out, float* dz_out, int dz_rows, int* status_out,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* The message of an edge-sharded step, packed by the library (round 4): first_s (device, int[P]) is the
+ * STRUCTURAL envelope of the pose system - first_s[b] = lowest free pose block row b can couple with, derived from the whole
+ * graph's edge list, the same table on every rank (pvo_amd/parallel.py: envelope_structure).
+ *   pvo_ba_packed_elems(first_host, P)  int64 elements of the message: 36 * sum_b (b - first[b] + 1) + 6P (host-side helper)
+ *   pvo_ba_pack(sys, first_s, msg, P)    after pvo_ba_local: the lower-triangle blocks (b, first_s[b] .. b) and the rhs of `sys`
+ *                                        gathered into msg (block row after block row, 36 entries per block, then the rhs);
+ *                                        `sys` is left ZEROED (the next pvo_ba_local may say so, bit 1 of motion_only)
+ *   -- caller all-reduces (sum) msg AS 64-BIT INTEGERS --
+ *   pvo_ba_finish_packed(..., msg, first_s, ...)   pvo_ba_finish reading the message instead of the dense system: numeric
+ *                                        envelope, fp64 + damping, (partitioned) solve, retraction, back-substitution.
+ * Results are bit-identical to all-reducing the dense `sys` and calling pvo_ba_finish (the entries outside the structural
+ * envelope are zero on every rank); the message is 124 KB instead of 1.15 MB at 63 poses of a radius-3 graph. */
+size_t pvo_ba_packed_elems(const int* first_host, int P);
+int pvo_ba_pack(void* sys, const int* first_s, void* msg, int P, void* stream);
+int pvo_ba_finish_packed(float* poses, float* disps, const void* msg, const int* first_s,
+                         const int64_t* ii, const int64_t* jj,
+                         int E, int nframes, int ht, int wd, int t0, int t1,
+                         float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                         float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* pvo_ba_finish with riders: the pose solve is one workgroup, the rest of the chip idles meanwhile, and no other queue may run
  * beside the bundle adjustment - so up to three independent jobs are computed by additional workgroups of the SAME dispatch
  * (a job with a NULL output is absent; none of them may alias a BA buffer):

@@ -73,6 +73,10 @@ SIGNATURES = {
                     _f, _f, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_plan": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "pvo_ba_last_partition": (_i, [_vp, _sz, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), _vp]),
+    "pvo_ba_packed_elems": (_sz, [ctypes.POINTER(ctypes.c_int), _i]),
+    "pvo_ba_pack": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "pvo_ba_finish_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,
+                                  _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_local": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                           _i, _vp, _vp, _sz, _vp]),
     "pvo_ba_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f,

@@ -123,8 +123,9 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.dx = reinterpret_cast<float*>(take(sizeof(float) * (n6 + 8)));
   w.part = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * ((HW + kChunkA - 1) / kChunkA) * 90 + 16));
   w.sys = reinterpret_cast<long long*>(take(sizeof(double) * (n6 * n6 + n6 + 8)));
-  w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? n6 * n6 + n6 + 27 * (n6 / 6) + 32 : 8)));
-  w.xchg = reinterpret_cast<double*>(take(sizeof(double) * (n6 > kLdsCholMax ? kXchgDoubles : 2)));
+  // (both at every size: a packed envelope message - pvo_ba_finish_packed - is factorised from the compact image whatever P is)
+  w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 * n6 + n6 + 27 * (n6 / 6) + 32)));
+  w.xchg = reinterpret_cast<double*>(take(sizeof(double) * kXchgDoubles));
   w.bytes = off;
   return w;
 }
@@ -1553,6 +1554,126 @@ __global__ __launch_bounds__(256) void ba_prepare_kernel(long long* __restrict__
   }
 }
 
+// ---- the edge-sharded step's message: the STRUCTURAL envelope of the pose system, packed -----------------------------------
+// Between pvo_ba_local and pvo_ba_finish an edge-sharded run all-reduces the lower-triangle blocks (b, first_s[b] .. b) and the
+// right-hand side (parallel.py: envelope_structure - derived from the whole graph's edge list, the same table on every rank).
+// ba_pack_kernel gathers exactly those entries of the dense fixed-point system into one contiguous int64 message, in the
+// compact layout of env_layout(first_s) - block row b = blocks first_s[b] .. b of 36 entries, then the 6P right-hand side - and
+// leaves `sys` zeroed; after the all-reduce ba_env_packed_kernel / ba_prepare_packed_kernel read the MESSAGE (124 KB at 63
+// poses) instead of the dense system (1.15 MB): numeric envelope, fp64 + damping into the solve's layout, partition.  No
+// index tensors, no scatter back, nothing of torch's between the two library calls and the collective.
+__global__ __launch_bounds__(256) void ba_pack_kernel(long long* __restrict__ sys, const int* __restrict__ first_s, long long* __restrict__ msg, int n) {
+  __shared__ int first[kMaxEnvBlocks], rowbase[kMaxEnvBlocks + 1];
+  __shared__ int blocks_s;
+  const int P = n / 6;
+  const int blocks = env_layout(first_s, P, first, rowbase, &blocks_s);
+  const int N = n * n + n;
+  const int base = blockIdx.x * 2048;
+  long long raw[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    raw[u] = idx < N ? sys[idx] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = base + u * 256 + threadIdx.x;
+    if (idx >= N) continue;
+    sys[idx] = 0;
+    if (idx >= n * n) { msg[blocks + (idx - n * n)] = raw[u]; continue; }
+    const int r = idx / n, c = idx - r * n;
+    const int rb = r / 6, cb = c / 6;
+    if (cb > rb || cb < first[rb]) continue;                // upper triangle (never written) / structural zeros
+    msg[rowbase[rb] + (cb - first[rb]) * 36 + (r - 6 * rb) * 6 + (c - 6 * cb)] = raw[u];
+  }
+}
+
+// block row of entry k of a packed image: the rb with rowbase[rb] <= k (rowbase ascending, k < total)
+__device__ __forceinline__ int packed_row(const int* rowbase, int P, int k) {
+  int lo = 0, hi = P;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowbase[mid] <= k) lo = mid; else hi = mid; }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void ba_env_packed_kernel(const long long* __restrict__ msg, const int* __restrict__ first_s, int* __restrict__ env, int n) {
+  __shared__ int first[kMaxEnvBlocks], rowbase[kMaxEnvBlocks + 1];
+  __shared__ int blocks_s;
+  constexpr int kSlots = 64;                                // 2048 entries span at most 57 block rows (36 entries each at least)
+  __shared__ int smin[kSlots];
+  const int P = n / 6;
+  const int blocks = env_layout(first_s, P, first, rowbase, &blocks_s);
+  const int base = blockIdx.x * 2048;
+  if (base >= blocks) return;
+  const int rb0 = packed_row(rowbase, P, base);
+  if (threadIdx.x < kSlots) smin[threadIdx.x] = 0x7fffffff;
+  __syncthreads();
+  long long raw[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = base + u * 256 + threadIdx.x;
+    raw[u] = k < blocks ? msg[k] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = base + u * 256 + threadIdx.x;
+    if (k >= blocks || raw[u] == 0) continue;
+    const int rb = packed_row(rowbase, P, k);
+    const int cb = first[rb] + (k - rowbase[rb]) / 36;
+    if (cb >= rb) continue;
+    const int slot = rb - rb0;
+    if (slot < kSlots) { if (cb < smin[slot]) atomicMin(&smin[slot], cb); }
+    else atomicMin(&env[rb], cb);
+  }
+  __syncthreads();
+  if (threadIdx.x < kSlots && smin[threadIdx.x] != 0x7fffffff) atomicMin(&env[rb0 + threadIdx.x], smin[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void ba_prepare_packed_kernel(const long long* __restrict__ msg, const int* __restrict__ first_s, double* __restrict__ out,
+                                                                const int* __restrict__ env, int n, float lm, float ep, long long lds_budget,
+                                                                int* __restrict__ xchg_i) {
+  __shared__ int sfirst[kMaxEnvBlocks], srow[kMaxEnvBlocks + 1];       // the message's (structural) layout
+  __shared__ int first[kMaxEnvBlocks], rowbase[kMaxEnvBlocks + 1];     // the solve's (numeric) layout
+  __shared__ int sblocks_s, blocks_s;
+  const int P = n / 6;
+  const int sblocks = env_layout(first_s, P, sfirst, srow, &sblocks_s);
+  const int blocks = env_layout(env, P, first, rowbase, &blocks_s);
+  const bool compact = env_lds_bytes(blocks, n, P) <= lds_budget;
+  if (xchg_i && blockIdx.x == 0) {                         // (block-uniform)
+    __shared__ int reach[kMaxEnvBlocks];
+    if (compact && P > 12) {
+      envelope_reach(first, reach, P);
+      choose_partition(first, reach, rowbase, P, blocks, lds_budget, xchg_i);
+    } else if (threadIdx.x == 0) {
+      xchg_i[0] = 0; xchg_i[1] = 0; xchg_i[2] = 0; xchg_i[3] = 0;
+    }
+  }
+  const int N = sblocks + n;
+  const int base = blockIdx.x * 2048;
+  long long raw[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = base + u * 256 + threadIdx.x;
+    raw[u] = k < N ? msg[k] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = base + u * 256 + threadIdx.x;
+    if (k >= N) continue;
+    double v = static_cast<double>(raw[u]) * kInvFix;
+    if (k >= sblocks) {                                     // rhs
+      const int i = k - sblocks;
+      out[compact ? blocks + i : static_cast<long long>(n) * n + i] = v;
+      continue;
+    }
+    const int rb = packed_row(srow, P, k);
+    const int q = k - srow[rb], cb = sfirst[rb] + q / 36, e = q % 36, ri = e / 6, ci = e - 6 * ri;
+    if (rb == cb && ri == ci) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
+    if (!compact) { out[static_cast<long long>(6 * rb + ri) * n + 6 * cb + ci] = v; continue; }
+    if (cb < first[rb]) continue;                           // inside the structural envelope, outside the numeric one: an exact zero
+    out[rowbase[rb] + (cb - first[rb]) * 36 + e] = v;
+  }
+}
+
 // The pose solve is ONE workgroup for ~20 us (a window) to ~170 us (63 free poses) while the rest of the chip idles - and
 // nothing else may run beside the bundle adjustment on another queue.  Work that is independent of it can ride in
 // the SAME dispatch instead: workgroups 1 .. of this launch run up to three jobs that share no buffer with the solve -
@@ -2286,6 +2407,14 @@ extern "C" int pvo_ba_finish_conv1x1(float* poses, float* disps, void* sys_,
                               dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes, cy ? &r : nullptr, stream);
 }
 
+static int ba_finish_impl(float* poses, float* disps, void* sys_, const long long* msg, const int* first_s,
+                          const int64_t* ii, const int64_t* jj,
+                          int E, int nframes, int ht, int wd, int t0, int t1,
+                          float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                          float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                          void* workspace, size_t workspace_bytes,
+                          const pvo_ba_riders* jobs, void* stream);
+
 extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
                                     const int64_t* ii, const int64_t* jj,
                                     int E, int nframes, int ht, int wd, int t0, int t1,
@@ -2293,6 +2422,50 @@ extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
                                     float* dx_out, float* dz_out, int dz_rows, int* status_out,
                                     void* workspace, size_t workspace_bytes,
                                     const pvo_ba_riders* jobs, void* stream) {
+  if (!sys_) return PVO_EINVAL;
+  return ba_finish_impl(poses, disps, sys_, nullptr, nullptr, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only, clamp_frames, disp_min,
+                        dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes, jobs, stream);
+}
+
+extern "C" size_t pvo_ba_packed_elems(const int* first_host, int P) {
+  if (!first_host || P < 0) return 0;
+  size_t blocks = 0;
+  for (int b = 0; b < P; ++b) {
+    const int f = first_host[b] < b ? (first_host[b] < 0 ? 0 : first_host[b]) : b;
+    blocks += static_cast<size_t>(b - f + 1) * 36;
+  }
+  return blocks + static_cast<size_t>(6) * P;
+}
+
+extern "C" int pvo_ba_pack(void* sys_, const int* first_s, void* msg, int P, void* stream) {
+  if (!sys_ || !first_s || !msg || P < 0) return PVO_EINVAL;
+  if (P > kMaxEnvBlocks) return PVO_EUNSUPPORTED;
+  if (P == 0) return PVO_OK;
+  const int n6 = 6 * P;
+  hipLaunchKernelGGL(ba_pack_kernel, dim3((n6 * n6 + n6 + 2047) / 2048), dim3(256), 0, pvo_stream(stream),
+                     static_cast<long long*>(sys_), first_s, static_cast<long long*>(msg), n6);
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+extern "C" int pvo_ba_finish_packed(float* poses, float* disps, const void* msg, const int* first_s,
+                                    const int64_t* ii, const int64_t* jj,
+                                    int E, int nframes, int ht, int wd, int t0, int t1,
+                                    float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                                    float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!msg || !first_s) return PVO_EINVAL;
+  return ba_finish_impl(poses, disps, nullptr, static_cast<const long long*>(msg), first_s, ii, jj, E, nframes, ht, wd, t0, t1, lm, ep, motion_only,
+                        clamp_frames, disp_min, dx_out, dz_out, dz_rows, status_out, workspace, workspace_bytes, nullptr, stream);
+}
+
+static int ba_finish_impl(float* poses, float* disps, void* sys_, const long long* msg, const int* first_s,
+                          const int64_t* ii, const int64_t* jj,
+                          int E, int nframes, int ht, int wd, int t0, int t1,
+                          float lm, float ep, int motion_only, int clamp_frames, float disp_min,
+                          float* dx_out, float* dz_out, int dz_rows, int* status_out,
+                          void* workspace, size_t workspace_bytes,
+                          const pvo_ba_riders* jobs, void* stream) {
   Riders rider{};
   size_t rider_lds = 0;
   if (jobs && jobs->cy && jobs->crows > 0) {
@@ -2327,13 +2500,13 @@ extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
   if (clamp_frames < 0 || clamp_frames > nframes) return PVO_EINVAL;
   const int P = t1 - t0, HW = ht * wd;
   long long* sys = static_cast<long long*>(sys_);
-  if (!poses || !disps || !sys || !workspace) return PVO_EINVAL;
+  if (!poses || !disps || (!sys && !msg) || !workspace) return PVO_EINVAL;
   if (P > kMaxEnvBlocks) return PVO_EUNSUPPORTED;           // (a 12288^2 fp64 system: 1.2 GB)
   if (workspace_bytes < pvo_ba_workspace_bytes(E, P, nframes, HW)) return PVO_EWORKSPACE;
   Ws w = carve(ws_base(workspace), E, P, nframes, HW);
   hipStream_t st = pvo_stream(stream);
   const int n6 = 6 * P;
-  const int use_lds = n6 <= kLdsCholMax;
+  const int use_lds = n6 <= kLdsCholMax && !msg;               // (a packed message is factorised from the compact image at every size)
   constexpr size_t kSolveLdsMax = 142000;      // dynamic LDS of the solve: the CU's 163840 B minus its 20528 B of static tables (envelope, reach, active rows, scan buffers)
   size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
   if (lds < rider_lds) lds = rider_lds;                                   // (the riders' tiles live in the dynamic segment)
@@ -2357,7 +2530,16 @@ extern "C" int pvo_ba_finish_riders(float* poses, float* disps, void* sys_,
   const int solver_pick = solver_env >= 0 ? solver_env : (use_lds ? (P > 12 ? 2 : 0) : 3);      // 0 blocked | 1 wave | 2 pipe | 3 partitioned
   const bool twin = solver_pick == 3 && !use_lds;
   const int solver_wave = solver_pick == 3 ? 2 : solver_pick;
-  if (!use_lds) {
+  if (msg) {
+    if (P == 0) return PVO_OK;
+    // (grid: the message is at most the lower triangle + the diagonal blocks' upper halves + the rhs; its exact length is on the device)
+    const int mgrid = (n6 * (n6 / 2 + 9) + 2047) / 2048 + 1;
+    hipLaunchKernelGGL(ba_env_packed_kernel, dim3(mgrid), dim3(256), 0, st, msg, first_s, w.plan.env, n6);
+    PVO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ba_prepare_packed_kernel, dim3(mgrid), dim3(256), 0, st, msg, first_s, w.chol, w.plan.env, n6, lm, ep,
+                       static_cast<long long>(kSolveLdsMax), twin ? reinterpret_cast<int*>(w.xchg) : nullptr);
+    PVO_CHECK_LAUNCH();
+  } else if (!use_lds) {
     hipLaunchKernelGGL(ba_env_kernel, dim3((n6 * n6 + 2047) / 2048), dim3(256), 0, st, sys, w.plan.env, n6);
     PVO_CHECK_LAUNCH();
     hipLaunchKernelGGL(ba_prepare_kernel, dim3((n6 * n6 + n6 + 2047) / 2048), dim3(256), 0, st, sys, w.chol, w.plan.env, n6, lm, ep,

@@ -601,13 +601,31 @@ def ba_local(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, mo
                                        _stream(dev)), "ba_local")
 
 
+def ba_packed_elems(first):
+    """int64 elements of the packed envelope message for the structural envelope `first` (a host list, one entry per free pose)"""
+    arr = (ctypes.c_int * len(first))(*[int(f) for f in first])
+    return int(_lib.load().pvo_ba_packed_elems(arr, len(first)))
+
+
+def ba_pack(sys, first_dev, msg):
+    """after ba_local: the structural envelope (first_dev: int32 [P] on the device) of `sys` -> msg (int64, ba_packed_elems long);
+    `sys` is left zeroed.  msg is what an edge-sharded step all-reduces; ba_finish(..., packed=(msg, first_dev)) consumes it."""
+    dev = _dev(sys, first_dev, msg)
+    if sys.dtype != torch.int64 or msg.dtype != torch.int64 or first_dev.dtype != torch.int32:
+        raise PvoHipError("ba_pack: sys / msg must be int64, first int32")
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_ba_pack(_ptr(sys), _ptr(first_dev), _ptr(msg), int(first_dev.shape[0]), _stream(dev)), "ba_pack")
+    return msg
+
+
 def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace, dz_rows=0, status=None, outputs=True,
-              clamp_frames=0, disp_min=0.001, rider=None):
+              clamp_frames=0, disp_min=0.001, rider=None, packed=None):
     """damp + solve the (all-reduced) system (left zeroed afterwards), retract poses, back-substitute this rank's depths -> [dx, dz]
     (outputs=False: poses / disps are updated in place and no dx / dz tensors are produced -> [None, None]).
     clamp_frames > 0: disps[:clamp_frames].clamp_(min=disp_min) in the same launch.
     rider = (x, w, bias): an independent 1x1 convolution of x [N,128,H,W] (conv1x1_c128 without ReLU) computed by additional
-    workgroups of the pose solve's dispatch (pvo_ba_finish_conv1x1); its result is appended to the returned list."""
+    workgroups of the pose solve's dispatch (pvo_ba_finish_conv1x1); its result is appended to the returned list.
+    packed = (msg, first_dev): the all-reduced envelope message of ba_pack instead of the dense `sys` (which is not read)."""
     dev = _dev(poses, disps, sys, ii, jj, workspace)
     rx = rw = rb = ry = None
     rrows = rC = rdt = 0
@@ -625,6 +643,20 @@ def ba_finish(poses, disps, sys, ii, jj, t0, t1, lm, ep, motion_only, workspace,
     dz = torch.zeros(int(dz_rows), ht * wd, dtype=torch.float32, device=dev) if outputs else None
     if not outputs:
         dz_rows = 0
+    if packed is not None:
+        msg, first_dev = packed
+        if rider is not None:
+            raise PvoHipError("ba_finish: a rider and a packed message together are not supported")
+        if msg.dtype != torch.int64 or first_dev.dtype != torch.int32 or first_dev.shape[0] != P:
+            raise PvoHipError("ba_finish: packed = (int64 message, int32 [P] structural envelope)")
+        with torch.cuda.device(dev):
+            check(_lib.load().pvo_ba_finish_packed(
+                _ptr(poses), _ptr(disps), _ptr(msg), _ptr(first_dev), _ptr(ii), _ptr(jj), ii.shape[0], F, ht, wd,
+                int(t0), int(t1), float(lm), float(ep), 1 if motion_only else 0,
+                int(clamp_frames), float(disp_min), _ptr(dx), _ptr(dz), int(dz_rows),
+                _ptr(status) if status is not None else ctypes.c_void_p(0),
+                ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(dev)), "ba_finish_packed")
+        return [dx, dz]
     with torch.cuda.device(dev):
         check(_lib.load().pvo_ba_finish_conv1x1(
             _ptr(poses), _ptr(disps), _ptr(sys), _ptr(ii), _ptr(jj), ii.shape[0], F, ht, wd,

@@ -98,6 +98,7 @@ class ShardedBA:
         self._plan_key = None
         self._env_idx = None
         self.always_pack = False        # tests: run the pack / unpack pair on a single rank too
+        self.torch_pack = False         # tests: index_select / index_copy_ around the collective although the backend packs natively
         self.collective_at_one = False  # run the all-reduce through the process group even when it has ONE rank (the RCCL path on a 1-GPU box)
         self.last_message_bytes = 0
 
@@ -137,8 +138,14 @@ class ShardedBA:
             self._plan_key, self._plan_edges = key, (ii_local, jj_local)
             self._env_idx = None
         multi = self._world() > 1 or (self.collective_at_one and self.communicate and dist.is_available() and dist.is_initialized())
+        native = hasattr(self.db, "ba_pack") and not self.torch_pack      # the HIP library packs / unpacks the message itself
         if structure is not None and self._env_idx is None and (multi or self.always_pack):
-            self._env_idx = envelope_index(envelope_structure(structure[0], structure[1], t0, t1), disps.device)
+            first = envelope_structure(structure[0], structure[1], t0, t1)
+            if native:
+                self._env_idx = (torch.tensor(first, dtype=torch.int32, device=disps.device),
+                                 torch.empty(self.db.ba_packed_elems(first), dtype=torch.int64, device=disps.device))
+            else:
+                self._env_idx = envelope_index(first, disps.device)
         sys_buf = self._sys
         dx = None
         ii_local, jj_local = self._plan_edges          # the tensors the plan was built from
@@ -147,6 +154,14 @@ class ShardedBA:
             kw = {"sys_is_zero": True} if fixed and it > 0 else {}
             self.db.ba_local(poses, disps, intrinsics, targets, weights, eta_local, ii_local, jj_local, t0, t1,
                              motion_only, sys_buf, ws, **kw)
+            if structure is not None and self._env_idx is not None and native:
+                first_dev, msg = self._env_idx
+                self.db.ba_pack(sys_buf, first_dev, msg)                           # envelope blocks + rhs -> msg, sys_buf zeroed: one launch
+                if multi:
+                    self._allreduce(msg)                                           # the one collective per step
+                self.last_message_bytes = msg.numel() * msg.element_size()
+                dx, _ = self.db.ba_finish(poses, disps, sys_buf, ii_local, jj_local, t0, t1, lm, ep, motion_only, ws, packed=(msg, first_dev))
+                continue
             if structure is not None and self._env_idx is not None:
                 msg = sys_buf.index_select(0, self._env_idx)                       # envelope blocks + rhs: one gather
                 if multi:

@@ -189,24 +189,30 @@ def test_ba_is_bitwise_reproducible(cuda):
 
 
 @pytest.mark.gpu
-def test_envelope_allreduce_path_is_bit_identical_on_the_hip_solver(cuda):
-    """ShardedBA with the pack -> (all-reduce) -> unpack of the envelope forced on one rank, 64-keyframe radius-3 graph with a
-    loop closure (the envelope Cholesky's compact LDS path): poses and depths bit-identical to the dense message."""
+@pytest.mark.parametrize("nf,ht,wd", [(64, 16, 24), (30, 8, 10), (8, 12, 16)])
+def test_envelope_allreduce_path_is_bit_identical_on_the_hip_solver(cuda, nf, ht, wd):
+    """ShardedBA with the envelope message forced on one rank - packed by the library (pvo_ba_pack / pvo_ba_finish_packed: the
+    message is read in place of the dense system) and, as before round 4, by index_select / index_copy_ around the dense
+    system - against the dense message: poses and depths bit-identical.  64 keyframes: the partitioned solve; 8: a window-sized
+    system, which the packed path factorises from the compact image too."""
     from test_geom_ba_gpu import _scene
-    s = _scene(13, 64, 16, 24, 3, 1)
+    s = _scene(13, nf, ht, wd, 3, 1)
     d = lambda t: t.to(cuda)
     outs = []
-    for structure in (None, (s["ii"].tolist(), s["jj"].tolist())):
+    for structure, torch_pack in ((None, False), ((s["ii"].tolist(), s["jj"].tolist()), False), ((s["ii"].tolist(), s["jj"].tolist()), True)):
         poses, disps = d(s["poses"].clone()), d(s["disps"].clone())
         sb = ShardedBA(structure=structure)
-        sb.always_pack = True
+        sb.always_pack, sb.torch_pack = True, torch_pack
         sb.ba(poses, disps, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]), s["t0"], s["t1"], itrs=2,
               lm=1e-5, ep=1e-2)
         outs.append((poses.clone(), disps.clone(), sb.last_message_bytes))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in (1, 2):
+        assert torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]), k
     assert (outs[0][0] - d(s["poses"])).abs().max() > 1e-4
     n6 = 6 * (s["t1"] - s["t0"])
-    assert 0 < outs[1][2] < 0.2 * 8 * (n6 * n6 + n6)                      # 63 free poses, radius 3: ~12 % of the dense message
+    assert outs[1][2] == outs[2][2]                                       # the same entries either way
+    if nf == 64:
+        assert 0 < outs[1][2] < 0.2 * 8 * (n6 * n6 + n6)                  # 63 free poses, radius 3: ~12 % of the dense message
 
 
 @pytest.mark.gpu
