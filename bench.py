@@ -631,7 +631,8 @@ def edge_sharded_leg(device, rank, world, steps=3):
                 torch.cuda.synchronize()
                 one_rank = {"backend": dist.get_backend(), "world_size": 1, "allreduce_us": (time.perf_counter() - t0) / 50 * 1e6,
                             "allreduce_bytes": int(res["rccl"][2]), "ba_2_steps_ms_with_the_collective": res["rccl"][0],
-                            "ba_2_steps_ms_pack_unpack_only": res["plain"][0],
+                            "ba_2_steps_ms_packed_message_no_collective": res["plain"][0],
+                            "message_packing": "library (pvo_ba_pack -> all-reduce -> pvo_ba_finish_packed): no torch launch in between",
                             "poses_bitwise_equal_with_and_without_the_collective": bool(torch.equal(res["rccl"][1], res["plain"][1]))}
                 del graph, video
                 torch.cuda.empty_cache()
