@@ -69,9 +69,10 @@ const char* pvo_strerror(int code);
 /* text of the HIP error behind this thread's most recent PVO_ELAUNCH (hipGetErrorString) */
 const char* pvo_last_hip_error(void);
 /* ABI version of the library that was loaded; PVO_ABI_VERSION is the one this header describes.  The argument structs below are
- * passed by pointer and have GROWN between versions (100 -> 101: pvo_graph_update_args.context_ahead / context_ready): a caller
+ * passed by pointer and have GROWN between versions (100 -> 101: pvo_graph_update_args.context_ahead / context_ready; 101 -> 102: no struct changed - new entry points
+ * pvo_ba_pack / pvo_ba_finish_packed / pvo_ba_last_partition, and pvo_ba_workspace_bytes returns more): a caller
  * checks pvo_version() == PVO_ABI_VERSION, or pvo_graph_update_args_size() == sizeof(pvo_graph_update_args), once after loading. */
-#define PVO_ABI_VERSION 101
+#define PVO_ABI_VERSION 102
 int pvo_version(void);
 size_t pvo_graph_update_args_size(void);
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpvo_hip.so")
 
 PVO_F32, PVO_F16, PVO_BF16, PVO_F64 = 0, 1, 2, 3
-PVO_ABI_VERSION = 101          # include/pvo_hip.h
+PVO_ABI_VERSION = 102          # include/pvo_hip.h
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t

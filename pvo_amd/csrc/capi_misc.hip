@@ -15,6 +15,7 @@ extern "C" const char* pvo_strerror(int code) {
 
 // 101: pvo_graph_update_args grew by context_ahead / context_ready (round 3) - a caller built against a 100 header passes a
 // shorter struct; pvo_graph_update_args_size() lets any caller compare its sizeof with the library's before the first call
+// 102: pvo_ba_pack / pvo_ba_finish_packed / pvo_ba_last_partition added, the BA workspace grew (round 4)
 extern "C" int pvo_version(void) { return PVO_ABI_VERSION; }
 extern "C" size_t pvo_graph_update_args_size(void) { return sizeof(pvo_graph_update_args); }
 
