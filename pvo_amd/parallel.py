@@ -97,6 +97,7 @@ class ShardedBA:
         self._ws = None
         self._plan_key = None
         self._env_idx = None
+        self._sys_clean = False
         self.always_pack = False        # tests: run the pack / unpack pair on a single rank too
         self.torch_pack = False         # tests: index_select / index_copy_ around the collective although the backend packs natively
         self.collective_at_one = False  # run the all-reduce through the process group even when it has ONE rank (the RCCL path on a 1-GPU box)
@@ -134,6 +135,7 @@ class ShardedBA:
         key = (E, P, F, ht * wd, K_eta, t0, t1, plan_key)
         if plan_key is None or self._plan_key != key:      # the plan and the system buffer belong to the edge set, not to the call
             self._sys = torch.zeros(n6 * n6 + n6, dtype=getattr(self.db, "BA_SYS_DTYPE", torch.float64), device=disps.device)
+            self._sys_clean = True                      # (the HIP library's finish / pack leave the buffer zeroed: no memset per call either)
             self.db.ba_plan(ii_local, jj_local, F, ht * wd, K_eta, t0, t1, ws)
             self._plan_key, self._plan_edges = key, (ii_local, jj_local)
             self._env_idx = None
@@ -151,7 +153,8 @@ class ShardedBA:
         ii_local, jj_local = self._plan_edges          # the tensors the plan was built from
         fixed = hasattr(self.db, "BA_SYS_DTYPE")       # the HIP library: finish leaves the buffer zeroed
         for it in range(itrs):
-            kw = {"sys_is_zero": True} if fixed and it > 0 else {}
+            kw = {"sys_is_zero": True} if fixed and (it > 0 or self._sys_clean) else {}
+            self._sys_clean = fixed
             self.db.ba_local(poses, disps, intrinsics, targets, weights, eta_local, ii_local, jj_local, t0, t1,
                              motion_only, sys_buf, ws, **kw)
             if structure is not None and self._env_idx is not None and native:
