@@ -153,8 +153,8 @@ class ShardedBA:
         ii_local, jj_local = self._plan_edges          # the tensors the plan was built from
         fixed = hasattr(self.db, "BA_SYS_DTYPE")       # the HIP library: finish leaves the buffer zeroed
         for it in range(itrs):
-            kw = {"sys_is_zero": True} if fixed and (it > 0 or self._sys_clean) else {}
-            self._sys_clean = fixed
+            kw = {"sys_is_zero": True} if fixed and self._sys_clean else {}
+            self._sys_clean = False                     # (until this step's finish has run)
             self.db.ba_local(poses, disps, intrinsics, targets, weights, eta_local, ii_local, jj_local, t0, t1,
                              motion_only, sys_buf, ws, **kw)
             if structure is not None and self._env_idx is not None and native:
@@ -164,6 +164,7 @@ class ShardedBA:
                     self._allreduce(msg)                                           # the one collective per step
                 self.last_message_bytes = msg.numel() * msg.element_size()
                 dx, _ = self.db.ba_finish(poses, disps, sys_buf, ii_local, jj_local, t0, t1, lm, ep, motion_only, ws, packed=(msg, first_dev))
+                self._sys_clean = fixed
                 continue
             if structure is not None and self._env_idx is not None:
                 msg = sys_buf.index_select(0, self._env_idx)                       # envelope blocks + rhs: one gather
@@ -175,6 +176,7 @@ class ShardedBA:
                 self._allreduce(sys_buf)                                           # the one collective per step
                 self.last_message_bytes = sys_buf.numel() * sys_buf.element_size()
             dx, _ = self.db.ba_finish(poses, disps, sys_buf, ii_local, jj_local, t0, t1, lm, ep, motion_only, ws)
+            self._sys_clean = fixed
         return dx
 
     def sync_disps(self, disps, disps_before):
