@@ -70,7 +70,7 @@ const char* pvo_strerror(int code);
 const char* pvo_last_hip_error(void);
 /* ABI version of the library that was loaded; PVO_ABI_VERSION is the one this header describes.  The argument structs below are
  * passed by pointer and have GROWN between versions (100 -> 101: pvo_graph_update_args.context_ahead / context_ready; 101 -> 102: no struct changed - new entry points
- * pvo_ba_pack / pvo_ba_finish_packed / pvo_ba_last_partition, and pvo_ba_workspace_bytes returns more): a caller
+ * pvo_ba_pack / pvo_ba_finish_packed / pvo_ba_last_partition / pvo_proj_transform[_vjp], and pvo_ba_workspace_bytes returns more): a caller
  * checks pvo_version() == PVO_ABI_VERSION, or pvo_graph_update_args_size() == sizeof(pvo_graph_update_args), once after loading. */
 #define PVO_ABI_VERSION 102
 int pvo_version(void);
@@ -478,6 +478,20 @@ int pvo_se3_binary(int op, const void* a, long long rep_a, const void* b, long l
 int pvo_se3_unary_vjp(int op, const void* x, const void* gy, void* gx, long long n, int dtype, void* stream);
 int pvo_se3_binary_vjp(int op, const void* a, long long rep_a, const void* b, long long rep_b, const void* gy,
                        void* ga, void* gb, long long n, int dtype, void* stream);
+
+/* projective_transform of the training path (VO_Module/droid_slam/geom/projective_ops.py:106-130: iproj, relative pose, actp, proj and
+ * their closed-form Jacobians) as ONE kernel per direction.  poses [B,P,7] (t, xyzw quaternion; world-to-camera), depths [B,P,ht,wd]
+ * inverse depth, intr [B,P,4], ii / jj [N] device int64; outputs x1 [B,N,ht,wd,nx] (nx = 2, or 3 with the inverse depth in frame j),
+ * valid [B,N,ht,wd] (Z > 0.2, as a number), and - all three or none - Ji, Jj [B,N,ht,wd,2,6], Jz [B,N,ht,wd,2].  dtype PVO_F32 / PVO_F64.
+ * _vjp: vector-Jacobian product in ambient coordinates (what torch.autograd returns for the PyTorch formulation,
+ * pvo_amd/geom/projective_ops.py); any of the four output gradients may be NULL; gposes [B,P,7] / gdepths [B,P,ht,wd] must be zero on
+ * entry and receive the sums over edges and pixels (fp atomics: the order of those sums is not fixed). */
+int pvo_proj_transform(const void* poses, const void* depths, const void* intr, const int64_t* ii, const int64_t* jj,
+                       int B, int P, int N, int ht, int wd, int nx, void* x1, void* valid, void* Ji, void* Jj, void* Jz,
+                       int dtype, void* stream);
+int pvo_proj_transform_vjp(const void* poses, const void* depths, const void* intr, const int64_t* ii, const int64_t* jj,
+                           int B, int P, int N, int ht, int wd, int nx, const void* g_x1, const void* g_Ji, const void* g_Jj, const void* g_Jz,
+                           void* gposes, void* gdepths, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Dense bundle adjustment                                                    */

@@ -58,6 +58,8 @@ SIGNATURES = {
     "pvo_se3_binary": (_i, [_i, _vp, _c.c_longlong, _vp, _c.c_longlong, _vp, _c.c_longlong, _i, _vp]),
     "pvo_se3_unary_vjp": (_i, [_i, _vp, _vp, _vp, _c.c_longlong, _i, _vp]),
     "pvo_se3_binary_vjp": (_i, [_i, _vp, _c.c_longlong, _vp, _c.c_longlong, _vp, _vp, _vp, _c.c_longlong, _i, _vp]),
+    "pvo_proj_transform": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pvo_proj_transform_vjp": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pvo_side_stream": (_i, [_c.POINTER(_vp)]),
     "pvo_probe_arm": (_i, [_i, _i]),
     "pvo_probe_arm_every": (_i, [_i, _i, _i]),

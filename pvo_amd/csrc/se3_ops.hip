@@ -220,6 +220,135 @@ __global__ __launch_bounds__(256) void se3_binary_kernel(int op, const F* __rest
   for (int k = 0; k < nb; ++k) y[i * nb + k] = o[k];
 }
 
+// ---- projective_transform (VO_Module/droid_slam/geom/projective_ops.py:106-130: iproj :21-41, actp :76-103, proj :44-73) ----------
+// The training path's reprojection i -> j with its closed-form Jacobians, ONE kernel per direction instead of the ~90 element-wise
+// operators of the PyTorch formulation (pvo_amd/geom/projective_ops.py, which stays the reference these are tested against and
+// what CPU tensors use).  Forward: one thread per (batch, edge, pixel).  Backward: the same template on dual numbers, one
+// evaluation per input component (7 + 7 pose numbers, the pixel's inverse depth) - ambient-coordinate vector-Jacobian products,
+// as for the group operations above; the pose gradients of a workgroup's pixels are summed in LDS before the atomics.
+//   out[0..2]  x, y, (inverse depth in frame j)      out[3..14]  Jj [2][6]      out[15..26]  Ji [2][6]      out[27..28]  Jz [2]
+// returns Z (the validity test Z > MIN_DEPTH is the caller's: :113)
+constexpr double kMinDepth = 0.2;
+template <typename F, typename S>
+__device__ __forceinline__ F proj_terms(const F* Pi, const F* Pj, F d, S u, S v, const S* Ki, const S* Kj, bool jac, F* out) {
+  F Pinv[7], G[7], X0[4], X1[4];
+  se3_inv(Pi, Pinv);
+  se3_bin(OP_MUL, Pj, Pinv, G);
+  X0[0] = F((u - Ki[2]) / Ki[0]); X0[1] = F((v - Ki[3]) / Ki[1]); X0[2] = F(S(1)); X0[3] = d;
+  se3_bin(OP_ACT4, G, X0, X1);
+  const F X = X1[0], Y = X1[1], Z = X1[2], W = X1[3];
+  const F fx = F(Kj[0]), fy = F(Kj[1]);
+  const F dinv = F(S(1)) / (Z < F(S(0.5 * kMinDepth)) ? F(S(1)) : Z);
+  out[0] = fx * (X * dinv) + F(Kj[2]);
+  out[1] = fy * (Y * dinv) + F(Kj[3]);
+  out[2] = W * dinv;
+  if (!jac) return Z;
+  const F fxd = fx * dinv, fyd = fy * dinv;
+  const F gx = -(fx * X * dinv * dinv), gy = -(fy * Y * dinv * dinv);
+  const F o = F(S(0));
+  F* Jj = out + 3;
+  Jj[0] = fxd * W; Jj[1] = o; Jj[2] = gx * W; Jj[3] = gx * Y; Jj[4] = fxd * Z - gx * X; Jj[5] = -(fxd * Y);
+  Jj[6] = o; Jj[7] = fyd * W; Jj[8] = gy * W; Jj[9] = gy * Y - fyd * Z; Jj[10] = -(gy * X); Jj[11] = fyd * X;
+  F* Ji = out + 15;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    F a[6];
+    se3_bin(OP_ADJT, G, Jj + 6 * r, a);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Ji[6 * r + k] = -a[k];
+  }
+  out[27] = fxd * G[0] + gx * G[2];
+  out[28] = fyd * G[1] + gy * G[2];
+  return Z;
+}
+
+// poses [B,P,7], depths [B,P,HW], intr [B,P,4], ii / jj [N]; x1 [B,N,HW,nx] (nx = 2 or 3), valid [B,N,HW], Jj / Ji [B,N,HW,2,6], Jz [B,N,HW,2]
+template <typename F>
+__global__ __launch_bounds__(256) void proj_fwd_kernel(const F* __restrict__ poses, const F* __restrict__ depths, const F* __restrict__ intr,
+                                                       const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int P, int N, int HW, int wd, int nx,
+                                                       F* __restrict__ x1, F* __restrict__ valid, F* __restrict__ Ji, F* __restrict__ Jj, F* __restrict__ Jz) {
+  const int px = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, b = blockIdx.z;
+  if (px >= HW) return;
+  const int i = static_cast<int>(ii[n]), j = static_cast<int>(jj[n]);
+  const F* Pi = poses + (static_cast<long long>(b) * P + i) * 7;
+  const F* Pj = poses + (static_cast<long long>(b) * P + j) * 7;
+  F pi[7], pj[7], Ki[4], Kj[4], out[29];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { pi[k] = Pi[k]; pj[k] = Pj[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { Ki[k] = intr[(static_cast<long long>(b) * P + i) * 4 + k]; Kj[k] = intr[(static_cast<long long>(b) * P + j) * 4 + k]; }
+  const F d = depths[(static_cast<long long>(b) * P + i) * HW + px];
+  const F Z = proj_terms<F, F>(pi, pj, d, F(px % wd), F(px / wd), Ki, Kj, Jj != nullptr, out);
+  const long long row = (static_cast<long long>(b) * N + n) * HW + px;
+  for (int k = 0; k < nx; ++k) x1[row * nx + k] = out[k];
+  valid[row] = Z > F(kMinDepth) ? F(1) : F(0);
+  if (Jj) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { Jj[row * 12 + k] = out[3 + k]; Ji[row * 12 + k] = out[15 + k]; }
+    Jz[row * 2] = out[27]; Jz[row * 2 + 1] = out[28];
+  }
+}
+
+// g_* : the incoming gradients of x1 / Ji / Jj / Jz (NULL = none); gposes [B,P,7] and gdepths [B,P,HW] are ACCUMULATED into (zeroed by the caller)
+template <typename F>
+__global__ __launch_bounds__(256) void proj_vjp_kernel(const F* __restrict__ poses, const F* __restrict__ depths, const F* __restrict__ intr,
+                                                       const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int P, int N, int HW, int wd, int nx,
+                                                       const F* __restrict__ g_x1, const F* __restrict__ g_Ji, const F* __restrict__ g_Jj, const F* __restrict__ g_Jz,
+                                                       F* __restrict__ gposes, F* __restrict__ gdepths) {
+  __shared__ F red[4][14];
+  const int px = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const int i = static_cast<int>(ii[n]), j = static_cast<int>(jj[n]);
+  const bool jac = g_Ji || g_Jj || g_Jz;
+  F s[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) s[k] = F(0);
+  if (px < HW) {
+    F pi[7], pj[7], Ki[4], Kj[4], g[29];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { pi[k] = poses[(static_cast<long long>(b) * P + i) * 7 + k]; pj[k] = poses[(static_cast<long long>(b) * P + j) * 7 + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { Ki[k] = intr[(static_cast<long long>(b) * P + i) * 4 + k]; Kj[k] = intr[(static_cast<long long>(b) * P + j) * 4 + k]; }
+    const F d = depths[(static_cast<long long>(b) * P + i) * HW + px];
+    const long long row = (static_cast<long long>(b) * N + n) * HW + px;
+#pragma unroll
+    for (int k = 0; k < 29; ++k) g[k] = F(0);
+    if (g_x1) for (int k = 0; k < nx; ++k) g[k] = g_x1[row * nx + k];
+    if (g_Jj) for (int k = 0; k < 12; ++k) g[3 + k] = g_Jj[row * 12 + k];
+    if (g_Ji) for (int k = 0; k < 12; ++k) g[15 + k] = g_Ji[row * 12 + k];
+    if (g_Jz) { g[27] = g_Jz[row * 2]; g[28] = g_Jz[row * 2 + 1]; }
+    const F u = F(px % wd), v = F(px / wd);
+#pragma unroll 1
+    for (int q = 0; q < 15; ++q) {
+      Dual<F> A[7], Bq[7], out[29];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { A[k] = Dual<F>(pi[k], k == q ? F(1) : F(0)); Bq[k] = Dual<F>(pj[k], k + 7 == q ? F(1) : F(0)); }
+      const Dual<F> dd(d, q == 14 ? F(1) : F(0));
+      proj_terms<Dual<F>, F>(A, Bq, dd, u, v, Ki, Kj, jac, out);
+      F acc = F(0);
+      const int nout = jac ? 29 : 3;
+      for (int k = 0; k < nout; ++k) acc += g[k] * out[k].d;
+      s[q] = acc;
+    }
+    // (i == j: both seeds move the same pose; the two partial derivatives add, which the two accumulations below do)
+    atomicAdd(&gdepths[(static_cast<long long>(b) * P + i) * HW + px], s[14]);
+  }
+  // the 14 pose sums of this workgroup's pixels: wave shuffle, then across the four waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 14; ++k) {
+    F v = s[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 14) {
+    const F v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const int k = threadIdx.x;
+    F* dst = gposes + (static_cast<long long>(b) * P + (k < 7 ? i : j)) * 7 + (k < 7 ? k : k - 7);
+    atomicAdd(dst, v);
+  }
+}
+
 }  // namespace
 
 extern "C" int pvo_se3_unary(int op, const void* x, void* y, long long n, int dtype, void* stream) {
@@ -282,6 +411,52 @@ extern "C" int pvo_se3_binary_vjp(int op, const void* a, long long rep_a, const 
   else if (dtype == PVO_F64)
     hipLaunchKernelGGL(se3_binary_vjp_kernel<double>, grid, dim3(256), 0, pvo_stream(stream), op, static_cast<const double*>(a), rep_a, static_cast<const double*>(b), rep_b,
                        static_cast<const double*>(gy), static_cast<double*>(ga), static_cast<double*>(gb), n);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+// projective_transform forward / backward (see proj_terms above).  Jj == NULL: coordinates and validity only.
+extern "C" int pvo_proj_transform(const void* poses, const void* depths, const void* intr, const int64_t* ii, const int64_t* jj,
+                                  int B, int P, int N, int ht, int wd, int nx, void* x1, void* valid, void* Ji, void* Jj, void* Jz,
+                                  int dtype, void* stream) {
+  if (B < 0 || P <= 0 || N < 0 || ht <= 0 || wd <= 0 || (nx != 2 && nx != 3)) return PVO_EINVAL;
+  if (B == 0 || N == 0) return PVO_OK;
+  if (!poses || !depths || !intr || !ii || !jj || !x1 || !valid) return PVO_EINVAL;
+  if ((Jj != nullptr) != (Ji != nullptr) || (Jj != nullptr) != (Jz != nullptr)) return PVO_EINVAL;
+  const int HW = ht * wd;
+  const dim3 grid((HW + 255) / 256, N, B);
+  if (dtype == PVO_F32)
+    hipLaunchKernelGGL(proj_fwd_kernel<float>, grid, dim3(256), 0, pvo_stream(stream), static_cast<const float*>(poses), static_cast<const float*>(depths),
+                       static_cast<const float*>(intr), ii, jj, P, N, HW, wd, nx, static_cast<float*>(x1), static_cast<float*>(valid),
+                       static_cast<float*>(Ji), static_cast<float*>(Jj), static_cast<float*>(Jz));
+  else if (dtype == PVO_F64)
+    hipLaunchKernelGGL(proj_fwd_kernel<double>, grid, dim3(256), 0, pvo_stream(stream), static_cast<const double*>(poses), static_cast<const double*>(depths),
+                       static_cast<const double*>(intr), ii, jj, P, N, HW, wd, nx, static_cast<double*>(x1), static_cast<double*>(valid),
+                       static_cast<double*>(Ji), static_cast<double*>(Jj), static_cast<double*>(Jz));
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+// gposes [B,P,7] and gdepths [B,P,ht*wd] must be ZERO on entry (the products of all edges and pixels are added into them)
+extern "C" int pvo_proj_transform_vjp(const void* poses, const void* depths, const void* intr, const int64_t* ii, const int64_t* jj,
+                                      int B, int P, int N, int ht, int wd, int nx, const void* g_x1, const void* g_Ji, const void* g_Jj, const void* g_Jz,
+                                      void* gposes, void* gdepths, int dtype, void* stream) {
+  if (B < 0 || P <= 0 || N < 0 || ht <= 0 || wd <= 0 || (nx != 2 && nx != 3)) return PVO_EINVAL;
+  if (B == 0 || N == 0) return PVO_OK;
+  if (!poses || !depths || !intr || !ii || !jj || !gposes || !gdepths) return PVO_EINVAL;
+  if (!g_x1 && !g_Ji && !g_Jj && !g_Jz) return PVO_OK;
+  const int HW = ht * wd;
+  const dim3 grid((HW + 255) / 256, N, B);
+  if (dtype == PVO_F32)
+    hipLaunchKernelGGL(proj_vjp_kernel<float>, grid, dim3(256), 0, pvo_stream(stream), static_cast<const float*>(poses), static_cast<const float*>(depths),
+                       static_cast<const float*>(intr), ii, jj, P, N, HW, wd, nx, static_cast<const float*>(g_x1), static_cast<const float*>(g_Ji),
+                       static_cast<const float*>(g_Jj), static_cast<const float*>(g_Jz), static_cast<float*>(gposes), static_cast<float*>(gdepths));
+  else if (dtype == PVO_F64)
+    hipLaunchKernelGGL(proj_vjp_kernel<double>, grid, dim3(256), 0, pvo_stream(stream), static_cast<const double*>(poses), static_cast<const double*>(depths),
+                       static_cast<const double*>(intr), ii, jj, P, N, HW, wd, nx, static_cast<const double*>(g_x1), static_cast<const double*>(g_Ji),
+                       static_cast<const double*>(g_Jj), static_cast<const double*>(g_Jz), static_cast<double*>(gposes), static_cast<double*>(gdepths));
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;

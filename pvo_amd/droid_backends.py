@@ -1263,6 +1263,41 @@ def se3_binary_vjp(op, a, rep_a, b, rep_b, gy, need_a=True, need_b=True):
     return ga, gb
 
 
+def proj_transform(poses, depths, intrinsics, ii, jj, jacobian=False, return_depth=False):
+    """projective_ops.projective_transform as ONE kernel (pvo_proj_transform): poses [B,P,7], depths [B,P,H,W], intrinsics [B,P,4]
+    (fp32 or fp64, one device), ii / jj int64 [N] on that device -> coords [B,N,H,W,2|3], valid [B,N,H,W,1] and, with
+    `jacobian`, (Ji [B,N,H,W,2,6], Jj [B,N,H,W,2,6], Jz [B,N,H,W,2,1])"""
+    dev = _dev(poses, depths, intrinsics, ii, jj)
+    for t, n in ((poses, "poses"), (depths, "depths"), (intrinsics, "intrinsics"), (ii, "ii"), (jj, "jj")):
+        _contig(t, n)
+    _long(ii, "ii"); _long(jj, "jj")
+    B, P, ht, wd = depths.shape
+    N, nx = ii.shape[0], 3 if return_depth else 2
+    if poses.shape != (B, P, 7) or intrinsics.shape != (B, P, 4) or poses.dtype != depths.dtype or intrinsics.dtype != depths.dtype:
+        raise PvoHipError("proj_transform: poses [B,P,7], depths [B,P,H,W], intrinsics [B,P,4] of one dtype")
+    new = lambda *sh: torch.empty(sh, dtype=depths.dtype, device=dev)
+    x1, valid = new(B, N, ht, wd, nx), new(B, N, ht, wd, 1)
+    Ji, Jj, Jz = (new(B, N, ht, wd, 2, 6), new(B, N, ht, wd, 2, 6), new(B, N, ht, wd, 2, 1)) if jacobian else (None, None, None)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_proj_transform(_ptr(poses), _ptr(depths), _ptr(intrinsics), _ptr(ii), _ptr(jj), B, P, N, ht, wd, nx,
+                                             _ptr(x1), _ptr(valid), _vp(Ji), _vp(Jj), _vp(Jz), _DT[depths.dtype], _stream(dev)), "proj_transform")
+    return (x1, valid, (Ji, Jj, Jz)) if jacobian else (x1, valid)
+
+
+def proj_transform_vjp(poses, depths, intrinsics, ii, jj, g_x1, g_Ji, g_Jj, g_Jz):
+    """gradients of proj_transform's outputs (any may be None) -> (grad poses [B,P,7], grad depths [B,P,H,W]), ambient coordinates"""
+    dev = _dev(poses, depths, intrinsics, ii, jj)
+    B, P, ht, wd = depths.shape
+    gs = [None if g is None else g.contiguous() for g in (g_x1, g_Ji, g_Jj, g_Jz)]
+    nx = gs[0].shape[-1] if gs[0] is not None else 2
+    gp, gd = torch.zeros_like(poses), torch.zeros_like(depths)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_proj_transform_vjp(_ptr(poses), _ptr(depths), _ptr(intrinsics), _ptr(ii), _ptr(jj), B, P, ii.shape[0], ht, wd, nx,
+                                                 _vp(gs[0]), _vp(gs[1]), _vp(gs[2]), _vp(gs[3]), _ptr(gp), _ptr(gd), _DT[depths.dtype], _stream(dev)),
+              "proj_transform_vjp")
+    return gp, gd
+
+
 STAGES = {"lookup": 0, "gates": 1, "candidate": 2, "ba": 3, "update": 4, "empty": 5}
 
 

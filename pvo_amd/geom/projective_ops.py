@@ -79,13 +79,52 @@ def actp(Gij, X0, jacobian=False):
     return X1, torch.stack(rows, dim=-2)
 
 
+class _ProjTransform(torch.autograd.Function):
+    """projective_transform as one HIP kernel per direction (pvo_proj_transform / _vjp, pvo_amd/csrc/se3_ops.hip): the PyTorch
+    formulation below is ~90 element-wise operators forward and as many backward, and a training step calls it ~75 times"""
+
+    @staticmethod
+    def forward(ctx, pdata, depths, intrinsics, ii, jj, jacobian, return_depth):
+        from .. import droid_backends as db
+        pdata, depths, intrinsics = pdata.contiguous(), depths.contiguous(), intrinsics.contiguous()
+        ctx.save_for_backward(pdata, depths, intrinsics, ii, jj)
+        ctx.jacobian = jacobian
+        out = db.proj_transform(pdata, depths, intrinsics, ii, jj, jacobian, return_depth)
+        valid = out[1].float()                              # (`.float()` in the reference, :113: fp32 whatever the inputs are)
+        ctx.mark_non_differentiable(valid)
+        return (out[0], valid) + tuple(out[2]) if jacobian else (out[0], valid)
+
+    @staticmethod
+    def backward(ctx, g_x1, g_valid, g_Ji=None, g_Jj=None, g_Jz=None):
+        from .. import droid_backends as db
+        pdata, depths, intrinsics, ii, jj = ctx.saved_tensors
+        gp, gd = db.proj_transform_vjp(pdata, depths, intrinsics, ii, jj, g_x1, g_Ji, g_Jj, g_Jz)
+        return gp, gd, None, None, None, None, None
+
+
+def _fused(poses, depths, intrinsics):
+    from . import se3
+    d = poses.data
+    return (not se3.FORCE_TORCH and depths.is_cuda and d.is_cuda and intrinsics.is_cuda and depths.dim() == 4 and d.dim() == 3
+            and depths.dtype in (torch.float32, torch.float64) and d.dtype == depths.dtype and intrinsics.dtype == depths.dtype
+            and not intrinsics.requires_grad)
+
+
 def projective_transform(poses, depths, intrinsics, ii, jj, jacobian=False, return_depth=False):
     """Map the pixels of frames ``ii`` into frames ``jj`` (projective_ops.py:106-130).
 
     poses: SE3 [B, P] (world-to-camera); depths: [B, P, H, W] inverse depth; intrinsics [B, P, 4].
     Returns coords [B, N, H, W, 2(3)], valid [B, N, H, W, 1] and, with ``jacobian``, the tuple
     (Ji [B,N,H,W,2,6], Jj [B,N,H,W,2,6], Jz [B,N,H,W,2,1]).
+    Device tensors (fp32 / fp64) take one fused kernel per direction; the formulation below is its reference, what CPU tensors
+    use, and what ``PVO_SE3_TORCH=1`` selects everywhere.
     """
+    if _fused(poses, depths, intrinsics):
+        dev = depths.device
+        ii_d = torch.as_tensor(ii, dtype=torch.long, device=dev).contiguous()
+        jj_d = torch.as_tensor(jj, dtype=torch.long, device=dev).contiguous()
+        out = _ProjTransform.apply(poses.data, depths, intrinsics, ii_d, jj_d, bool(jacobian), bool(return_depth))
+        return (out[0], out[1], (out[2], out[3], out[4])) if jacobian else (out[0], out[1])
     X0, _ = iproj(depths[:, ii], intrinsics[:, ii])
     Gij = poses[:, jj] * poses[:, ii].inv()
     X1 = Gij[:, :, None, None] * X0

@@ -51,6 +51,22 @@ for a in range(k0, k0 + 6):
     for r in rows[lo:hi]:
         e = gap_rows.setdefault(short(r["Kernel_Name"]), [0, 0])
         e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+# ... and the schedule of the LONGEST of those six gaps (the keyframe boundary)
+best = None
+for a in range(k0, k0 + 6):
+    lo, hi = ends[a] + 1, starts[a + 1]
+    if hi > lo:
+        d = int(rows[hi]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"])
+        if best is None or d > best[0]:
+            best = (d, lo, hi)
+if best:
+    d, lo, hi = best
+    tb = int(rows[lo - 1]["End_Timestamp"])
+    print()
+    print("the keyframe boundary: %.1f us between the last BA kernel of one update and the first kernel of the next; dispatches in it:" % (d / 1e3))
+    for r in rows[lo:hi]:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print("%9.1f %8.1f  q%-3s %s  [%s x %s]" % ((s - tb) / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?")[-1:], short(r["Kernel_Name"]), r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
 print()
 print("between the updates of six consecutive graph updates (one keyframe step): %.1f us of wall time; kernels there:" % (span / 1e3))
 for n, (c, t) in sorted(gap_rows.items(), key=lambda kv: -kv[1][1])[:25]:
