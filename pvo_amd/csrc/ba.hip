@@ -599,7 +599,33 @@ __device__ __forceinline__ void ba_schur_body(
   }
 
   BA_WG_PROBE(1, 3);                     // depth phase issued
-  if (tid == 0) {                         // row table (a handful of rows: sequential is fine)
+  if (in_lds && deg_all <= 64) {
+    // row table by wave 0, one lane per out-edge: the position of an edge's six rows = the number of free target poses before it
+    // (ballot + popcount) - the same order as the sequential walk below, which took 1.9 us of this kernel at S-B
+    if (tid < 64) {
+      const bool free_pose = tid < deg_all && s_pose[tid] >= 0 && s_pose[tid] < P;      // fixed target pose: drops out (:1125, :1227)
+      const unsigned long long mask = __ballot(free_pose);
+      const bool self = pself >= 0 && pself < P;
+      const int base = self ? 6 : 0;
+      if (free_pose) {
+        const int r = base + 6 * __popcll(mask & ((1ull << tid) - 1ull));
+        const int e = s_edge[tid], p = s_pose[tid];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { rowptr[r + n] = (gfloat*)(Eij + (static_cast<long long>(e) * 6 + n) * HW); rowout[r + n] = 6 * p + n; }
+      }
+      if (tid == 0) {
+        if (self) {
+#pragma unroll
+          for (int n = 0; n < 6; ++n) { rowptr[n] = (gfloat*)(Ei + (static_cast<long long>(pself) * 6 + n) * HW); rowout[n] = 6 * pself + n; }
+        }
+        int r = base + 6 * __popcll(mask);
+        if (r > 0) { rowptr[r] = (gfloat*)(w + static_cast<long long>(k) * HW); rowout[r] = -2; ++r; }
+        const int padded = (r + 15) & ~15;
+        for (int q = r; q < padded; ++q) { rowptr[q] = nullptr; rowout[q] = -1; }
+        nrows_s = r;
+      }
+    }
+  } else if (tid == 0) {                  // any degree: sequential
     int r = 0;
     if (pself >= 0 && pself < P) {
       for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Ei + (static_cast<long long>(pself) * 6 + n) * HW); rowout[r] = 6 * pself + n; ++r; }
