@@ -359,8 +359,61 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
     }
   }
   BA_WG_PROBE(0, 1);                     // pixel terms done (stores issued)
-  // 90 sums: wave shuffle reduce, 4 partials through LDS
+  // 90 sums per wave.  Ninety separate wave reductions (6 DPP steps each) were 5.2 of this kernel's 9.5 us at S-B
+  // (profiles/r04_ba_kernel_timeline.txt); a reduce-SCATTER does the same work in a third of the instructions: the values sit in
+  // 96 registers, and at every step a lane and its partner each keep one half of the array and add the other's copy of it -
+  // 48, 24, 12, 6, 3 additions, then one plain exchange.  Partners: lane ^ 32 and lane ^ 16 by v_permlane32_swap /
+  // v_permlane16_swap (gfx950: the two halves change places in one instruction, no select), then the DPP mirrors inside a row
+  // (i <-> 15 - i, i <-> 7 - i, i <-> 3 - i) and quad_perm [1,0,3,2]; which half a lane keeps is its bit 5, 4, 3, 2, 1 in turn,
+  // so lane L ends with the sums of entries [48 b5 + 24 b4 + 12 b3 + 6 b2 + 3 b1, + 3).  A fixed order of additions, as before.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifndef PVO_SCHED_DEBUG
+  {
+    float c[96];
+#pragma unroll
+    for (int l = 0; l < 78; ++l) c[l] = h[l];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) { c[78 + n] = vi[n]; c[84 + n] = vj[n]; c[90 + n] = 0.0f; }
+    auto fbits = [](float x) { return __builtin_bit_cast(unsigned, x); };
+    auto bitsf = [](unsigned x) { return __builtin_bit_cast(float, x); };
+#pragma unroll
+    for (int q = 0; q < 48; ++q) {
+      const auto r = __builtin_amdgcn_permlane32_swap(fbits(c[q]), fbits(c[q + 48]), false, false);
+      c[q] = bitsf(r[0]) + bitsf(r[1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+      const auto r = __builtin_amdgcn_permlane16_swap(fbits(c[q]), fbits(c[q + 24]), false, false);
+      c[q] = bitsf(r[0]) + bitsf(r[1]);
+    }
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const float keep = b3 ? c[q + 12] : c[q], send = b3 ? c[q] : c[q + 12];
+      c[q] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x140, 0xf, 0xf, true));      // row_mirror
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const float keep = b2 ? c[q + 6] : c[q], send = b2 ? c[q] : c[q + 6];
+      c[q] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x141, 0xf, 0xf, true));      // row_half_mirror
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float keep = b1 ? c[q + 3] : c[q], send = b1 ? c[q] : c[q + 3];
+      c[q] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x1b, 0xf, 0xf, true));       // quad_perm [3,2,1,0]
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      c[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c[q]), 0xb1, 0xf, 0xf, true));             // quad_perm [1,0,3,2]
+    const int start = ((lane >> 5) & 1) * 48 + ((lane >> 4) & 1) * 24 + ((lane >> 3) & 1) * 12 + ((lane >> 2) & 1) * 6 + ((lane >> 1) & 1) * 3;
+    if (!(lane & 1)) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (start + q < 90) red[wave][start + q] = c[q];
+    }
+  }
+#else
+  // (the schedule-debug build keeps the ninety separate reductions: tools/sched_bisect.py dumps every wave's sums before LDS)
 #pragma unroll
   for (int l = 0; l < 78; ++l) {
     const float s = pvo_wave_sum(h[l]);
@@ -380,6 +433,7 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
     }
 #endif
   }
+#endif
   __syncthreads();
   BA_WG_PROBE(0, 2);                     // wave reductions done
   const int t = threadIdx.x;
