@@ -613,19 +613,24 @@ __device__ __forceinline__ void ba_schur_body(
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
-    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA) {
+    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows) {
   __shared__ gfloat* rowptr[kMaxRows];
   __shared__ int rowout[kMaxRows];        // 6*pose + comp for an M row, -2 for the w row, -1 padding
   __shared__ int nrows_s;
   __shared__ float red[4 * (kFastTiles * (kFastTiles + 1) / 2) * 256];   // 40 KB
-  // the assembly's chunk sums, per edge: edges are dealt over ALL workgroups of the launch (also those without a depth frame)
-  if (part && threadIdx.x < 90) {
-    const int nwg = gridDim.x * gridDim.y;
-    for (int e = blockIdx.y * gridDim.x + blockIdx.x; e < E; e += nwg) {
-      double val = 0.0;
-      for (int c = 0; c < chunksA; ++c) val += static_cast<double>(part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]);
-      pose_block_scatter(threadIdx.x, val, static_cast<int>(ii[e]) - t0, static_cast<int>(jj[e]) - t0, P, sys, pl.meta);
+  // the assembly's chunk sums, per edge, are added up and scattered by workgroups of their OWN: the last `deal_rows` rows of the
+  // grid (at most two edges each).  Dealt over the depth frames' workgroups, as in round 3, the 36 of 96 that had an edge at S-B
+  // started their own work 3.5 us late - and the kernel ends with its slowest workgroup (profiles/r04_ba_kernel_timeline.txt).
+  if (static_cast<int>(blockIdx.y) >= static_cast<int>(gridDim.y) - deal_rows) {
+    if (part && threadIdx.x < 90) {
+      const int nd = deal_rows * gridDim.x;
+      for (int e = (blockIdx.y - (gridDim.y - deal_rows)) * gridDim.x + blockIdx.x; e < E; e += nd) {
+        double val = 0.0;
+        for (int c = 0; c < chunksA; ++c) val += static_cast<double>(part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]);
+        pose_block_scatter(threadIdx.x, val, static_cast<int>(ii[e]) - t0, static_cast<int>(jj[e]) - t0, P, sys, pl.meta);
+      }
     }
+    return;
   }
   const int k = blockIdx.y;
   BA_WG_PROBE(1, 0);
@@ -745,8 +750,8 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
-    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA) {
-  ba_schur_body<VEC4, PIX>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA);
+    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows) {
+  ba_schur_body<VEC4, PIX>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA, deal_rows);
 }
 
 // ---------------------------------------------------------------------------
@@ -2452,9 +2457,11 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     // partial sums, and an edge-sharded run must form the same ones as the whole graph)
     const long long wg256 = static_cast<long long>((HW + 255) / 256) * nframes;
     const int pix = (pix_env == 256 || pix_env == 512 || pix_env == 1024) ? pix_env : (wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024));
-    const dim3 sgrid((HW + pix - 1) / pix, Kmax);
+    const int gx = (HW + pix - 1) / pix;
+    const int deal_rows = two_stage ? (E + 2 * gx - 1) / (2 * gx) : 0;      // workgroups that add up the assembly's chunk sums: two edges each
+    const dim3 sgrid(gx, Kmax + deal_rows);
 #define PVO_SCHUR_LAUNCH(V, PX) hipLaunchKernelGGL((ba_schur_mfma_kernel<V, PX>), sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, \
-                                                   w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA)
+                                                   w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA, deal_rows)
     if ((HW & 3) == 0) { if (pix == 256) PVO_SCHUR_LAUNCH(true, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(true, 512); else PVO_SCHUR_LAUNCH(true, 1024); }
     else { if (pix == 256) PVO_SCHUR_LAUNCH(false, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(false, 512); else PVO_SCHUR_LAUNCH(false, 1024); }
 #undef PVO_SCHUR_LAUNCH
