@@ -1673,46 +1673,33 @@ __global__ __launch_bounds__(256) void ba_pack_kernel(long long* __restrict__ sy
   }
 }
 
-// block row of entry k of a packed image: the rb with rowbase[rb] <= k (rowbase ascending, k < total)
-__device__ __forceinline__ int packed_row(const int* rowbase, int P, int k) {
-  int lo = 0, hi = P;
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowbase[mid] <= k) lo = mid; else hi = mid; }
-  return lo;
-}
-
+// One workgroup per BLOCK ROW of the message (its blocks are contiguous: no search for the row of an entry; a flat split of the
+// message with a binary search per entry made these two kernels twice as long as their dense counterparts).
 __global__ __launch_bounds__(256) void ba_env_packed_kernel(const long long* __restrict__ msg, const int* __restrict__ first_s, int* __restrict__ env, int n) {
   __shared__ int first[kMaxEnvBlocks], rowbase[kMaxEnvBlocks + 1];
-  __shared__ int blocks_s;
-  constexpr int kSlots = 64;                                // 2048 entries span at most 57 block rows (36 entries each at least)
-  __shared__ int smin[kSlots];
+  __shared__ int blocks_s, smin;
   const int P = n / 6;
-  const int blocks = env_layout(first_s, P, first, rowbase, &blocks_s);
-  const int base = blockIdx.x * 2048;
-  if (base >= blocks) return;
-  const int rb0 = packed_row(rowbase, P, base);
-  if (threadIdx.x < kSlots) smin[threadIdx.x] = 0x7fffffff;
+  env_layout(first_s, P, first, rowbase, &blocks_s);
+  const int rb = blockIdx.x;
+  if (threadIdx.x == 0) smin = 0x7fffffff;
   __syncthreads();
-  long long raw[8];
+  const int f = first[rb], nsub = (rb - f) * 36;                         // entries left of the diagonal block
+  const long long* row = msg + rowbase[rb];
+  for (int base = 0; base < nsub; base += 8 * 256) {
+    long long raw[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int k = base + u * 256 + threadIdx.x;
-    raw[u] = k < blocks ? msg[k] : 0;
-  }
+    for (int u = 0; u < 8; ++u) { const int k = base + u * 256 + threadIdx.x; raw[u] = k < nsub ? row[k] : 0; }
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int k = base + u * 256 + threadIdx.x;
-    if (k >= blocks || raw[u] == 0) continue;
-    const int rb = packed_row(rowbase, P, k);
-    const int cb = first[rb] + (k - rowbase[rb]) / 36;
-    if (cb >= rb) continue;
-    const int slot = rb - rb0;
-    if (slot < kSlots) { if (cb < smin[slot]) atomicMin(&smin[slot], cb); }
-    else atomicMin(&env[rb], cb);
+    for (int u = 0; u < 8; ++u) {
+      const int k = base + u * 256 + threadIdx.x;
+      if (k < nsub && raw[u] != 0) { const int cb = f + k / 36; if (cb < smin) atomicMin(&smin, cb); }
+    }
   }
   __syncthreads();
-  if (threadIdx.x < kSlots && smin[threadIdx.x] != 0x7fffffff) atomicMin(&env[rb0 + threadIdx.x], smin[threadIdx.x]);
+  if (threadIdx.x == 0 && smin != 0x7fffffff) env[rb] = smin;             // (this workgroup alone writes env[rb]; INT_MAX between solves)
 }
 
+// grid: P block rows + one workgroup for the right-hand side
 __global__ __launch_bounds__(256) void ba_prepare_packed_kernel(const long long* __restrict__ msg, const int* __restrict__ first_s, double* __restrict__ out,
                                                                 const int* __restrict__ env, int n, float lm, float ep, long long lds_budget,
                                                                 int* __restrict__ xchg_i) {
@@ -1732,30 +1719,29 @@ __global__ __launch_bounds__(256) void ba_prepare_packed_kernel(const long long*
       xchg_i[0] = 0; xchg_i[1] = 0; xchg_i[2] = 0; xchg_i[3] = 0;
     }
   }
-  const int N = sblocks + n;
-  const int base = blockIdx.x * 2048;
-  long long raw[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int k = base + u * 256 + threadIdx.x;
-    raw[u] = k < N ? msg[k] : 0;
+  const int rb = blockIdx.x;
+  if (rb == P) {                                            // rhs
+    for (int i = threadIdx.x; i < n; i += 256)
+      out[compact ? blocks + i : static_cast<long long>(n) * n + i] = static_cast<double>(msg[sblocks + i]) * kInvFix;
+    return;
   }
+  const int sf = sfirst[rb], f = first[rb], nrow = (rb - sf + 1) * 36;
+  const long long* row = msg + srow[rb];
+  for (int base = 0; base < nrow; base += 8 * 256) {
+    long long raw[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int k = base + u * 256 + threadIdx.x;
-    if (k >= N) continue;
-    double v = static_cast<double>(raw[u]) * kInvFix;
-    if (k >= sblocks) {                                     // rhs
-      const int i = k - sblocks;
-      out[compact ? blocks + i : static_cast<long long>(n) * n + i] = v;
-      continue;
+    for (int u = 0; u < 8; ++u) { const int k = base + u * 256 + threadIdx.x; raw[u] = k < nrow ? row[k] : 0; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = base + u * 256 + threadIdx.x;
+      if (k >= nrow) continue;
+      double v = static_cast<double>(raw[u]) * kInvFix;
+      const int q = k / 36, cb = sf + q, e = k - 36 * q, ri = e / 6, ci = e - 6 * ri;
+      if (rb == cb && ri == ci) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
+      if (!compact) { out[static_cast<long long>(6 * rb + ri) * n + 6 * cb + ci] = v; continue; }
+      if (cb < f) continue;                                 // inside the structural envelope, outside the numeric one: an exact zero
+      out[rowbase[rb] + (cb - f) * 36 + e] = v;
     }
-    const int rb = packed_row(srow, P, k);
-    const int q = k - srow[rb], cb = sfirst[rb] + q / 36, e = q % 36, ri = e / 6, ci = e - 6 * ri;
-    if (rb == cb && ri == ci) v += static_cast<double>(ep) + static_cast<double>(lm) * v;   // droid_kernels.cu:1176
-    if (!compact) { out[static_cast<long long>(6 * rb + ri) * n + 6 * cb + ci] = v; continue; }
-    if (cb < first[rb]) continue;                           // inside the structural envelope, outside the numeric one: an exact zero
-    out[rowbase[rb] + (cb - first[rb]) * 36 + e] = v;
   }
 }
 
@@ -2619,11 +2605,9 @@ static int ba_finish_impl(float* poses, float* disps, void* sys_, const long lon
   const int solver_wave = solver_pick == 3 ? 2 : solver_pick;
   if (msg) {
     if (P == 0) return PVO_OK;
-    // (grid: the message is at most the lower triangle + the diagonal blocks' upper halves + the rhs; its exact length is on the device)
-    const int mgrid = (n6 * (n6 / 2 + 9) + 2047) / 2048 + 1;
-    hipLaunchKernelGGL(ba_env_packed_kernel, dim3(mgrid), dim3(256), 0, st, msg, first_s, w.plan.env, n6);
+    hipLaunchKernelGGL(ba_env_packed_kernel, dim3(P), dim3(256), 0, st, msg, first_s, w.plan.env, n6);
     PVO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ba_prepare_packed_kernel, dim3(mgrid), dim3(256), 0, st, msg, first_s, w.chol, w.plan.env, n6, lm, ep,
+    hipLaunchKernelGGL(ba_prepare_packed_kernel, dim3(P + 1), dim3(256), 0, st, msg, first_s, w.chol, w.plan.env, n6, lm, ep,
                        static_cast<long long>(kSolveLdsMax), twin ? reinterpret_cast<int*>(w.xchg) : nullptr);
     PVO_CHECK_LAUNCH();
   } else if (!use_lds) {
