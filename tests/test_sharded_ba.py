@@ -118,6 +118,17 @@ def test_envelope_structure_covers_every_coupling_of_the_pose_system():
         assert not lower.reshape(-1)[~keep[:n * n]].any()                 # nothing of the lower triangle is left out
 
 
+def test_packed_message_length_of_the_library_equals_the_index_path():
+    """pvo_ba_packed_elems (host helper of the C ABI; no GPU needed) counts the entries envelope_index enumerates: the library's
+    packed message and the index_select message are the same entries (the GPU test compares their sums bit for bit)"""
+    from pvo_amd import droid_backends as db
+    g = np.random.default_rng(5)
+    for P in (1, 7, 21, 63, 200):
+        first = [int(g.integers(0, b + 1)) if g.random() < 0.7 else b for b in range(P)]
+        assert db.ba_packed_elems(first) == envelope_index(first, "cpu").numel() == 36 * sum(b - f + 1 for b, f in enumerate(first)) + 6 * P
+    assert db.ba_packed_elems([0, 5, 9]) == db.ba_packed_elems([0, 1, 2])          # entries beyond the diagonal are clamped to it
+
+
 def test_two_rank_sharded_ba_equals_single_process_gloo():
     world = 2
     mgr = mp.get_context("spawn").Manager()
