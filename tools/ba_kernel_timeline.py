@@ -51,6 +51,6 @@ def show(name, k, labels, last):
             print("    %-58s median %6.2f us   max %6.2f   (%d workgroups)" % (lab, np.median(dtt), dtt.max(), ok.sum()))
 show("ba_assemble_kernel", 0, [(0, 1, "entry -> pixel terms computed, rows stored"), (1, 2, "the waves' 90 sums (reduce-scatter) + barrier"), (2, 3, "chunk sums stored / atomics issued"), (0, 3, "whole workgroup")], 3)
 show("ba_schur_mfma_kernel", 1, [(0, 1, "entry -> meta read (the chunk sums are other workgroups' now)"), (1, 2, "edge list -> LDS"), (2, 3, "depth phase (C, w, Q, Ei) issued"),
-                                 (3, 4, "row table + barrier (depth rows visible)"), (4, 5, "16 steps of row loads + MFMA (wave 0)"), (5, 6, "products -> LDS + barrier"),
+                                 (3, 4, "row table + barrier (depth rows visible)"), (4, 5, "row loads + MFMA, PIX / 64 steps (wave 0)"), (5, 6, "products -> LDS + barrier"),
                                  (6, 7, "4-wave sums + fixed-point atomics"), (0, 7, "whole workgroup")], 7)
 show("ba_backsub_kernel", 2, [(0, 1, "rows / dx -> LDS + barrier"), (1, 2, "rows x dx, depth update"), (0, 2, "whole workgroup")], 2)
