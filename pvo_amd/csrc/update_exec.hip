@@ -167,6 +167,14 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   // the side stream that chain ended ~55 us after corr_encoder[2]; a third stream for it changed nothing.
   void* s2 = sc ? static_cast<void*>(sc->side) : stream;
   void* s3 = stream;
+  // PVO_TRUNK_ORDER=1 (round-4 experiment; default off): the 7x7 convolution FIRST and alone on the launch stream
+  // (19 us; beside the lookup it takes 49), the fork behind it: the side stream then runs only flow_encoder[2] beside the lookup.
+  // Measured A/B on one box: 229.6 / 230.2 against 232.8 / 233.3 keyframe updates/s - flow_encoder[2] beside the lookup takes 81 us
+  // (53 beside corr_encoder[2]) and the lookup 55-66 (profiles/r04_update_timeline_7x7_first.txt): whatever is paired with the lookup
+  // pays for the memory system it saturates
+  static const bool seven_first = [] { const char* e = getenv("PVO_TRUNK_ORDER"); return e && e[0] == '1'; }();
+  const bool early7 = seven_first && sc && !mj;
+  if (early7) RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, stream));
   if (sc) {
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
@@ -196,7 +204,7 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   const int E_main = (sc && fe_two) ? (E * split_pct) / 100 : 0, E_side = E - E_main;
   const size_t px = static_cast<size_t>(H) * W;
   if (fe_two) {
-    RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
+    if (!early7) RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
     if (E_main > 0 && hipEventRecord(sc->mid, sc->side) != hipSuccess) return PVO_ELAUNCH;       // (`mid` is free here: run_agg records it later)
     if (E_side > 0) RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E_side, H, W, 64, 1, 192, 128, dt, s2));
   } else {
