@@ -172,10 +172,14 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   // Measured A/B on one box: 229.6 / 230.2 against 232.8 / 233.3 keyframe updates/s - flow_encoder[2] beside the lookup takes 81 us
   // (53 beside corr_encoder[2]) and the lookup 55-66 (profiles/r04_update_timeline_7x7_first.txt): whatever is paired with the lookup
   // pays for the memory system it saturates
-  static const bool seven_first = [] { const char* e = getenv("PVO_TRUNK_ORDER"); return e && e[0] == '1'; }();
-  const bool early7 = seven_first && sc && !mj;
+  // PVO_TRUNK_ORDER=2 (experiment, default off): the fork BEHIND the lookup - the lookup alone, then the 7x7 (write-bound) beside
+  // corr_encoder[2] (matrix-bound), flow_encoder[2] last.  229.2 / 229.2 against 236.7 / 235.5 on one box: the 7x7 takes 41 us beside
+  // corr_encoder[2] too, and the gate convolution starts at 164 us (profiles/r04_update_timeline_fork_behind_lookup.txt)
+  static const int trunk_order = [] { const char* e = getenv("PVO_TRUNK_ORDER"); return e ? atoi(e) : 0; }();
+  const bool early7 = trunk_order == 1 && sc && !mj;
+  const bool late_fork = trunk_order == 2 && sc && !mj && a->levels[0];
   if (early7) RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, stream));
-  if (sc) {
+  if (sc && !late_fork) {
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
   }
@@ -185,6 +189,10 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     probe_mark(PVO_STAGE_LOOKUP, 0, stream);
     RUN(pvo_corr_lookup_encode_tiled(a->levels, a->coords, w->enc0_w, w->enc0_b, b.c1, E, H, W, dt, a->slots, a->num_slots, stream));
     probe_mark(PVO_STAGE_LOOKUP, 1, stream);
+    if (late_fork) {
+      if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
+      if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
+    }
   } else {
     if (!a->corr) return PVO_EINVAL;
     RUN(pvo_corr_encode(a->corr, w->enc0_w, w->enc0_b, b.c1, rows, dt, stream));
