@@ -683,6 +683,143 @@ def edge_sharded_leg(device, rank, world, steps=3):
 _REAL_STDOUT = None
 
 
+class _Split:
+    """wall-clock split of a run by component: every wrapped call is bracketed by device synchronisations (the instrumented
+    pass is therefore slower than the plain one - it apportions the time, the plain pass gives the rate)"""
+    def __init__(self):
+        self.t, self.n, self.stack = {}, {}, []
+
+    def wrap(self, obj, name, key):
+        fn = getattr(obj, name)
+        split = self
+
+        def timed(*a, **kw):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            split.stack.append(0.0)
+            try:
+                return fn(*a, **kw)
+            finally:
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                inner = split.stack.pop()
+                split.t[key] = split.t.get(key, 0.0) + dt - inner            # exclusive time: nested wrapped calls are subtracted
+                split.n[key] = split.n.get(key, 0) + 1
+                if split.stack:
+                    split.stack[-1] += dt
+        setattr(obj, name, timed)
+
+
+def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None, record=None, terminate=True, seed=0):
+    """tools/test_vo.py's loop (evaluation_scripts/test_vo.py:88-108) on the synthetic stream: Droid.track per frame, then
+    terminate (backend x2 + trajectory filler)"""
+    from pvo_amd.droid import Droid, default_args
+    from pvo_amd.synthetic import drifting_texture_stream
+    torch.manual_seed(seed)
+    args = default_args(device=str(device), image_size=[240, 808], buffer=max(64, n_frames + 40), segm_filter=True, thresh=0.8,
+                        filter_thresh=filter_thresh, keyframe_thresh=keyframe_thresh)
+    droid = Droid(args)
+    fe, mf = droid.frontend, droid.filterx
+    counts = {"keyframe_updates": 0, "keyframes_removed": 0, "graph_updates": 0}
+    upd, rmk = fe._update, fe.graph.rm_keyframe
+
+    def _upd():
+        counts["keyframe_updates"] += 1
+        return upd()
+
+    def _rmk(ix):
+        counts["keyframes_removed"] += 1
+        return rmk(ix)
+    fe._update, fe.graph.rm_keyframe = _upd, _rmk
+    gupd = fe.graph.update
+
+    def _gupd(*a, **kw):
+        counts["graph_updates"] += 1
+        return gupd(*a, **kw)
+    fe.graph.update = _gupd
+    if record is not None:                       # calibration pass: the two quantities the thresholds are compared with
+        op, dist = mf.update, droid.video.distance
+
+        def _op(*a, **kw):
+            out = op(*a, **kw)
+            record["motion"].append(float(out[1][..., 0:2].float().norm(dim=-1).mean()))
+            return out
+
+        def _dist(ii=None, jj=None, **kw):
+            d = dist(ii, jj, **kw)
+            if ii is not None and len(ii) == 1:
+                record["keyframe_distance"].append(float(d.reshape(-1)[0]))
+            return d
+        mf.update, droid.video.distance = _op, _dist
+    if split is not None:
+        # (the graphed calls, not the modules: a device synchronisation inside a captured region is illegal)
+        split.wrap(mf, "_features_g", "encoders (fnet, cnet)"); split.wrap(mf, "_context_g", "encoders (fnet, cnet)")
+        split.wrap(mf, "track", "motion filter (volume + lookup + operator + test)")
+        split.wrap(fe.graph, "add_proximity_factors", "edge bookkeeping + proximity (distance matrix, add / rm factors, volume build)")
+        split.wrap(fe.graph, "rm_factors", "edge bookkeeping + proximity (distance matrix, add / rm factors, volume build)")
+        split.wrap(fe.graph, "rm_keyframe", "edge bookkeeping + proximity (distance matrix, add / rm factors, volume build)")
+        split.wrap(fe.graph, "update", "frontend graph updates")
+        split.wrap(fe, "_initialize", "frontend initialisation (12-keyframe bootstrap)")
+        split.wrap(fe, "_update", "frontend other (keyframe test .item(), pose / depth seed)")
+        split.wrap(droid, "backend", "backend (global BA x2)")
+        split.wrap(droid, "traj_filler", "trajectory filler")
+    frames = list(drifting_texture_stream(n_frames, seed=seed))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t, image, intr, segm in frames:
+        droid.track(t, image, intrinsics=intr, segments=segm)
+    torch.cuda.synchronize(); t_track = time.perf_counter() - t0
+    out = dict(counts, frames=n_frames, keyframes=int(droid.video.counter), track_s=t_track,
+               edges_at_end=len(fe.graph._ii_h), finite=bool(torch.isfinite(droid.video.poses[:droid.video.counter]).all()))
+    if terminate:
+        t0 = time.perf_counter()
+        traj = droid.terminate(iter(frames), need_inv=True)
+        torch.cuda.synchronize(); out["terminate_s"] = time.perf_counter() - t0
+        out["trajectory_rows"] = int(traj.shape[0]); out["finite"] = out["finite"] and bool((traj == traj).all())
+    del droid
+    torch.cuda.empty_cache()
+    return out
+
+
+def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
+    """The run the metric is named after (BASELINE.json configs[1] "full sequence"; evaluation_scripts/test_vo.py:88-164): a seeded
+    synthetic 240 x 808 stream with panoptic segments through Droid.track per frame and Droid.terminate (backend x2 + filler), random-
+    init weights.  No checkpoint exists here, so WHICH frames become keyframes is decided by a random network; the two thresholds
+    are therefore calibrated on a warm-up pass (motion filter: the median of the first 48 frames' one-step flow magnitudes;
+    keyframe test: the lower quartile of the frontend's distances) so that every branch of the loop runs - frames dropped by the filter,
+    keyframes removed again, keyframes kept + 2 more updates.  Three passes: warm-up + calibration, plain (the rates), instrumented
+    (the split; device synchronisations around every component)."""
+    rec = {"motion": [], "keyframe_distance": []}
+    _sequence_pass(device, min(n_frames, 48), 0.0, 0.0, record=rec, terminate=True)
+    med = lambda v, q: sorted(v)[int(q * (len(v) - 1))] if v else 0.0
+    f_th, k_th = med(rec["motion"], 0.5), med(rec["keyframe_distance"], 0.25)
+    if cprofile:
+        import cProfile, io, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+    plain = _sequence_pass(device, n_frames, f_th, k_th)
+    if cprofile:
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(70)
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(45)
+        with open(cprofile, "w") as f:
+            f.write(buf.getvalue())
+    sp = _Split()
+    inst = _sequence_pass(device, n_frames, f_th, k_th, split=sp) if instrumented else {"track_s": float("nan")}
+    total = sum(sp.t.values())
+    return {"workload": "synthetic 240x808 stream (30x101 maps), %d frames, panoptic segments (segm_filter), random-init weights; "
+                        "tools/test_vo.py's loop: Droid.track per frame, terminate = backend(7) + backend(12) + trajectory filler" % n_frames,
+            "thresholds": {"filter_thresh": f_th, "keyframe_thresh": k_th,
+                           "how": "calibrated on a 48-frame warm-up pass (a random network decides): median one-step flow magnitude, lower quartile of the keyframe distances"},
+            "frames_per_s": plain["frames"] / plain["track_s"], "keyframe_updates_per_s": plain["keyframe_updates"] / plain["track_s"],
+            "graph_updates_per_s": plain["graph_updates"] / plain["track_s"],
+            "ms_per_keyframe_update_all_in": 1e3 * plain["track_s"] / max(plain["keyframe_updates"], 1),
+            "terminate_s": plain.get("terminate_s"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},
+            "finite": plain["finite"],
+            "split_instrumented_pass": {"note": "exclusive wall time per component with a device synchronisation on both sides of every call (this pass: %.2f s of tracking against %.2f s plain)" % (inst["track_s"], plain["track_s"]),
+                                        "seconds": {k: round(v, 4) for k, v in sorted(sp.t.items(), key=lambda kv: -kv[1])},
+                                        "calls": sp.n, "share": {k: round(v / total, 3) for k, v in sorted(sp.t.items(), key=lambda kv: -kv[1])} if total else None}}
+
+
 def _own_stdout():
     """Everything that any library writes to file descriptor 1 during the run goes to stderr instead (RCCL prints a five-line version
     banner to stdout when a process group comes up, from C, flushed at exit - i.e. AFTER the result line); the ONE JSON line of the
@@ -701,17 +838,23 @@ def emit(obj):
 
 
 def main():
-    _own_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the S-A workload and the edge-sharded leg")
+    ap.add_argument("--sequence-only", action="store_true", help="run only the full-sequence leg (Droid.track / terminate on the synthetic "
+                    "240x808 stream) and print its object: the command tools/sequence_timeline.sh profiles")
+    ap.add_argument("--sequence-frames", type=int, default=160)
+    ap.add_argument("--sequence-plain", action="store_true", help="with --sequence-only: skip the instrumented pass (profiler runs)")
+    ap.add_argument("--sequence-cprofile", default=None, help="with --sequence-only: host profile (cProfile) of the plain pass -> this file")
     ap.add_argument("--steps-only", action="store_true", help="priming, warm-up and the timed steps ONLY (for profilers: no stage probes, no "
                     "isolated kernel loops, no measurement kernels); prints a reduced line")
     args = ap.parse_args()
-
+    # (behind the parser: --help and argument errors keep the real stdout.  Descriptor 1 is NOT handed back afterwards: RCCL's
+    # banner sits in a C stdio buffer that is flushed at exit, and must not land behind the result line)
+    _own_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -733,6 +876,9 @@ def main():
     from pvo_amd import _lib
     from pvo_amd import droid_backends as db
     _lib.load()                                         # fail loudly if the HIP library is missing
+    if args.sequence_only:
+        emit({"sequence": sequence_leg(device, args.sequence_frames, instrumented=not args.sequence_plain, cprofile=args.sequence_cprofile)})
+        return
     video, graph = make_window(device, seed=rank)
     if not graph._fused_ok():
         raise SystemExit("the native update path is not active")
@@ -881,7 +1027,8 @@ def main():
     if not args.no_extras:
         if world == 1:
             for key, leg in (("workload_S_A", lambda: workload_sa(device, max(10, args.steps // 2))), ("workload_S_1", lambda: workload_s1(device)),
-                             ("train_step", lambda: train_step_leg(device))):
+                             ("train_step", lambda: train_step_leg(device)),
+                             ("sequence", lambda: sequence_leg(device, args.sequence_frames))):
                 try:
                     extra[key] = leg()
                 except Exception as e:      # a failure here must not cost the headline line

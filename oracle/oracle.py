@@ -174,6 +174,18 @@ def ba(poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iteratio
     return out
 
 
+def pose_retr(poses, dx, t0, t1, xi45_zero=False):
+    """pose_retr_kernel (droid_kernels.cu:877-910): poses[k] <- retrSE3(dx[k - t0], poses[k]) for k in [t0, t1); xi45_zero
+    reproduces "the out-of-bounds read xi[45] of expSE3 (:154) returned 0", the default is upstream's xi[5]"""
+    out = _f32c(poses).copy()
+    dx = _f32c(dx)
+    for k in range(t0, t1):
+        p1 = np.zeros(7, np.float32)
+        lib().oracle_retrSE3(_p(np.ascontiguousarray(dx[k - t0])), _p(np.ascontiguousarray(out[k])), _p(p1), int(xi45_zero))
+        out[k] = p1
+    return out
+
+
 def ba_assemble(poses, disps, intrinsics, targets, weights, ii, jj):
     """projective_transform_kernel alone (droid_kernels.cu:177-403): dict(Hs, vs [fp64 sums], Eii, Eij, Cii, bz [fp32])"""
     poses, disps, intrinsics = _f32c(poses), _f32c(disps), _f32c(intrinsics)

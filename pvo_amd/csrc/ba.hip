@@ -2438,11 +2438,14 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     // pixels per workgroup: 256 while the grid fits the chip's resident slots (two 55 KB workgroups per CU); a global bundle
     // adjustment (64 keyframes x 12 chunks: 768 workgroups in two rounds, every one issuing ~1000 atomics into the same 63 x 63
     // blocks) takes bigger chunks - fewer, longer workgroups, a fraction of the atomics
-    static const int pix_env = [] { const char* e = getenv("PVO_SCHUR_PIX"); return e ? atoi(e) : 0; }();
-    // (a function of the map size and the buffer length only - not of this rank's edge count: the chunking fixes the fp32
-    // partial sums, and an edge-sharded run must form the same ones as the whole graph)
-    const long long wg256 = static_cast<long long>((HW + 255) / 256) * nframes;
-    const int pix = (pix_env == 256 || pix_env == 512 || pix_env == 1024) ? pix_env : (wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024));
+    // (a function of the map size and the POSE WINDOW only - never of this rank's edge count: the chunking fixes the fp32
+    // partial sums, and an edge-sharded run must form the same ones as the whole graph; t0 / t1 are the same on every rank.
+    // Depth frames optimised = the window's frames + the few source frames in front of it, so P + 1 stands for their number.
+    // Until round 5 this was the BUFFER length: a 1024-frame video buffer - the reference driver's default - put every window-
+    // sized BA on 1024-pixel chunks, 3 x K workgroups, 443 us instead of 20: found by the full-sequence run of bench.py)
+    const int frames_opt = (nframes < P + 1) ? nframes : (P + 1);
+    const long long wg256 = static_cast<long long>((HW + 255) / 256) * frames_opt;
+    const int pix = wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024);
     const int gx = (HW + pix - 1) / pix;
     const int deal_rows = two_stage ? (E + 2 * gx - 1) / (2 * gx) : 0;      // workgroups that add up the assembly's chunk sums: two edges each
     const dim3 sgrid(gx, Kmax + deal_rows);

@@ -1,0 +1,83 @@
+"""HIP-graph replay of fixed-shape per-frame work (the encoders of MotionFilter / PoseTrajectoryFiller).
+
+The reference issues its per-frame encoders (VO_Module/droid_slam/motion_filter.py:52-60, trajectory_filler.py:32-38) as ~70 eager
+PyTorch / cuDNN launches per network.  On the sequence run of bench.py that is 4.6 ms of HOST time per network call for ~0.3 ms of
+device work: the device idles 73 % of a tracked sequence.  `GraphedCall` captures such a callable once per input signature into a HIP
+graph (torch.cuda.CUDAGraph = hipGraph on ROCm) and replays it with one launch; the inputs are copied into the capture's static
+buffers, the outputs are the capture's static buffers (a caller that keeps one across calls clones it).
+
+Safe by construction: the first `warmup` calls run eagerly (MIOpen picks its kernels there), the first replay is compared with
+an eager run of the same input, and any failure - capture not supported, mismatch - switches the instance back to eager for good.
+`PVO_HIP_GRAPHS=0` in the environment disables capture process-wide.
+"""
+import os
+
+import torch
+
+ENABLED = os.environ.get("PVO_HIP_GRAPHS", "1") != "0"
+
+
+def _flat(out):
+    return (out,) if isinstance(out, torch.Tensor) else tuple(out)
+
+
+class GraphedCall:
+    def __init__(self, fn, warmup=2, rtol=2e-3, name=None, guard=None):
+        """fn(*tensors) -> tensor or tuple of tensors; no host synchronisation and no data-dependent shapes inside.
+        guard() (optional) -> a hashable that must be unchanged for a capture to stay valid (e.g. the storage of the weights)"""
+        self.fn, self.warmup, self.rtol, self.name = fn, warmup, rtol, name or getattr(fn, "__name__", "call")
+        self.guard = guard
+        self.cache = {}
+        self.disabled = not ENABLED
+        self.replays = 0
+
+    def _key(self, args):
+        return tuple((tuple(a.shape), a.dtype, a.device, a.stride()) for a in args) + ((self.guard(),) if self.guard else ())
+
+    def __call__(self, *args):
+        if self.disabled or not args or not all(isinstance(a, torch.Tensor) and a.is_cuda for a in args) or torch.is_grad_enabled():
+            return self.fn(*args)
+        key = self._key(args)
+        st = self.cache.get(key)
+        if st is None:
+            if len(self.cache) >= 4:            # (a guard that keeps changing: do not pile up captures)
+                self.cache.clear()
+            st = self.cache[key] = {"n": 0, "graph": None}
+        if st["graph"] is None:
+            if st["n"] < self.warmup:
+                st["n"] += 1
+                return self.fn(*args)
+            try:
+                self._capture(st, args)
+            except Exception as e:              # capture unsupported for something inside fn: stay eager
+                self.disabled = True
+                self.error = repr(e)
+                torch.cuda.synchronize()
+                return self.fn(*args)
+            if self.disabled:
+                return self.fn(*args)
+        for s, a in zip(st["in"], args):
+            s.copy_(a)
+        st["graph"].replay()
+        self.replays += 1
+        return st["out"] if st["single"] else tuple(st["outs"])
+
+    def _capture(self, st, args):
+        static_in = [torch.empty_like(a).copy_(a) for a in args]
+        want = _flat(self.fn(*static_in))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self.fn(*static_in)
+        outs = _flat(out)
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(outs, want):
+            scale = float(b.float().abs().max()) + 1e-12
+            if a.shape != b.shape or not bool(torch.isfinite(a.float()).all()) == bool(torch.isfinite(b.float()).all()) or \
+                    float((a.float() - b.float()).abs().max()) > self.rtol * scale:
+                self.disabled = True
+                self.error = "replay differs from the eager run"
+                return
+        st.update(graph=g, out=out, outs=outs, single=isinstance(out, torch.Tensor))
+        st["in"] = static_in

@@ -181,6 +181,7 @@ class DynamicUpdateModule(nn.Module):
 
     def _drop_derived(self):
         self.__dict__.pop("_packed", None)
+        self.__dict__.pop("_param_list", None)
         self._fused_heads = None
         self.gru._fused = None
 
@@ -197,7 +198,11 @@ class DynamicUpdateModule(nn.Module):
         16-bit filters, fp32 biases, the z|r gate filters fused and split into their dynamic ([net|corr|flow]) and static
         (`inp`) input channels, the four heads' first stages side by side.  Cached; rebuilt when a parameter changes."""
         from .. import droid_backends as db
-        ps = list(self.parameters())
+        # (the parameter OBJECTS are listed once - walking the module tree costs 0.7 ms, and this runs once per graph update;
+        # .to() / .half() / train() / load_state_dict() drop the list, in-place changes show in the version counters)
+        ps = self.__dict__.get("_param_list")
+        if ps is None:
+            ps = self.__dict__["_param_list"] = list(self.parameters())
         key = (dt, ps[0].device, tuple(p._version for p in ps), _CONV128_WIDE, _AGG_SIDE_STREAM, _ENC_SIDE_STREAM)
         hit = self.__dict__.get("_packed")
         if hit is not None and hit[0] == key and hit[1] is not None:

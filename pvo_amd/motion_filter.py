@@ -5,11 +5,25 @@ adds the first frame unconditionally and afterwards only frames whose one-step f
 the last keyframe exceeds `thresh` pixels (mean norm); `track_vo` adds every frame.  The one-step
 estimate is a 1-edge correlation volume (HIP build), a lookup at the identity grid (HIP lookup) and one
 pass of the update operator; one scalar is read back per frame.
+
+Per-frame host cost (round 5, bench.py `sequence`): the frame goes up as uint8, the BGR flip / scaling happen on the device,
+and each encoder is ONE HIP-graph launch after its first two calls
+(pvo_amd/graphs.py: the eager ~70-launch forward cost 4.6 ms of host time per network for ~0.3 ms of device work).
 """
 import torch
 
 from .geom.projective_ops import coords_grid
+from .graphs import GraphedCall
 from .modules.corr import CorrBlock
+
+
+def _weights_guard(module):
+    """what a captured graph of `module` stays valid for: the storage and dtype of its parameters (.half() / .to() re-allocate them;
+    load_state_dict copies in place, which a replay sees)"""
+    def guard():
+        p = next(iter(module.parameters()), None) if hasattr(module, "parameters") else None
+        return None if p is None else (p.data_ptr(), p.dtype)
+    return guard
 
 
 class MotionFilter:
@@ -20,6 +34,32 @@ class MotionFilter:
         self.MEAN = torch.as_tensor([0.485, 0.456, 0.406], device=self.device)[:, None, None]
         self.STDV = torch.as_tensor([0.229, 0.224, 0.225], device=self.device)[:, None, None]
         self.net = self.inp = self.fmap = None
+        self._coords0 = None
+        self._features_g = GraphedCall(self._features_dev, name="fnet", guard=_weights_guard(self.fnet))
+        self._context_g = GraphedCall(self._context_dev, name="cnet", guard=_weights_guard(self.cnet))
+
+    def _upload(self, image):
+        """host frame -> device.  Integer frames travel as uint8 (an image decoder's own type; a quarter of the int32 bytes the
+        reference's `.int()` stream carries) straight from pageable memory: staging through a pinned buffer was tried and is
+        SLOWER here - CPU writes into hipHostMalloc'ed memory ran at ~150 MB/s on the MI355X boxes (16 ms per 2.3 MB frame)."""
+        if image.device.type == "cpu" and self.device.type == "cuda" and not image.is_floating_point() and image.dtype != torch.uint8:
+            image = image.to(torch.uint8)                  # pixel values are 0..255 (motion_filter.py:52: `/ 255.0`)
+        return image.to(self.device, non_blocking=True)
+
+    def _normalise_dev(self, image_dev):
+        # (flip(0) = the reference's channel gather [2, 1, 0] without an index tensor: a list index is uploaded from the host on
+        # every call, which cannot be captured into a graph)
+        x = image_dev.flip(0)[None, None].float() / 255.0
+        return (x - self.MEAN) / self.STDV
+
+    def _features_dev(self, image_dev):
+        """frame on the device -> feature map [1,128,h,w]"""
+        with self._autocast():
+            return self.fnet(self._normalise_dev(image_dev)).squeeze(0)
+
+    def _context_dev(self, image_dev):
+        with self._autocast():
+            return self._context(self._normalise_dev(image_dev))
 
     def _autocast(self):
         return torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda")
@@ -41,37 +81,38 @@ class MotionFilter:
     @torch.no_grad()
     def track(self, tstamp, image, depth=None, intrinsics=None, segments=None):
         """run on every incoming frame (motion_filter.py:46-87); image [3,H,W] BGR 0..255"""
-        ident = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0], device=self.device)
         ht, wd = image.shape[-2] // 8, image.shape[-1] // 8
+        img = self._upload(image)
+        gmap = self._features_g(img)                                           # [1,128,h,w]
+        if self.video.counter == 0:
+            ident = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0], device=self.device)
+            net, inp = self._context_g(img)
+            self.net, self.inp, self.fmap = net.clone(), inp.clone(), gmap.clone()      # (graph outputs are static buffers)
+            self._append(tstamp, image, ident, 1.0, intrinsics.to(self.device), gmap, net, inp, segments)
+            return True
         with self._autocast():
-            x = self._normalise(image)
-            gmap = self.fnet(x).squeeze(0)                                     # [1,128,h,w]
-            if self.video.counter == 0:
-                net, inp = self._context(x)
-                self.net, self.inp, self.fmap = net, inp, gmap
-                self._append(tstamp, image, ident, 1.0, intrinsics.to(self.device), gmap, net, inp, segments)
-                return True
-            coords0 = coords_grid(ht, wd, device=self.device)[None, None]
+            if self._coords0 is None or self._coords0.shape[-3:-1] != (ht, wd):
+                self._coords0 = coords_grid(ht, wd, device=self.device)[None, None]
             half = lambda t: t if t.dtype in (torch.float16, torch.bfloat16) or self.device.type != "cuda" else t.half()
-            corr = CorrBlock(half(self.fmap[None]), half(gmap[None]))(coords0)
+            corr = CorrBlock(half(self.fmap[None]), half(gmap[None]))(self._coords0)
             _, delta, _, _ = self.update(self.net[None], self.inp[None], corr)
-            if delta[..., 0:2].float().norm(dim=-1).mean().item() > self.thresh:
-                self.count = 0
-                net, inp = self._context(x)
-                self.net, self.inp, self.fmap = net, inp, gmap
-                self._append(tstamp, image, None, None, intrinsics.to(self.device), gmap, net, inp, segments)
-                return True
-            self.count += 1
-            return False
+            moved = delta[..., 0:2].float().norm(dim=-1).mean().item() > self.thresh
+        if moved:
+            self.count = 0
+            net, inp = self._context_g(img)
+            self.net, self.inp, self.fmap = net.clone(), inp.clone(), gmap.clone()
+            self._append(tstamp, image, None, None, intrinsics.to(self.device), gmap, net, inp, segments)
+            return True
+        self.count += 1
+        return False
 
     @torch.no_grad()
     def track_vo(self, tstamp, image, depth=None, intrinsics=None, segments=None):
         """every frame becomes a keyframe (motion_filter.py:89-109)"""
         ident = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0], device=self.device)
-        with self._autocast():
-            x = self._normalise(image)
-            gmap = self.fnet(x).squeeze(0)
-            net, inp = self._context(x)
+        img = self._upload(image)
+        gmap = self._features_g(img)
+        net, inp = self._context_g(img)
         first = self.video.counter == 0
         self._append(tstamp, image, ident if first else None, 1.0 if first else None, intrinsics.to(self.device),
                      gmap, net, inp, segments)

@@ -156,3 +156,34 @@ class TrainClips(torch.utils.data.Dataset):
         segments = torch.zeros(self.n, ht, wd, dtype=torch.int32)
         return (torch.stack(images), scene.poses.clone(), scene.disps.clone(), scene.intr[None].repeat(self.n, 1),
                 torch.stack(masks), torch.ones(self.n, ht, wd, 1), segments)
+
+
+def drifting_texture_stream(n_frames, ht=240, wd=808, seed=0, segments=True, fast=9, slow=1, period=4):
+    """A seeded image stream in the item layout of evaluation_scripts/test_vo.py:19-56 - (t, image [3,H,W] uint8 BGR,
+    intrinsics [4], segm [1,1,H/8,W/8] int or None) - at the reference driver's own input size (240 x 808).  A smoothed random
+    texture drifts under the window, `fast` pixels per frame except every `period`-th frame (`slow` pixels: frames a motion
+    filter would drop); the panoptic labels are eight rectangles of which two move (the S-3 pattern of SURVEY.md 8d).  The
+    content carries no geometry - no checkpoint exists in this environment, so the frames only have to exercise every stage
+    of the pipeline (bench.py `sequence`)."""
+    g = torch.Generator().manual_seed(seed)
+    span = fast * n_frames + wd + 64
+    big = torch.randint(0, 256, (3, ht + 32, span), generator=g).float()
+    big = torch.nn.functional.avg_pool2d(big[None], 5, stride=1, padding=2)[0]
+    big = ((big - big.mean()) * 3.0 + 127.5).clamp(0, 255)
+    intr = torch.tensor([wd * 0.9, wd * 0.9, wd / 2.0, ht / 2.0])
+    h8, w8 = ht // 8, wd // 8
+    x = 0
+    for t in range(n_frames):
+        x += slow if (t % period == period - 1) else fast
+        image = big[:, 8:8 + ht, x:x + wd].round().to(torch.uint8).contiguous()      # uint8, as cv2.imread / torch.from_numpy hand it over (test_vo.py:33-44)
+        segm = None
+        if segments:
+            seg = torch.zeros(h8, w8, dtype=torch.int32)
+            bh, bw = h8 // 2, w8 // 4
+            for n in range(8):
+                r, c = divmod(n, 4)
+                shift = (t % 8) if n + 1 in (3, 6) else 0
+                y0, x0 = r * bh + 2, c * bw + 2 + shift
+                seg[y0:y0 + bh - 4, max(x0, 0):min(x0 + bw - 4, w8)] = 1000 * (n + 1) + 7      # raw ids: category * 1000 + instance
+            segm = seg[None, None]
+        yield t, image, intr.clone(), segm

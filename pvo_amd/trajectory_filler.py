@@ -9,6 +9,7 @@ import torch
 from .factor_graph import FactorGraph
 from .geom import se3 as lie
 from .geom.se3 import SE3
+from .graphs import GraphedCall
 
 
 class PoseTrajectoryFiller:
@@ -17,11 +18,28 @@ class PoseTrajectoryFiller:
         self.count, self.video, self.device = 0, video, torch.device(device)
         self.MEAN = torch.as_tensor([0.485, 0.456, 0.406], device=self.device)[:, None, None]
         self.STDV = torch.as_tensor([0.229, 0.224, 0.225], device=self.device)[:, None, None]
+        from .motion_filter import _weights_guard
+        self._one = GraphedCall(self._features_one, name="fnet (filler)", guard=_weights_guard(self.fnet))
+
+    def _features_one(self, image_dev):
+        """one frame [3,H,W] on the device -> [1,128,h,w]"""
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
+            x = image_dev.flip(0)[None, None].float() / 255.0
+            return self.fnet((x - self.MEAN) / self.STDV).squeeze(0)
 
     def _features(self, images):
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
-            x = images[None, :, [2, 1, 0]].to(self.device).float() / 255.0
-            return self.fnet((x - self.MEAN) / self.STDV).squeeze(0)
+        """feature maps of a chunk of frames [M,3,H,W].  On the GPU frame by frame through ONE captured graph: the encoder is
+        instance-normalised (per image), so the result is the batched call's, MIOpen has no tuned kernel for the 16-image
+        shapes (the batched call fell to its naive convolution: 3.1 ms per layer, bench.py `sequence`), and the one-image
+        graph is the launch the motion filter's shapes already warmed."""
+        if self.device.type != "cuda":
+            with torch.autocast("cuda", dtype=torch.float16, enabled=False):
+                x = images[None, :, [2, 1, 0]].to(self.device).float() / 255.0
+                return self.fnet((x - self.MEAN) / self.STDV).squeeze(0)
+        if not images.is_floating_point() and images.dtype != torch.uint8:
+            images = images.to(torch.uint8)                  # 0..255: a quarter of the bytes over PCIe
+        dev = images.to(self.device)
+        return torch.cat([self._one(dev[k]).clone() for k in range(dev.shape[0])], 0)
 
     def _fill(self, tstamps, images, intrinsics):
         v = self.video

@@ -229,11 +229,31 @@ static void blockReduce(volatile float *sdata) {
 """
 
 
-def _droid_module():
+def _patched(text, old, new):
+    """one token of the extracted text replaced at generation time; the substitution must hit exactly once"""
+    assert text.count(old) == 1, (old, text.count(old))
+    return text.replace(old, new)
+
+
+def _droid_module(tag="plain", cflags=("-ffp-contract=off",), retr=None):
+    """retr: None (the retraction kernels are left out), "xi45_zero" or "xi5" - pose_retr_kernel's `float xi[6]` is a local
+    array and expSE3 (:154) reads xi[45], out of bounds.  Two defined readings are generated, each with ONE token of the text
+    replaced at generation time: "xi45_zero" pads the local array to 46 zero-initialised floats (`float xi[6]` ->
+    `float xi[46] = {}`: the read returns 0), "xi5" replaces `xi[45]` by `xi[5]` (upstream DROID-SLAM's statement)."""
     path = os.path.join(SRC, "droid_kernels.cu")
+    helpers = _lines(path, 58, 176)      # actSO3 ... expSE3 (the SE3 helpers)
+    retr_text = ""
+    if retr is not None:
+        retr_text = _lines(path, 856, 925)          # retrSE3, pose_retr_kernel, disp_retr_kernel
+        if retr == "xi45_zero":
+            retr_text = _patched(retr_text, "float xi[6],", "float xi[46] = {},")
+        elif retr == "xi5":
+            helpers = _patched(helpers, "xi[45]", "xi[5]")
+        else:
+            raise ValueError(retr)
     text = "\n".join([
         _lines(path, 26, 29),       # MIN_DEPTH, THREADS, NUM_BLOCKS
-        _lines(path, 58, 176),      # actSO3 ... expSE3 (the SE3 helpers)
+        helpers,
         _lines(path, 177, 403),     # projective_transform_kernel
         _lines(path, 406, 495),     # projmap_kernel
         _lines(path, 497, 636),     # frame_distance_kernel
@@ -241,7 +261,24 @@ def _droid_module():
         _lines(path, 758, 829),     # iproj_kernel
         _lines(path, 833, 853),     # accum_kernel
         _lines(path, 980, 1094),    # EEt6x6_kernel, Ev6x1_kernel, EvT6x1_kernel
+        retr_text,
     ])
+    retr_wrappers = r"""
+// pose_retr_kernel<<<1, THREADS>>>(poses, dx, t0, t1) and disp_retr_kernel<<<kx.size(0), THREADS>>>(disps, dz, kx)
+// (droid_kernels.cu:1202-1203, 1393-1394); both update in place, the wrappers return the updated copies
+torch::Tensor pose_retr(torch::Tensor poses, torch::Tensor dx, int64_t t0, int64_t t1) {
+  auto out = poses.clone();
+  shim_dim3 g;
+  shim_launch(g, THREADS, [&]() { pose_retr_kernel(A2(out, float), A2(dx, float), (int)t0, (int)t1); });
+  return out;
+}
+torch::Tensor disp_retr(torch::Tensor disps, torch::Tensor dz, torch::Tensor inds) {
+  auto out = disps.clone();
+  shim_dim3 g; g.x = inds.size(0);
+  shim_launch(g, THREADS, [&]() { disp_retr_kernel(A3(out, float), A2(dz, float), A1(inds, long)); });
+  return out;
+}
+""" if retr is not None else ""
     cpp = _COMMON + _BLOCK_SHIM + text + r"""
 #define A1(t, T) t.packed_accessor32<T,1,torch::DefaultPtrTraits>()
 #define A2(t, T) t.packed_accessor32<T,2,torch::DefaultPtrTraits>()
@@ -314,10 +351,11 @@ torch::Tensor EvT6x1(torch::Tensor E, torch::Tensor x, torch::Tensor idx) {
   shim_launch(g, THREADS, [&]() { EvT6x1_kernel(A3(E, float), A2(x, float), A1(idx, long), A2(dw, float)); });
   return dw;
 }
-"""
-    return _load("pvo_ref_droid", cpp, ["frame_distance", "projmap", "depth_filter", "iproj", "ba_assemble",
-                                        "accum", "EEt6x6", "Ev6x1", "EvT6x1"],
-                 ["-ffp-contract=off", "-pthread"])
+""" + retr_wrappers
+    return _load("pvo_ref_droid_" + tag + ("_" + retr if retr else ""), cpp,
+                 ["frame_distance", "projmap", "depth_filter", "iproj", "ba_assemble", "accum", "EEt6x6", "Ev6x1", "EvT6x1"] +
+                 (["pose_retr", "disp_retr"] if retr is not None else []),
+                 list(cflags) + ["-pthread"])
 
 
 def _accum(m, data, ix, jx):
@@ -416,8 +454,30 @@ def geom_scene(seed, P=7, ht=9, wd=13):
     return poses, disps.astype(np.float32), intr
 
 
+def retr_cases():
+    """poses and tangent updates for the retraction: the identity update, an update below expSE3's theta > 1e-4 test, one inside
+    expSO3's theta^2 < 1e-8 series branch, moderate updates, one near pi, and one whose sixth component dominates (where the
+    xi[45] read matters most)"""
+    g = np.random.default_rng(71)
+    P = 12
+    poses, _, _ = geom_scene(72, P, 4, 4)
+    poses[:, :3] += g.normal(0, 0.5, (P, 3)).astype(np.float32)
+    dx = g.normal(0, 0.15, (P, 6)).astype(np.float32)
+    dx[0] = 0.0
+    dx[1, 3:] = np.array([2e-5, -3e-5, 1e-5], np.float32)
+    dx[2, 3:] = np.array([4e-5, 5e-5, -2e-5], np.float32)            # theta^2 = 4.5e-9 < 1e-8
+    dx[3, 3:] = np.array([1.8, -2.2, 1.1], np.float32)               # |phi| = 3.05
+    dx[4, 3:] = np.array([0.001, -0.002, 0.9], np.float32)
+    dx[5, :3] = 0.0
+    return poses.astype(np.float32), dx
+
+
 def gen_geom_kernels():
-    m = _droid_module()
+    m = _droid_module("plain", ["-ffp-contract=off"])
+    mf = _droid_module("fma", ["-mfma", "-ffp-contract=fast"])      # nvcc's default -fmad=true (as for the lookup's fixture)
+    retr = {"xi45_zero": _droid_module("plain", ["-ffp-contract=off"], retr="xi45_zero"),
+            "xi5": _droid_module("plain", ["-ffp-contract=off"], retr="xi5"),
+            "xi5_fma": _droid_module("fma", ["-mfma", "-ffp-contract=fast"], retr="xi5")}
     out = {}
     for name, seed, P, ht, wd in (("a", 51, 7, 9, 13), ("b", 52, 5, 18, 16)):
         poses, disps, intr = geom_scene(seed, P, ht, wd)
@@ -430,16 +490,30 @@ def gen_geom_kernels():
         tii, tjj = torch.from_numpy(ii), torch.from_numpy(jj)
         out[name + "_poses"], out[name + "_disps"], out[name + "_intr"] = poses, disps, intr
         out[name + "_ii"], out[name + "_jj"] = ii, jj
-        for beta in (0.3, 1.0, 0.0):
-            out[name + "_frame_distance_beta%g" % beta] = m.frame_distance(tp, td, ti, tii, tjj, beta).numpy()
-        co, va = m.projmap(tp, td, ti, tii, tjj)
-        out[name + "_projmap_coords"], out[name + "_projmap_valid"] = co.numpy(), va.numpy()
-        out[name + "_iproj"] = m.iproj(tp, td, ti).numpy()
-        ix = np.arange(P, dtype=np.int64)
-        for t in (0.005, 0.05):
-            th = np.full(P, t, np.float32)
-            out[name + "_depth_filter_t%g" % t] = m.depth_filter(tp, td, ti, torch.from_numpy(ix), torch.from_numpy(th)).numpy()
+        # every output twice: as the text reads with every rounding explicit (no suffix) and with the multiply-adds contracted
+        # the way nvcc does by default ("_fma"; g++ -mfma -ffp-contract=fast chooses the contractions, not nvcc: see the header)
+        for mod, sfx in ((m, ""), (mf, "_fma")):
+            for beta in (0.3, 1.0, 0.0):
+                out[name + "_frame_distance_beta%g" % beta + sfx] = mod.frame_distance(tp, td, ti, tii, tjj, beta).numpy()
+            co, va = mod.projmap(tp, td, ti, tii, tjj)
+            out[name + "_projmap_coords" + sfx], out[name + "_projmap_valid" + sfx] = co.numpy(), va.numpy()
+            out[name + "_iproj" + sfx] = mod.iproj(tp, td, ti).numpy()
+            ix = np.arange(P, dtype=np.int64)
+            for t in (0.005, 0.05):
+                th = np.full(P, t, np.float32)
+                out[name + "_depth_filter_t%g" % t + sfx] = mod.depth_filter(tp, td, ti, torch.from_numpy(ix), torch.from_numpy(th)).numpy()
+    # the retraction (pose_retr_kernel, droid_kernels.cu:877-910) on its own inputs, in both defined readings of xi[45]
+    rp, rdx = retr_cases()
+    out["retr_poses"], out["retr_dx"] = rp, rdx
+    for tag, mod in retr.items():
+        out["retr_out_" + tag] = mod.pose_retr(torch.from_numpy(rp), torch.from_numpy(rdx), 0, len(rp)).numpy()
     np.savez_compressed(os.path.join(HERE, "geom_kernels.npz"), **out)
+    print("retraction: xi[45] = 0 against xi[5]: max |pose difference| %.3g; fma changes %d of %d values" % (
+        np.abs(out["retr_out_xi45_zero"] - out["retr_out_xi5"]).max(), int((out["retr_out_xi5"] != out["retr_out_xi5_fma"]).sum()), out["retr_out_xi5"].size))
+    print("contraction changes: projmap %d of %d values, iproj %d, depth_filter counts %d (case b)" % (
+        int((out["b_projmap_coords"] != out["b_projmap_coords_fma"]).sum()), out["b_projmap_coords"].size,
+        int((out["b_iproj"] != out["b_iproj_fma"]).sum()),
+        int((out["b_depth_filter_t0.05"] != out["b_depth_filter_t0.05_fma"]).sum())))
     print("geom_kernels.npz:", {k: v.shape for k, v in out.items() if "frame_distance_beta0.3" in k or "depth_filter_t0.05" in k},
           "fd>=1000:", int((out["b_frame_distance_beta0.3"] >= 1000).sum()),
           "filter counts:", np.unique(out["b_depth_filter_t0.05"]).tolist())
@@ -464,12 +538,22 @@ def gen_geom_kernels():
             outb[name + "_" + k] = v
         for k, v in zip(("Hs", "vs", "Eii", "Eij", "Cii", "bz"), res):
             outb[name + "_" + k] = v.numpy()
+        for k, v in zip(("Hs", "vs", "Eii", "Eij", "Cii", "bz"), mf.ba_assemble(targets, weights, tp, td, ti, torch.from_numpy(ii), torch.from_numpy(jj))):
+            outb[name + "_" + k + "_fma"] = v.numpy()
         # the whole step (t0 = 1: frame 0 fixed; edges out of frame 0 make it a depth frame outside the pose window)
         eta = torch.from_numpy(g.uniform(1e-3, 2e-2, (P, ht, wd)).astype(np.float32))   # one row per depth frame 0..P-1
         step = ref_ba_step(m, tp, td, ti, targets, weights, eta, torch.from_numpy(ii), torch.from_numpy(jj), 1, P, 1e-4, 0.1)
         outb[name + "_eta"] = eta.numpy()
         for k, v in step.items():
             outb[name + "_step_" + k] = v
+        step_f = ref_ba_step(mf, tp, td, ti, targets, weights, eta, torch.from_numpy(ii), torch.from_numpy(jj), 1, P, 1e-4, 0.1)
+        outb[name + "_step_dx_fma"], outb[name + "_step_dz_fma"] = step_f["dx"], step_f["dz"]
+        # ... and the end of the iteration (droid_kernels.cu:1393-1397): disp_retr_kernel on the depth frames kx, pose_retr_kernel
+        # on poses t0 .. t1 - 1, from the text, in both readings of xi[45]
+        tdx, tdz, tkx = torch.from_numpy(step["dx"]), torch.from_numpy(step["dz"]), torch.from_numpy(step["kx"])
+        outb[name + "_step_disps"] = retr["xi5"].disp_retr(td, tdz.contiguous(), tkx).numpy()
+        for tag in ("xi45_zero", "xi5"):
+            outb[name + "_step_poses_" + tag] = retr[tag].pose_retr(tp, tdx.contiguous(), 1, P).numpy()
     np.savez_compressed(os.path.join(HERE, "ba_assemble_kernel.npz"), **outb)
     print("ba_assemble_kernel.npz:", {k: v.shape for k, v in outb.items() if k.startswith("b_") and k[2:] in ("Hs", "vs", "Eii", "Cii")})
 

@@ -92,6 +92,41 @@ def test_oracle_geometry_kernels_against_the_kernel_text(geom, case):
         assert (geom["b_frame_distance_beta0.3"] >= 1000).sum() >= 2
 
 
+def test_oracle_geometry_against_the_contracted_kernel_text(geom):
+    """the same kernels with the multiply-adds contracted as nvcc does by default ("_fma" arrays; g++ chose the contractions):
+    the oracle states every rounding, so it equals the uncontracted run bit for bit (above) and the contracted one to a few
+    ulp; the integer outputs (validity masks, depth-filter counts) are the same in both runs of the text"""
+    for case in "ab":
+        poses, disps, intr, ii, jj = (geom[case + "_" + k] for k in ("poses", "disps", "intr", "ii", "jj"))
+        co, va = O.projmap(poses, disps, intr, ii, jj)
+        ref = geom[case + "_projmap_coords_fma"]
+        ok = np.isfinite(ref) & (np.abs(ref) < 1e6)
+        np.testing.assert_allclose(co[ok], ref[ok], rtol=3e-6, atol=3e-5)
+        assert np.array_equal(va, geom[case + "_projmap_valid_fma"])
+        np.testing.assert_allclose(O.iproj(poses, disps, intr), geom[case + "_iproj_fma"], rtol=3e-6, atol=1e-5)
+        for t in (0.005, 0.05):
+            assert np.array_equal(geom[case + "_depth_filter_t%g" % t], geom[case + "_depth_filter_t%g_fma" % t])
+        for beta in (0.3, 1.0, 0.0):
+            a, b = geom[case + "_frame_distance_beta%g" % beta], geom[case + "_frame_distance_beta%g_fma" % beta]
+            assert np.array_equal(a >= 1000, b >= 1000)
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
+    assert (geom["b_projmap_coords"] != geom["b_projmap_coords_fma"]).any()       # the two forms do differ
+
+
+def test_oracle_retraction_is_the_kernel_text_bit_for_bit(geom):
+    """pose_retr_kernel (droid_kernels.cu:877-910) run from its text in both DEFINED readings of expSE3's out-of-bounds
+    xi[45] (:154): the local `float xi[6]` padded with zeros ("xi45_zero") and upstream's xi[5] ("xi5").  Identity update,
+    the theta <= 1e-4 and theta^2 < 1e-8 branches, a rotation near pi and one about the z axis are among the rows."""
+    poses, dx = geom["retr_poses"], geom["retr_dx"]
+    for tag, z in (("xi45_zero", True), ("xi5", False)):
+        got = O.pose_retr(poses, dx, 0, len(poses), xi45_zero=z)
+        assert np.array_equal(_bits(got), _bits(geom["retr_out_" + tag])), tag
+    assert np.array_equal(geom["retr_out_xi5"][0], poses[0])                      # the identity update
+    d = np.abs(geom["retr_out_xi45_zero"] - geom["retr_out_xi5"]).max(axis=1)
+    assert d[4] > 1e-2 and d[0] == 0                                               # the read matters where xi[5] is large
+    np.testing.assert_allclose(geom["retr_out_xi5_fma"], geom["retr_out_xi5"], rtol=0, atol=2e-6)
+
+
 # ---------------------------------------------------------------------------------------------------- BA, CPU
 @pytest.mark.parametrize("case", "ab")
 def test_oracle_ba_assembly_per_pixel_rows_are_the_kernel_text(bak, case):
@@ -124,6 +159,20 @@ def test_oracle_ba_step_against_the_kernel_text_chain(bak, case):
     assert np.abs(r["dx"] - dx).max() <= tol_dx * np.abs(dx).max()
     assert np.abs(r["dz"] - dz).max() <= tol_dz * np.abs(dz).max()
     assert r["K"] == len(bak[case + "_step_kx"]) and not r["failed"]
+    # the end of the iteration from the text as well: disp_retr_kernel (:912-925) and pose_retr_kernel (:877-910, xi[5] reading)
+    kx = bak[case + "_step_kx"]
+    want_d, want_p = bak[case + "_step_disps"], bak[case + "_step_poses_xi5"]
+    assert np.abs(r["disps"] - want_d).max() <= tol_dz * max(np.abs(dz).max(), 1e-3)
+    assert np.array_equal(np.delete(r["disps"], kx, axis=0), np.delete(a["disps"], kx, axis=0))       # other frames untouched
+    assert np.abs(r["poses"] - want_p).max() <= 2 * tol_dx * max(np.abs(dx).max(), 1e-3) and np.array_equal(r["poses"][0], a["poses"][0])
+    # the retraction alone, on the text's own dx: bit for bit in both readings
+    for tag, z in (("xi45_zero", True), ("xi5", False)):
+        assert np.array_equal(_bits(O.pose_retr(a["poses"], dx, 1, P, xi45_zero=z)), _bits(bak[case + "_step_poses_" + tag])), tag
+    # contraction (nvcc's default) moves the step by fp32 rounding only
+    assert np.abs(bak[case + "_step_dx_fma"] - dx).max() <= (1e-5 if case == "a" else 2e-3) * np.abs(dx).max()
+    for k in ("Eii", "Eij", "Cii", "bz"):
+        ref, fma = bak[case + "_" + k], bak[case + "_" + k + "_fma"]
+        assert np.abs(fma - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0), k
 
 
 # ==================================================================================================== GPU (C ABI)
@@ -191,17 +240,18 @@ def test_hip_fused_pyramid_lookup_equals_the_kernel_text_per_level(cuda, corr, c
 def test_hip_geometry_kernels_against_the_kernel_text(cuda, geom, case):
     from pvo_amd import droid_backends as db
     poses, disps, intr, ii, jj = (torch.from_numpy(geom[case + "_" + k]).to(cuda) for k in ("poses", "disps", "intr", "ii", "jj"))
+    # geom.hip is compiled without multiply-add contraction (pvo_amd/build.py EXTRA_FLAGS): the kernels perform the roundings the
+    # reference's text states, so everything per pixel is bit for bit the uncontracted run of that text - the integer outputs
+    # (validity, the depth filter's counts) included, as this tier asks of integer work
     co, va = db.projmap(poses, disps, intr, ii, jj)
-    np.testing.assert_allclose(co.cpu().numpy(), geom[case + "_projmap_coords"], rtol=2e-6, atol=2e-5)   # hipcc contracts FMAs
+    assert np.array_equal(_bits(co.cpu().numpy()), _bits(geom[case + "_projmap_coords"]))
     assert np.array_equal(va.cpu().numpy(), geom[case + "_projmap_valid"])
-    np.testing.assert_allclose(db.iproj(poses, disps, intr).cpu().numpy(), geom[case + "_iproj"], rtol=2e-6, atol=1e-5)
+    assert np.array_equal(_bits(db.iproj(poses, disps, intr).cpu().numpy()), _bits(geom[case + "_iproj"]))
     P = poses.shape[0]
     for t in (0.005, 0.05):
         th = torch.full((P,), t, device=cuda)
         got = db.depth_filter(poses, disps, intr, torch.arange(P, device=cuda), th).cpu().numpy()
-        ref = geom[case + "_depth_filter_t%g" % t]
-        # a count can differ only where |1/dj - 1/d| sits within rounding of the threshold: allow 0.5 % of the pixels
-        assert (got != ref).mean() <= 0.005 and np.abs(got - ref).max() <= 1
+        assert np.array_equal(got, geom[case + "_depth_filter_t%g" % t])
     for beta in (0.3, 1.0, 0.0):
         got = db.frame_distance(poses, disps, intr, ii, jj, beta).cpu().numpy()
         ref = geom[case + "_frame_distance_beta%g" % beta]
@@ -223,6 +273,25 @@ def test_hip_ba_step_against_the_kernel_text_chain(cuda, bak, case):
     assert np.abs(dx.cpu().numpy() - rdx).max() <= tol_dx * max(np.abs(rdx).max(), 1e-3)
     assert np.abs(dz.cpu().numpy() - rdz).max() <= tol_dz * max(np.abs(rdz).max(), 1e-3)
     assert status.cpu().numpy()[0] == 0
+    # ... and the state the iteration leaves behind against pose_retr_kernel / disp_retr_kernel run from their text on the
+    # text's own dx / dz (the library retracts with xi[5], upstream's reading of droid_kernels.cu:154)
+    want_p, want_d = bak[case + "_step_poses_xi5"], bak[case + "_step_disps"]
+    assert np.abs(a["poses"].cpu().numpy() - want_p).max() <= 2 * tol_dx * max(np.abs(rdx).max(), 1e-3)
+    assert np.abs(a["disps"].cpu().numpy() - want_d).max() <= tol_dz * max(np.abs(rdz).max(), 1e-3)
+    assert torch.equal(a["poses"][0].cpu(), torch.from_numpy(bak[case + "_poses"][0]))
+
+
+@pytest.mark.gpu
+def test_hip_retraction_against_the_kernel_text(cuda, geom):
+    """the SE3 retraction the product uses elsewhere (pvo_amd.geom.se3, HIP kernels of se3_ops.hip: lietorch's formulas) against
+    pose_retr_kernel run from its text with xi[5]: the two exponentials are different closed forms of the same map"""
+    from pvo_amd.geom.se3 import SE3
+    poses, dx = torch.from_numpy(geom["retr_poses"]).to(cuda), torch.from_numpy(geom["retr_dx"]).to(cuda)
+    got = SE3(poses).retr(dx).data.cpu().numpy()
+    want = geom["retr_out_xi5"]
+    sign = np.sign((got[:, 3:] * want[:, 3:]).sum(1, keepdims=True))               # q and -q are the same rotation
+    np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(got[:, 3:] * sign, want[:, 3:], rtol=0, atol=2e-6)
 
 
 @pytest.mark.gpu

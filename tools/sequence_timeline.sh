@@ -1,0 +1,52 @@
+# usage (on the GPU box): bash tools/sequence_timeline.sh <tag> [frames]   -> gpurun_out/sequence_timeline_<tag>.txt
+# rocprofv3 --kernel-trace of the full-sequence leg (bench.py --sequence-only --sequence-plain: warm-up / calibration pass, then the
+# plain pass).  The summary is about the LAST pass (passes are separated by the longest idle stretches of the trace: a new Droid is
+# built in between): how busy the device is while frames are tracked, which kernels the time goes to, and how many dispatches a
+# frame costs - i.e. what the per-frame loop of evaluation_scripts/test_vo.py:99-108 pays beside the graph updates.
+TAG=${1:-r05}
+FRAMES=${2:-120}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/sequence_timeline_$TAG.txt
+cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/st
+rocprofv3 --kernel-trace -f csv -d /tmp/st -- python $GRAFT_REPO_ROOT/bench.py --sequence-only --sequence-plain --sequence-frames $FRAMES > /tmp/st_bench.log 2>&1
+python - > $OUT <<PY
+import csv, glob, json, collections
+rows = list(csv.DictReader(open(glob.glob("/tmp/st/*/*kernel_trace.csv")[0])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+S = [int(r["Start_Timestamp"]) for r in rows]; E = [int(r["End_Timestamp"]) for r in rows]
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:64]
+# the two longest idle stretches separate [warm-up pass | plain pass: tracking | ...]; take everything behind the longest gap that
+# lies in the first two thirds of the trace (the plain pass is the longer one)
+run, g_all = 0, []
+for i in range(len(rows) - 1):
+    run = max(run, E[i])
+    g_all.append((S[i + 1] - run, i))
+gaps = sorted(g_all, reverse=True)[:6]
+print("trace: %d dispatches over %.2f s; longest idle stretches (ms at dispatch index): %s" %
+      (len(rows), (E[-1] - S[0]) / 1e9, ", ".join("%.0f@%d" % (g / 1e6, i) for g, i in gaps)))
+cut = max((i for g, i in gaps[:3] if i < 0.66 * len(rows)), default=0)
+seg = rows[cut + 1:]
+t0, t1 = int(seg[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in seg)
+# union of busy intervals
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg)
+busy, cs, ce = 0, iv[0][0], iv[0][1]
+for s, e in iv[1:]:
+    if s > ce: busy += ce - cs; cs, ce = s, e
+    else: ce = max(ce, e)
+busy += ce - cs
+print("last pass: %d dispatches, %.3f s from first to last kernel, device busy (union of kernel intervals) %.3f s = %.1f %%" %
+      (len(seg), (t1 - t0) / 1e9, busy / 1e9, 100.0 * busy / (t1 - t0)))
+agg = collections.OrderedDict()
+for r in seg:
+    a = agg.setdefault(short(r["Kernel_Name"]), [0, 0])
+    a[0] += 1; a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+tot = sum(v[1] for v in agg.values())
+print("kernel time by name (sum of durations %.3f s):" % (tot / 1e9))
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print("  %-64s x%-6d %9.2f ms  %5.1f %%  avg %7.1f us" % (n, c, t / 1e6, 100.0 * t / tot, t / 1e3 / c))
+own = sum(t for n, (c, t) in agg.items() if not (n.startswith("at::") or "rocclr" in n or n.startswith("miopen") or "Cijk" in n or n.startswith("ck::") or "MIOpen" in n or "igemm" in n or "naive" in n))
+print("share of kernel time in libpvo_hip kernels: %.1f %%; PyTorch / MIOpen / blit kernels: %.1f %%" % (100.0 * own / tot, 100.0 * (tot - own) / tot))
+PY
+tail -c 3000 /tmp/st_bench.log >> $OUT
