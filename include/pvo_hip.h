@@ -72,9 +72,23 @@ const char* pvo_last_hip_error(void);
  * passed by pointer and have GROWN between versions (100 -> 101: pvo_graph_update_args.context_ahead / context_ready; 101 -> 102: no struct changed - new entry points
  * pvo_ba_pack / pvo_ba_finish_packed / pvo_ba_last_partition / pvo_proj_transform[_vjp], and pvo_ba_workspace_bytes returns more): a caller
  * checks pvo_version() == PVO_ABI_VERSION, or pvo_graph_update_args_size() == sizeof(pvo_graph_update_args), once after loading. */
-#define PVO_ABI_VERSION 102
+#define PVO_ABI_VERSION 103
 int pvo_version(void);
 size_t pvo_graph_update_args_size(void);
+
+/* Test hook (102 -> 103).  Until round 5 eleven environment variables read inside the library selected experiment variants; a
+ * process environment is invisible at a call site and two ranks could differ in it.  The experiments are gone from the source and
+ * the THREE selections the test-suite needs - it compares bit-identical forms of the same computation - are set by this one call,
+ * process-wide, not thread-safe against running calls.  A product caller never needs it: every knob defaults to 0 = "the shipped
+ * choice".  Returns PVO_EINVAL for an unknown knob.  (Reference counterpart: none - droid.cpp has no such switches.) */
+enum {
+  PVO_KNOB_BA_SOLVER = 0,         /* 0 shipped choice by size | 1 blocked | 2 one wave | 3 pipelined | 4 partitioned (two workgroups) */
+  PVO_KNOB_HEADS_GATHER_FLAT = 1, /* 1: pvo_heads_gather without its LDS-tiled form */
+  PVO_KNOB_NO_RIDERS = 2,         /* 1: pvo_graph_update computes the upsampling mask and the next gate context as launches of their own */
+  PVO_KNOB_COUNT = 3
+};
+int pvo_debug_config(int knob, int value);
+int pvo_knob(int knob); /* current value (0 for an unknown knob) */
 
 /* ------------------------------------------------------------------------- */
 /* Correlation lookup                                                         */

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpvo_hip.so")
 
 PVO_F32, PVO_F16, PVO_BF16, PVO_F64 = 0, 1, 2, 3
-PVO_ABI_VERSION = 102          # include/pvo_hip.h
+PVO_ABI_VERSION = 103          # include/pvo_hip.h
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
@@ -21,6 +21,8 @@ SIGNATURES = {
     "pvo_version": (_i, []),
     "pvo_graph_update_args_size": (_sz, []),
     "pvo_last_hip_error": (_c.c_char_p, []),
+    "pvo_debug_config": (_i, [_i, _i]),
+    "pvo_knob": (_i, [_i]),
     "pvo_corr_index_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_index_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_corr_pyramid_lookup": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -120,6 +122,7 @@ class GraphUpdateArgs(_c.Structure):
 
 
 PVO_OP_CONV128_WIDE, PVO_OP_SINGLE_STREAM, PVO_OP_ENC_SIDE_STREAM = 1, 2, 4
+PVO_KNOB_BA_SOLVER, PVO_KNOB_HEADS_GATHER_FLAT, PVO_KNOB_NO_RIDERS = 0, 1, 2
 
 _lib = None
 

@@ -607,6 +607,55 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
     }
 }
 
+// Row tile ti against the CNT row tiles tj0 .. tj0 + CNT - 1 (tj0 >= ti) in one pass over the pixels: what a depth frame with more
+// than kFastTiles row tiles (> 9 free neighbours: a frontend window with its inactive edges, found by the full-sequence run of
+// bench.py - the replayed S-B / S-A windows have no inactive edges and never came here) used to do one tile PAIR at a time, two
+// workgroup barriers per pair: 15 to 36 rounds, 118 us per launch.  Per pair the SAME chain of MFMAs in the same order and the
+// same (w0 + w1) + (w2 + w3) reduction as every other path: bit-identical sums.
+template <int CNT, bool VEC4, int PIX>
+__device__ __forceinline__ void schur_rowpass(gfloat* const* rowptr, const int* rowout, gfloat* __restrict__ qrow, float* red,
+                                              long long* __restrict__ sys, int HW, int n6, int pix_base, int* meta, int ti, int tj0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int idx = lane & 15, kq = lane >> 4;
+  gfloat* __restrict__ ra = rowptr[ti * 16 + idx];
+  gfloat* rb[CNT];
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) rb[t] = rowptr[(tj0 + t) * 16 + idx];
+  f32x4 acc[CNT];
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int s = 0; s < PIX / 64; ++s) {
+    const int p = pix_base + s * 16 + 4 * kq;
+    const f32x4 q = load4<VEC4>(qrow, p, HW);
+    const f32x4 a0 = load4<VEC4>(ra, p, HW);
+    const f32x4 a = a0 * q;
+    f32x4 b[CNT];
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) b[t] = load4<VEC4>(rb[t], p, HW);
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    float* r = red + (static_cast<size_t>(wave) * CNT + t) * 256;
+    r[lane] = acc[t].x; r[64 + lane] = acc[t].y; r[128 + lane] = acc[t].z; r[192 + lane] = acc[t].w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    const float* r0 = red + static_cast<size_t>(t) * 256 + tid;
+    const float v = (r0[0] + r0[static_cast<size_t>(CNT) * 256]) + (r0[static_cast<size_t>(2 * CNT) * 256] + r0[static_cast<size_t>(3 * CNT) * 256]);
+    scatter_tile(v, tid >> 6, tid & 63, ti, tj0 + t, rowout, sys, n6, meta);
+  }
+  __syncthreads();                        // `red` is rewritten by the next pass
+}
+
 template <bool VEC4, int PIX>
 __device__ __forceinline__ void ba_schur_body(
     const Plan& pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
@@ -716,30 +765,21 @@ __device__ __forceinline__ void ba_schur_body(
     case 4: schur_pass<4, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
     default: break;
   }
-  // any degree: one tile pair at a time, row tiles re-read from L2
-  const int idx = lane & 15, kq = lane >> 4;
+  // any degree: one ROW TILE against up to eight others per pass (row tiles re-read from L2 once per pass)
+  constexpr int kPassTiles = 8;           // 8 x 4 x 256 floats of `red` = 32 KB
   for (int ti = 0; ti < T; ++ti) {
-    gfloat* __restrict__ ra = rowptr[ti * 16 + idx];
-    for (int tj = ti; tj < T; ++tj) {
-      gfloat* __restrict__ rb = rowptr[tj * 16 + idx];
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int s = 0; s < PIX / 64; ++s) {
-        const int p = pix_base + s * 16 + 4 * kq;
-        const f32x4 a = load4<VEC4>(ra, p, HW);
-        const f32x4 b = (ti == tj) ? a : load4<VEC4>(rb, p, HW);
-        const f32x4 q = load4<VEC4>(qrow, p, HW);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x * q.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y * q.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z * q.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w * q.w, b.w, acc, 0, 0, 0);
+    for (int tj0 = ti; tj0 < T; tj0 += kPassTiles) {
+      const int cnt = (T - tj0 < kPassTiles) ? T - tj0 : kPassTiles;
+      switch (cnt) {
+        case 1: schur_rowpass<1, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 2: schur_rowpass<2, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 3: schur_rowpass<3, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 4: schur_rowpass<4, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 5: schur_rowpass<5, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 6: schur_rowpass<6, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 7: schur_rowpass<7, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        default: schur_rowpass<8, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
       }
-      float* r = red + static_cast<size_t>(wave) * 256;
-      r[lane] = acc.x; r[64 + lane] = acc.y; r[128 + lane] = acc.z; r[192 + lane] = acc.w;
-      __syncthreads();
-      const float v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-      scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6, pl.meta);
-      __syncthreads();
     }
   }
 }
@@ -2425,8 +2465,7 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
   motion_only &= 1;
   if (!clean && !only_schur && hipMemsetAsync(sys, 0, sizeof(long long) * (n6 * n6 + n6), st) != hipSuccess) return PVO_ELAUNCH;
   if (E == 0) return PVO_OK;
-  static const bool direct = [] { const char* e = getenv("PVO_BA_POSE_ATOMICS"); return e && e[0] == 'd'; }();      // (A/B: "direct")
-  const bool two_stage = !motion_only && !direct;      // the chunk sums go through the Schur kernel (there is none in a motion-only BA)
+  const bool two_stage = !motion_only;      // the chunk sums go through the Schur kernel (there is none in a motion-only BA)
   const int chunksA = (HW + kChunkA - 1) / kChunkA;
   if (!only_schur)
   hipLaunchKernelGGL(ba_assemble_kernel, dim3((HW + kChunkA - 1) / kChunkA, E), dim3(256), 0, st,
@@ -2598,11 +2637,11 @@ static int ba_finish_impl(float* poses, float* disps, void* sys_, const long lon
   // chol_solve_wave: one wave, none; chol_solve_pipe: wave 0 on the critical chain, three worker waves behind it).  Measured
   // with tools/ba_solve_timeline.py, cycles of the whole kernel: 7 free poses 44.8 k blocked / 48.0 k wave / 52.1 k pipe,
   // 12: 87.5 k blocked / 86.0 k pipe, 21: 168 k / 157 k, 63: 578 k blocked / 485 k wave / 364 k pipe - the pipeline wins once the
-  // envelope makes most of a step's candidate rows inactive.  PVO_BA_SOLVER = blocked | wave | pipe overrides (tests compare
+  // envelope makes most of a step's candidate rows inactive.  pvo_debug_config(PVO_KNOB_BA_SOLVER, ..) overrides (tests compare
   // the three bit for bit).
   // Beyond the dense LDS path a fourth form, the PARTITIONED solve (ba_solve_twin_kernel: two workgroups eliminate the pose
   // chain from both ends, tools/ba_solve_timeline.py), is the default; its result equals the others' to fp64 rounding.
-  static const int solver_env = [] { const char* e = getenv("PVO_BA_SOLVER"); return !e ? -1 : (e[0] == 'b' ? 0 : (e[0] == 'w' ? 1 : (e[0] == 'p' ? 2 : (e[0] == 't' ? 3 : -1)))); }();
+  const int solver_env = pvo_knob(PVO_KNOB_BA_SOLVER) - 1;      // (pvo_debug_config: -1 = the choice by size below)
   const int solver_pick = solver_env >= 0 ? solver_env : (use_lds ? (P > 12 ? 2 : 0) : 3);      // 0 blocked | 1 wave | 2 pipe | 3 partitioned
   const bool twin = solver_pick == 3 && !use_lds;
   const int solver_wave = solver_pick == 3 ? 2 : solver_pick;

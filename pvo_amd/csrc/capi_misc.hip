@@ -16,7 +16,16 @@ extern "C" const char* pvo_strerror(int code) {
 // 101: pvo_graph_update_args grew by context_ahead / context_ready (round 3) - a caller built against a 100 header passes a
 // shorter struct; pvo_graph_update_args_size() lets any caller compare its sizeof with the library's before the first call
 // 102: pvo_ba_pack / pvo_ba_finish_packed / pvo_ba_last_partition added, the BA workspace grew (round 4)
+// 103: pvo_debug_config / pvo_knob replace the library's environment switches (round 5)
 extern "C" int pvo_version(void) { return PVO_ABI_VERSION; }
+
+static int g_knobs[PVO_KNOB_COUNT] = {0, 0, 0};
+extern "C" int pvo_debug_config(int knob, int value) {
+  if (knob < 0 || knob >= PVO_KNOB_COUNT) return PVO_EINVAL;
+  g_knobs[knob] = value;
+  return PVO_OK;
+}
+extern "C" int pvo_knob(int knob) { return (knob < 0 || knob >= PVO_KNOB_COUNT) ? 0 : g_knobs[knob]; }
 extern "C" size_t pvo_graph_update_args_size(void) { return sizeof(pvo_graph_update_args); }
 
 static thread_local int g_last_hip_error = 0;

@@ -361,7 +361,7 @@ extern "C" int pvo_heads_gather(const float* z, const float* bias2, void* y, int
   if (E == 0 || H == 0 || W == 0) return PVO_OK;
   if (!z || !bias2 || !y || (reinterpret_cast<uintptr_t>(z) & 7) || (reinterpret_cast<uintptr_t>(y) & 3)) return PVO_EINVAL;
   hipStream_t st = pvo_stream(stream);
-  static const bool flat = [] { const char* e = getenv("PVO_HEADS_GATHER_TILED"); return e && e[0] == '0'; }();
+  const bool flat = pvo_knob(PVO_KNOB_HEADS_GATHER_FLAT) != 0;      // (pvo_debug_config: a test compares the two forms bit for bit)
   if (!flat && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && E <= 65535) {
     const dim3 grid((W + kHgTW - 1) / kHgTW, (H + kHgTH - 1) / kHgTH, E);
     constexpr size_t lds = static_cast<size_t>(kHgPos) * kHgRow;                      // 54720 B

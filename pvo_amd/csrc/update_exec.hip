@@ -28,7 +28,7 @@ struct SideCtx { hipStream_t side; hipEvent_t fork, join, mid; bool ok; };
 // (tools/sched_bisect.py, profiles/r03_sched_bisect.txt): bit-identical results over 1500 two-update runs either way, the update
 // 1 % shorter without the fences - and cache-maintenance operations in flight beside a resident kernel of ANOTHER queue are
 // exactly what made the BA irreproducible in the overlapped arrangements.
-unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;
+constexpr unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;
 SideCtx g_side_ctx[64] = {};
 SideCtx* side_ctx() {
   SideCtx* ctx = g_side_ctx;
@@ -39,12 +39,7 @@ SideCtx* side_ctx() {
     // HIGH priority: in both places it is used the side stream carries the chain the launch stream ends up waiting for
     // (GraphAgg beside the heads: conv1 84 us instead of 105 when its workgroups are dispatched first; update 757 -> 728 us)
     int least = 0, greatest = 0;
-    if (const char* e = getenv("PVO_EVENT_SYSTEM_FENCE"))       // A/B switch for the measurement in DESIGN.md section 5
-      g_event_flags = (e[0] == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
-#ifdef PVO_SCHED_DEBUG
-    if (const char* e = getenv("PVO_SIDE_PRIO")) { if (e[0] == 'n') greatest = 0; else if (e[0] == 'l') greatest = least; }   // experiment: normal / low priority
-#endif
     if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.fork, g_event_flags) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&c.join, g_event_flags) != hipSuccess) return nullptr;
@@ -134,13 +129,10 @@ void* ws_base(void* workspace) {
   return reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
 }
 
-// tools/sched_bisect.py builds this file with -DPVO_SCHED_DEBUG: alternative stream arrangements of the BA inside
-// pvo_graph_update (round 2 found two of them irreproducible in the last bits of the poses) and a tap that copies the
-// BA's intermediate buffers after every stage, so that the first buffer that differs between two runs can be named.
-#ifdef PVO_SCHED_DEBUG
-struct SchedDebug { int mode; char* tap; size_t tap_bytes; size_t slot; int n; int no_marker; };
-SchedDebug g_sched = {0, nullptr, 0, 0, 0, 0};
-#endif
+// (Rounds 2-4 kept alternative stream arrangements of the BA, a buffer tap and three trunk orders in this file behind
+// PVO_SCHED_DEBUG / environment switches - the experiments of DESIGN.md section 5 and profiles/r04_*.  They were measured, none
+// shipped, and round 5 removed them from the product source: `git show f406a59:pvo_amd/csrc/update_exec.hip` is the tree
+// tools/sched_bisect.py and those profiles refer to.)
 
 #define RUN(call)                    \
   do {                               \
@@ -167,19 +159,7 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   // the side stream that chain ended ~55 us after corr_encoder[2]; a third stream for it changed nothing.
   void* s2 = sc ? static_cast<void*>(sc->side) : stream;
   void* s3 = stream;
-  // PVO_TRUNK_ORDER=1 (round-4 experiment; default off): the 7x7 convolution FIRST and alone on the launch stream
-  // (19 us; beside the lookup it takes 49), the fork behind it: the side stream then runs only flow_encoder[2] beside the lookup.
-  // Measured A/B on one box: 229.6 / 230.2 against 232.8 / 233.3 keyframe updates/s - flow_encoder[2] beside the lookup takes 81 us
-  // (53 beside corr_encoder[2]) and the lookup 55-66 (profiles/r04_update_timeline_7x7_first.txt): whatever is paired with the lookup
-  // pays for the memory system it saturates
-  // PVO_TRUNK_ORDER=2 (experiment, default off): the fork BEHIND the lookup - the lookup alone, then the 7x7 (write-bound) beside
-  // corr_encoder[2] (matrix-bound), flow_encoder[2] last.  229.2 / 229.2 against 236.7 / 235.5 on one box: the 7x7 takes 41 us beside
-  // corr_encoder[2] too, and the gate convolution starts at 164 us (profiles/r04_update_timeline_fork_behind_lookup.txt)
-  static const int trunk_order = [] { const char* e = getenv("PVO_TRUNK_ORDER"); return e ? atoi(e) : 0; }();
-  const bool early7 = trunk_order == 1 && sc && !mj;
-  const bool late_fork = trunk_order == 2 && sc && !mj && a->levels[0];
-  if (early7) RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, stream));
-  if (sc && !late_fork) {
+  if (sc) {
     if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
   }
@@ -189,46 +169,25 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
     probe_mark(PVO_STAGE_LOOKUP, 0, stream);
     RUN(pvo_corr_lookup_encode_tiled(a->levels, a->coords, w->enc0_w, w->enc0_b, b.c1, E, H, W, dt, a->slots, a->num_slots, stream));
     probe_mark(PVO_STAGE_LOOKUP, 1, stream);
-    if (late_fork) {
-      if (hipEventRecord(sc->fork, st) != hipSuccess) return PVO_ELAUNCH;
-      if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
-    }
   } else {
     if (!a->corr) return PVO_EINVAL;
     RUN(pvo_corr_encode(a->corr, w->enc0_w, w->enc0_b, b.c1, rows, dt, stream));
   }
   if (mj) RUN(pvo_graph_motion(mj->target, mj->coords, mj->delta_dy, mj->raw_mask, mj->motion, E, H, W, dt, s2));
-  // The flow encoder as two kernels.  pvo_flow_encoder (one kernel, the 128-channel intermediate in LDS; PVO_FLOW_ENCODER_FUSED=1)
-  // is bit-identical and shorter alone, but this stretch of the update is throughput-bound: beside it corr_encoder[2] on the
-  // launch stream takes 74 instead of 41 us (its redundant 7x7 halo work occupies the matrix cores) and the gate convolution
-  // starts 8 us LATER (226.9 -> 225.2 keyframe updates/s).
-  static const bool fe_two = [] { const char* e = getenv("PVO_FLOW_ENCODER_FUSED"); return !(e && e[0] == '1'); }();
-  // Round 4 experiment, kept behind a switch: the two chains in front of the gates are unequal (timeline r03n: launch stream
-  // done at 99 us, side stream at 120, then a wait that has to be WOKEN), so PVO_TRUNK_SPLIT=<percent> moves the last edges of
-  // flow_encoder[2] onto the launch stream behind corr_encoder[2] (one more event: the 7x7 output of all edges).  Measured at
-  // 0 / 20 / 33 / 45 %: 193.8 / 193.7 / 192.7 / 192.8 keyframe updates/s on one (slow) box - no gain, the stretch is bound by the
-  // sum of the work, not by the longer chain.  Default 0 = the round-3 arrangement.
-  static const int split_pct = [] { const char* e = getenv("PVO_TRUNK_SPLIT"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
-  const int E_main = (sc && fe_two) ? (E * split_pct) / 100 : 0, E_side = E - E_main;
-  const size_t px = static_cast<size_t>(H) * W;
-  if (fe_two) {
-    if (!early7) RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
-    if (E_main > 0 && hipEventRecord(sc->mid, sc->side) != hipSuccess) return PVO_ELAUNCH;       // (`mid` is free here: run_agg records it later)
-    if (E_side > 0) RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E_side, H, W, 64, 1, 192, 128, dt, s2));
-  } else {
-    RUN(pvo_flow_encoder(a->motion, w->fenc0_w, w->fenc0_b, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 192, 128, dt, s2));
-  }
+  // The flow encoder as two kernels.  pvo_flow_encoder (one kernel, the 128-channel intermediate in LDS) is bit-identical and
+  // shorter alone, but this stretch of the update is throughput-bound: beside it corr_encoder[2] on the launch stream takes 74
+  // instead of 41 us (its redundant 7x7 halo work occupies the matrix cores) and the gate convolution starts 8 us LATER
+  // (226.9 -> 225.2 keyframe updates/s, round 3).  Also measured and not shipped (round 4, profiles/r04_update_timeline_*): part
+  // of flow_encoder[2]'s edges on the launch stream (no gain at 20 / 33 / 45 %), the 7x7 first and alone on the launch stream,
+  // the fork behind the lookup (both slower: whatever runs beside the lookup pays for the memory request rate it saturates).
+  RUN(pvo_conv7x7_c8(a->motion, w->fenc0_w, w->fenc0_b, b.f1, E, H, W, dt, s2));
+  RUN(pvo_conv3x3_c128(b.f1, w->fenc2_w, w->fenc2_b, b.CF, E, H, W, 64, 1, 192, 128, dt, s2));
   if (sc && hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
   // the encoders' second layers write relu(features + bias) side by side: CF = [corr features (128) | flow features (64)]
   if (w->flags & PVO_OP_CONV128_WIDE)
     RUN(pvo_conv3x3(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 128, 1, 192, 0, dt, stream));
   else
     RUN(pvo_conv3x3_c128(b.c1, w->cenc2_w, w->cenc2_b, b.CF, E, H, W, 128, 1, 192, 0, dt, stream));
-  if (E_main > 0) {
-    if (hipStreamWaitEvent(st, sc->mid, 0) != hipSuccess) return PVO_ELAUNCH;
-    RUN(pvo_conv3x3_c128(b.f1 + static_cast<size_t>(E_side) * px * 128 * 2, w->fenc2_w, w->fenc2_b,
-                         b.CF + static_cast<size_t>(E_side) * px * 192 * 2, E_main, H, W, 64, 1, 192, 128, dt, stream));
-  }
   if (!context_ready) {           // (else b.g already holds it: computed inside the previous update's pose solves)
     RUN(pvo_gru_glo_fused(a->net, w->glo_w, w->glo_b, b.part, E, H * W, dt, s3));
     RUN(pvo_gate_context(b.part, w->gate_wt, w->gate_b, b.g, E, pvo_gru_glo_chunks(H * W), s3));
@@ -384,7 +343,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   a.eta = u->op.eta ? u->op.eta : s.eta;          // (a caller that runs the BA itself - edge sharding - supplies the buffer)
   if (u->want_upmask && !a.upmask) a.upmask = s.upmask;
   // the gate context may already be in the workspace: computed ahead by the previous call, for exactly this input
-  static const bool ahead_off = [] { const char* e = getenv("PVO_CONTEXT_AHEAD"); return e && e[0] == '0'; }();
+  const bool ahead_off = pvo_knob(PVO_KNOB_NO_RIDERS) != 0;      // (pvo_debug_config: tests compare with and without the riders)
   ContextAhead* ca = ctx_ahead_slot();
   const bool ctx_ready = ca && ca->valid && u->context_ready && !ahead_off && ca->ws == workspace && ca->weights == w &&
                          ca->glo_w == w->glo_w && ca->gate_wt == w->gate_wt && ca->net == a.net && ca->E == E && ca->H == H &&
@@ -399,23 +358,15 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
                      u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW, u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW,
                      u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
                      S, u->vote_thresh, dt, stream));
-  static const bool rider_off = [] { const char* e = getenv("PVO_UPMASK_RIDER"); return e && e[0] == '0'; }();
+  const bool rider_off = pvo_knob(PVO_KNOB_NO_RIDERS) != 0;
   // (the rider has preconditions the stand-alone convolution does not: at most 2^24 rows and 16-byte aligned operands,
   // pvo_ba_finish_riders - beyond them the mask is computed the old way, on this stream, instead of failing the update)
   const bool rider_fits = static_cast<long long>(K) * HW <= (1LL << 24) &&
                           !((reinterpret_cast<uintptr_t>(b.a2) | reinterpret_cast<uintptr_t>(w->up_w) | reinterpret_cast<uintptr_t>(a.upmask)) & 15);
-  const bool mask_rides = u->itrs > 0 && a.K > 0 && a.upmask && !rider_off && rider_fits
-#ifdef PVO_SCHED_DEBUG
-                          && g_sched.mode == 0
-#endif
-      ;
+  const bool mask_rides = u->itrs > 0 && a.K > 0 && a.upmask && !rider_off && rider_fits;
   // ... and so does the gate context of the NEXT update (a function of this update's net_out and the weights): its partial
   // means in the first solve, the 1x1 context convolutions in the second
-  const bool context_ahead = u->context_ahead && u->itrs >= 2 && !u->motion_only && !ahead_off
-#ifdef PVO_SCHED_DEBUG
-                             && g_sched.mode == 0
-#endif
-      ;
+  const bool context_ahead = u->context_ahead && u->itrs >= 2 && !u->motion_only && !ahead_off;
   // The upsampling mask - which nothing here reads - rides in the dispatch of the first pose solve (one workgroup solves, the
   // mask convolution's workgroups fill the idle chip: pvo_ba_finish_conv1x1), unless there is no solve to ride.  Before round 3
   // (and still without a BA iteration): The aggregation branch ends at the eta head on the side stream (`mid`); the mask
@@ -429,43 +380,8 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // hardware queue's kernel while cache write-back / invalidate operations are in flight read stale 64-byte sectors or lose
   // 8-byte atomics on this platform; alone on the device 0 of 3000 runs differ.  DESIGN 7g, profiles/r03_sched_bisect.txt,
   // tests/...::test_native_updates_are_reproducible.)
-#ifdef PVO_SCHED_DEBUG
-  // mode 1: the mask convolution on the side stream behind the eta head, the BA beside it;  mode 2: additionally the first
-  // assembly launched BEFORE the wait on `mid` (arranged below);  mode 3: as shipped but the mask convolution after the BA
-  // round 4: mode 4 = mode 1 with a FILL of the mask buffer (a blit kernel, none of ours) in place of the mask convolution;
-  // mode 5 = mode 1 + an empty kernel on the launch stream between the wait and the first BA kernel;  mode 6 = mode 1 with the
-  // BA waiting for the side stream's mask convolution as well (nothing of another queue resident beside the BA: control)
-  if (g_sched.mode == 1 || g_sched.mode == 2 || (g_sched.mode >= 4 && g_sched.mode <= 9)) {
-    if (pending) {
-      // mode 7: another MFMA + LDS kernel of ours (the 3x3 convolution of the aggregation branch, over the K frames) instead of the
-      // mask convolution;  mode 8: three plain streaming passes (no LDS, no matrix cores) over the mask buffer;  mode 9: the mask
-      // convolution over 64 rows only (one workgroup per channel block)
-      if (g_sched.mode == 4) {
-        if (a.upmask && hipMemsetAsync(a.upmask, 0, static_cast<size_t>(K) * HW * 576 * 2, pending->side) != hipSuccess) return PVO_ELAUNCH;
-      } else if (g_sched.mode == 7) {
-        RUN(pvo_conv3x3_c128(b.am, w->agg2_w, w->agg2_b, a.upmask, K, H, W, 128, 1, 0, 0, dt, pending->side));
-      } else if (g_sched.mode == 8) {
-        const long long nf = static_cast<long long>(K) * HW * 288;
-        for (int rep = 0; rep < 3; ++rep) {
-          hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((nf + 255) / 256)), dim3(256), 0, pending->side, reinterpret_cast<float*>(a.upmask), nf, -3.0e38f);
-          PVO_CHECK_LAUNCH();
-        }
-      } else if (g_sched.mode == 9) {
-        RUN(pvo_conv1x1_c128(b.a2, w->up_w, w->up_b, a.upmask, 64, 576, 0, w->dtype, pending->side));
-      } else RUN(run_upmask(w, &a, b, pending->side));
-      if (!g_sched.no_marker && hipEventRecord(pending->join, pending->side) != hipSuccess) return PVO_ELAUNCH;
-    } else RUN(run_upmask(w, &a, b, stream));
-    if (g_sched.mode != 2 && pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
-    if (g_sched.mode == 6 && pending && hipStreamWaitEvent(st, pending->join, 0) != hipSuccess) return PVO_ELAUNCH;
-    if (g_sched.mode == 5) { hipLaunchKernelGGL(clamp_min_kernel, dim3(1), dim3(64), 0, st, u->disps, 0LL, 0.0f); PVO_CHECK_LAUNCH(); }
-  } else if (g_sched.mode == 3) {
-    if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
-  } else
-#endif
-  {
   if (pending && hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
   if (!mask_rides) RUN(run_upmask(w, &a, b, stream));
-  }
   // :302 dense bundle adjustment on [inactive | active] edges, planned by the caller (pvo_ba_plan) for this edge set
   const int Eb = u->n_in + E;
   probe_mark(PVO_STAGE_BA, 0, stream);
@@ -473,31 +389,8 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // depth clamp of depth_video.py:214 rides on the last back-substitution.
   for (int it = 0; it < u->itrs; ++it) {
     const bool last = it + 1 == u->itrs;
-#ifdef PVO_SCHED_DEBUG
-    if (g_sched.mode == 2 && it == 0 && pending) {
-      // assembly (does not read the damping) before the wait, Schur behind it
-      RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
-                       H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | 2 | 4, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
-      if (hipStreamWaitEvent(st, pending->mid, 0) != hipSuccess) return PVO_ELAUNCH;
-      RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
-                       H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | 2 | 8, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
-    } else
-#endif
     RUN(pvo_ba_local(u->poses, u->disps, u->intrinsics, u->target_ba, u->weight_ba, a.eta, u->ii_ba, u->jj_ba, Eb, u->nframes,
                      H, W, R, u->t0, u->t1, (u->motion_only ? 1 : 0) | 2, u->sys, u->ba_ws, u->ba_ws_bytes, stream));
-#ifdef PVO_SCHED_DEBUG
-    auto tap = [&]() -> int {
-      if (!g_sched.tap) return PVO_OK;
-      const size_t n6 = static_cast<size_t>(6) * (u->t1 - u->t0), sb = 8 * (n6 * n6 + n6);
-      if ((g_sched.n + 1) * g_sched.slot > g_sched.tap_bytes || sb + u->ba_ws_bytes > g_sched.slot) return PVO_OK;
-      char* dst = g_sched.tap + g_sched.n * g_sched.slot;
-      if (hipMemcpyAsync(dst, u->sys, sb, hipMemcpyDeviceToDevice, st) != hipSuccess) return PVO_ELAUNCH;
-      if (hipMemcpyAsync(dst + ((sb + 255) & ~size_t(255)), u->ba_ws, u->ba_ws_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return PVO_ELAUNCH;
-      ++g_sched.n;
-      return PVO_OK;
-    };
-    RUN(tap());
-#endif
     pvo_ba_riders jobs{};
     if (mask_rides && it == 0) {
       jobs.cx = b.a2; jobs.cw = w->up_w; jobs.cbias = w->up_b; jobs.cy = a.upmask;
@@ -512,14 +405,8 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
     RUN(pvo_ba_finish_riders(u->poses, u->disps, u->sys, u->ii_ba, u->jj_ba, Eb, u->nframes, H, W, u->t0, u->t1, u->lm, u->ep,
                              u->motion_only, last && !u->motion_only ? u->clamp_frames : 0, u->disp_min,
                              nullptr, nullptr, 0, nullptr, u->ba_ws, u->ba_ws_bytes, &jobs, stream));
-#ifdef PVO_SCHED_DEBUG
-    RUN(tap());
-#endif
   }
   probe_mark(PVO_STAGE_BA, 1, stream);
-#ifdef PVO_SCHED_DEBUG
-  if (g_sched.mode == 3) RUN(run_upmask(w, &a, b, stream));
-#endif
   if (u->clamp_frames > 0 && (u->itrs == 0 || u->motion_only)) {      // (no back-substitution ran: clamp on its own)
     const long long n = static_cast<long long>(u->clamp_frames) * HW;
     hipLaunchKernelGGL(clamp_min_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, u->disps, n, u->disp_min);
@@ -528,35 +415,11 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   // No second join here: the side stream's last work is the eta head, `mid` was recorded behind it, and this stream has waited
   // for `mid` above (the branch's `join` event is recorded right behind `mid` with nothing in between).  A satisfied wait
   // still costs the launch stream ~6 us (tools/update_timeline.sh).
-#ifdef PVO_SCHED_DEBUG
-  if (g_sched.mode == 1 || g_sched.mode == 2 || (g_sched.mode >= 4 && g_sched.mode <= 9)) RUN(join(pending, stream));      // (these put the mask convolution behind `mid`)
-#endif
   if (ca && context_ahead)
     *ca = ContextAhead{workspace, w, w->glo_w, w->gate_wt, a.net_out, E, H, W, dt, true};
   probe_mark(PVO_STAGE_UPDATE, 1, stream);
   return PVO_OK;
 }
-
-#ifdef PVO_SCHED_DEBUG
-// recreate the library's fork / join / mid events with other flags (hipEventDisableSystemFence, hipEventReleaseToDevice ...)
-extern "C" int pvo_debug_event_flags(unsigned flags) {
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
-  g_event_flags = flags;
-  for (SideCtx& c : g_side_ctx) {
-    if (!c.ok) continue;
-    (void)hipEventDestroy(c.fork); (void)hipEventDestroy(c.join); (void)hipEventDestroy(c.mid);
-    if (hipEventCreateWithFlags(&c.fork, flags) != hipSuccess || hipEventCreateWithFlags(&c.join, flags) != hipSuccess ||
-        hipEventCreateWithFlags(&c.mid, flags) != hipSuccess) return 2;
-  }
-  return 0;
-}
-extern "C" int pvo_debug_sched(int mode, void* tap, size_t tap_bytes, size_t slot_bytes) {
-  g_sched.no_marker = (mode >> 8) & 1; mode &= 255;
-  g_sched.mode = mode; g_sched.tap = static_cast<char*>(tap); g_sched.tap_bytes = tap_bytes; g_sched.slot = slot_bytes; g_sched.n = 0;
-  return 0;
-}
-extern "C" int pvo_debug_sched_taps(void) { return g_sched.n; }
-#endif
 
 extern "C" int pvo_side_stream(void** stream_out) {
   if (!stream_out) return PVO_EINVAL;

@@ -38,6 +38,7 @@ class DepthVideo:
         self.full_flow = torch.ones(buffer, h8, w8, 2, dtype=torch.float, **kw)
         self.segm_filter, self.thresh = segm_filter, thresh
         self.max_segments = 1024
+        self._segments_seen = 1            # the largest number of dense labels any stored frame has had (segments_bound)
 
     # ------------------------------------------------------------------ bookkeeping
     def _fmap_cl(self, f, channels_last):
@@ -66,7 +67,16 @@ class DepthVideo:
         n = int(u.numel()) + (1 if u.numel() and int(u[0]) != 0 else 0)
         if n > self.max_segments:
             raise ValueError("frame has %d panoptic segments, more than max_segments = %d" % (n, self.max_segments))
+        self._segments_seen = max(self._segments_seen, n)
         return inv.to(torch.int32).reshape(seg.shape)
+
+    def segments_bound(self):
+        """the histogram width the panoptic vote needs: a power of two above every dense label stored so far (at least 16, at most
+        max_segments) - a frame has tens of segments, and a 1024-wide table per edge is filled and cleared in every update"""
+        b = 16
+        while b < self._segments_seen:
+            b *= 2
+        return max(1, min(self.max_segments, b))
 
     def append(self, tstamp, pose, disp, intrinsics, fmap, net, inp, segm=None, image=None, channels_last=None):
         """store one keyframe; fmap may be [128,h,w] (reference layout) or [h,w,128] (see _fmap_cl)"""

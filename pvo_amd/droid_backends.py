@@ -1188,6 +1188,16 @@ def update_operator(weights, net, motion, inp=None, P=None, pool=None, coords=No
     return net_out, heads, eta, upmask
 
 
+def debug_config(knob, value):
+    """the library's test hook (include/pvo_hip.h pvo_debug_config): "ba_solver" = None | "blocked" | "wave" | "pipe" | "twin",
+    "heads_gather_flat" = bool, "no_riders" = bool.  Process-wide; tests that compare bit-identical forms call it in a process of
+    their own.  (These were environment variables read inside the library until round 5.)"""
+    knobs = {"ba_solver": _lib.PVO_KNOB_BA_SOLVER, "heads_gather_flat": _lib.PVO_KNOB_HEADS_GATHER_FLAT, "no_riders": _lib.PVO_KNOB_NO_RIDERS}
+    if knob == "ba_solver":
+        value = {None: 0, "": 0, "blocked": 1, "wave": 2, "pipe": 3, "twin": 4}[value]
+    check(_lib.load().pvo_debug_config(knobs[knob], int(value)), "pvo_debug_config")
+
+
 def graph_update_workspace(E, K, R, H, W, max_segments, device):
     n = _lib.load().pvo_graph_update_workspace_bytes(int(E), int(K), int(R), int(H), int(W), int(max_segments))
     return _op_workspace(("up", torch.device(device).index), torch.device(device), n)

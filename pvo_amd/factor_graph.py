@@ -664,8 +664,9 @@ class FactorGraph:
         if t1 is None:
             t1 = max(max(self._ii_h), max(self._jj_h)) + 1
         vote = bool(segm_vote and v.segm_filter)
+        S = (v.segments_bound() if hasattr(v, "segments_bound") else v.max_segments) if vote else 0
         key = (self._version, t0, t1, bool(use_inactive), bool(motion_only), E, float(eta_scale), float(lm), float(ep), sharded is not None,
-               vote)
+               vote, S)
         st = self._cache.get("fused")
         if st is None or st["key"] != key:
             src = sorted(set(self._ii_h))
@@ -701,7 +702,6 @@ class FactorGraph:
                 ba = self._ba_plan(ii_ba, jj_ba, t0, t1, motion_only, n_in, len(rows))
             else:                                                  # the sharded BA plans for itself (pvo_amd/parallel.py)
                 ba = {"ii": ii_ba.contiguous(), "jj": jj_ba.contiguous(), "sys": None, "ws": None}
-            S = v.max_segments if vote else 0
             st = self._cache["fused"] = dict(
                 key=key, n_in=n_in, target_ba=target_ba, weight_ba=weight_ba, ii_ba=ba["ii"], jj_ba=ba["jj"], frames=frames_t,
                 pos=pos_t, seg=seg, ba=ba, R=len(rows), S=S, ii=self.ii.contiguous(), jj=self.jj.contiguous(),

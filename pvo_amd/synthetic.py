@@ -159,7 +159,7 @@ class TrainClips(torch.utils.data.Dataset):
 
 
 def drifting_texture_stream(n_frames, ht=240, wd=808, seed=0, segments=True, fast=9, slow=1, period=4):
-    """A seeded image stream in the item layout of evaluation_scripts/test_vo.py:19-56 - (t, image [3,H,W] uint8 BGR,
+    """A seeded image stream in the item layout of evaluation_scripts/test_vo.py:19-56 - (t, image [3,H,W] int BGR 0..255,
     intrinsics [4], segm [1,1,H/8,W/8] int or None) - at the reference driver's own input size (240 x 808).  A smoothed random
     texture drifts under the window, `fast` pixels per frame except every `period`-th frame (`slow` pixels: frames a motion
     filter would drop); the panoptic labels are eight rectangles of which two move (the S-3 pattern of SURVEY.md 8d).  The
@@ -175,7 +175,7 @@ def drifting_texture_stream(n_frames, ht=240, wd=808, seed=0, segments=True, fas
     x = 0
     for t in range(n_frames):
         x += slow if (t % period == period - 1) else fast
-        image = big[:, 8:8 + ht, x:x + wd].round().to(torch.uint8).contiguous()      # uint8, as cv2.imread / torch.from_numpy hand it over (test_vo.py:33-44)
+        image = big[:, 8:8 + ht, x:x + wd].round().int().contiguous()              # int32, as test_vo.py:41 hands it over
         segm = None
         if segments:
             seg = torch.zeros(h8, w8, dtype=torch.int32)

@@ -435,7 +435,7 @@ def test_reproject_with_motion_features_equals_the_two_kernels(cuda, dtype):
 def test_context_computed_ahead_inside_the_pose_solves_changes_nothing(cuda):
     """pvo_graph_update computes the NEXT update's gate context (a function of the hidden state and the weights) inside this
     update's two pose-solve dispatches and the next call uses it if nobody wrote `net` in between: two keyframe steps (12
-    updates, the first of every step recomputes - the step restores `net`) end in the same bits as with PVO_CONTEXT_AHEAD=0
+    updates, the first of every step recomputes - the step restores `net`) end in the same bits as with the riders off (pvo_debug_config: no_riders)
     and with the riders off altogether.  The choice is read once per process: one process per setting."""
     import subprocess
     import sys
@@ -447,9 +447,11 @@ def test_context_computed_ahead_inside_the_pose_solves_changes_nothing(cuda):
             "[bench.keyframe_update(video, graph, snap) for _ in range(4)]; torch.cuda.synchronize(); "
             "torch.save([t.cpu() for t in (video.poses, video.disps, graph.damping, graph.net, graph.target_cam, graph.weight)], sys.argv[1])") % root
     outs = []
-    for env in ({}, {"PVO_CONTEXT_AHEAD": "0"}, {"PVO_CONTEXT_AHEAD": "0", "PVO_UPMASK_RIDER": "0"}):
+    prelude = ("import sys; sys.path.insert(0, %r); from pvo_amd import droid_backends as _dbk; "
+               "[_dbk.debug_config(kv.split('=')[0], int(kv.split('=')[1])) for kv in sys.argv[2:]]; ") % root
+    for knobs in ([], ["no_riders=1"]):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, **env), stdout=subprocess.PIPE,
+            r = subprocess.run([sys.executable, "-c", prelude + code, f.name] + knobs, stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=600)
             assert r.returncode == 0, r.stdout[-2000:]
             outs.append(torch.load(f.name))

@@ -11,6 +11,10 @@ import torch
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
+
+# subprocess prelude: the library's test hook (include/pvo_hip.h pvo_debug_config) from "knob=value" arguments
+_KNOBS = ("import sys; sys.path.insert(0, %r); from pvo_amd import droid_backends as _dbk; "
+          "[_dbk.debug_config(kv.split('=')[0], kv.split('=')[1]) for kv in sys.argv[2:]]; ") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -100,6 +104,23 @@ def test_ba_long_window_envelope_cholesky_matches_oracle(cuda, P, closure):
     assert np.abs(poses - want["poses"]).max() < 1e-4
     assert np.abs(disps - want["disps"]).max() < 1e-4
     assert np.abs(dx - want["dx"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("radius,ht,wd", [(7, 8, 10), (13, 9, 11), (5, 9, 11)])
+def test_ba_frames_with_many_neighbours_match_oracle(cuda, radius, ht, wd):
+    """depth frames with more than nine free neighbours - a frontend window WITH its inactive edges (factor_graph.py:281-289,
+    use_inactive) - have more than four 16-row tiles in the Schur kernel: the row-pass path (radius 7: six tiles, one pass per
+    row tile; radius 13: ten tiles, passes of eight + two), on a map whose pixel count is and is not a multiple of four"""
+    P = 26
+    s = _scene(900 + radius, P, ht, wd, radius, 1)
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
+    assert status[0] == 0 and status[1] == want["K"] and status[2] == 0
+    assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
+    assert np.abs(dx - want["dx"]).max() < 1e-4 and np.abs(dz - want["dz"]).max() < 1e-4
+    again = _run_ba(s, cuda, 2)
+    assert np.array_equal(poses, again[0]) and np.array_equal(disps, again[1])          # fixed summation order: bitwise repeatable
 
 
 def test_ba_matches_oracle_at_SA_size(cuda):
@@ -225,7 +246,7 @@ def test_partitioned_pose_solve_reports_a_non_spd_system(cuda):
 
 
 def test_partitioned_and_one_chain_solves_agree(cuda):
-    """the same system through ba_solve_twin_kernel and through the one-chain pipeline (PVO_BA_SOLVER, read once per process):
+    """the same system through ba_solve_twin_kernel and through the one-chain pipeline (pvo_debug_config, set in a process of its own):
     fp64 rounding apart (the order of elimination differs), far inside fp32"""
     import subprocess
     import sys
@@ -238,7 +259,7 @@ def test_partitioned_and_one_chain_solves_agree(cuda):
     outs = {}
     for solver in ("pipe", "twin"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, PVO_BA_SOLVER=solver), stdout=subprocess.PIPE,
+            r = subprocess.run([sys.executable, "-c", _KNOBS + code, f.name, "ba_solver=" + solver], stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=300)
             assert r.returncode == 0, r.stdout[-2000:]
             outs[solver] = torch.load(f.name)
@@ -337,7 +358,7 @@ def test_wave_and_blocked_cholesky_are_bit_identical(P, ht, wd, radius):
     outs = []
     for solver in ("wave", "blocked", "pipe"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, PVO_BA_SOLVER=solver), stdout=subprocess.PIPE,
+            r = subprocess.run([sys.executable, "-c", _KNOBS + code, f.name, "ba_solver=" + solver], stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=300)
             assert r.returncode == 0, r.stdout[-2000:]
             outs.append(torch.load(f.name))

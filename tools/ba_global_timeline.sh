@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/ba_global_timeline.sh [NF] [HT] [WD]   kernel sequence of ONE pvo_ba call (2 Gauss-Newton steps) at S-20 size
-# under rocprofv3 --kernel-trace: start, duration, gap to the previous kernel.  PVO_BA_SOLVER=pipe|twin selects the pose solve.
+# under rocprofv3 --kernel-trace: start, duration, gap to the previous kernel.  TOOL_BA_SOLVER=pipe|twin selects the pose solve (pvo_debug_config).
 NF=${1:-64}; HT=${2:-48}; WD=${3:-64}
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/bgt
 cat > /tmp/bgt_run.py <<PY
@@ -8,6 +8,7 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"]); sys.path.insert(0, os.path.jo
 import torch
 from pvo_amd import droid_backends as db
 from test_geom_ba_gpu import _scene
+db.debug_config("ba_solver", os.environ.get("TOOL_BA_SOLVER"))
 s = _scene(7, $NF, $HT, $WD, 3, 1)
 d = lambda t: t.cuda()
 args = [d(s[k]) for k in ("intr", "target", "weight", "eta", "ii", "jj")]

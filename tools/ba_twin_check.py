@@ -8,6 +8,7 @@ import torch
 
 def child(path):
     from pvo_amd import droid_backends as db
+    db.debug_config("ba_solver", os.environ.get("TOOL_BA_SOLVER"))          # (the library's test hook; this tool's own variable)
     from test_geom_ba_gpu import _scene
     nf, ht, wd = int(os.environ.get("NF", "64")), int(os.environ.get("HT", "8")), int(os.environ.get("WD", "10"))
     s = _scene(7, nf, ht, wd, 3, 1)
@@ -37,7 +38,7 @@ if len(sys.argv) > 1:
 out = {}
 for solver in ("pipe", "twin"):
     with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), f.name], env=dict(os.environ, PVO_BA_SOLVER=solver), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), f.name], env=dict(os.environ, TOOL_BA_SOLVER=solver), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         if r.returncode != 0:
             print(solver, "FAILED\n", r.stdout[-3000:]); sys.exit(1)
         out[solver] = torch.load(f.name)

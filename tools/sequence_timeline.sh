@@ -46,6 +46,19 @@ tot = sum(v[1] for v in agg.values())
 print("kernel time by name (sum of durations %.3f s):" % (tot / 1e9))
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print("  %-64s x%-6d %9.2f ms  %5.1f %%  avg %7.1f us" % (n, c, t / 1e6, 100.0 * t / tot, t / 1e3 / c))
+# one graph update of the frontend from the second half of the tracking phase (kernel schedule: start, duration, queue)
+ups = [i for i, r in enumerate(seg[:-30]) if "reproject_motion_kernel" in r["Kernel_Name"]]
+if ups:
+    # the frontend's updates come before terminate's (backend / filler): take one around 60 % of them
+    i0 = ups[int(0.6 * len(ups))]
+    i1 = next((j for j in ups if j > i0), i0 + 40)
+    tb = int(seg[i0]["Start_Timestamp"])
+    print()
+    print("one graph update of the frontend (%d dispatches, %.1f us to the next update's first kernel):" % (i1 - i0, (int(seg[i1]["Start_Timestamp"]) - tb) / 1e3))
+    for r in seg[i0:i1 + 1]:
+        s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print("%9.1f %8.1f  q%-3s %s  [%s x %s]" % ((s_ - tb) / 1e3, (e_ - s_) / 1e3, r.get("Queue_Id", "?")[-1:], short(r["Kernel_Name"]), r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
+    # ... and everything between two keyframes' first updates (one keyframe of the frontend: motion filter frames, edge changes, updates)
 own = sum(t for n, (c, t) in agg.items() if not (n.startswith("at::") or "rocclr" in n or n.startswith("miopen") or "Cijk" in n or n.startswith("ck::") or "MIOpen" in n or "igemm" in n or "naive" in n))
 print("share of kernel time in libpvo_hip kernels: %.1f %%; PyTorch / MIOpen / blit kernels: %.1f %%" % (100.0 * own / tot, 100.0 * (tot - own) / tot))
 PY

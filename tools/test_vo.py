@@ -28,7 +28,7 @@ def rgb2id(color):
 
 
 def image_stream(datapath, image_size=(240, 808), mode="val", segm_filter=False):
-    """yields (t, image [3,H,W] uint8 BGR, intrinsics [4], segm [1,1,H/8,W/8] int or None)  (test_vo.py:19-56)"""
+    """yields (t, image [3,H,W] int BGR, intrinsics [4], segm [1,1,H/8,W/8] int or None)  (test_vo.py:19-56)"""
     from PIL import Image
     fx, fy, cx, cy = VKITTI2_INTRINSICS
     images = sorted(glob.glob(os.path.join(datapath, SPLIT[mode], "frames/rgb/Camera_0/*.jpg")))
@@ -39,7 +39,7 @@ def image_stream(datapath, image_size=(240, 808), mode="val", segm_filter=False)
         w0, h0 = im.size
         rgb = np.asarray(im.resize((w1, h1), Image.BILINEAR))
         rgb = rgb[:h1 - h1 % 8, :w1 - w1 % 8]
-        image = torch.as_tensor(rgb[..., ::-1].copy()).permute(2, 0, 1)                # uint8 BGR, as cv2.imread returns (test_vo.py:33-44)
+        image = torch.as_tensor(rgb[..., ::-1].copy()).int().permute(2, 0, 1)          # BGR, as cv2.imread returns; int32 as test_vo.py:41
         segm = None
         if segm_filter:
             ids = rgb2id(np.asarray(Image.open(segms[t]).convert("RGB")))
