@@ -39,6 +39,12 @@ class DepthVideo:
         self.segm_filter, self.thresh = segm_filter, thresh
         self.max_segments = 1024
         self._segments_seen = 1            # the largest number of dense labels any stored frame has had (segments_bound)
+        # feature maps of EVERY tracked frame by time stamp (keyframe or not): the motion filter computes them anyway, the
+        # trajectory filler needs them again at the end (trajectory_filler.py:32-38 re-encodes every image).  0.78 MB per
+        # 240 x 808 frame: a 10 000-frame sequence is 7.8 GB of the 288 GB - kept resident instead of recomputed, up to this budget
+        self.frame_fmaps = {}
+        self.frame_fmaps_budget = 32 << 30
+        self._frame_fmaps_bytes = 0
 
     # ------------------------------------------------------------------ bookkeeping
     def _fmap_cl(self, f, channels_last):
@@ -69,6 +75,14 @@ class DepthVideo:
             raise ValueError("frame has %d panoptic segments, more than max_segments = %d" % (n, self.max_segments))
         self._segments_seen = max(self._segments_seen, n)
         return inv.to(torch.int32).reshape(seg.shape)
+
+    def remember_features(self, tstamp, fmap):
+        """keep a tracked frame's feature map [..,128,h,w] (a copy) for the trajectory filler"""
+        n = fmap.numel() * fmap.element_size()
+        if self.frame_fmaps_budget <= 0 or self._frame_fmaps_bytes + n > self.frame_fmaps_budget:
+            return
+        self.frame_fmaps[float(tstamp)] = fmap.detach().clone()
+        self._frame_fmaps_bytes += n
 
     def segments_bound(self):
         """the histogram width the panoptic vote needs: a power of two above every dense label stored so far (at least 16, at most

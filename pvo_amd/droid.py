@@ -50,7 +50,11 @@ class Droid:
             self.net.load_state_dict(OrderedDict((k.replace("module.", ""), v) for k, v in sd.items()))
         self.net.to(self.args.device).eval()
         if getattr(self.args, "half_update", True) and torch.device(self.args.device).type == "cuda":
-            self.net.update.half()          # the fused 16-bit operator path; encoders stay fp32 under autocast
+            self.net.update.half()          # the fused 16-bit operator path
+            if getattr(self.args, "half_encoders", True):
+                # the encoders run under fp16 autocast (motion_filter.py:50): every convolution, norm and add is an fp16 operation
+                # either way, but fp32 parameters are cast again in EVERY forward - 33 tiny kernels of ~120 per frame.  Cast once.
+                self.net.fnet.half(); self.net.cnet.half()
 
     def track(self, tstamp, image, depth=None, intrinsics=None, segments=None):
         with torch.no_grad():

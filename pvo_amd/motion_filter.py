@@ -6,7 +6,7 @@ the last keyframe exceeds `thresh` pixels (mean norm); `track_vo` adds every fra
 estimate is a 1-edge correlation volume (HIP build), a lookup at the identity grid (HIP lookup) and one
 pass of the update operator; one scalar is read back per frame.
 
-Per-frame host cost (round 5, bench.py `sequence`): the frame goes up as uint8, the BGR flip / scaling happen on the device,
+Per-frame host cost (round 5, bench.py `sequence`): the frame goes up as it arrives, the BGR flip / scaling happen on the device,
 and each encoder is ONE HIP-graph launch after its first two calls
 (pvo_amd/graphs.py: the eager ~70-launch forward cost 4.6 ms of host time per network for ~0.3 ms of device work).
 """
@@ -34,16 +34,22 @@ class MotionFilter:
         self.MEAN = torch.as_tensor([0.485, 0.456, 0.406], device=self.device)[:, None, None]
         self.STDV = torch.as_tensor([0.229, 0.224, 0.225], device=self.device)[:, None, None]
         self.net = self.inp = self.fmap = None
+        self.keep_features = True          # every frame's feature map stays resident for the trajectory filler (DepthVideo.remember_features)
         self._coords0 = None
         self._features_g = GraphedCall(self._features_dev, name="fnet", guard=_weights_guard(self.fnet))
         self._context_g = GraphedCall(self._context_dev, name="cnet", guard=_weights_guard(self.cnet))
+        # a whole tracked frame - encoder, 1-edge volume, lookup, one operator pass, the mean flow norm - as ONE captured launch:
+        # issued eagerly the ~25 launches behind the encoder left the device idle for 0.4 of a frame's 1.4 ms (bench.py `sequence`)
+        self._frame_g = GraphedCall(self._frame_dev, name="motion filter frame",
+                                    guard=lambda: (_weights_guard(self.fnet)(), _weights_guard(self.update)()))
+        self._static = None                # conv(W[:, inp], inp) of the reference keyframe's context: constant until the next keyframe
 
     def _upload(self, image):
-        """host frame -> device.  Integer frames travel as uint8 (an image decoder's own type; a quarter of the int32 bytes the
-        reference's `.int()` stream carries) straight from pageable memory: staging through a pinned buffer was tried and is
-        SLOWER here - CPU writes into hipHostMalloc'ed memory ran at ~150 MB/s on the MI355X boxes (16 ms per 2.3 MB frame)."""
-        if image.device.type == "cpu" and self.device.type == "cuda" and not image.is_floating_point() and image.dtype != torch.uint8:
-            image = image.to(torch.uint8)                  # pixel values are 0..255 (motion_filter.py:52: `/ 255.0`)
+        """host frame -> device, as it is (the reference's stream hands over int32, test_vo.py:41): NO tensor operation on the host.
+        On the 128-core hosts of the MI355X boxes every CPU tensor op on a frame - a dtype cast, the [2, 1, 0] channel gather of
+        motion_filter.py:52, torch.stack in the filler - costs 2-20 ms (an OpenMP team is woken for 0.6 M elements); the copy of
+        2.3 MB costs 0.2 ms and the flip / cast / scaling belong to the captured device graph.  (A pinned staging buffer was tried
+        too: CPU writes into hipHostMalloc'ed memory ran at ~150 MB/s here, 16 ms per frame.)"""
         return image.to(self.device, non_blocking=True)
 
     def _normalise_dev(self, image_dev):
@@ -60,6 +66,25 @@ class MotionFilter:
     def _context_dev(self, image_dev):
         with self._autocast():
             return self._context(self._normalise_dev(image_dev))
+
+    def _frame_dev(self, image_dev, fmap_ref, net_ref, inp_ref, *static):
+        """one tracked frame against the reference keyframe (motion_filter.py:52-72): its feature map and the mean norm of the
+        one-step flow estimate [1]"""
+        gmap = self._features_dev(image_dev)
+        with self._autocast():
+            half = lambda t: t if t.dtype in (torch.float16, torch.bfloat16) or self.device.type != "cuda" else t.half()
+            corr = CorrBlock(half(fmap_ref[None]), half(gmap[None]))(self._coords0)
+            kw = {"static_terms": tuple(static)} if static else {}
+            _, delta, _, _ = self.update(net_ref[None], inp_ref[None], corr, **kw)
+            return gmap, delta[..., 0:2].float().norm(dim=-1).mean().reshape(1)
+
+    def _new_reference(self, gmap, net, inp):
+        """the frame just stored becomes the reference of the motion test (graph outputs are static buffers: copies)"""
+        self.net, self.inp, self.fmap = net.clone(), inp.clone(), gmap.clone()
+        self._static = None
+        if self.device.type == "cuda" and hasattr(self.update, "static_terms") and getattr(self.update, "fused_gru", False) \
+                and next(self.update.parameters()).dtype in (torch.float16, torch.bfloat16):
+            self._static = tuple(self.update.static_terms(self.inp))      # (16-bit operator: the ConvGRU's static-input terms, once per keyframe)
 
     def _autocast(self):
         return torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda")
@@ -83,28 +108,31 @@ class MotionFilter:
         """run on every incoming frame (motion_filter.py:46-87); image [3,H,W] BGR 0..255"""
         ht, wd = image.shape[-2] // 8, image.shape[-1] // 8
         img = self._upload(image)
-        gmap = self._features_g(img)                                           # [1,128,h,w]
         if self.video.counter == 0:
+            gmap = self._features_g(img)                                       # [1,128,h,w]
+            self._remember(tstamp, gmap)
             ident = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0], device=self.device)
             net, inp = self._context_g(img)
-            self.net, self.inp, self.fmap = net.clone(), inp.clone(), gmap.clone()      # (graph outputs are static buffers)
+            self._new_reference(gmap, net, inp)
             self._append(tstamp, image, ident, 1.0, intrinsics.to(self.device), gmap, net, inp, segments)
             return True
-        with self._autocast():
-            if self._coords0 is None or self._coords0.shape[-3:-1] != (ht, wd):
+        if self._coords0 is None or self._coords0.shape[-3:-1] != (ht, wd):
+            with self._autocast():
                 self._coords0 = coords_grid(ht, wd, device=self.device)[None, None]
-            half = lambda t: t if t.dtype in (torch.float16, torch.bfloat16) or self.device.type != "cuda" else t.half()
-            corr = CorrBlock(half(self.fmap[None]), half(gmap[None]))(self._coords0)
-            _, delta, _, _ = self.update(self.net[None], self.inp[None], corr)
-            moved = delta[..., 0:2].float().norm(dim=-1).mean().item() > self.thresh
-        if moved:
+        gmap, mag = self._frame_g(img, self.fmap, self.net, self.inp, *(self._static or ()))
+        self._remember(tstamp, gmap)
+        if mag.item() > self.thresh:
             self.count = 0
             net, inp = self._context_g(img)
-            self.net, self.inp, self.fmap = net.clone(), inp.clone(), gmap.clone()
+            self._new_reference(gmap, net, inp)
             self._append(tstamp, image, None, None, intrinsics.to(self.device), gmap, net, inp, segments)
             return True
         self.count += 1
         return False
+
+    def _remember(self, tstamp, gmap):
+        if self.keep_features and hasattr(self.video, "remember_features"):
+            self.video.remember_features(tstamp, gmap)
 
     @torch.no_grad()
     def track_vo(self, tstamp, image, depth=None, intrinsics=None, segments=None):

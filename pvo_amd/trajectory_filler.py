@@ -18,6 +18,7 @@ class PoseTrajectoryFiller:
         self.count, self.video, self.device = 0, video, torch.device(device)
         self.MEAN = torch.as_tensor([0.485, 0.456, 0.406], device=self.device)[:, None, None]
         self.STDV = torch.as_tensor([0.229, 0.224, 0.225], device=self.device)[:, None, None]
+        self.reuse_features = True
         from .motion_filter import _weights_guard
         self._one = GraphedCall(self._features_one, name="fnet (filler)", guard=_weights_guard(self.fnet))
 
@@ -33,18 +34,18 @@ class PoseTrajectoryFiller:
         shapes (the batched call fell to its naive convolution: 3.1 ms per layer, bench.py `sequence`), and the one-image
         graph is the launch the motion filter's shapes already warmed."""
         if self.device.type != "cuda":
+            images = torch.stack(list(images), 0) if not isinstance(images, torch.Tensor) else images
             with torch.autocast("cuda", dtype=torch.float16, enabled=False):
                 x = images[None, :, [2, 1, 0]].to(self.device).float() / 255.0
                 return self.fnet((x - self.MEAN) / self.STDV).squeeze(0)
-        if not images.is_floating_point() and images.dtype != torch.uint8:
-            images = images.to(torch.uint8)                  # 0..255: a quarter of the bytes over PCIe
-        dev = images.to(self.device)
-        return torch.cat([self._one(dev[k]).clone() for k in range(dev.shape[0])], 0)
+        # (each frame goes up as it is and is never touched on the host: a torch.stack of 16 frames took 19 ms on a 128-core host)
+        return torch.cat([self._one(im.to(self.device, non_blocking=True)).clone() for im in images], 0)
 
     def _fill(self, tstamps, images, intrinsics):
         v = self.video
         tt = torch.as_tensor(tstamps, device=self.device, dtype=torch.float)
-        images = torch.stack(images, 0)
+        if self.device.type != "cuda" or getattr(self.video, "images", True) is not None:
+            images = torch.stack(images, 0)                # (on the GPU only a video that stores its frames needs them as one tensor)
         intrinsics = torch.stack(intrinsics, 0).to(self.device)
         N, M = v.counter, len(tstamps)
         ts = v.tstamp[:N]
@@ -57,7 +58,14 @@ class PoseTrajectoryFiller:
         vel = (Ps[t1] * Ps[t0].inv()).log() / dt.unsqueeze(-1)
         Gs = SE3.exp(vel * (tt - ts[t0]).unsqueeze(-1)) * Ps[t0]
 
-        fmap = self._features(images)
+        # the motion filter encoded every one of these frames when it was tracked and the video kept the maps (same time stamp =
+        # same frame: test_vo.py hands terminate() the stream it tracked; `reuse_features = False` re-encodes as the reference does)
+        kept = getattr(v, "frame_fmaps", None) if self.reuse_features else None
+        cached = [kept.get(float(t)) for t in tstamps] if kept else [None]
+        if all(c is not None for c in cached):
+            fmap = torch.cat(cached, 0)
+        else:
+            fmap = self._features(images)
         v.counter += M
         v[N:N + M] = (tt, images, Gs.data, 1.0, intrinsics / 8.0, fmap)
 

@@ -58,7 +58,19 @@ if ups:
     for r in seg[i0:i1 + 1]:
         s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         print("%9.1f %8.1f  q%-3s %s  [%s x %s]" % ((s_ - tb) / 1e3, (e_ - s_) / 1e3, r.get("Queue_Id", "?")[-1:], short(r["Kernel_Name"]), r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
-    # ... and everything between two keyframes' first updates (one keyframe of the frontend: motion filter frames, edge changes, updates)
+# one frame of the motion filter (the 1-edge lookup in the reference's layout marks it): from the frame's first kernel behind
+# the previous frame's last to the scalar read-back
+mf = [i for i, r in enumerate(seg) if "corr_lookup_r3_kernel" in r["Kernel_Name"] and "enc" not in r["Kernel_Name"]]
+if len(mf) > 20:
+    c = mf[int(0.6 * len(mf))]
+    prev = mf[int(0.6 * len(mf)) - 1]
+    lo = max(prev + 25, c - 140)
+    tb = int(seg[lo]["Start_Timestamp"])
+    print()
+    print("one frame of the motion filter (dispatches %d .. %d of the pass; encoder graph, 1-edge volume, lookup, operator, test):" % (lo, c + 40))
+    for r in seg[lo:c + 40]:
+        s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print("%9.1f %8.1f  q%-3s %s  [%s x %s]" % ((s_ - tb) / 1e3, (e_ - s_) / 1e3, r.get("Queue_Id", "?")[-1:], short(r["Kernel_Name"]), r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
 own = sum(t for n, (c, t) in agg.items() if not (n.startswith("at::") or "rocclr" in n or n.startswith("miopen") or "Cijk" in n or n.startswith("ck::") or "MIOpen" in n or "igemm" in n or "naive" in n))
 print("share of kernel time in libpvo_hip kernels: %.1f %%; PyTorch / MIOpen / blit kernels: %.1f %%" % (100.0 * own / tot, 100.0 * (tot - own) / tot))
 PY
