@@ -731,9 +731,22 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
     fe._update, fe.graph.rm_keyframe = _upd, _rmk
     gupd = fe.graph.update
 
+    windows = []
+
     def _gupd(*a, **kw):
         counts["graph_updates"] += 1
-        return gupd(*a, **kw)
+        r = gupd(*a, **kw)
+        st = fe.graph._cache.get("fused")
+        if st is not None and counts["graph_updates"] % 50 == 0:          # what a BA of this run looks like (host lists only)
+            g = fe.graph
+            m_l = [(i >= st["key"][1] - 3) and (j >= st["key"][1] - 3) for i, j in zip(g._ii_inac_h, g._jj_inac_h)]
+            src = list(g._ii_h) + [i for i, k in zip(g._ii_inac_h, m_l) if k]
+            deg = {}
+            for i in src:
+                deg[i] = deg.get(i, 0) + 1
+            windows.append({"poses": st["key"][2] - st["key"][1], "active_edges": len(g._ii_h), "inactive_edges_in_ba": st["n_in"],
+                            "max_out_degree": max(deg.values()), "depth_frames": len(deg)})
+        return r
     fe.graph.update = _gupd
     from pvo_amd.factor_graph import FactorGraph as _FG
     backend_graphs = []
@@ -774,7 +787,7 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
     for t, image, intr, segm in frames:
         droid.track(t, image, intrinsics=intr, segments=segm)
     torch.cuda.synchronize(); t_track = time.perf_counter() - t0
-    out = dict(counts, frames=n_frames, keyframes=int(droid.video.counter), track_s=t_track,
+    out = dict(counts, ba_windows_sampled=windows, frames=n_frames, keyframes=int(droid.video.counter), track_s=t_track,
                edges_at_end=len(fe.graph._ii_h), finite=bool(torch.isfinite(droid.video.poses[:droid.video.counter]).all()))
     try:
         if terminate:
@@ -828,7 +841,7 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
             "frames_per_s": plain["frames"] / plain["track_s"], "keyframe_updates_per_s": plain["keyframe_updates"] / plain["track_s"],
             "graph_updates_per_s": plain["graph_updates"] / plain["track_s"],
             "ms_per_keyframe_update_all_in": 1e3 * plain["track_s"] / max(plain["keyframe_updates"], 1),
-            "terminate_s": plain.get("terminate_s"), "backend_graphs": plain.get("backend_graphs"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},
+            "ba_windows_sampled": plain.get("ba_windows_sampled"), "terminate_s": plain.get("terminate_s"), "backend_graphs": plain.get("backend_graphs"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},
             "finite": plain["finite"],
             "split_instrumented_pass": {"note": "exclusive wall time per component with a device synchronisation on both sides of every call (this pass: %.2f s of tracking against %.2f s plain)" % (inst["track_s"], plain["track_s"]),
                                         "seconds": {k: round(v, 4) for k, v in sorted(sp.t.items(), key=lambda kv: -kv[1])},

@@ -66,7 +66,7 @@ constexpr int kLdsCholMax = 126;        // (6P) up to which the fp64 system live
 __device__ unsigned long long* g_ba_wg_probe = nullptr;
 #define BA_WG_PROBE(kern, slot)                                                                                         \
   do {                                                                                                                  \
-    if (g_ba_wg_probe && threadIdx.x == 0) {                                                                            \
+    if (g_ba_wg_probe && threadIdx.x == 0 && blockIdx.z == 0) {                                                         \
       const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
       if (wg_ < 4096u) g_ba_wg_probe[((kern) * 4096u + wg_) * 8u + (slot)] = wall_clock64();                            \
     }                                                                                                                   \
@@ -670,7 +670,13 @@ __device__ __forceinline__ void ba_schur_body(
   // the assembly's chunk sums, per edge, are added up and scattered by workgroups of their OWN: the last `deal_rows` rows of the
   // grid (at most two edges each).  Dealt over the depth frames' workgroups, as in round 3, the 36 of 96 that had an edge at S-B
   // started their own work 3.5 us late - and the kernel ends with its slowest workgroup (profiles/r04_ba_kernel_timeline.txt).
+  // gridDim.z slices: the row-tile passes of a depth frame with MANY neighbours (more than kFastTiles row tiles: a frontend window
+  // with its inactive edges) are dealt over the slices, ti = z, z + gridDim.z, ...; everything else is slice 0's and the other
+  // slices leave at once.  Every slice that stays runs the depth phase itself (identical values to identical addresses - the
+  // rows a slice reads are the ones it wrote) and every tile pair is still summed by ONE workgroup in the fixed order.
+  const int zi = blockIdx.z, Z = gridDim.z;
   if (static_cast<int>(blockIdx.y) >= static_cast<int>(gridDim.y) - deal_rows) {
+    if (zi != 0) return;
     if (part && threadIdx.x < 90) {
       const int nd = deal_rows * gridDim.x;
       for (int e = (blockIdx.y - (gridDim.y - deal_rows)) * gridDim.x + blockIdx.x; e < E; e += nd) {
@@ -693,6 +699,7 @@ __device__ __forceinline__ void ba_schur_body(
   const int e0 = pl.eptr[k], deg_all = pl.eptr[k + 1] - e0;
   const int pself = pl.kx[k] - t0;
   const bool in_lds = deg_all <= 256;
+  if (zi > 0 && 6 * deg_all + 7 <= 16 * kFastTiles) return;      // at most kFastTiles row tiles whatever the poses: slice 0 alone
   if (in_lds && tid < deg_all) {
     const int e = pl.eidx[e0 + tid];
     s_edge[tid] = e;
@@ -700,13 +707,6 @@ __device__ __forceinline__ void ba_schur_body(
   }
   __syncthreads();
   BA_WG_PROBE(1, 2);                     // edge list in LDS
-#pragma unroll
-  for (int h = 0; h < PIX / 256; ++h) {                // depth phase for this workgroup's pixels
-    const int x = blockIdx.x * PIX + h * 256 + tid;
-    if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
-  }
-
-  BA_WG_PROBE(1, 3);                     // depth phase issued
   if (in_lds && deg_all <= 64) {
     // row table by wave 0, one lane per out-edge: the position of an edge's six rows = the number of free target poses before it
     // (ballot + popcount) - the same order as the sequential walk below, which took 1.9 us of this kernel at S-B
@@ -751,10 +751,20 @@ __device__ __forceinline__ void ba_schur_body(
     nrows_s = r;
   }
   __syncthreads();
-  BA_WG_PROBE(1, 4);                     // row table built, depth rows stored
+  BA_WG_PROBE(1, 3);                     // row table built
   const int nrows = nrows_s;
-  if (nrows == 0) return;
   const int T = (nrows + 15) >> 4;
+  if (zi > 0 && T <= kFastTiles) return;                           // (uniform: nrows_s is the workgroup's)
+#pragma unroll
+  for (int h = 0; h < PIX / 256; ++h) {                // depth phase for this workgroup's pixels
+    const int x = blockIdx.x * PIX + h * 256 + tid;
+    if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
+  }
+
+  __syncthreads();
+  BA_WG_PROBE(1, 4);                     // depth rows stored
+  if (nrows == 0) return;
+
   gfloat* __restrict__ qrow = (gfloat*)(Q + static_cast<long long>(k) * HW);
   const int pix_base = blockIdx.x * PIX + wave * (PIX / 4);
 
@@ -767,7 +777,7 @@ __device__ __forceinline__ void ba_schur_body(
   }
   // any degree: one ROW TILE against up to eight others per pass (row tiles re-read from L2 once per pass)
   constexpr int kPassTiles = 8;           // 8 x 4 x 256 floats of `red` = 32 KB
-  for (int ti = 0; ti < T; ++ti) {
+  for (int ti = zi; ti < T; ti += Z) {
     for (int tj0 = ti; tj0 < T; tj0 += kPassTiles) {
       const int cnt = (T - tj0 < kPassTiles) ? T - tj0 : kPassTiles;
       switch (cnt) {
@@ -782,6 +792,7 @@ __device__ __forceinline__ void ba_schur_body(
       }
     }
   }
+  BA_WG_PROBE(1, 7);
 }
 
 template <bool VEC4, int PIX>
@@ -1548,7 +1559,7 @@ __device__ __forceinline__ void chol_solve_pipe(Mat A, double* Ld, int n, int* f
 __device__ __forceinline__ int env_layout(const int* __restrict__ env, int P, int* first, int* rowbase, int* total_s) {
   for (int b = threadIdx.x; b < P; b += blockDim.x) {
     const int e = env[b];
-    const int f = e < b ? e : b;
+    const int f = e < b ? (e < 0 ? 0 : e) : b;             // clamped to [0, b] on BOTH sides, as pvo_ba_packed_elems sizes the message
     first[b] = f;
     rowbase[b] = (b - f + 1) * 36;                         // sizes, scanned below
   }
@@ -2487,7 +2498,7 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     const int pix = wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024);
     const int gx = (HW + pix - 1) / pix;
     const int deal_rows = two_stage ? (E + 2 * gx - 1) / (2 * gx) : 0;      // workgroups that add up the assembly's chunk sums: two edges each
-    const dim3 sgrid(gx, Kmax + deal_rows);
+    const dim3 sgrid(gx, Kmax + deal_rows, 4);       // (z: slices for the row-tile passes of many-neighbour frames, see ba_schur_body)
 #define PVO_SCHUR_LAUNCH(V, PX) hipLaunchKernelGGL((ba_schur_mfma_kernel<V, PX>), sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, \
                                                    w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA, deal_rows)
     if ((HW & 3) == 0) { if (pix == 256) PVO_SCHUR_LAUNCH(true, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(true, 512); else PVO_SCHUR_LAUNCH(true, 1024); }

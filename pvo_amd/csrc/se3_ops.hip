@@ -269,7 +269,21 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(const F* __restrict__ pos
                                                        F* __restrict__ x1, F* __restrict__ valid, F* __restrict__ Ji, F* __restrict__ Jj, F* __restrict__ Jz) {
   const int px = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, b = blockIdx.z;
   if (px >= HW) return;
-  const int i = static_cast<int>(ii[n]), j = static_cast<int>(jj[n]);
+  // frame indices as torch indexing reads them: a negative index counts from the end; anything still outside [0, P) - which the
+  // PyTorch formulation answers with an IndexError - leaves this edge NaN / invalid instead of reading beside the buffers
+  long long i = ii[n], j = jj[n];
+  i += (i < 0) ? P : 0; j += (j < 0) ? P : 0;
+  if (i < 0 || i >= P || j < 0 || j >= P) {
+    const long long row = (static_cast<long long>(b) * N + n) * HW + px;
+    const F nan = F(0) / F(0);
+    for (int k = 0; k < nx; ++k) x1[row * nx + k] = nan;
+    valid[row] = F(0);
+    if (Jj) {
+      for (int k = 0; k < 12; ++k) { Jj[row * 12 + k] = nan; Ji[row * 12 + k] = nan; }
+      Jz[row * 2] = nan; Jz[row * 2 + 1] = nan;
+    }
+    return;
+  }
   const F* Pi = poses + (static_cast<long long>(b) * P + i) * 7;
   const F* Pj = poses + (static_cast<long long>(b) * P + j) * 7;
   F pi[7], pj[7], Ki[4], Kj[4], out[29];
@@ -297,7 +311,9 @@ __global__ __launch_bounds__(256) void proj_vjp_kernel(const F* __restrict__ pos
                                                        F* __restrict__ gposes, F* __restrict__ gdepths) {
   __shared__ F red[4][14];
   const int px = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, b = blockIdx.z;
-  const int i = static_cast<int>(ii[n]), j = static_cast<int>(jj[n]);
+  long long i = ii[n], j = jj[n];                           // (as in the forward kernel: negatives wrap, an edge outside [0, P) adds nothing)
+  i += (i < 0) ? P : 0; j += (j < 0) ? P : 0;
+  if (i < 0 || i >= P || j < 0 || j >= P) return;           // (uniform over the workgroup: n is blockIdx.y)
   const bool jac = g_Ji || g_Jj || g_Jz;
   F s[15];
 #pragma unroll
@@ -424,6 +440,7 @@ extern "C" int pvo_proj_transform(const void* poses, const void* depths, const v
   if (B == 0 || N == 0) return PVO_OK;
   if (!poses || !depths || !intr || !ii || !jj || !x1 || !valid) return PVO_EINVAL;
   if ((Jj != nullptr) != (Ji != nullptr) || (Jj != nullptr) != (Jz != nullptr)) return PVO_EINVAL;
+  if (N > 65535 || B > 65535) return PVO_EUNSUPPORTED;      // an edge / batch index is a grid coordinate (include/pvo_hip.h "Limits")
   const int HW = ht * wd;
   const dim3 grid((HW + 255) / 256, N, B);
   if (dtype == PVO_F32)
@@ -447,6 +464,7 @@ extern "C" int pvo_proj_transform_vjp(const void* poses, const void* depths, con
   if (B == 0 || N == 0) return PVO_OK;
   if (!poses || !depths || !intr || !ii || !jj || !gposes || !gdepths) return PVO_EINVAL;
   if (!g_x1 && !g_Ji && !g_Jj && !g_Jz) return PVO_OK;
+  if (N > 65535 || B > 65535) return PVO_EUNSUPPORTED;
   const int HW = ht * wd;
   const dim3 grid((HW + 255) / 256, N, B);
   if (dtype == PVO_F32)

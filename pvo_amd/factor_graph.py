@@ -548,38 +548,45 @@ class FactorGraph:
         ix, jx = list(range(t0, t)), list(range(t1, t))
         if not ix or not jx:
             return
-        ii = [i for i in ix for _ in jx]
-        jj = [j for _ in ix for j in jx]
-        d = self.video.distance(ii, jj, beta=beta).float().cpu().tolist()
-        inf = float("inf")
-        nj = t - t1
-        for k, (i, j) in enumerate(zip(ii, jj)):
-            if i - rad < j or d[k] > 100:
-                d[k] = inf
+        import numpy as np
+        ni, nj = len(ix), len(jx)
+        ii, jj = np.repeat(np.arange(t0, t), nj), np.tile(np.arange(t1, t), ni)      # (arrays, not lists: a list of 14 000 ints costs 1 ms to turn into a tensor)
+        # the selection below is the reference's greedy loop on a [ni, nj] array: the suppression of everything near an existing
+        # edge is one array operation per window offset (it was a Python loop per edge and offset: 0.57 s of a 1.75 s sequence
+        # with 119 keyframes, bench.py `sequence`), the greedy pass visits only the candidates under the threshold
+        D = self.video.distance(ii, jj, beta=beta).float().cpu().numpy().astype(np.float64).reshape(ni, nj)
+        I = np.arange(t0, t)[:, None]
+        J = np.arange(t1, t)[None, :]
+        D = np.where((I - rad < J) | ~(D <= 100), np.inf, D)         # (~(D <= 100): values above 100 and NaN drop out)
+        offsets = [(di, dj) for di in range(-nms, nms + 1) for dj in range(-nms, nms + 1)]
 
-        def suppress(i, j):
-            for di in range(-nms, nms + 1):
-                for dj in range(-nms, nms + 1):
-                    if abs(di) + abs(dj) <= max(min(abs(i - j) - 2, nms), 0):
-                        i1, j1 = i + di, j + dj
-                        if t0 <= i1 < t and t1 <= j1 < t:
-                            d[(i1 - t0) * nj + (j1 - t1)] = inf
+        def suppress_many(hi, hj):
+            """D = inf inside the diamond |di| + |dj| <= max(min(|i - j| - 2, nms), 0) around every (i, j) of (hi, hj)"""
+            r = np.maximum(np.minimum(np.abs(hi - hj) - 2, nms), 0)
+            for di, dj in offsets:
+                m = (abs(di) + abs(dj) <= r)
+                a, b = hi[m] + di - t0, hj[m] + dj - t1
+                ok = (a >= 0) & (a < ni) & (b >= 0) & (b < nj)
+                D[a[ok], b[ok]] = np.inf
 
-        have = list(zip(self._ii_h, self._jj_h)) + list(zip(self.ii_bad.tolist(), self.jj_bad.tolist())) + \
-            list(zip(self._ii_inac_h, self._jj_inac_h))
-        for i, j in have:
-            if abs(i - j) > 2:
-                suppress(i, j)
+        have_i = np.array(list(self._ii_h) + self.ii_bad.tolist() + list(self._ii_inac_h), dtype=np.int64)
+        have_j = np.array(list(self._jj_h) + self.jj_bad.tolist() + list(self._jj_inac_h), dtype=np.int64)
+        far = np.abs(have_i - have_j) > 2
+        if far.any():
+            suppress_many(have_i[far], have_j[far])
         es = []
         for i in range(t0, t):
             for j in range(i + 1, min(i + rad + 1, t)):
                 es += [(i, j), (j, i)]
-        for k in sorted(range(len(d)), key=lambda k: d[k]):          # argsort(d), stable
-            if d[k] > thresh:
+        flat = D.ravel()                                              # (a view: suppress_many writes through)
+        order = np.argsort(flat, kind="stable")
+        order = order[:int(np.count_nonzero(flat <= thresh))]        # sorted: everything behind is above the threshold already
+        for k in order.tolist():
+            if not flat[k] <= thresh:                                 # suppressed since the sort
                 continue
-            i, j = ii[k], jj[k]
+            i, j = int(ii[k]), int(jj[k])
             es += [(i, j), (j, i)]                                    # bidirectional
-            suppress(i, j)
+            suppress_many(np.array([i], dtype=np.int64), np.array([j], dtype=np.int64))
         if es:
             self.add_factors([e[0] for e in es], [e[1] for e in es], remove)
 

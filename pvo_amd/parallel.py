@@ -141,6 +141,9 @@ class ShardedBA:
             self._env_idx = None
         multi = self._world() > 1 or (self.collective_at_one and self.communicate and dist.is_available() and dist.is_initialized())
         native = hasattr(self.db, "ba_pack") and not self.torch_pack      # the HIP library packs / unpacks the message itself
+        if getattr(self, "_env_native", native) != native:                # (torch_pack / db changed between two calls on one plan:
+            self._env_idx = None                                          # the cached message index has the other form)
+        self._env_native = native
         if structure is not None and self._env_idx is None and (multi or self.always_pack):
             first = envelope_structure(structure[0], structure[1], t0, t1)
             if native:

@@ -139,6 +139,17 @@ def corr_cases():
     case("a", 2, 6, 7, 9, 11, 3, 3.0)              # level-0 like: most windows cross a border somewhere
     case("b", 2, 5, 9, 4, 6, 3, 2.0, 4.0)          # a coarse level: the window is larger than the plane
     case("c", 1, 4, 5, 8, 8, 2, 40.0)              # radius 2; most coordinates far outside (all-zero windows)
+    # ... and four coordinates as far out as a diverged pose puts them: +-1e7 (static_cast<int>(floor(x)) is still defined
+    # there, correlation_kernels.cu:49-50).  Beyond the int range (3e9) and for NaN the conversion is undefined behaviour in C++:
+    # x86 returns INT_MIN for both, PTX's cvt.rzi.s32.f32 saturates and maps NaN to 0 - what a host compilation of the text
+    # does with them says nothing about the reference, so they stay out of the fixture (tests/test_corr_lookup_gpu.py checks
+    # the HIP kernel against the oracle's saturating conversion there).
+    co_c = out[-1][2].copy()
+    co_c[0, :, 0, 0] = (1.0e7, 3.0)
+    co_c[0, :, 0, 1] = (-1.0e7, -1.0e7)
+    co_c[0, :, 1, 0] = (4.0, 1.0e7)
+    co_c[0, :, 1, 1] = (9999999.5, -9999999.5)
+    out[-1] = ("c", out[-1][1], co_c, 2)
     case("d", 1, 3, 4, 7, 5, 3, 1.0)
     # integer coordinates (dx = dy = 0), half-pixel, and the exact borders -r-1, h2+r
     co = out[-1][2].copy()

@@ -287,6 +287,79 @@ def test_proximity_factor_selection_matches_reference():
         assert int(got["remove"]) == int(z["remove_%d" % n])
 
 
+def _greedy_selection_loops(t, t0, t1, rad, nms, thresh, d, have):
+    """the reference's selection (factor_graph.py:372-429) loop for loop on a host list - the form round 4 shipped and the
+    fixture above pins - as the yardstick for the array formulation"""
+    ix, jx = list(range(t0, t)), list(range(t1, t))
+    ii = [i for i in ix for _ in jx]
+    jj = [j for _ in ix for j in jx]
+    d = list(d)
+    inf, nj = float("inf"), t - t1
+    for k, (i, j) in enumerate(zip(ii, jj)):
+        if i - rad < j or d[k] > 100:
+            d[k] = inf
+
+    def suppress(i, j):
+        for di in range(-nms, nms + 1):
+            for dj in range(-nms, nms + 1):
+                if abs(di) + abs(dj) <= max(min(abs(i - j) - 2, nms), 0):
+                    i1, j1 = i + di, j + dj
+                    if t0 <= i1 < t and t1 <= j1 < t:
+                        d[(i1 - t0) * nj + (j1 - t1)] = inf
+    for i, j in have:
+        if abs(i - j) > 2:
+            suppress(i, j)
+    es = []
+    for i in range(t0, t):
+        for j in range(i + 1, min(i + rad + 1, t)):
+            es += [(i, j), (j, i)]
+    for k in sorted(range(len(d)), key=lambda k: d[k]):
+        if d[k] > thresh:
+            continue
+        i, j = ii[k], jj[k]
+        es += [(i, j), (j, i)]
+        suppress(i, j)
+    return es
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_proximity_factor_selection_array_form_equals_the_loops(seed):
+    """random distance matrices (ties, values above 100, windows of the frontend's and the backend's shapes) and random existing
+    edges: the array formulation selects the same edges in the same order as the reference's loops"""
+    import numpy as np
+    from pvo_amd.factor_graph import FactorGraph
+    g = np.random.default_rng(seed)
+    t = int(g.integers(8, 40))
+    t0, t1 = (int(g.integers(0, t - 2)), int(g.integers(0, t - 2))) if seed % 2 else (0, 0)
+    rad, nms = int(g.integers(1, 4)), int(g.integers(0, 4))
+    thresh = float(g.uniform(2.0, 30.0))
+    full = np.round(g.uniform(0.0, 60.0, (t, t)), 1).astype(np.float32)        # one decimal: ties
+    full[g.uniform(size=(t, t)) < 0.05] = 250.0
+    n_have = int(g.integers(0, 60))
+    have = [(int(a), int(b)) for a, b in zip(g.integers(0, t, n_have), g.integers(0, t, n_have))]
+    third = len(have) // 3
+
+    class Video:
+        pass
+    v = Video()
+    v.ht, v.wd, v.counter, v.segm_filter = 64, 64, t, False
+    v.disps = torch.ones(t, 8, 8)
+    dmat = torch.from_numpy(full)
+    v.distance = lambda ii, jj, beta=0.3: dmat[torch.as_tensor(ii).long(), torch.as_tensor(jj).long()].clone()
+    fg = FactorGraph(v, None, device="cpu")
+    a, b, c = have[:third], have[third:2 * third], have[2 * third:]
+    fg._ii_h, fg._jj_h = [e[0] for e in a], [e[1] for e in a]
+    fg.ii_bad, fg.jj_bad = torch.tensor([e[0] for e in b], dtype=torch.long), torch.tensor([e[1] for e in b], dtype=torch.long)
+    fg._ii_inac_h, fg._jj_inac_h = [e[0] for e in c], [e[1] for e in c]
+    got = {}
+    fg.add_factors = lambda ii, jj, remove=False: got.update(es=list(zip(ii, jj)))
+    fg.add_proximity_factors(t0, t1, rad=rad, nms=nms, beta=0.3, thresh=thresh)
+    ix, jx = list(range(t0, t)), list(range(t1, t))
+    d = [float(full[i, j]) for i in ix for j in jx]
+    want = _greedy_selection_loops(t, t0, t1, rad, nms, thresh, d, a + b + c)
+    assert got.get("es", []) == want
+
+
 def test_edge_bookkeeping_matches_reference():
     """add_neighborhood_factors / add_factors (duplicates, age-based eviction with storage) / rm_keyframe / rm_factors
     against the reference's FactorGraph on a mock video (tests/golden/gen_golden.py: gen_bookkeeping), state compared after

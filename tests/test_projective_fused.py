@@ -83,3 +83,29 @@ def test_the_differentiable_ba_runs_on_the_fused_kernels_and_matches(cuda):
     for a, b in zip(got, want):
         assert (a - b).abs().max() <= 1e-9 * max(1.0, b.abs().max().item())
     assert want[2].abs().max() > 1e-6
+
+
+def test_frame_indices_outside_the_buffer_are_contained(cuda):
+    """the fused kernels index poses / depths / intrinsics with ii, jj.  A negative index counts from the end, as in
+    the torch formulation (which wraps it); an index still outside [0, P) - an IndexError there - gives that edge NaN coordinates,
+    validity 0 and no gradient, instead of reads and atomics beside the buffers; the other edges are untouched."""
+    from pvo_amd import droid_backends as db
+    xi, depths, intr, ii, jj = _case(cuda, torch.float64)
+    poses = SE3.exp(xi).data.contiguous()
+    P = depths.shape[1]
+    ref, ref_v = db.proj_transform(poses, depths, intr, ii, jj)
+    neg_i = torch.where(ii == P - 1, torch.full_like(ii, -1), ii)                  # frame P - 1 spelled -1
+    got, got_v = db.proj_transform(poses, depths, intr, neg_i, jj)
+    assert torch.equal(got, ref) and torch.equal(got_v, ref_v)
+    bad = jj.clone(); bad[2] = P + 3; bad[5] = -P - 1
+    got, got_v, (Ji, Jj, Jz) = db.proj_transform(poses, depths, intr, ii, bad, jacobian=True)
+    for n in range(ii.shape[0]):
+        if n in (2, 5):
+            assert torch.isnan(got[:, n]).all() and not got_v[:, n].any() and torch.isnan(Ji[:, n]).all()
+        else:
+            assert torch.equal(got[:, n], ref[:, n]) and torch.equal(got_v[:, n], ref_v[:, n])
+    g = torch.ones_like(ref)
+    gp, gd = db.proj_transform_vjp(poses, depths, intr, ii, bad, g, None, None, None)
+    keep = torch.tensor([n for n in range(ii.shape[0]) if n not in (2, 5)], device=ii.device)
+    gp2, gd2 = db.proj_transform_vjp(poses, depths, intr, ii[keep].contiguous(), jj[keep].contiguous(), g[:, keep].contiguous(), None, None, None)
+    assert torch.isfinite(gp).all() and torch.allclose(gp, gp2, rtol=1e-12, atol=1e-12) and torch.allclose(gd, gd2, rtol=1e-12, atol=1e-12)

@@ -24,7 +24,8 @@ from pvo_amd import droid_backends as db
 from test_geom_ba_gpu import _scene
 dev = torch.device("cuda:0")
 nf = int(os.environ.get("NF", "8"))
-s = _scene(0, nf, 48, 64, 3, 1)
+s = _scene(0, nf, int(os.environ.get("HT", "48")), int(os.environ.get("WD", "64")), int(os.environ.get("RAD", "3")), 1)      # RAD 8: frames with 16 neighbours (a frontend window with its inactive edges)
+print("keyframes %d, edges %d, map %s x %s, radius %s" % (nf, s["ii"].shape[0], os.environ.get("HT", "48"), os.environ.get("WD", "64"), os.environ.get("RAD", "3")))
 d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()}
 lib = _lib.load()
 lib.pvo_debug_ba_wg_probe.restype = ctypes.c_int; lib.pvo_debug_ba_wg_probe.argtypes = [ctypes.c_void_p]
@@ -50,7 +51,7 @@ def show(name, k, labels, last):
             dtt = (a[ok, j] - a[ok, i]) * 0.01
             print("    %-58s median %6.2f us   max %6.2f   (%d workgroups)" % (lab, np.median(dtt), dtt.max(), ok.sum()))
 show("ba_assemble_kernel", 0, [(0, 1, "entry -> pixel terms computed, rows stored"), (1, 2, "the waves' 90 sums (reduce-scatter) + barrier"), (2, 3, "chunk sums stored / atomics issued"), (0, 3, "whole workgroup")], 3)
-show("ba_schur_mfma_kernel", 1, [(0, 1, "entry -> meta read (the chunk sums are other workgroups' now)"), (1, 2, "edge list -> LDS"), (2, 3, "depth phase (C, w, Q, Ei) issued"),
-                                 (3, 4, "row table + barrier (depth rows visible)"), (4, 5, "row loads + MFMA, PIX / 64 steps (wave 0)"), (5, 6, "products -> LDS + barrier"),
-                                 (6, 7, "4-wave sums + fixed-point atomics"), (0, 7, "whole workgroup")], 7)
+show("ba_schur_mfma_kernel", 1, [(0, 1, "entry -> meta read (the chunk sums are other workgroups' now)"), (1, 2, "edge list -> LDS"), (2, 3, "row table + barrier"),
+                                 (3, 4, "depth phase (C, w, Q, Ei) + barrier (rows visible)"), (4, 5, "fast path: row loads + MFMA, PIX / 64 steps (wave 0)"), (5, 6, "fast path: products -> LDS + barrier"),
+                                 (6, 7, "fast path: 4-wave sums + fixed-point atomics"), (4, 7, "all tile pairs (fast path or this slice's row passes)"), (0, 7, "whole workgroup (slice 0)")], 7)
 show("ba_backsub_kernel", 2, [(0, 1, "rows / dx -> LDS + barrier"), (1, 2, "rows x dx, depth update"), (0, 2, "whole workgroup")], 2)
