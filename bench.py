@@ -23,7 +23,9 @@ duration = HIP events around it inside the timed steps minus what an event pair 
 "roofline_wide_conv" (matrix-core roofline of the wide 3x3 convolution, the kernel with the largest share of the step,
 with the shader clock the chip sustains under it and inside a step: pvo_clock_probe), "stage_us_in_step", "host",
 "workload_S_A" (the reference driver's 30x101 maps), "workload_S_1" (configs[0]: one tools/test_vo2.py clip at 47x156 maps),
-"train_step" (configs[4]: one tools/train.py optimizer step at S-T size, bf16 volume), "edge_sharded" (64-keyframe global
+"train_step" (configs[4]: one tools/train.py optimizer step at S-T size, bf16 volume), "sequence" (configs[1]'s FULL SEQUENCE: Droid.track
+per frame + Droid.terminate on a seeded synthetic 240x808 stream - frames/s, keyframe updates/s, graph updates/s with every stage of the
+pipeline in the loop, and the split by component), "edge_sharded" (64-keyframe global
 update, edges sharded over the ranks, one integer all-reduce of the pose system's envelope per Gauss-Newton step; at N > 1
 with the one-GPU time of the same job and the speed-up against it), "cpu_baseline" (the reference's CPU formulations timed on
 this host, rank 0, N=1), "ate_rmse" (synthetic closed loop; ground-truth correspondences stand in for the learned operator -
@@ -1001,6 +1003,34 @@ def main():
     idle_ghz = db.clock_ghz(idle_clk)
     gates_us, gates_ghz = gates_run(20, False)
     gates_zero_us, gates_zero_ghz = gates_run(20, True)
+
+    # what the vendor's GEMM sustains on this box under the same conditions (random fp16 operands, back to back, the clock the
+    # chip holds meanwhile): the gate convolution's own implicit-GEMM shape [E*H*W, 9*320] x [9*320, 256] - with none of the
+    # convolution's halo handling, segment gathers or GRU epilogue - and a large square one (the guide's 1.25 PFLOP/s figure)
+    def gemm_run(M, K, N, n=20):
+        A = torch.randn(M, K, device=device).half()
+        Bm = torch.randn(K, N, device=device).half()
+        for _ in range(3):
+            torch.matmul(A, Bm)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        clk = None
+        for i in range(n):
+            torch.matmul(A, Bm)
+            if i == 4:
+                side.wait_stream(torch.cuda.current_stream())
+                clk = db.clock_probe(side, iters=4000)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        return {"shape": [M, K, N], "us": us, "tflops": 2.0 * M * K * N / (us * 1e-6) / 1e12, "frac": 2.0 * M * K * N / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                "shader_clock_ghz": db.clock_ghz(clk)}
+    try:
+        vendor_gemm = {"same_shape_as_the_gate_convolution": gemm_run(Eg * H8 * W8, 9 * 320, 256), "square_8192": gemm_run(8192, 8192, 8192, n=10),
+                       "library": "hipBLASLt / rocBLAS through torch.matmul, fp16, random operands, back to back"}
+    except Exception as e:
+        vendor_gemm = {"error": repr(e)}
     gates_flop = 2.0 * Eg * H8 * W8 * 9 * 320 * 256
     # the clock inside a full step (probe beside the third graph update of an extra, untimed step)
     step_clk = []
@@ -1047,6 +1077,7 @@ def main():
                 "zero_operands_us": gates_zero_us, "zero_operands_frac": gates_flop / (gates_zero_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
                 "frac_of_peak_at_sustained_clock": gates_flop / (gates_us * 1e-6) / 1e12 / (MFMA_PEAK_TFLOPS * gates_ghz / 2.4),
                 "note": "power-limited: on random operands the chip drops from 2.4 GHz to the clock above, and the dense peak scales with it",
+                "vendor_gemm": vendor_gemm,
                 "share_of_update_time": stage_us["gates"] / stage_us["update"] if stage_us["update"] else None},
             "stage_us_in_step": dict(stage_us, lookup=1e3 * sum(in_step_lookup) / max(len(in_step_lookup), 1)),
         }
