@@ -309,6 +309,16 @@ int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, l
  *                     10 (1-bin)); full_flow = coords1 + delta_dy - coords0; target_ba / weight_ba [E,2,H,W] are the
  *                     layouts pvo_ba reads                                                (:249-306)
  * target / delta_dy may alias the tensors pvo_graph_motion read. */
+/* Per-frame encoders (round 5).  Reference: BasicEncoder / ResidualBlock, VO_Module/droid_slam/modules/extractor.py:6-56,116-201, run
+ * once per frame by MotionFilter.track (motion_filter.py:52-60) under fp16 autocast.  No native entry point exists for them in
+ * droid.cpp (cuDNN + ATen element-wise kernels do the work); here everything BETWEEN two convolutions of an encoder layer is one
+ * kernel: t = x + bias[c]; if norm: instance norm over the plane (biased variance, fp32 statistics, eps); if relu_inner: relu;
+ * if residual: t = residual + t; if relu_outer: relu - every step rounded to `dtype` (PVO_F16 / PVO_BF16) as the separate
+ * ATen kernels round it.  x, residual (or NULL), y: [planes = N * C, HW] contiguous planes (NCHW), 4-byte aligned; bias [C] in
+ * `dtype` or NULL.  y may alias x. */
+int pvo_bias_norm_act(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
+                      int norm, float eps, int relu_inner, int relu_outer, int dtype, void* stream);
+
 /* (pvo_graph_motion: inside pvo_graph_update the motion features are written by pvo_reproject_motion since round 3; this
  * entry point serves pvo_update_operator callers that reproject themselves, and tests) */
 int pvo_graph_motion(const float* target, const float* coords1, const float* delta_dy, const float* raw_mask,

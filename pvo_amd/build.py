@@ -28,6 +28,7 @@ HIP_SOURCES = [
     "operator_small.hip",
     "update_exec.hip",
     "se3_ops.hip",
+    "encoder_ops.hip",
     "ba.hip",
 ]
 # -target-feature -packed-fp32-ops: NO v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32 in the device code.  On MI355X

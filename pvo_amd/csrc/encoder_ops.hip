@@ -1,0 +1,122 @@
+// encoder_ops.hip — what follows every convolution of the per-frame encoders, as ONE kernel per layer.
+//
+// The reference's BasicEncoder (VO_Module/droid_slam/modules/extractor.py:116-201; ResidualBlock :6-56) runs once per frame in
+// MotionFilter.track (motion_filter.py:52-60) under fp16 autocast.  Per convolution PyTorch issues: the convolution (MIOpen), the
+// bias add, instance norm as batch_norm_collect_statistics + a 256-element kernel for invstd + batch_norm_transform_input, ReLU, and
+// per residual block an add and another ReLU - ~95 kernels of 4-20 us per network even when replayed from a HIP graph, 0.9 ms of a
+// tracked frame's 1.4 ms (bench.py `sequence`, profiles/r05_sequence_timeline.txt).  pvo_bias_norm_act is everything between two
+// convolutions:
+//     t = round16(x + bias[c])                                   (the convolution's bias, as `conv(x) + b` rounds it)
+//     t = round16((t - mean) * rsqrt(var + eps))   if norm        (InstanceNorm2d, affine = False: biased variance over the plane,
+//                                                                 fp32 statistics - what batch_norm computes for a 16-bit input)
+//     t = max(t, 0)                                if relu_inner
+//     t = round16(residual + t)                    if residual   (ResidualBlock's x + y)
+//     t = max(t, 0)                                if relu_outer
+// x, residual, y: [N, C, HW] planes (NCHW, contiguous), 16-bit; one workgroup per plane: the plane (6-97 KB) is read from L2 three
+// times (mean, variance about the mean, output) - the statistics are two-pass, not E[x^2] - E[x]^2.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float eo_val(uint16_t b);
+template <> __device__ __forceinline__ float eo_val<pvo_half>(uint16_t b) {
+  union { uint16_t u; _Float16 h; } c; c.u = b; return static_cast<float>(c.h);
+}
+template <> __device__ __forceinline__ float eo_val<pvo_bf16>(uint16_t b) { return pvo_bf16_to_f32(b); }
+template <typename T> __device__ __forceinline__ uint16_t eo_bits(float x);
+template <> __device__ __forceinline__ uint16_t eo_bits<pvo_half>(float x) {
+  union { _Float16 h; uint16_t u; } c; c.h = static_cast<_Float16>(x); return c.u;
+}
+template <> __device__ __forceinline__ uint16_t eo_bits<pvo_bf16>(float x) { return pvo_f32_to_bf16(x); }
+template <typename T> __device__ __forceinline__ float eo_round(float x) { return eo_val<T>(eo_bits<T>(x)); }
+
+// sum over the workgroup (every thread gets it); `red` holds one float per wave
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = pvo_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();                                    // (`red` may still be read from the previous sum)
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.0f;
+  for (int w = 0; w < nw; ++w) s += red[w];
+  return s;
+}
+
+template <typename T>
+__global__ void bias_norm_act_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual,
+                                     uint16_t* __restrict__ y, int C, int HW, int norm, float eps, int relu_inner, int relu_outer) {
+  __shared__ float red[16];
+  const long long plane = blockIdx.x;
+  const int c = static_cast<int>(plane % C);
+  const uint16_t* xp = x + plane * HW;
+  const uint16_t* rp = residual ? residual + plane * HW : nullptr;
+  uint16_t* yp = y + plane * HW;
+  const float b = bias ? eo_val<T>(bias[c]) : 0.0f;
+  const bool pairs = (HW & 1) == 0;                   // planes of an even pixel count are read / written two values at a time
+  float mean = 0.0f, invstd = 1.0f;
+  if (norm) {
+    float s = 0.0f;
+    if (pairs) {
+      for (int i = threadIdx.x; i < HW / 2; i += blockDim.x) {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(xp)[i];
+        s += eo_round<T>(eo_val<T>(static_cast<uint16_t>(v & 0xffffu)) + b) + eo_round<T>(eo_val<T>(static_cast<uint16_t>(v >> 16)) + b);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) s += eo_round<T>(eo_val<T>(xp[i]) + b);
+    }
+    mean = block_sum(s, red) / static_cast<float>(HW);
+    float q = 0.0f;
+    if (pairs) {
+      for (int i = threadIdx.x; i < HW / 2; i += blockDim.x) {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(xp)[i];
+        const float d0 = eo_round<T>(eo_val<T>(static_cast<uint16_t>(v & 0xffffu)) + b) - mean;
+        const float d1 = eo_round<T>(eo_val<T>(static_cast<uint16_t>(v >> 16)) + b) - mean;
+        q += d0 * d0 + d1 * d1;
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = eo_round<T>(eo_val<T>(xp[i]) + b) - mean; q += d * d; }
+    }
+    invstd = 1.0f / sqrtf(block_sum(q, red) / static_cast<float>(HW) + eps);
+  }
+  auto finish = [&](uint16_t xv, uint16_t rv) -> uint16_t {
+    float t = eo_round<T>(eo_val<T>(xv) + b);
+    if (norm) t = eo_round<T>((t - mean) * invstd);
+    if (relu_inner) t = fmaxf(t, 0.0f);
+    if (rp) t = eo_round<T>(eo_val<T>(rv) + t);
+    if (relu_outer) t = fmaxf(t, 0.0f);
+    return eo_bits<T>(t);
+  };
+  if (pairs) {
+    for (int i = threadIdx.x; i < HW / 2; i += blockDim.x) {
+      const uint32_t v = reinterpret_cast<const uint32_t*>(xp)[i];
+      const uint32_t r = rp ? reinterpret_cast<const uint32_t*>(rp)[i] : 0u;
+      const uint32_t lo = finish(static_cast<uint16_t>(v & 0xffffu), static_cast<uint16_t>(r & 0xffffu));
+      const uint32_t hi = finish(static_cast<uint16_t>(v >> 16), static_cast<uint16_t>(r >> 16));
+      reinterpret_cast<uint32_t*>(yp)[i] = lo | (hi << 16);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) yp[i] = finish(xp[i], rp ? rp[i] : static_cast<uint16_t>(0));
+  }
+}
+
+}  // namespace
+
+extern "C" int pvo_bias_norm_act(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
+                                 int norm, float eps, int relu_inner, int relu_outer, int dtype, void* stream) {
+  if (planes < 0 || C <= 0 || HW < 0 || (planes % C) != 0) return PVO_EINVAL;
+  if (planes == 0 || HW == 0) return PVO_OK;
+  if (!x || !y || planes > 0x7fffffffLL) return PVO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 3) return PVO_EINVAL;
+  const int threads = HW >= 16384 ? 1024 : (HW >= 2048 ? 512 : 256);
+  const dim3 grid(static_cast<unsigned>(planes));
+  hipStream_t st = pvo_stream(stream);
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(bias_norm_act_kernel<pvo_half>, grid, dim3(threads), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(bias),
+                       static_cast<const uint16_t*>(residual), static_cast<uint16_t*>(y), C, HW, norm, eps, relu_inner, relu_outer);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(bias_norm_act_kernel<pvo_bf16>, grid, dim3(threads), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(bias),
+                       static_cast<const uint16_t*>(residual), static_cast<uint16_t*>(y), C, HW, norm, eps, relu_inner, relu_outer);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}

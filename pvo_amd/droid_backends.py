@@ -1188,6 +1188,28 @@ def update_operator(weights, net, motion, inp=None, P=None, pool=None, coords=No
     return net_out, heads, eta, upmask
 
 
+def bias_norm_act(x, bias=None, residual=None, norm=False, eps=1e-5, relu_inner=False, relu_outer=False, out=None):
+    """what sits between two convolutions of an encoder layer, as one kernel (pvo_bias_norm_act): x [N,C,H,W] contiguous 16-bit ->
+    relu_outer(residual + relu_inner(instance_norm(x + bias[c]))), every step rounded to x's dtype.  `out` may be x itself."""
+    dev = _dev(x, bias, residual)
+    _contig(x, "x")
+    if x.dim() != 4 or x.dtype not in (torch.float16, torch.bfloat16):
+        raise PvoHipError("bias_norm_act: x must be a contiguous 16-bit [N,C,H,W] tensor")
+    N, C, H, W = x.shape
+    for t, n in ((bias, "bias"), (residual, "residual")):
+        if t is not None:
+            _contig(t, n)
+            if t.dtype != x.dtype:
+                raise PvoHipError("bias_norm_act: %s must have x's dtype" % n)
+    if bias is not None and bias.numel() != C or residual is not None and residual.shape != x.shape:
+        raise PvoHipError("bias_norm_act: bias [C], residual of x's shape")
+    y = torch.empty_like(x) if out is None else out
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_bias_norm_act(_ptr(x), _vp(bias), _vp(residual), _ptr(y), N * C, C, H * W, 1 if norm else 0, float(eps),
+                                            1 if relu_inner else 0, 1 if relu_outer else 0, _dtype_code(x, "x"), _stream(dev)), "bias_norm_act")
+    return y
+
+
 def debug_config(knob, value):
     """the library's test hook (include/pvo_hip.h pvo_debug_config): "ba_solver" = None | "blocked" | "wave" | "pipe" | "twin",
     "heads_gather_flat" = bool, "no_riders" = bool.  Process-wide; tests that compare bit-identical forms call it in a process of

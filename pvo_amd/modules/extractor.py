@@ -6,8 +6,14 @@ with `load_state_dict` and a seeded construction gives identical weights.
 
 These run once per frame (MotionFilter) and are vendor-library convolutions (MIOpen); they are
 caller-side plumbing of the hot path, not a hand-written kernel.
+
+Round 5: `BasicEncoder.forward_inference` is the same network for 16-bit inference on the GPU with everything BETWEEN the
+convolutions - bias, instance norm, ReLU, the residual add - as one kernel per layer (`pvo_bias_norm_act`): 36 launches instead
+of ~95 per network and frame (the full-sequence run of bench.py spends a tracked frame's 0.9 of 1.4 ms in those small kernels).
 """
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 DIM = 32
 
@@ -43,6 +49,24 @@ class ResidualBlock(nn.Module):
         if self.downsample is not None:
             x = self.downsample(x)
         return self.relu(x + y)
+
+    def forward_inference(self, x, norm, act):
+        """the same block on a 16-bit NCHW tensor: convolutions without their bias, `act` (droid_backends.bias_norm_act) for the rest"""
+        y = act(_conv(self.conv1, x), _b(self.conv1, x), None, norm, True, False)
+        y2 = _conv(self.conv2, y)
+        if self.downsample is not None:
+            d = self.downsample[0]
+            x = act(_conv(d, x), _b(d, x), None, norm, False, False)
+        return act(y2, _b(self.conv2, x), x, norm, True, True, out=y2)          # relu(x + relu(norm2(conv2(y))))
+
+
+def _conv(m, x):
+    w = m.weight if m.weight.dtype == x.dtype else m.weight.to(x.dtype)
+    return F.conv2d(x, w, None, m.stride, m.padding)
+
+
+def _b(m, x):
+    return None if m.bias is None else (m.bias if m.bias.dtype == x.dtype else m.bias.to(x.dtype))
 
 
 class BasicEncoder(nn.Module):
@@ -83,3 +107,24 @@ class BasicEncoder(nn.Module):
         x = self.relu1(self.norm1(self.conv1(x.reshape(b * n, c, h, w))))
         x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         return x.view(b, n, *x.shape[1:])
+
+    def forward_inference(self, x, dtype=torch.float16):
+        """forward() for 16-bit inference on the GPU (what fp16 autocast computes: every convolution, norm and add in `dtype`),
+        the work between the convolutions fused per layer.  Falls back to forward() where that does not apply."""
+        if not x.is_cuda or torch.is_grad_enabled() or self.training or self.norm_fn not in ("instance", "none") or self.dropout is not None:
+            return self.forward(x)
+        from .. import droid_backends as db
+        norm = self.norm_fn == "instance"
+        eps = 1e-5
+
+        def act(t, bias, residual, nrm, relu_in, relu_out, out=None):
+            return db.bias_norm_act(t.contiguous(), bias, residual, norm=nrm, eps=eps, relu_inner=relu_in, relu_outer=relu_out,
+                                    out=out if out is not None and out.is_contiguous() else None)
+        b, n, c, h, w = x.shape
+        t = x.reshape(b * n, c, h, w).to(dtype)
+        t = act(_conv(self.conv1, t), _b(self.conv1, t), None, norm, True, False)
+        for layer in (self.layer1, self.layer2, self.layer3):
+            for block in layer:
+                t = block.forward_inference(t, norm, act)
+        t = act(_conv(self.conv2, t), _b(self.conv2, t), None, False, False, False)
+        return t.view(b, n, *t.shape[1:])

@@ -34,6 +34,7 @@ class MotionFilter:
         self.MEAN = torch.as_tensor([0.485, 0.456, 0.406], device=self.device)[:, None, None]
         self.STDV = torch.as_tensor([0.229, 0.224, 0.225], device=self.device)[:, None, None]
         self.net = self.inp = self.fmap = None
+        self.fused_encoders = True         # BasicEncoder.forward_inference: bias / instance norm / ReLU / residual add as one kernel per layer
         self.keep_features = True          # every frame's feature map stays resident for the trajectory filler (DepthVideo.remember_features)
         self._coords0 = None
         self._features_g = GraphedCall(self._features_dev, name="fnet", guard=_weights_guard(self.fnet))
@@ -61,7 +62,7 @@ class MotionFilter:
     def _features_dev(self, image_dev):
         """frame on the device -> feature map [1,128,h,w]"""
         with self._autocast():
-            return self.fnet(self._normalise_dev(image_dev)).squeeze(0)
+            return self._encode(self.fnet, self._normalise_dev(image_dev)).squeeze(0)
 
     def _context_dev(self, image_dev):
         with self._autocast():
@@ -89,8 +90,13 @@ class MotionFilter:
     def _autocast(self):
         return torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda")
 
+    def _encode(self, net, x):
+        """an encoder on the GPU inference path: its fused per-layer form (BasicEncoder.forward_inference) where it has one"""
+        fused = getattr(net, "forward_inference", None) if self.device.type == "cuda" and self.fused_encoders else None
+        return fused(x) if fused is not None else net(x)
+
     def _context(self, x):
-        net, inp = self.cnet(x).split([128, 128], dim=2)
+        net, inp = self._encode(self.cnet, x).split([128, 128], dim=2)
         return net.tanh().squeeze(0), inp.relu().squeeze(0)
 
     def _normalise(self, image):

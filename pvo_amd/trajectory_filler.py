@@ -26,7 +26,8 @@ class PoseTrajectoryFiller:
         """one frame [3,H,W] on the device -> [1,128,h,w]"""
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
             x = image_dev.flip(0)[None, None].float() / 255.0
-            return self.fnet((x - self.MEAN) / self.STDV).squeeze(0)
+            enc = getattr(self.fnet, "forward_inference", self.fnet)
+            return enc((x - self.MEAN) / self.STDV).squeeze(0)
 
     def _features(self, images):
         """feature maps of a chunk of frames [M,3,H,W].  On the GPU frame by frame through ONE captured graph: the encoder is
