@@ -497,7 +497,7 @@ def lookup_traffic():
     of the kernel (it records the sha256 of corr_lookup.hip); otherwise None: a counter value is not carried over a code change"""
     import hashlib
     sha = hashlib.sha256(open(os.path.join(ROOT, "pvo_amd", "csrc", "corr_lookup.hip"), "rb").read()).hexdigest()
-    for name in ("r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json"):
+    for name in ("r05_lookup_pmc.json", "r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
