@@ -830,6 +830,8 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
         buf = io.StringIO()
         pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(70)
         pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(45)
+        for fn in ("as_tensor", "'to' of", "'item' of", "'cpu' of", "'tolist' of"):
+            pstats.Stats(pr, stream=buf).sort_stats("tottime").print_callers(fn)
         with open(cprofile, "w") as f:
             f.write(buf.getvalue())
     sp = _Split()

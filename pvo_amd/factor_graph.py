@@ -569,6 +569,17 @@ class FactorGraph:
                 ok = (a >= 0) & (a < ni) & (b >= 0) & (b < nj)
                 D[a[ok], b[ok]] = np.inf
 
+        diamonds = [np.add.outer(np.abs(np.arange(-r, r + 1)), np.abs(np.arange(-r, r + 1))) <= r for r in range(nms + 1)]
+
+        def suppress_one(i, j):
+            """the same for ONE accepted edge: a masked assignment on the (2r + 1)^2 window, clipped to the array"""
+            r = max(min(abs(i - j) - 2, nms), 0)
+            a0, b0 = i - r - t0, j - r - t1
+            a1, b1 = a0 + 2 * r + 1, b0 + 2 * r + 1
+            ca0, cb0, ca1, cb1 = max(a0, 0), max(b0, 0), min(a1, ni), min(b1, nj)
+            if ca0 < ca1 and cb0 < cb1:
+                D[ca0:ca1, cb0:cb1][diamonds[r][ca0 - a0:ca1 - a0, cb0 - b0:cb1 - b0]] = np.inf
+
         have_i = np.array(list(self._ii_h) + self.ii_bad.tolist() + list(self._ii_inac_h), dtype=np.int64)
         have_j = np.array(list(self._jj_h) + self.jj_bad.tolist() + list(self._jj_inac_h), dtype=np.int64)
         far = np.abs(have_i - have_j) > 2
@@ -586,7 +597,7 @@ class FactorGraph:
                 continue
             i, j = int(ii[k]), int(jj[k])
             es += [(i, j), (j, i)]                                    # bidirectional
-            suppress_many(np.array([i], dtype=np.int64), np.array([j], dtype=np.int64))
+            suppress_one(i, j)
         if es:
             self.add_factors([e[0] for e in es], [e[1] for e in es], remove)
 
