@@ -2498,7 +2498,11 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     const int pix = wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024);
     const int gx = (HW + pix - 1) / pix;
     const int deal_rows = two_stage ? (E + 2 * gx - 1) / (2 * gx) : 0;      // workgroups that add up the assembly's chunk sums: two edges each
-    const dim3 sgrid(gx, Kmax + deal_rows, 4);       // (z: slices for the row-tile passes of many-neighbour frames, see ba_schur_body)
+    // rows of the grid = depth frames: the caller's eta has one row per depth frame (K_eta == K, checked by the plan kernel and
+    // reported in the status words), so that is the count; only a broadcast eta (one row) leaves the host with the bound P + E -
+    // which at a real window's 48 + 400 edges meant 454 grid rows x 12 chunks x 4 slices for 27 depth frames
+    const int Kgrid = (K_eta > 1 && K_eta <= Kmax) ? K_eta : Kmax;
+    const dim3 sgrid(gx, Kgrid + deal_rows, 4);      // (z: slices for the row-tile passes of many-neighbour frames, see ba_schur_body)
 #define PVO_SCHUR_LAUNCH(V, PX) hipLaunchKernelGGL((ba_schur_mfma_kernel<V, PX>), sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, \
                                                    w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA, deal_rows)
     if ((HW & 3) == 0) { if (pix == 256) PVO_SCHUR_LAUNCH(true, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(true, 512); else PVO_SCHUR_LAUNCH(true, 1024); }
