@@ -739,6 +739,11 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
         counts["graph_updates"] += 1
         r = gupd(*a, **kw)
         st = fe.graph._cache.get("fused")
+        if st is not None and counts["graph_updates"] == 600 and os.environ.get("PVO_BENCH_DUMP_BA"):      # (tools/ba_kernel_timeline.py BA_DUMP=...)
+            v = fe.graph.video
+            torch.save({k: (x.detach().cpu() if torch.is_tensor(x) else x) for k, x in dict(
+                poses=v.poses, disps=v.disps, intr=v.intrinsics[0], target=st["target_ba"], weight=st["weight_ba"], ii=st["ii_ba"], jj=st["jj_ba"],
+                t0=st["key"][1], t1=st["key"][2], rows=st["frames"], damping=fe.graph.damping).items()}, os.environ["PVO_BENCH_DUMP_BA"])
         if st is not None and counts["graph_updates"] % 50 == 0:          # what a BA of this run looks like (host lists only)
             g = fe.graph
             m_l = [(i >= st["key"][1] - 3) and (j >= st["key"][1] - 3) for i, j in zip(g._ii_inac_h, g._jj_inac_h)]

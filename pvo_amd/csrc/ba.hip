@@ -95,6 +95,7 @@ struct Ws {
   long long* sys;        // [(6P)^2 + 6P] fixed point
   double* chol;          // [(6P)^2 + 6P] scratch for the global-memory factorisation
   double* xchg;          // partitioned pose solve: [2 doubles = 4 ints: flags, split | separator terms | separator solution] (kXchgDoubles)
+  float* Mrg;            // [E][6][HW]: the summed Eij rows of edges that share source AND target frame (Schur kernel), at the first one's index
   size_t bytes;
 };
 
@@ -126,6 +127,7 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   // (both at every size: a packed envelope message - pvo_ba_finish_packed - is factorised from the compact image whatever P is)
   w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 * n6 + n6 + 27 * (n6 / 6) + 32)));
   w.xchg = reinterpret_cast<double*>(take(sizeof(double) * kXchgDoubles));
+  w.Mrg = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * 6 * HW));
   w.bytes = off;
   return w;
 }
@@ -304,10 +306,6 @@ __device__ __forceinline__ void pose_block_scatter(int t, double val, int pi, in
   }
 }
 
-#ifdef PVO_SCHED_DEBUG
-__device__ unsigned long long* g_dbg_log_ba = nullptr;       // see graph_glue.hip
-__device__ float* g_dbg_partials = nullptr;                   // [E][chunks][4 waves][90]: every wave's sums BEFORE they cross LDS
-#endif
 __global__ __launch_bounds__(256) void ba_assemble_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps, const float* __restrict__ intr,
     const float* __restrict__ targets, const float* __restrict__ weights,
@@ -320,12 +318,6 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   // a sixth of the atomics, issued while its own work starts.
   __shared__ float red[4][90];
   BA_WG_PROBE(0, 0);
-#ifdef PVO_SCHED_DEBUG
-  if (g_dbg_log_ba && threadIdx.x == 0) {
-    const unsigned long long i_ = atomicAdd(&g_dbg_log_ba[0], 1ull);
-    if (i_ < 16000ull) g_dbg_log_ba[1 + i_] = (2ull << 62) | (wall_clock64() & ((1ull << 62) - 1));
-  }
-#endif
   const int e = blockIdx.y;
   const int ix = static_cast<int>(ii[e]), jx = static_cast<int>(jj[e]);
   EdgeGeom g;
@@ -367,7 +359,6 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
   // (i <-> 15 - i, i <-> 7 - i, i <-> 3 - i) and quad_perm [1,0,3,2]; which half a lane keeps is its bit 5, 4, 3, 2, 1 in turn,
   // so lane L ends with the sums of entries [48 b5 + 24 b4 + 12 b3 + 6 b2 + 3 b1, + 3).  A fixed order of additions, as before.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifndef PVO_SCHED_DEBUG
   {
     float c[96];
 #pragma unroll
@@ -412,28 +403,6 @@ __global__ __launch_bounds__(256) void ba_assemble_kernel(
         if (start + q < 90) red[wave][start + q] = c[q];
     }
   }
-#else
-  // (the schedule-debug build keeps the ninety separate reductions: tools/sched_bisect.py dumps every wave's sums before LDS)
-#pragma unroll
-  for (int l = 0; l < 78; ++l) {
-    const float s = pvo_wave_sum(h[l]);
-    if (lane == 0) red[wave][l] = s;
-#ifdef PVO_SCHED_DEBUG
-    if (g_dbg_partials && lane == 0) g_dbg_partials[((static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 90 + l] = s;
-#endif
-  }
-#pragma unroll
-  for (int n = 0; n < 6; ++n) {
-    const float a = pvo_wave_sum(vi[n]), b = pvo_wave_sum(vj[n]);
-    if (lane == 0) { red[wave][78 + n] = a; red[wave][84 + n] = b; }
-#ifdef PVO_SCHED_DEBUG
-    if (g_dbg_partials && lane == 0) {
-      g_dbg_partials[((static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 90 + 78 + n] = a;
-      g_dbg_partials[((static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 90 + 84 + n] = b;
-    }
-#endif
-  }
-#endif
   __syncthreads();
   BA_WG_PROBE(0, 2);                     // wave reductions done
   const int t = threadIdx.x;
@@ -479,7 +448,8 @@ __device__ __forceinline__ void depth_pixel(const Plan& pl, int k, int x, const 
   // iteration was two dependent round trips (eidx[o], then the rows of edge e) - 6 x 2 of them in front of the first product
   const bool self_in = pself >= 0 && pself < P;
   float C = 0.0f, ww = 0.0f, ei[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 2
+  // (six edges' 48 loads in flight: a frame of a real window has ~18 out-edges and this loop was a third of the kernel at unroll 2)
+#pragma unroll 6
   for (int o = 0; o < deg; ++o) {
     const int e = edges[o];
     C += Cii[static_cast<long long>(e) * HW + x];
@@ -662,7 +632,8 @@ __device__ __forceinline__ void ba_schur_body(
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
-    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows) {
+    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows,
+    float* __restrict__ Mrg) {
   __shared__ gfloat* rowptr[kMaxRows];
   __shared__ int rowout[kMaxRows];        // 6*pose + comp for an M row, -2 for the w row, -1 padding
   __shared__ int nrows_s;
@@ -696,6 +667,7 @@ __device__ __forceinline__ void ba_schur_body(
   // this depth frame's out-edges and their target poses, fetched ONCE and in parallel into LDS: eptr -> eidx -> jj is a chain
   // of three dependent loads that the depth phase and the row table used to walk per edge (12 + 12 serial round trips at S-B)
   __shared__ int s_edge[256], s_pose[256];
+  __shared__ int s_lead[64], s_merged[64], any_merged_s;      // (the ballot path below: at most 64 out-edges)
   const int e0 = pl.eptr[k], deg_all = pl.eptr[k + 1] - e0;
   const int pself = pl.kx[k] - t0;
   const bool in_lds = deg_all <= 256;
@@ -710,16 +682,39 @@ __device__ __forceinline__ void ba_schur_body(
   if (in_lds && deg_all <= 64) {
     // row table by wave 0, one lane per out-edge: the position of an edge's six rows = the number of free target poses before it
     // (ballot + popcount) - the same order as the sequential walk below, which took 1.9 us of this kernel at S-B
+    // Round 5: edges of this frame that share their TARGET pose (a frontend window keeps every aged-out edge as an inactive one,
+    // factor_graph.py:281-289: the same frame pair several times - 18 out-edges to ~7 distinct poses) contribute row blocks that
+    // only ever meet as their SUM: S gets (sum_e E_e) Q (sum_e E_e)^T for that pose.  The first edge of each target (the "leader",
+    // in edge order) stands for the group; a leader with followers reads the group's summed rows from `Mrg` (written below by
+    // this workgroup for its own pixels, in edge order), one without reads its own Eij rows as before.  Rows 6 x 18 + 7 -> 6 x 7 + 7:
+    // four row tiles, the one-pass path.  Frames without repeated targets take exactly the path they took (bit-identical).
     if (tid < 64) {
       const bool free_pose = tid < deg_all && s_pose[tid] >= 0 && s_pose[tid] < P;      // fixed target pose: drops out (:1125, :1227)
-      const unsigned long long mask = __ballot(free_pose);
+      int lead = tid;
+      if (free_pose) {
+        const int p = s_pose[tid];
+        for (int u = 0; u < tid; ++u) if (s_pose[u] == p) { lead = u; break; }
+      }
+      s_lead[tid] = free_pose ? lead : -1;
+      const bool is_lead = free_pose && lead == tid;
+      const unsigned long long mask = __ballot(is_lead);
+      // followers per leader: a leader has some iff another lane names it
+      const int named = (free_pose && lead != tid) ? lead : -1;
+      unsigned long long has_f = 0ull;
+      for (int u = 0; u < 64; ++u) {
+        const int lu = __shfl(named, u);
+        if (lu >= 0) has_f |= 1ull << lu;
+      }
       const bool self = pself >= 0 && pself < P;
       const int base = self ? 6 : 0;
-      if (free_pose) {
+      const bool merged = is_lead && ((has_f >> tid) & 1ull);
+      s_merged[tid] = merged ? 1 : 0;
+      if (is_lead) {
         const int r = base + 6 * __popcll(mask & ((1ull << tid) - 1ull));
         const int e = s_edge[tid], p = s_pose[tid];
+        const float* src = merged ? Mrg : Eij;
 #pragma unroll
-        for (int n = 0; n < 6; ++n) { rowptr[r + n] = (gfloat*)(Eij + (static_cast<long long>(e) * 6 + n) * HW); rowout[r + n] = 6 * p + n; }
+        for (int n = 0; n < 6; ++n) { rowptr[r + n] = (gfloat*)(src + (static_cast<long long>(e) * 6 + n) * HW); rowout[r + n] = 6 * p + n; }
       }
       if (tid == 0) {
         if (self) {
@@ -731,9 +726,11 @@ __device__ __forceinline__ void ba_schur_body(
         const int padded = (r + 15) & ~15;
         for (int q = r; q < padded; ++q) { rowptr[q] = nullptr; rowout[q] = -1; }
         nrows_s = r;
+        any_merged_s = has_f != 0ull ? 1 : 0;
       }
     }
   } else if (tid == 0) {                  // any degree: sequential
+    any_merged_s = 0;
     int r = 0;
     if (pself >= 0 && pself < P) {
       for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Ei + (static_cast<long long>(pself) * 6 + n) * HW); rowout[r] = 6 * pself + n; ++r; }
@@ -759,6 +756,27 @@ __device__ __forceinline__ void ba_schur_body(
   for (int h = 0; h < PIX / 256; ++h) {                // depth phase for this workgroup's pixels
     const int x = blockIdx.x * PIX + h * 256 + tid;
     if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
+  }
+  if (in_lds && deg_all <= 64 && any_merged_s) {        // the summed rows of every target group with more than one edge, this workgroup's pixels
+#pragma unroll
+    for (int h = 0; h < PIX / 256; ++h) {
+      const int x = blockIdx.x * PIX + h * 256 + tid;
+      if (x >= HW) continue;
+      for (int L = 0; L < deg_all; ++L) {
+        if (!s_merged[L]) continue;                       // (uniform over the workgroup)
+        float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int t = L; t < deg_all; ++t) {
+          if (s_lead[t] != L) continue;
+          const int e = s_edge[t];
+#pragma unroll
+          for (int n = 0; n < 6; ++n) m[n] += Eij[(static_cast<long long>(e) * 6 + n) * HW + x];
+        }
+        const int el = s_edge[L];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) Mrg[(static_cast<long long>(el) * 6 + n) * HW + x] = m[n];
+      }
+    }
   }
 
   __syncthreads();
@@ -801,8 +819,9 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     const float* __restrict__ Eii, const float* __restrict__ Cii, const float* __restrict__ bz,
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
-    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows) {
-  ba_schur_body<VEC4, PIX>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA, deal_rows);
+    int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows,
+    float* __restrict__ Mrg) {
+  ba_schur_body<VEC4, PIX>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA, deal_rows, Mrg);
 }
 
 // ---------------------------------------------------------------------------
@@ -2407,27 +2426,7 @@ extern "C" int pvo_debug_ba_wg_probe(void* buf) { return hipMemcpyToSymbol(HIP_S
 extern "C" int pvo_debug_ba_probe(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ba_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
 #endif
 
-#ifdef PVO_SCHED_DEBUG
-// byte offsets of the workspace's parts (tools/sched_bisect.py names the first buffer that differs between two runs)
-extern "C" int pvo_debug_ba_layout(int E, int P, int nframes, int HW, size_t* out /*[16]*/) {
-  char* base = reinterpret_cast<char*>(4096);
-  Ws w = carve(base, E, P, nframes, HW);
-  const void* parts[14] = {w.plan.kidx, w.plan.kx, w.plan.eptr, w.plan.eidx, w.plan.meta, w.plan.env, w.Eii, w.Eij, w.Cii, w.bz, w.Ei, w.Q, w.w, w.dx};
-  for (int i = 0; i < 14; ++i) out[i] = static_cast<size_t>(static_cast<const char*>(parts[i]) - base);
-  out[14] = static_cast<size_t>(reinterpret_cast<char*>(w.sys) - base);
-  out[15] = w.bytes;
-  return 0;
-}
-#endif
 
-#ifdef PVO_SCHED_DEBUG
-extern "C" int pvo_debug_partials(void* buf) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_partials), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
-}
-extern "C" int pvo_debug_log_ba(void* buf) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_log_ba), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
-}
-#endif
 
 extern "C" size_t pvo_ba_workspace_bytes(int E, int P, int nframes, int HW) {
   if (E < 0 || P < 0 || nframes < 0 || HW < 0) return 0;
@@ -2504,7 +2503,7 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     const int Kgrid = (K_eta > 1 && K_eta <= Kmax) ? K_eta : Kmax;
     const dim3 sgrid(gx, Kgrid + deal_rows, 4);      // (z: slices for the row-tile passes of many-neighbour frames, see ba_schur_body)
 #define PVO_SCHUR_LAUNCH(V, PX) hipLaunchKernelGGL((ba_schur_mfma_kernel<V, PX>), sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, \
-                                                   w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA, deal_rows)
+                                                   w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA, deal_rows, w.Mrg)
     if ((HW & 3) == 0) { if (pix == 256) PVO_SCHUR_LAUNCH(true, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(true, 512); else PVO_SCHUR_LAUNCH(true, 1024); }
     else { if (pix == 256) PVO_SCHUR_LAUNCH(false, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(false, 512); else PVO_SCHUR_LAUNCH(false, 1024); }
 #undef PVO_SCHUR_LAUNCH

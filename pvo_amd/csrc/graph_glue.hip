@@ -44,22 +44,6 @@ __device__ __forceinline__ float h2f_(uint32_t bits) {
   else return pvo_bf16_to_f32(static_cast<uint16_t>(bits));
 }
 
-#ifdef PVO_SCHED_DEBUG
-// tools/sched_bisect.py --times: every workgroup of graph_post appends (1 << 62 | constant-rate clock) when its stores are issued
-// and every workgroup of the BA's assembly (2 << 62 | clock) when it starts: does the first kernel behind a cross-stream wait start
-// before the kernel in front of the wait has finished?
-__device__ unsigned long long* g_dbg_log_graph = nullptr;
-#define PVO_DBG_STAMP(logp, tag)                                                                                     \
-  do {                                                                                                                \
-    if ((logp) && threadIdx.x == 0) {                                                                                 \
-      const unsigned long long i_ = atomicAdd(&(logp)[0], 1ull);                                                      \
-      if (i_ < 16000ull) (logp)[1 + i_] = (static_cast<unsigned long long>(tag) << 62) | (wall_clock64() & ((1ull << 62) - 1)); \
-    }                                                                                                                 \
-  } while (0)
-#else
-#define PVO_DBG_STAMP(logp, tag)
-#endif
-
 template <typename T>
 __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restrict__ coords1, const uint16_t* __restrict__ y8,
                                                          float2* __restrict__ raw_mask, float2* __restrict__ target,
@@ -99,19 +83,10 @@ __global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restric
   const size_t ob = static_cast<size_t>(e) * 2 * HW + pix;
   target_ba[ob] = tg.x; target_ba[ob + HW] = tg.y;
   weight_ba[ob] = wt.x; weight_ba[ob + HW] = wt.y;
-#ifdef PVO_SCHED_DEBUG
-  __builtin_amdgcn_s_waitcnt(0);          // (vmcnt / lgkmcnt 0: this wave's stores have been acknowledged)
-  PVO_DBG_STAMP(g_dbg_log_graph, 1);
-#endif
 }
 
 }  // namespace
 
-#ifdef PVO_SCHED_DEBUG
-extern "C" int pvo_debug_log_graph(void* buf) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_log_graph), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
-}
-#endif
 
 extern "C" int pvo_graph_motion(const float* target, const float* coords1, const float* delta_dy, const float* raw_mask,
                                 void* motn, int E, int H, int W, int dtype, void* stream) {

@@ -123,6 +123,30 @@ def test_ba_frames_with_many_neighbours_match_oracle(cuda, radius, ht, wd):
     assert np.array_equal(poses, again[0]) and np.array_equal(disps, again[1])          # fixed summation order: bitwise repeatable
 
 
+@pytest.mark.parametrize("copies,ht,wd", [(3, 8, 10), (4, 9, 11)])
+def test_ba_edges_that_repeat_a_frame_pair_match_oracle(cuda, copies, ht, wd):
+    """A frontend window keeps its aged-out edges as inactive ones (factor_graph.py:281-289): the same (i, j) pair several times,
+    each copy with its own target and weight.  The Schur kernel sums the row blocks of a frame's edges per TARGET pose before the
+    products (`Mrg`): against the oracle, which treats every edge on its own; interleaved copies, a frame whose repeated target is
+    the fixed pose 0, and one pair that appears once"""
+    P = 10
+    s = _scene(700 + copies, P, ht, wd, 2, 1)
+    g = torch.Generator().manual_seed(copies)
+    E = s["ii"].shape[0]
+    order = torch.cat([torch.randperm(E, generator=g) for _ in range(copies)])[:-1]       # (the last copy of one edge is left out)
+    tgt = s["target"][order] + 0.2 * torch.randn(order.shape[0], 2, ht, wd, generator=g)
+    wgt = torch.rand(order.shape[0], 2, ht, wd, generator=g)
+    s = dict(s, ii=s["ii"][order].contiguous(), jj=s["jj"][order].contiguous(), target=tgt.contiguous(), weight=wgt.contiguous())
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
+    assert status[0] == 0 and status[1] == want["K"] and status[2] == 0
+    assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
+    assert np.abs(dx - want["dx"]).max() < 1e-4 and np.abs(dz - want["dz"]).max() < 1e-4
+    again = _run_ba(s, cuda, 2)
+    assert np.array_equal(poses, again[0]) and np.array_equal(disps, again[1])
+
+
 def test_ba_matches_oracle_at_SA_size(cuda):
     """S-A: 30x101 maps, 10 keyframes, 48 edges - the window shape of the reference's own driver"""
     P, ht, wd = 10, 30, 101

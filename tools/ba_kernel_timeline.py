@@ -25,12 +25,26 @@ from test_geom_ba_gpu import _scene
 dev = torch.device("cuda:0")
 nf = int(os.environ.get("NF", "8"))
 s = _scene(0, nf, int(os.environ.get("HT", "48")), int(os.environ.get("WD", "64")), int(os.environ.get("RAD", "3")), 1)      # RAD 8: frames with 16 neighbours (a frontend window with its inactive edges)
+copies = int(os.environ.get("COPIES", "1"))      # COPIES 3, RAD 3: what a frontend window with its inactive edges looks like (450 edges, 18 per frame to 6 poses)
+if copies > 1:
+    s = dict(s, ii=s["ii"].repeat(copies), jj=s["jj"].repeat(copies), target=s["target"].repeat(copies, 1, 1, 1).contiguous(),
+             weight=s["weight"].repeat(copies, 1, 1, 1).contiguous())
 print("keyframes %d, edges %d, map %s x %s, radius %s" % (nf, s["ii"].shape[0], os.environ.get("HT", "48"), os.environ.get("WD", "64"), os.environ.get("RAD", "3")))
 d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()}
+if os.environ.get("BA_DUMP"):        # a BA of a real run (bench.py --sequence-only with PVO_BENCH_DUMP_BA=<file>): the frontend's window with its inactive edges
+    z = torch.load(os.environ["BA_DUMP"])
+    nfb = z["poses"].shape[0]
+    eta = (0.2 * z["damping"][z["rows"]] + 1e-7).contiguous()
+    d = dict(poses=z["poses"].to(dev), disps=z["disps"].to(dev), intr=z["intr"].to(dev), target=z["target"].to(dev).contiguous(), weight=z["weight"].to(dev).contiguous(),
+             eta=eta.to(dev), ii=z["ii"].to(dev), jj=z["jj"].to(dev))
+    t0_, nf = int(z["t0"]), int(z["t1"])
+    print("real window: poses %d..%d, %d edges, %d depth frames, buffer %d" % (t0_, nf, d["ii"].shape[0], eta.shape[0], nfb))
+else:
+    t0_ = 1
 lib = _lib.load()
 lib.pvo_debug_ba_wg_probe.restype = ctypes.c_int; lib.pvo_debug_ba_wg_probe.argtypes = [ctypes.c_void_p]
 buf = torch.zeros(3 * 4096 * 8, dtype=torch.int64, device=dev)
-run = lambda it: db.ba(d["poses"].clone(), d["disps"].clone(), d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], 1, nf, it, 1e-4, 0.1, False)
+run = lambda it: db.ba(d["poses"].clone(), d["disps"].clone(), d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], t0_, nf, it, 1e-4, 0.1, False)
 for _ in range(5):
     run(2)
 torch.cuda.synchronize()
