@@ -52,6 +52,7 @@ __device__ __forceinline__ void fix_add(long long* sys, long long idx, double v,
   if (!(fabs(v) < 3.0e10)) { meta[4] = 1; return; }
   atomicAdd(reinterpret_cast<unsigned long long*>(sys + idx), static_cast<unsigned long long>(__double2ll_rn(v * kFix)));
 }
+constexpr int kDealEdges = 2;           // edges (consecutive in the plan's by-source order) per chunk-sum workgroup of the Schur kernel
 constexpr int kPPT = 2;                 // pixels per thread in assemble (1: 432 workgroups, measured slower - profiles/r03_ba_ablation.txt)
 constexpr int kChunkA = 256 * kPPT;     // pixels per assemble workgroup
 constexpr int kMaxSep = 12;                                      // separator poses of the partitioned solve (beyond: not partitioned)
@@ -303,6 +304,30 @@ __device__ __forceinline__ void pose_block_scatter(int t, double val, int pi, in
     if (iok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pi + (t - 78), val, meta);
   } else {
     if (jok) fix_add(sys, static_cast<long long>(n6) * n6 + 6 * pj + (t - 84), val, meta);
+  }
+}
+
+// The (at most two) entries of the pose system pose_block_scatter adds entry t of edge (pi -> pj) to; -1 = none.  Same case
+// analysis, kept beside it.
+__device__ __forceinline__ void pose_block_targets(int t, int pi, int pj, int P, long long idx[2]) {
+  const bool iok = pi >= 0 && pi < P, jok = pj >= 0 && pj < P;
+  const long long n6 = 6 * P;
+  idx[0] = idx[1] = -1;
+  if (t < 78) {
+    int n = 0, base = 0;
+    while (base + n + 1 <= t) { base += n + 1; ++n; }
+    const int m = t - base;
+    if (n < 6) {
+      if (iok) { idx[0] = (6 * pi + n) * n6 + 6 * pi + m; if (n != m) idx[1] = (6 * pi + m) * n6 + 6 * pi + n; }
+    } else if (m < 6) {
+      if (iok && jok) idx[0] = (pi > pj) ? (6 * pi + m) * n6 + 6 * pj + (n - 6) : (6 * pj + (n - 6)) * n6 + 6 * pi + m;
+    } else {
+      if (jok) { idx[0] = (6 * pj + n - 6) * n6 + 6 * pj + m - 6; if (n != m) idx[1] = (6 * pj + m - 6) * n6 + 6 * pj + n - 6; }
+    }
+  } else if (t < 84) {
+    if (iok) idx[0] = n6 * n6 + 6 * pi + (t - 78);
+  } else {
+    if (jok) idx[0] = n6 * n6 + 6 * pj + (t - 84);
   }
 }
 
@@ -649,12 +674,34 @@ __device__ __forceinline__ void ba_schur_body(
   if (static_cast<int>(blockIdx.y) >= static_cast<int>(gridDim.y) - deal_rows) {
     if (zi != 0) return;
     if (part && threadIdx.x < 90) {
-      const int nd = deal_rows * gridDim.x;
-      for (int e = (blockIdx.y - (gridDim.y - deal_rows)) * gridDim.x + blockIdx.x; e < E; e += nd) {
+      // kDealEdges edges per workgroup, CONSECUTIVE in the plan's by-source order: an edge's (ii, ii) block and vi entries land on
+      // the same addresses as its neighbours' (same source frame), so their fixed-point addends are summed in a register and
+      // leave as one atomic when the address changes - integer sums: the system is bit for bit what one atomic per edge gave.
+      // (A real window's 342 edges were 30 780 memory-side atomics, up to ~33 deep on a diagonal entry: half of the launch's
+      // 105 us, bench.py `sequence`; two edges a workgroup apart in the edge list shared nothing.)
+      const int t = threadIdx.x;
+      const int wgi = (blockIdx.y - (gridDim.y - deal_rows)) * gridDim.x + blockIdx.x;
+      const int p0 = wgi * kDealEdges, p1 = (p0 + kDealEdges < E) ? p0 + kDealEdges : E;
+      long long pend_idx[2] = {-1, -1}, pend_acc[2] = {0, 0};
+      for (int pos = p0; pos < p1; ++pos) {
+        const int e = pl.eidx[pos];
         double val = 0.0;
-        for (int c = 0; c < chunksA; ++c) val += static_cast<double>(part[(static_cast<long long>(e) * chunksA + c) * 90 + threadIdx.x]);
-        pose_block_scatter(threadIdx.x, val, static_cast<int>(ii[e]) - t0, static_cast<int>(jj[e]) - t0, P, sys, pl.meta);
+        for (int c = 0; c < chunksA; ++c) val += static_cast<double>(part[(static_cast<long long>(e) * chunksA + c) * 90 + t]);
+        if (!(fabs(val) < 3.0e10)) { pl.meta[4] = 1; continue; }       // (fix_add's range check)
+        const long long q = __double2ll_rn(val * kFix);
+        long long idx[2];
+        pose_block_targets(t, static_cast<int>(ii[e]) - t0, static_cast<int>(jj[e]) - t0, P, idx);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          if (idx[sl] < 0) continue;
+          if (idx[sl] == pend_idx[sl]) { pend_acc[sl] += q; continue; }
+          if (pend_idx[sl] >= 0) atomicAdd(reinterpret_cast<unsigned long long*>(sys + pend_idx[sl]), static_cast<unsigned long long>(pend_acc[sl]));
+          pend_idx[sl] = idx[sl]; pend_acc[sl] = q;
+        }
       }
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+        if (pend_idx[sl] >= 0) atomicAdd(reinterpret_cast<unsigned long long*>(sys + pend_idx[sl]), static_cast<unsigned long long>(pend_acc[sl]));
     }
     return;
   }
@@ -2496,7 +2543,7 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     const long long wg256 = static_cast<long long>((HW + 255) / 256) * frames_opt;
     const int pix = wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024);
     const int gx = (HW + pix - 1) / pix;
-    const int deal_rows = two_stage ? (E + 2 * gx - 1) / (2 * gx) : 0;      // workgroups that add up the assembly's chunk sums: two edges each
+    const int deal_rows = two_stage ? (E + kDealEdges * gx - 1) / (kDealEdges * gx) : 0;      // workgroups that add up the assembly's chunk sums: kDealEdges edges each
     // rows of the grid = depth frames: the caller's eta has one row per depth frame (K_eta == K, checked by the plan kernel and
     // reported in the status words), so that is the count; only a broadcast eta (one row) leaves the host with the bound P + E -
     // which at a real window's 48 + 400 edges meant 454 grid rows x 12 chunks x 4 slices for 27 depth frames
