@@ -2541,7 +2541,11 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     // sized BA on 1024-pixel chunks, 3 x K workgroups, 443 us instead of 20: found by the full-sequence run of bench.py)
     const int frames_opt = (nframes < P + 1) ? nframes : (P + 1);
     const long long wg256 = static_cast<long long>((HW + 255) / 256) * frames_opt;
-    const int pix = wg256 <= 512 ? 256 : (wg256 <= 1024 ? 512 : 1024);
+    // (256-pixel chunks only up to ~190 workgroups, i.e. windows of up to 15 poses at 12 chunks a frame: a frontend window of the
+    // full-sequence run - 21-25 poses, frames with 18 neighbours - took 86.5 us with 256-pixel chunks and 73.4 with 512: half the
+    // tile-pair atomics and half the workgroups that each redo row table and depth phase per z-slice; 2 / 8 slices and 1024-pixel
+    // chunks were all slower, tools/_probe sweep of a dumped window)
+    const int pix = wg256 <= 192 ? 256 : (wg256 <= 1024 ? 512 : 1024);
     const int gx = (HW + pix - 1) / pix;
     const int deal_rows = two_stage ? (E + kDealEdges * gx - 1) / (kDealEdges * gx) : 0;      // workgroups that add up the assembly's chunk sums: kDealEdges edges each
     // rows of the grid = depth frames: the caller's eta has one row per depth frame (K_eta == K, checked by the plan kernel and
