@@ -17,6 +17,13 @@ import torch
 ENABLED = os.environ.get("PVO_HIP_GRAPHS", "1") != "0"
 
 
+def _version(t):
+    try:
+        return t._version
+    except RuntimeError:                        # (inference tensors carry no version counter: always copied)
+        return None
+
+
 def _flat(out):
     return (out,) if isinstance(out, torch.Tensor) else tuple(out)
 
@@ -56,8 +63,23 @@ class GraphedCall:
                 return self.fn(*args)
             if self.disabled:
                 return self.fn(*args)
-        for s, a in zip(st["in"], args):
-            s.copy_(a)
+        # an argument that is the SAME tensor object as at the previous replay and has not been written since (its version counter)
+        # is already in the capture's static buffer: the motion filter hands its reference keyframe's maps - five to seven tensors -
+        # to every frame's replay, and each device-to-device blit is ~48 us of host time in front of the launch (bench.py `sequence`).
+        # (Identity, not address: the previous argument is kept alive here, so no new tensor can take its place in memory.)
+        held = st["held"]
+        dst, src = [], []
+        for i, (s, a) in enumerate(zip(st["in"], args)):
+            h = held[i]
+            ver = _version(a)
+            if h is not None and h[0] is a and ver is not None and h[1] == ver:
+                continue
+            dst.append(s); src.append(a)
+            held[i] = (a, ver)
+        if len(dst) == 1:
+            dst[0].copy_(src[0])
+        elif dst:
+            torch._foreach_copy_(dst, src)
         st["graph"].replay()
         self.replays += 1
         return st["out"] if st["single"] else tuple(st["outs"])
@@ -81,3 +103,4 @@ class GraphedCall:
                 return
         st.update(graph=g, out=out, outs=outs, single=isinstance(out, torch.Tensor))
         st["in"] = static_in
+        st["held"] = [None] * len(static_in)

@@ -81,7 +81,14 @@ class MotionFilter:
 
     def _new_reference(self, gmap, net, inp):
         """the frame just stored becomes the reference of the motion test (graph outputs are static buffers: copies)"""
-        self.net, self.inp, self.fmap = net.clone(), inp.clone(), gmap.clone()
+        src = [net, inp, gmap]
+        dst = [torch.empty_like(x) for x in src]
+        if self.device.type == "cuda":
+            torch._foreach_copy_(dst, src)           # (one launch: three device-to-device blits are ~48 us of host time each)
+        else:
+            for d, x in zip(dst, src):
+                d.copy_(x)
+        self.net, self.inp, self.fmap = dst
         self._static = None
         if self.device.type == "cuda" and hasattr(self.update, "static_terms") and getattr(self.update, "fused_gru", False) \
                 and next(self.update.parameters()).dtype in (torch.float16, torch.bfloat16):

@@ -365,3 +365,29 @@ def test_motion_filter_graph_replay_and_fused_encoders_match_the_eager_path(cuda
     assert torch.allclose(a, b, rtol=3e-2, atol=1e-3), (a, b)
     fa, fb = out["eager"][1], out["graphs"][1]
     assert float((fa - fb).abs().max()) <= 1e-2 * float(fa.abs().max())
+
+
+@pytest.mark.gpu
+def test_graphed_call_skips_only_arguments_that_cannot_have_changed():
+    """pvo_amd.graphs.GraphedCall copies an argument into the capture's static buffer unless it is the same tensor object, unwritten
+    since the previous replay - an in-place write, a new tensor at any address, or new values must all be seen"""
+    from pvo_amd.graphs import GraphedCall
+    dev = torch.device("cuda:0")
+    g = GraphedCall(lambda a, b: a * 2.0 + b, warmup=1)
+    a, b = torch.arange(8.0, device=dev), torch.ones(8, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            out = g(a, b).clone()                      # eager, capture, replay
+        assert g.replays >= 1 and torch.equal(out, a * 2 + b)
+        b.add_(1.0)                                    # same object, written in place
+        assert torch.equal(g(a, b), a * 2 + b)
+        for k in range(4):                             # a fresh tensor per call (freed ones may come back at the same address)
+            c = torch.full((8,), float(k), device=dev)
+            assert torch.equal(g(a, c), a * 2 + c)
+            del c
+        a2 = a.clone()
+        assert torch.equal(g(a2, b), a2 * 2 + b)
+        a2.mul_(3.0)
+        assert torch.equal(g(a2, b), a2 * 2 + b)
+        n = g.replays
+        assert torch.equal(g(a2, b), a2 * 2 + b) and g.replays == n + 1      # nothing changed: still replayed, same result

@@ -71,6 +71,21 @@ if len(mf) > 20:
     for r in seg[lo:c + 40]:
         s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         print("%9.1f %8.1f  q%-3s %s  [%s x %s]" % ((s_ - tb) / 1e3, (e_ - s_) / 1e3, r.get("Queue_Id", "?")[-1:], short(r["Kernel_Name"]), r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
+# where the device waits for the host: idle stretches of the pass (no kernel running on any queue), grouped by the kernels on either side
+idle = collections.OrderedDict()
+run_end, prev = int(seg[0]["End_Timestamp"]), seg[0]
+for r in seg[1:]:
+    s_ = int(r["Start_Timestamp"])
+    if s_ > run_end:
+        a = idle.setdefault((short(prev["Kernel_Name"])[:44], short(r["Kernel_Name"])[:44]), [0, 0])
+        a[0] += 1; a[1] += s_ - run_end
+    if int(r["End_Timestamp"]) > run_end:
+        run_end, prev = int(r["End_Timestamp"]), r
+tot_idle = sum(v[1] for v in idle.values())
+print()
+print("device idle in the pass: %.3f s in %d stretches; by (last kernel before -> first kernel after), top 25:" % (tot_idle / 1e9, sum(v[0] for v in idle.values())))
+for (a, b), (c, t) in sorted(idle.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("  %9.2f ms  x%-5d avg %7.1f us   %s -> %s" % (t / 1e6, c, t / 1e3 / c, a, b))
 own = sum(t for n, (c, t) in agg.items() if not (n.startswith("at::") or "rocclr" in n or n.startswith("miopen") or "Cijk" in n or n.startswith("ck::") or "MIOpen" in n or "igemm" in n or "naive" in n))
 print("share of kernel time in libpvo_hip kernels: %.1f %%; PyTorch / MIOpen / blit kernels: %.1f %%" % (100.0 * own / tot, 100.0 * (tot - own) / tot))
 PY
