@@ -514,6 +514,26 @@ constexpr int kFastTiles = 4;            // up to 4 row tiles (63 rows + w) accu
 // this kernel, each counting against both vmcnt and lgkmcnt)
 typedef const float __attribute__((address_space(1))) gfloat;
 
+// The LDS row table says, per row of M, where the row lives - a source array and a row index in it, packed into one int - and which
+// entry of the pose system its sums go to (a short).  6 KB for kMaxRows rows instead of the 12 KB that pointers + ints took: with the
+// 40 KB of `red` the workgroup stays under a third of the CU's 160 KB (three workgroups per CU instead of two; a frontend window
+// with its inactive edges launches 550-700 of them).
+constexpr int kRowEij = 0, kRowMrg = 1, kRowEi = 2, kRowW = 3;
+__device__ __forceinline__ int row_code(int src, long long row) { return (src << 28) | static_cast<int>(row); }
+struct RowTab {
+  const int* code;           // LDS: (source << 28) | row index, -1 = padding
+  const short* out;          // LDS: 6 * pose + comp for an M row, -2 for the w row, -1 padding
+  const float* base[4];      // Eij, Mrg, Ei, w
+  int HW;
+  __device__ __forceinline__ gfloat* ptr(int r) const {
+    const int c = code[r];
+    if (c < 0) return nullptr;
+    const int src = c >> 28;
+    const float* b = src == kRowEij ? base[0] : (src == kRowMrg ? base[1] : (src == kRowEi ? base[2] : base[3]));
+    return (gfloat*)(b + static_cast<long long>(c & 0x0fffffff) * HW);
+  }
+};
+
 template <bool VEC4>
 __device__ __forceinline__ f32x4 load4(gfloat* __restrict__ row, int p, int HW) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -529,7 +549,7 @@ __device__ __forceinline__ f32x4 load4(gfloat* __restrict__ row, int p, int HW) 
 }
 
 // scatter one reduced 16x16 tile (ti,tj) of -S into the pose system
-__device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, int tj, const int* rowout,
+__device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, int tj, const short* rowout,
                                              long long* __restrict__ sys, int n6, int* meta) {
   // D[i][j]: i = 4*(lane>>4)+reg (row in tile ti), j = lane&15 (row in tile tj)
   const int oi = rowout[ti * 16 + 4 * (l >> 4) + reg];
@@ -549,7 +569,7 @@ __device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, in
 
 // all T(T+1)/2 tile pairs in ONE pass over the pixels (rows read once, accumulators static)
 template <int T, bool VEC4, int PIX>
-__device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* rowout,
+__device__ __forceinline__ void schur_pass(const RowTab& rt,
                                            gfloat* __restrict__ qrow, float* red /*[4][NT*4][64]*/,
                                            long long* __restrict__ sys, int HW, int n6, int pix_base, int* meta) {
   constexpr int NT = T * (T + 1) / 2;
@@ -557,7 +577,7 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
   const int idx = lane & 15, kq = lane >> 4;
   gfloat* rows[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) rows[t] = rowptr[t * 16 + idx];
+  for (int t = 0; t < T; ++t) rows[t] = rt.ptr(t * 16 + idx);
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -597,7 +617,7 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
       const float* r0 = red + static_cast<size_t>(n) * 256 + tid;
       const float v = (r0[0] + r0[static_cast<size_t>(NT) * 256]) +
                       (r0[static_cast<size_t>(2 * NT) * 256] + r0[static_cast<size_t>(3 * NT) * 256]);
-      scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6, meta);
+      scatter_tile(v, tid >> 6, tid & 63, ti, tj, rt.out, sys, n6, meta);
       ++n;
     }
 }
@@ -608,14 +628,14 @@ __device__ __forceinline__ void schur_pass(gfloat* const* rowptr, const int* row
 // workgroup barriers per pair: 15 to 36 rounds, 118 us per launch.  Per pair the SAME chain of MFMAs in the same order and the
 // same (w0 + w1) + (w2 + w3) reduction as every other path: bit-identical sums.
 template <int CNT, bool VEC4, int PIX>
-__device__ __forceinline__ void schur_rowpass(gfloat* const* rowptr, const int* rowout, gfloat* __restrict__ qrow, float* red,
+__device__ __forceinline__ void schur_rowpass(const RowTab& rt, gfloat* __restrict__ qrow, float* red,
                                               long long* __restrict__ sys, int HW, int n6, int pix_base, int* meta, int ti, int tj0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int idx = lane & 15, kq = lane >> 4;
-  gfloat* __restrict__ ra = rowptr[ti * 16 + idx];
+  gfloat* __restrict__ ra = rt.ptr(ti * 16 + idx);
   gfloat* rb[CNT];
 #pragma unroll
-  for (int t = 0; t < CNT; ++t) rb[t] = rowptr[(tj0 + t) * 16 + idx];
+  for (int t = 0; t < CNT; ++t) rb[t] = rt.ptr((tj0 + t) * 16 + idx);
   f32x4 acc[CNT];
 #pragma unroll
   for (int t = 0; t < CNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -646,7 +666,7 @@ __device__ __forceinline__ void schur_rowpass(gfloat* const* rowptr, const int* 
   for (int t = 0; t < CNT; ++t) {
     const float* r0 = red + static_cast<size_t>(t) * 256 + tid;
     const float v = (r0[0] + r0[static_cast<size_t>(CNT) * 256]) + (r0[static_cast<size_t>(2 * CNT) * 256] + r0[static_cast<size_t>(3 * CNT) * 256]);
-    scatter_tile(v, tid >> 6, tid & 63, ti, tj0 + t, rowout, sys, n6, meta);
+    scatter_tile(v, tid >> 6, tid & 63, ti, tj0 + t, rt.out, sys, n6, meta);
   }
   __syncthreads();                        // `red` is rewritten by the next pass
 }
@@ -659,8 +679,8 @@ __device__ __forceinline__ void ba_schur_body(
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
     int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows,
     float* __restrict__ Mrg) {
-  __shared__ gfloat* rowptr[kMaxRows];
-  __shared__ int rowout[kMaxRows];        // 6*pose + comp for an M row, -2 for the w row, -1 padding
+  __shared__ int rowcode[kMaxRows];       // see RowTab
+  __shared__ short rowout[kMaxRows];
   __shared__ int nrows_s;
   __shared__ float red[4 * (kFastTiles * (kFastTiles + 1) / 2) * 256];   // 40 KB
   // the assembly's chunk sums, per edge, are added up and scattered by workgroups of their OWN: the last `deal_rows` rows of the
@@ -759,19 +779,19 @@ __device__ __forceinline__ void ba_schur_body(
       if (is_lead) {
         const int r = base + 6 * __popcll(mask & ((1ull << tid) - 1ull));
         const int e = s_edge[tid], p = s_pose[tid];
-        const float* src = merged ? Mrg : Eij;
+        const int src = merged ? kRowMrg : kRowEij;
 #pragma unroll
-        for (int n = 0; n < 6; ++n) { rowptr[r + n] = (gfloat*)(src + (static_cast<long long>(e) * 6 + n) * HW); rowout[r + n] = 6 * p + n; }
+        for (int n = 0; n < 6; ++n) { rowcode[r + n] = row_code(src, static_cast<long long>(e) * 6 + n); rowout[r + n] = static_cast<short>(6 * p + n); }
       }
       if (tid == 0) {
         if (self) {
 #pragma unroll
-          for (int n = 0; n < 6; ++n) { rowptr[n] = (gfloat*)(Ei + (static_cast<long long>(pself) * 6 + n) * HW); rowout[n] = 6 * pself + n; }
+          for (int n = 0; n < 6; ++n) { rowcode[n] = row_code(kRowEi, static_cast<long long>(pself) * 6 + n); rowout[n] = static_cast<short>(6 * pself + n); }
         }
         int r = base + 6 * __popcll(mask);
-        if (r > 0) { rowptr[r] = (gfloat*)(w + static_cast<long long>(k) * HW); rowout[r] = -2; ++r; }
+        if (r > 0) { rowcode[r] = row_code(kRowW, k); rowout[r] = -2; ++r; }
         const int padded = (r + 15) & ~15;
-        for (int q = r; q < padded; ++q) { rowptr[q] = nullptr; rowout[q] = -1; }
+        for (int q = r; q < padded; ++q) { rowcode[q] = -1; rowout[q] = -1; }
         nrows_s = r;
         any_merged_s = has_f != 0ull ? 1 : 0;
       }
@@ -780,18 +800,18 @@ __device__ __forceinline__ void ba_schur_body(
     any_merged_s = 0;
     int r = 0;
     if (pself >= 0 && pself < P) {
-      for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Ei + (static_cast<long long>(pself) * 6 + n) * HW); rowout[r] = 6 * pself + n; ++r; }
+      for (int n = 0; n < 6; ++n) { rowcode[r] = row_code(kRowEi, static_cast<long long>(pself) * 6 + n); rowout[r] = static_cast<short>(6 * pself + n); ++r; }
     }
     for (int o = 0; o < deg_all; ++o) {
       const int e = in_lds ? s_edge[o] : pl.eidx[e0 + o];
       const int p = in_lds ? s_pose[o] : static_cast<int>(jj[e]) - t0;
       if (p < 0 || p >= P) continue;      // fixed target pose: drops out (:1125, :1227)
       if (r + 7 > kMaxRows) { pl.meta[3] = 1; break; }   // > 169 free neighbours of one frame: flagged
-      for (int n = 0; n < 6; ++n) { rowptr[r] = (gfloat*)(Eij + (static_cast<long long>(e) * 6 + n) * HW); rowout[r] = 6 * p + n; ++r; }
+      for (int n = 0; n < 6; ++n) { rowcode[r] = row_code(kRowEij, static_cast<long long>(e) * 6 + n); rowout[r] = static_cast<short>(6 * p + n); ++r; }
     }
-    if (r > 0) { rowptr[r] = (gfloat*)(w + static_cast<long long>(k) * HW); rowout[r] = -2; ++r; }
+    if (r > 0) { rowcode[r] = row_code(kRowW, k); rowout[r] = -2; ++r; }
     const int padded = (r + 15) & ~15;
-    for (int q = r; q < padded; ++q) { rowptr[q] = nullptr; rowout[q] = -1; }
+    for (int q = r; q < padded; ++q) { rowcode[q] = -1; rowout[q] = -1; }
     nrows_s = r;
   }
   __syncthreads();
@@ -831,13 +851,14 @@ __device__ __forceinline__ void ba_schur_body(
   if (nrows == 0) return;
 
   gfloat* __restrict__ qrow = (gfloat*)(Q + static_cast<long long>(k) * HW);
+  const RowTab rt = {rowcode, rowout, {Eij, Mrg, Ei, w}, HW};
   const int pix_base = blockIdx.x * PIX + wave * (PIX / 4);
 
   switch (T) {
-    case 1: schur_pass<1, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
-    case 2: schur_pass<2, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
-    case 3: schur_pass<3, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
-    case 4: schur_pass<4, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 1: schur_pass<1, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 2: schur_pass<2, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 3: schur_pass<3, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
+    case 4: schur_pass<4, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta); BA_WG_PROBE(1, 7); return;
     default: break;
   }
   // any degree: one ROW TILE against up to eight others per pass (row tiles re-read from L2 once per pass)
@@ -846,14 +867,14 @@ __device__ __forceinline__ void ba_schur_body(
     for (int tj0 = ti; tj0 < T; tj0 += kPassTiles) {
       const int cnt = (T - tj0 < kPassTiles) ? T - tj0 : kPassTiles;
       switch (cnt) {
-        case 1: schur_rowpass<1, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
-        case 2: schur_rowpass<2, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
-        case 3: schur_rowpass<3, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
-        case 4: schur_rowpass<4, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
-        case 5: schur_rowpass<5, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
-        case 6: schur_rowpass<6, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
-        case 7: schur_rowpass<7, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
-        default: schur_rowpass<8, VEC4, PIX>(rowptr, rowout, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 1: schur_rowpass<1, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 2: schur_rowpass<2, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 3: schur_rowpass<3, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 4: schur_rowpass<4, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 5: schur_rowpass<5, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 6: schur_rowpass<6, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        case 7: schur_rowpass<7, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
+        default: schur_rowpass<8, VEC4, PIX>(rt, qrow, red, sys, HW, n6, pix_base, pl.meta, ti, tj0); break;
       }
     }
   }
@@ -2511,6 +2532,7 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
   if (!poses || !disps || !intrinsics || !sys || !workspace) return PVO_EINVAL;
   if (E > 0 && (!targets || !weights || !ii || !jj)) return PVO_EINVAL;
   if (!motion_only && !eta) return PVO_EINVAL;
+  if (P > 5400 || nframes >= (1 << 28)) return PVO_EUNSUPPORTED;      // (the Schur kernel's row table: 6 P + 5 in a short, row indices in 28 bits)
   if (workspace_bytes < pvo_ba_workspace_bytes(E, P, nframes, HW)) return PVO_EWORKSPACE;
   Ws w = carve(ws_base(workspace), E, P, nframes, HW);
   hipStream_t st = pvo_stream(stream);
