@@ -71,6 +71,21 @@ if len(mf) > 20:
     for r in seg[lo:c + 40]:
         s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         print("%9.1f %8.1f  q%-3s %s  [%s x %s]" % ((s_ - tb) / 1e3, (e_ - s_) / 1e3, r.get("Queue_Id", "?")[-1:], short(r["Kernel_Name"]), r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
+# everything between two keyframes' graph updates: from the last BA kernel of one keyframe step to the first reprojection of the next
+# step's first update (tracked frames of the motion filter, the keyframe's context encoder, edge bookkeeping, proximity, volume build)
+if len(ups) > 40:
+    gaps_u = [(int(seg[ups[j + 1]]["Start_Timestamp"]) - int(seg[ups[j]]["Start_Timestamp"]), j) for j in range(int(0.5 * len(ups)), int(0.7 * len(ups)))]
+    big = sorted(g for g in gaps_u)[len(gaps_u) * 9 // 10][0]              # a typical LONG gap = a keyframe boundary
+    j = next(j for g, j in gaps_u if g >= big)
+    a = next(i for i in range(ups[j + 1], ups[j], -1) if "ba_backsub_kernel" in seg[i]["Kernel_Name"])
+    tb = int(seg[a]["End_Timestamp"])
+    print()
+    print("between two keyframe steps (%d dispatches, %.1f us from the last BA kernel to the next step's first reprojection):" % (ups[j + 1] - a - 1, (int(seg[ups[j + 1]]["Start_Timestamp"]) - tb) / 1e3))
+    prev_end = tb
+    for r in seg[a + 1:ups[j + 1] + 1]:
+        s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print("%9.1f %8.1f  idle %7.1f  q%-3s %s  [%s x %s]" % ((s_ - tb) / 1e3, (e_ - s_) / 1e3, max(0.0, (s_ - prev_end) / 1e3), r.get("Queue_Id", "?")[-1:], short(r["Kernel_Name"])[:70], r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
+        prev_end = max(prev_end, e_)
 # where the device waits for the host: idle stretches of the pass (no kernel running on any queue), grouped by the kernels on either side
 idle = collections.OrderedDict()
 run_end, prev = int(seg[0]["End_Timestamp"]), seg[0]
