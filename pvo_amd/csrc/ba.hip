@@ -746,6 +746,17 @@ __device__ __forceinline__ void ba_schur_body(
   }
   __syncthreads();
   BA_WG_PROBE(1, 2);                     // edge list in LDS
+  // The depth phase needs the edge list only.  Slice 0 issues it BEFORE wave 0 builds the row table, so the table's ~1 us of LDS
+  // work hides behind the depth phase's loads (as up to round 4; with the table in front S-B's Schur launch took 17.5 us
+  // instead of 16.2); ONE barrier behind both publishes table and rows together.
+  auto depth_phase = [&]() {
+#pragma unroll
+    for (int h = 0; h < PIX / 256; ++h) {
+      const int x = blockIdx.x * PIX + h * 256 + tid;
+      if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
+    }
+  };
+  if (zi == 0) depth_phase();
   if (in_lds && deg_all <= 64) {
     // row table by wave 0, one lane per out-edge: the position of an edge's six rows = the number of free target poses before it
     // (ballot + popcount) - the same order as the sequential walk below, which took 1.9 us of this kernel at S-B
@@ -768,7 +779,7 @@ __device__ __forceinline__ void ba_schur_body(
       // followers per leader: a leader has some iff another lane names it
       const int named = (free_pose && lead != tid) ? lead : -1;
       unsigned long long has_f = 0ull;
-      for (int u = 0; u < 64; ++u) {
+      for (int u = 1; u < deg_all; ++u) {          // (lane 0 leads itself; uniform bound: deg_all is the workgroup's)
         const int lu = __shfl(named, u);
         if (lu >= 0) has_f |= 1ull << lu;
       }
@@ -814,16 +825,17 @@ __device__ __forceinline__ void ba_schur_body(
     for (int q = r; q < padded; ++q) { rowcode[q] = -1; rowout[q] = -1; }
     nrows_s = r;
   }
+  // Slice 0 has issued its depth phase in front of the table (above); the other slices need the tile count first - most of them
+  // leave here - and run the depth phase now.
+  if (zi > 0) {
+    __syncthreads();
+    if (((nrows_s + 15) >> 4) <= kFastTiles) return;               // (uniform: nrows_s is the workgroup's)
+    depth_phase();
+  }
+  BA_WG_PROBE(1, 3);                     // row table built, depth phase issued
   __syncthreads();
-  BA_WG_PROBE(1, 3);                     // row table built
   const int nrows = nrows_s;
   const int T = (nrows + 15) >> 4;
-  if (zi > 0 && T <= kFastTiles) return;                           // (uniform: nrows_s is the workgroup's)
-#pragma unroll
-  for (int h = 0; h < PIX / 256; ++h) {                // depth phase for this workgroup's pixels
-    const int x = blockIdx.x * PIX + h * 256 + tid;
-    if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
-  }
   if (in_lds && deg_all <= 64 && any_merged_s) {        // the summed rows of every target group with more than one edge, this workgroup's pixels
 #pragma unroll
     for (int h = 0; h < PIX / 256; ++h) {
@@ -844,10 +856,9 @@ __device__ __forceinline__ void ba_schur_body(
         for (int n = 0; n < 6; ++n) Mrg[(static_cast<long long>(el) * 6 + n) * HW + x] = m[n];
       }
     }
+    __syncthreads();                      // (uniform: any_merged_s is the workgroup's)
   }
-
-  __syncthreads();
-  BA_WG_PROBE(1, 4);                     // depth rows stored
+  BA_WG_PROBE(1, 4);                     // depth rows (and merged rows) stored
   if (nrows == 0) return;
 
   gfloat* __restrict__ qrow = (gfloat*)(Q + static_cast<long long>(k) * HW);
