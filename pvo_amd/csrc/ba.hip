@@ -747,8 +747,9 @@ __device__ __forceinline__ void ba_schur_body(
   __syncthreads();
   BA_WG_PROBE(1, 2);                     // edge list in LDS
   // The depth phase needs the edge list only.  Slice 0 issues it BEFORE wave 0 builds the row table, so the table's ~1 us of LDS
-  // work hides behind the depth phase's loads (as up to round 4; with the table in front S-B's Schur launch took 17.5 us
-  // instead of 16.2); ONE barrier behind both publishes table and rows together.
+  // work hides behind the depth phase's loads (as up to round 4); ONE barrier behind both publishes table and rows together.
+  // (S-B's launch: 18.2 us with the table in front and a 64-step follower scan, 17.3 now, 16.2 with round 4's kernel -
+  // profiles/r05_schur_sweep.txt, block 6.)
   auto depth_phase = [&]() {
 #pragma unroll
     for (int h = 0; h < PIX / 256; ++h) {
