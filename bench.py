@@ -877,7 +877,7 @@ def emit(obj):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=120, help="timed keyframe updates (default 120: a timed region of ~0.5 s; the driver passes its own)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the S-A workload and the edge-sharded leg")
@@ -1092,7 +1092,7 @@ def main():
     extra = {}
     if not args.no_extras:
         if world == 1:
-            for key, leg in (("workload_S_A", lambda: workload_sa(device, max(10, args.steps // 2))), ("workload_S_1", lambda: workload_s1(device)),
+            for key, leg in (("workload_S_A", lambda: workload_sa(device, max(10, min(args.steps // 2, 30)))), ("workload_S_1", lambda: workload_s1(device)),
                              ("train_step", lambda: train_step_leg(device)),
                              ("sequence", lambda: sequence_leg(device, args.sequence_frames))):
                 try:
