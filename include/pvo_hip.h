@@ -85,7 +85,8 @@ enum {
   PVO_KNOB_BA_SOLVER = 0,         /* 0 shipped choice by size | 1 blocked | 2 one wave | 3 pipelined | 4 partitioned (two workgroups) */
   PVO_KNOB_HEADS_GATHER_FLAT = 1, /* 1: pvo_heads_gather without its LDS-tiled form */
   PVO_KNOB_NO_RIDERS = 2,         /* 1: pvo_graph_update computes the upsampling mask and the next gate context as launches of their own */
-  PVO_KNOB_COUNT = 3
+  PVO_KNOB_POST_SEPARATE = 3,     /* 1: pvo_graph_update runs pvo_graph_post as a launch of its own instead of as the epilogue of the heads' gather */
+  PVO_KNOB_COUNT = 4
 };
 int pvo_debug_config(int knob, int value);
 int pvo_knob(int knob); /* current value (0 for an unknown knob) */

@@ -123,7 +123,7 @@ class GraphUpdateArgs(_c.Structure):
 
 
 PVO_OP_CONV128_WIDE, PVO_OP_SINGLE_STREAM, PVO_OP_ENC_SIDE_STREAM = 1, 2, 4
-PVO_KNOB_BA_SOLVER, PVO_KNOB_HEADS_GATHER_FLAT, PVO_KNOB_NO_RIDERS = 0, 1, 2
+PVO_KNOB_BA_SOLVER, PVO_KNOB_HEADS_GATHER_FLAT, PVO_KNOB_NO_RIDERS, PVO_KNOB_POST_SEPARATE = 0, 1, 2, 3
 
 _lib = None
 

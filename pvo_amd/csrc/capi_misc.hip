@@ -19,7 +19,7 @@ extern "C" const char* pvo_strerror(int code) {
 // 103: pvo_debug_config / pvo_knob replace the library's environment switches (round 5)
 extern "C" int pvo_version(void) { return PVO_ABI_VERSION; }
 
-static int g_knobs[PVO_KNOB_COUNT] = {0, 0, 0};
+static int g_knobs[PVO_KNOB_COUNT] = {};
 extern "C" int pvo_debug_config(int knob, int value) {
   if (knob < 0 || knob >= PVO_KNOB_COUNT) return PVO_EINVAL;
   g_knobs[knob] = value;

@@ -9,6 +9,7 @@
 // In PyTorch this is ~25 element-wise / cat / permute launches over 1-2 MB tensors per graph update (launch-bound);
 // the head outputs are read straight from the [E,H,W,8] tensor heads_out writes (delta | delta_dy | weight | delta_mask).
 #include "common.h"
+#include "graph_post.h"
 
 namespace {
 
@@ -39,50 +40,14 @@ __global__ __launch_bounds__(256) void graph_motion_kernel(const float2* __restr
 }
 
 template <typename T>
-__device__ __forceinline__ float h2f_(uint32_t bits) {
-  if constexpr (__is_same(T, pvo_half)) { union { uint16_t u; _Float16 h; } c; c.u = static_cast<uint16_t>(bits); return static_cast<float>(c.h); }
-  else return pvo_bf16_to_f32(static_cast<uint16_t>(bits));
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void graph_post_kernel(const float2* __restrict__ coords1, const uint16_t* __restrict__ y8,
-                                                         float2* __restrict__ raw_mask, float2* __restrict__ target,
-                                                         float2* __restrict__ delta_dy, float2* __restrict__ weight,
-                                                         float* __restrict__ target_ba, float* __restrict__ weight_ba,
-                                                         float2* __restrict__ full_flow, int E, int HW, int W, float dy_thresh,
+__global__ __launch_bounds__(256) void graph_post_kernel(GraphPostArgs g, const uint16_t* __restrict__ y8, int E, int HW, int W,
                                                          const int* __restrict__ segm, const int* __restrict__ vote_tot,
                                                          const int* __restrict__ vote_dyn, int S, float vote_thresh) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= E * HW) return;
   const int e = idx / HW, pix = idx - e * HW;
-  const float x0 = static_cast<float>(pix % W), y0 = static_cast<float>(pix / W);
   const uint4 q = *reinterpret_cast<const uint4*>(y8 + static_cast<size_t>(idx) * 8);
-  const float d0 = h2f_<T>(q.x & 0xffffu), d1 = h2f_<T>(q.x >> 16);      // delta
-  const float g0 = h2f_<T>(q.y & 0xffffu), g1 = h2f_<T>(q.y >> 16);      // delta_dy (raw)
-  const float w0 = h2f_<T>(q.z & 0xffffu), w1 = h2f_<T>(q.z >> 16);      // weight logits
-  const float m0 = h2f_<T>(q.w & 0xffffu), m1 = h2f_<T>(q.w >> 16);      // delta_mask
-  const float2 c1 = coords1[idx];
-  float2 rm = raw_mask[idx];
-  rm.x += m0; rm.y += m1;
-  raw_mask[idx] = rm;
-  float b0 = (1.0f / (1.0f + expf(-rm.x)) >= dy_thresh) ? 1.0f : 0.0f;    // 1: static, 0: dynamic
-  float b1 = (1.0f / (1.0f + expf(-rm.y)) >= dy_thresh) ? 1.0f : 0.0f;
-  if (segm) {      // panoptic vote (factor_graph.py:256-276): a segment (id != 0) whose dynamic fraction on this edge exceeds the threshold is forced dynamic
-    int sg = segm[idx];
-    sg = sg < 0 ? 0 : (sg >= S ? S - 1 : sg);
-    if (sg != 0) {
-      const float tot = static_cast<float>(vote_tot[static_cast<size_t>(e) * S + sg]), dyn = static_cast<float>(vote_dyn[static_cast<size_t>(e) * S + sg]);
-      if (dyn / fmaxf(tot, 1.0f) > vote_thresh) { b0 = 0.0f; b1 = 0.0f; }
-    }
-  }
-  const float2 tg = {c1.x + d0, c1.y + d1};
-  const float2 dd = {g0 * (1.0f - b0), g1 * (1.0f - b1)};
-  const float2 wt = {1.0f / (1.0f + expf(-(w0 + (1.0f - b0) * 10.0f))), 1.0f / (1.0f + expf(-(w1 + (1.0f - b1) * 10.0f)))};
-  target[idx] = tg; delta_dy[idx] = dd; weight[idx] = wt;
-  full_flow[idx] = {c1.x + dd.x - x0, c1.y + dd.y - y0};
-  const size_t ob = static_cast<size_t>(e) * 2 * HW + pix;
-  target_ba[ob] = tg.x; target_ba[ob + HW] = tg.y;
-  weight_ba[ob] = wt.x; weight_ba[ob + HW] = wt.y;
+  graph_post_pixel<T>(idx, e, pix, q, g, HW, W, segm, vote_tot, vote_dyn, S, vote_thresh);      // (graph_post.h)
 }
 
 }  // namespace
@@ -121,10 +86,11 @@ extern "C" int pvo_graph_post(const float* coords1, const void* heads, float* ra
   hipStream_t st = pvo_stream(stream);
   const dim3 grid(static_cast<unsigned>((n + 255) / 256));
   auto f2 = [](float* p) { return reinterpret_cast<float2*>(p); };
+  const GraphPostArgs g = {reinterpret_cast<const float2*>(coords1), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), dy_thresh};
   if (dtype == PVO_F16)
-    hipLaunchKernelGGL(graph_post_kernel<pvo_half>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, segm, vote_tot, vote_dyn, max_segments, vote_thresh);
+    hipLaunchKernelGGL(graph_post_kernel<pvo_half>, grid, dim3(256), 0, st, g, static_cast<const uint16_t*>(heads), E, H * W, W, segm, vote_tot, vote_dyn, max_segments, vote_thresh);
   else if (dtype == PVO_BF16)
-    hipLaunchKernelGGL(graph_post_kernel<pvo_bf16>, grid, dim3(256), 0, st, reinterpret_cast<const float2*>(coords1), static_cast<const uint16_t*>(heads), f2(raw_mask), f2(target), f2(delta_dy), f2(weight), target_ba, weight_ba, f2(full_flow), E, H * W, W, dy_thresh, segm, vote_tot, vote_dyn, max_segments, vote_thresh);
+    hipLaunchKernelGGL(graph_post_kernel<pvo_bf16>, grid, dim3(256), 0, st, g, static_cast<const uint16_t*>(heads), E, H * W, W, segm, vote_tot, vote_dyn, max_segments, vote_thresh);
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;

@@ -5,6 +5,7 @@
 //   heads_out   the second stage of the four output heads, 4 x (ReLU + Conv3x3(128 -> 2)) (droid_net.py:184-210)
 // Layout: channels-last fp16/bf16 rows ([E, H*W, C]); 8 channels (16 B) per thread per access; arithmetic in fp32.
 #include "common.h"
+#include "graph_post.h"
 #include <stdlib.h>
 
 namespace {
@@ -310,9 +311,13 @@ __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restri
 // 8-byte reads per thread that each touch a different 72-byte segment of a row.  Same sums in the same order: bit-identical.
 constexpr int kHgTH = 8, kHgTW = 16, kHgPos = (kHgTH + 2) * (kHgTW + 2), kHgRow = 288 + 16;      // (+16: rows of one pixel column land on different banks)
 
-template <typename T>
+// POST: the pixel's four heads sit in four consecutive lanes (delta | delta_dy | weight logits | delta_mask, the order pvo_graph_post
+// reads them in); the lane of head 0 collects the four packed pairs - rounded to 16 bits exactly as they are stored - and runs
+// graph_post_pixel (graph_post.h) on them: FactorGraph.update's mask / target / weight arithmetic without a launch of its own
+// (4.6 us + a kernel boundary per graph update at S-B).  Without the panoptic vote only - that needs the edge's whole histogram first.
+template <typename T, bool POST>
 __global__ __launch_bounds__(256) void heads_gather_tiled_kernel(const float* __restrict__ z, const float* __restrict__ bias2,
-                                                                 uint16_t* __restrict__ y, int H, int W) {
+                                                                 uint16_t* __restrict__ y, int H, int W, GraphPostArgs gp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hgs[];
   const int e = blockIdx.z, y0 = blockIdx.y * kHgTH, x0 = blockIdx.x * kHgTW, tid = threadIdx.x;
   const float* ze = z + static_cast<size_t>(e) * H * W * 72;
@@ -350,13 +355,26 @@ __global__ __launch_bounds__(256) void heads_gather_tiled_kernel(const float* __
       }
     }
     const uint32_t lo = H8<T>::to_bits(Elem<T>::from_f32(a0)), hi = H8<T>::to_bits(Elem<T>::from_f32(a1));
-    *reinterpret_cast<uint32_t*>(y + ((static_cast<size_t>(e) * H + py) * W + px) * 8 + 2 * head) = lo | (hi << 16);
+    const uint32_t mine = (lo & 0xffffu) | (hi << 16);
+    *reinterpret_cast<uint32_t*>(y + ((static_cast<size_t>(e) * H + py) * W + px) * 8 + 2 * head) = mine;
+    if (POST) {
+      // (the four lanes of a pixel are all here or all gone: `continue` above depends on the pixel only)
+      const int quad = (tid & 63) & ~3;
+      uint4 q;
+      q.x = __shfl(mine, quad); q.y = __shfl(mine, quad + 1); q.z = __shfl(mine, quad + 2); q.w = __shfl(mine, quad + 3);
+      if (head == 0) {
+        const int pix = py * W + px;
+        graph_post_pixel<T>(e * (H * W) + pix, e, pix, q, gp, H * W, W, nullptr, nullptr, nullptr, 0, 0.0f);
+      }
+    }
   }
 }
 
 }  // namespace
 
-extern "C" int pvo_heads_gather(const float* z, const float* bias2, void* y, int E, int H, int W, int dtype, void* stream) {
+static int heads_gather_launch(const float* z, const float* bias2, void* y, const GraphPostArgs* post, int* fused,
+                               int E, int H, int W, int dtype, void* stream) {
+  if (fused) *fused = 0;
   if (E < 0 || H < 0 || W < 0) return PVO_EINVAL;
   if (E == 0 || H == 0 || W == 0) return PVO_OK;
   if (!z || !bias2 || !y || (reinterpret_cast<uintptr_t>(z) & 7) || (reinterpret_cast<uintptr_t>(y) & 3)) return PVO_EINVAL;
@@ -367,14 +385,25 @@ extern "C" int pvo_heads_gather(const float* z, const float* bias2, void* y, int
     constexpr size_t lds = static_cast<size_t>(kHgPos) * kHgRow;                      // 54720 B
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_half>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_half, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_half, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(heads_gather_tiled_kernel<pvo_bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
         return PVO_ELAUNCH;
       attr_set = true;
     }
-    if (dtype == PVO_F16) hipLaunchKernelGGL(heads_gather_tiled_kernel<pvo_half>, grid, dim3(256), lds, st, z, bias2, static_cast<uint16_t*>(y), H, W);
-    else if (dtype == PVO_BF16) hipLaunchKernelGGL(heads_gather_tiled_kernel<pvo_bf16>, grid, dim3(256), lds, st, z, bias2, static_cast<uint16_t*>(y), H, W);
-    else return PVO_EUNSUPPORTED;
+    if (dtype != PVO_F16 && dtype != PVO_BF16) return PVO_EUNSUPPORTED;
+    const bool with_post = post != nullptr && static_cast<long long>(E) * H * W < (1LL << 31);
+    const GraphPostArgs gp = with_post ? *post : GraphPostArgs{};
+    uint16_t* yp = static_cast<uint16_t*>(y);
+    if (with_post) {
+      if (dtype == PVO_F16) hipLaunchKernelGGL((heads_gather_tiled_kernel<pvo_half, true>), grid, dim3(256), lds, st, z, bias2, yp, H, W, gp);
+      else hipLaunchKernelGGL((heads_gather_tiled_kernel<pvo_bf16, true>), grid, dim3(256), lds, st, z, bias2, yp, H, W, gp);
+      if (fused) *fused = 1;
+    } else {
+      if (dtype == PVO_F16) hipLaunchKernelGGL((heads_gather_tiled_kernel<pvo_half, false>), grid, dim3(256), lds, st, z, bias2, yp, H, W, gp);
+      else hipLaunchKernelGGL((heads_gather_tiled_kernel<pvo_bf16, false>), grid, dim3(256), lds, st, z, bias2, yp, H, W, gp);
+    }
     PVO_CHECK_LAUNCH();
     return PVO_OK;
   }
@@ -385,6 +414,15 @@ extern "C" int pvo_heads_gather(const float* z, const float* bias2, void* y, int
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;
+}
+
+extern "C" int pvo_heads_gather(const float* z, const float* bias2, void* y, int E, int H, int W, int dtype, void* stream) {
+  return heads_gather_launch(z, bias2, y, nullptr, nullptr, E, H, W, dtype, stream);
+}
+
+int pvo_internal_heads_gather_post(const float* z, const float* bias2, void* y, const GraphPostArgs* post, int* fused,
+                                   int E, int H, int W, int dtype, void* stream) {
+  return heads_gather_launch(z, bias2, y, post, fused, E, H, W, dtype, stream);
 }
 
 extern "C" int pvo_heads_out(const void* h1, const float* bias1, const void* w2, const float* bias2, void* y,

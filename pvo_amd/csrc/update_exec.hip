@@ -12,6 +12,7 @@
 //   pvo_graph_update      FactorGraph.update (factor_graph.py:227-307): reproject -> motion features -> operator ->
 //                         (panoptic vote) -> mask / weight glue -> eta / damping -> dense BA x itrs -> depth clamp
 #include "common.h"
+#include "graph_post.h"
 #include <stdlib.h>
 
 namespace {
@@ -211,11 +212,14 @@ int run_trunk(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, 
   return PVO_OK;
 }
 
-int run_heads(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream) {
+// post != nullptr: the graph update's mask / target / weight arithmetic (pvo_graph_post without the panoptic vote) runs as the
+// gather's epilogue where the gather's tiled form applies; *post_fused says whether it did
+int run_heads(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream,
+              const GraphPostArgs* post = nullptr, int* post_fused = nullptr) {
   const int E = a->E, H = a->H, W = a->W, dt = w->dtype;
   // (b.h1 holds z [E,H,W,4,18] f32: the hidden tensor itself stays in the first launch's LDS)
   RUN(pvo_conv3x3_heads(a->net_out, w->heads1_w, w->heads1_b, w->heads2_w, reinterpret_cast<float*>(b.h1), E, H, W, dt, stream));
-  RUN(pvo_heads_gather(reinterpret_cast<const float*>(b.h1), w->heads2_b, a->heads, E, H, W, dt, stream));
+  RUN(pvo_internal_heads_gather_post(reinterpret_cast<const float*>(b.h1), w->heads2_b, a->heads, post, post_fused, E, H, W, dt, stream));
   return PVO_OK;
 }
 
@@ -257,7 +261,8 @@ int check_op(const pvo_update_weights* w, const pvo_operator_args* a) {
 // leaves the join to the caller (pvo_graph_update joins only in front of the BA, so the K-frame kernels of the
 // aggregation branch, which occupy a fraction of the chip, also overlap the mask / weight glue).
 int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& b, void* stream, SideCtx** pending,
-                 const MotionJob* mj = nullptr, bool upmask_on_side = true, bool context_ready = false) {
+                 const MotionJob* mj = nullptr, bool upmask_on_side = true, bool context_ready = false,
+                 const GraphPostArgs* post = nullptr, int* post_fused = nullptr) {
   const void *P_zr, *P_q;
   RUN(run_trunk(w, a, b, stream, &P_zr, &P_q, mj, context_ready));
   hipStream_t st = pvo_stream(stream);
@@ -267,10 +272,10 @@ int run_operator(const pvo_update_weights* w, const pvo_operator_args* a, OpWs& 
     if (hipStreamWaitEvent(sc->side, sc->fork, 0) != hipSuccess) return PVO_ELAUNCH;
     RUN(run_agg(w, a, b, sc->side, sc, upmask_on_side));
     if (hipEventRecord(sc->join, sc->side) != hipSuccess) return PVO_ELAUNCH;
-    RUN(run_heads(w, a, b, stream));
+    RUN(run_heads(w, a, b, stream, post, post_fused));
     *pending = sc;
   } else {
-    RUN(run_heads(w, a, b, stream));
+    RUN(run_heads(w, a, b, stream, post, post_fused));
     RUN(run_agg(w, a, b, stream, nullptr, upmask_on_side));
     *pending = nullptr;
   }
@@ -350,14 +355,22 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
                          ca->W == W && ca->dtype == dt;
   if (ca) ca->valid = false;
   SideCtx* pending = nullptr;
-  RUN(run_operator(w, &a, b, stream, &pending, nullptr, false, ctx_ready));
-  // :249-306: mask update, (panoptic vote), weights, targets in the BA's layout, full flow
+  // :249-306: mask update, (panoptic vote), weights, targets in the BA's layout, full flow.  Without the vote it is the epilogue of
+  // the output heads' gather (graph_post.h; pvo_debug_config(PVO_KNOB_POST_SEPARATE) keeps the launch of its own: a test compares)
+  float* const tba = u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW;
+  float* const wba = u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW;
+  const GraphPostArgs gpa = {reinterpret_cast<const float2*>(s.coords), reinterpret_cast<float2*>(u->raw_mask), reinterpret_cast<float2*>(u->target),
+                             reinterpret_cast<float2*>(u->delta_dy), reinterpret_cast<float2*>(u->weight), tba, wba,
+                             reinterpret_cast<float2*>(u->full_flow), u->dy_thresh};
+  const bool post_in_gather = !u->segm && pvo_knob(PVO_KNOB_POST_SEPARATE) == 0;
+  int post_fused = 0;
+  RUN(run_operator(w, &a, b, stream, &pending, nullptr, false, ctx_ready, post_in_gather ? &gpa : nullptr, &post_fused));
   if (u->segm)
     RUN(pvo_segment_hist(u->segm, u->raw_mask, s.heads, s.vote_tot, s.vote_dyn, E, HW, S, u->dy_thresh, dt, stream));
-  RUN(pvo_graph_post(s.coords, s.heads, u->raw_mask, u->target, u->delta_dy, u->weight,
-                     u->target_ba + static_cast<size_t>(u->n_in) * 2 * HW, u->weight_ba + static_cast<size_t>(u->n_in) * 2 * HW,
-                     u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
-                     S, u->vote_thresh, dt, stream));
+  if (!post_fused)
+    RUN(pvo_graph_post(s.coords, s.heads, u->raw_mask, u->target, u->delta_dy, u->weight, tba, wba,
+                       u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,
+                       S, u->vote_thresh, dt, stream));
   const bool rider_off = pvo_knob(PVO_KNOB_NO_RIDERS) != 0;
   // (the rider has preconditions the stand-alone convolution does not: at most 2^24 rows and 16-byte aligned operands,
   // pvo_ba_finish_riders - beyond them the mask is computed the old way, on this stream, instead of failing the update)

@@ -522,7 +522,7 @@ def test_context_computed_ahead_inside_the_pose_solves_changes_nothing(cuda):
     outs = []
     prelude = ("import sys; sys.path.insert(0, %r); from pvo_amd import droid_backends as _dbk; "
                "[_dbk.debug_config(kv.split('=')[0], int(kv.split('=')[1])) for kv in sys.argv[2:]]; ") % root
-    for knobs in ([], ["no_riders=1"]):
+    for knobs in ([], ["no_riders=1"], ["post_separate=1"]):       # (post_separate: pvo_graph_post as a launch of its own, not the gather's epilogue)
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
             r = subprocess.run([sys.executable, "-c", prelude + code, f.name] + knobs, stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=600)
