@@ -31,7 +31,10 @@ def _flat(out):
 class GraphedCall:
     def __init__(self, fn, warmup=2, rtol=2e-3, name=None, guard=None):
         """fn(*tensors) -> tensor or tuple of tensors; no host synchronisation and no data-dependent shapes inside.
-        guard() (optional) -> a hashable that must be unchanged for a capture to stay valid (e.g. the storage of the weights)"""
+        guard() (optional) -> a hashable that must be unchanged for a capture to stay valid (e.g. the storage of the weights).
+        An argument that is the same tensor object as at the previous call with an unchanged version counter is not copied again:
+        arguments must therefore only ever be written through torch (a native kernel writing through data_ptr() does not count as
+        a write) - the callers here pass frames, clones and convolution outputs that nothing writes afterwards."""
         self.fn, self.warmup, self.rtol, self.name = fn, warmup, rtol, name or getattr(fn, "__name__", "call")
         self.guard = guard
         self.cache = {}

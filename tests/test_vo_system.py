@@ -391,3 +391,15 @@ def test_graphed_call_skips_only_arguments_that_cannot_have_changed():
         assert torch.equal(g(a2, b), a2 * 2 + b)
         n = g.replays
         assert torch.equal(g(a2, b), a2 * 2 + b) and g.replays == n + 1      # nothing changed: still replayed, same result
+
+
+def test_graphed_call_is_a_plain_call_off_the_gpu():
+    """CPU tensors, gradients enabled or no arguments: pvo_amd.graphs.GraphedCall just calls through (nothing is captured)"""
+    from pvo_amd.graphs import GraphedCall
+    calls = []
+    g = GraphedCall(lambda a, b: (calls.append(1), a + b)[1], warmup=0)
+    a, b = torch.ones(3), torch.arange(3.0)
+    with torch.no_grad():
+        for _ in range(4):
+            assert torch.equal(g(a, b), a + b)
+    assert len(calls) == 4 and g.replays == 0 and not g.cache
