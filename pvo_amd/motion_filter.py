@@ -26,6 +26,16 @@ def _weights_guard(module):
     return guard
 
 
+def upload_frame(image, device):
+    """pageable host tensor -> device, a plain blocking copy on the current stream.
+    Measured on an MI355X box (2.3 MB int32 frame, 1.7 ms of kernels queued on the stream in front of it): this form 1.78 ms per
+    frame all in, non_blocking=True from pageable memory 10.1 ms (the runtime stages the copy in pieces that each wait behind the
+    queued kernels), a stream of its own 1.70 ms.  In the tracker itself the three forms are within the run-to-run spread or worse
+    (side stream: 90-92 frames/s against 102-110; blocking against non_blocking: 105-111 both) - the tracked sequence is device-bound
+    where the frame goes up - so the form that cannot hit the 10 ms case stays."""
+    return image.to(device) if isinstance(image, torch.Tensor) else image
+
+
 class MotionFilter:
     def __init__(self, net, video, thresh=2.5, device="cuda:0"):
         self.cnet, self.fnet, self.update = net.cnet, net.fnet, net.update
@@ -46,12 +56,11 @@ class MotionFilter:
         self._static = None                # conv(W[:, inp], inp) of the reference keyframe's context: constant until the next keyframe
 
     def _upload(self, image):
-        """host frame -> device, as it is (the reference's stream hands over int32, test_vo.py:41): NO tensor operation on the host.
-        On the 128-core hosts of the MI355X boxes every CPU tensor op on a frame - a dtype cast, the [2, 1, 0] channel gather of
-        motion_filter.py:52, torch.stack in the filler - costs 2-20 ms (an OpenMP team is woken for 0.6 M elements); the copy of
-        2.3 MB costs 0.2 ms and the flip / cast / scaling belong to the captured device graph.  (A pinned staging buffer was tried
-        too: CPU writes into hipHostMalloc'ed memory ran at ~150 MB/s here, 16 ms per frame.)"""
-        return image.to(self.device, non_blocking=True)
+        """host frame -> device, as it is (the reference's stream hands over int32, test_vo.py:41): NO tensor operation on the host
+        (on the 128-core hosts of the MI355X boxes every CPU tensor op on a frame - a dtype cast, the [2, 1, 0] channel gather of
+        motion_filter.py:52, torch.stack in the filler - costs 2-20 ms: an OpenMP team is woken for 0.6 M elements), and the copy
+        goes over a stream of its own (`upload_frame`)."""
+        return upload_frame(image, self.device)
 
     def _normalise_dev(self, image_dev):
         # (flip(0) = the reference's channel gather [2, 1, 0] without an index tensor: a list index is uploaded from the host on

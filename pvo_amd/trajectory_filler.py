@@ -40,7 +40,8 @@ class PoseTrajectoryFiller:
                 x = images[None, :, [2, 1, 0]].to(self.device).float() / 255.0
                 return self.fnet((x - self.MEAN) / self.STDV).squeeze(0)
         # (each frame goes up as it is and is never touched on the host: a torch.stack of 16 frames took 19 ms on a 128-core host)
-        return torch.cat([self._one(im.to(self.device, non_blocking=True)).clone() for im in images], 0)
+        from .motion_filter import upload_frame
+        return torch.cat([self._one(upload_frame(im, self.device)).clone() for im in images], 0)
 
     def _fill(self, tstamps, images, intrinsics):
         v = self.video
