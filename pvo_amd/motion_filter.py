@@ -58,8 +58,7 @@ class MotionFilter:
     def _upload(self, image):
         """host frame -> device, as it is (the reference's stream hands over int32, test_vo.py:41): NO tensor operation on the host
         (on the 128-core hosts of the MI355X boxes every CPU tensor op on a frame - a dtype cast, the [2, 1, 0] channel gather of
-        motion_filter.py:52, torch.stack in the filler - costs 2-20 ms: an OpenMP team is woken for 0.6 M elements), and the copy
-        goes over a stream of its own (`upload_frame`)."""
+        motion_filter.py:52, torch.stack in the filler - costs 2-20 ms: an OpenMP team is woken for 0.6 M elements); the copy itself: `upload_frame`."""
         return upload_frame(image, self.device)
 
     def _normalise_dev(self, image_dev):
