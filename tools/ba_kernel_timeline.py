@@ -65,7 +65,7 @@ def show(name, k, labels, last):
             dtt = (a[ok, j] - a[ok, i]) * 0.01
             print("    %-58s median %6.2f us   max %6.2f   (%d workgroups)" % (lab, np.median(dtt), dtt.max(), ok.sum()))
 show("ba_assemble_kernel", 0, [(0, 1, "entry -> pixel terms computed, rows stored"), (1, 2, "the waves' 90 sums (reduce-scatter) + barrier"), (2, 3, "chunk sums stored / atomics issued"), (0, 3, "whole workgroup")], 3)
-show("ba_schur_mfma_kernel", 1, [(0, 1, "entry -> meta read (the chunk sums are other workgroups' now)"), (1, 2, "edge list -> LDS"), (2, 3, "row table + barrier"),
-                                 (3, 4, "depth phase (C, w, Q, Ei) + barrier (rows visible)"), (4, 5, "fast path: row loads + MFMA, PIX / 64 steps (wave 0)"), (5, 6, "fast path: products -> LDS + barrier"),
+show("ba_schur_mfma_kernel", 1, [(0, 1, "entry -> meta read (the chunk sums are other workgroups' now)"), (1, 2, "edge list -> LDS"), (2, 3, "depth phase issued, row table built (wave 0; slices > 0: table, barrier, depth phase)"),
+                                 (3, 4, "barrier: rows and table visible (+ merged rows)"), (4, 5, "fast path: row loads + MFMA, PIX / 64 steps (wave 0)"), (5, 6, "fast path: products -> LDS + barrier"),
                                  (6, 7, "fast path: 4-wave sums + fixed-point atomics"), (4, 7, "all tile pairs (fast path or this slice's row passes)"), (0, 7, "whole workgroup (slice 0)")], 7)
 show("ba_backsub_kernel", 2, [(0, 1, "rows / dx -> LDS + barrier"), (1, 2, "rows x dx, depth update"), (0, 2, "whole workgroup")], 2)

@@ -23,9 +23,10 @@ if os.environ.get("BA_DUMP"):
 else:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_geom_ba_gpu import _scene
-    sc = _scene(0, 8, 48, 64, 3, 1)
+    nf = int(os.environ.get("NF", "8"))            # NF / HT / WD / RAD: a synthetic window (NF=26 RAD=8 HT=30 WD=101: 16 neighbours per frame)
+    sc = _scene(0, nf, int(os.environ.get("HT", "48")), int(os.environ.get("WD", "64")), int(os.environ.get("RAD", "3")), 1)
     d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.items()}
-    t0, t1 = 1, 8
+    t0, t1 = 1, nf
 for _ in range(40):
     db.ba(d["poses"].clone(), d["disps"].clone(), d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], t0, t1, 2, 1e-4, 0.1, False)
 torch.cuda.synchronize()
