@@ -302,7 +302,7 @@ int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, l
  *   pvo_segment_hist  panoptic vote, counting half (:256-261): tot[e,s] = pixels of segment s on edge e, dyn[e,s] = those
  *                     whose UPDATED mask (raw_mask + delta_mask, read from heads) is dynamic on either channel;
  *                     segm int32 [E,H,W] dense segment labels in [0, max_segments), 0 = no segment; tot/dyn int32
- *                     [E,max_segments] (zeroed here)
+ *                     [E,max_segments] (zeroed here: two fills of exactly E*max_segments*4 bytes, nothing else is written)
  *   pvo_graph_post    heads [E,H,W,8] (`dtype`) = delta | delta_dy | weight logits | delta_mask as pvo_heads_out writes them:
  *                     raw_mask += delta_mask (in place); bin = sigmoid(raw_mask) >= dy_thresh; with segm != NULL, bin = 0
  *                     on both channels where the pixel's segment s != 0 has dyn[e,s] / max(tot[e,s],1) > vote_thresh
@@ -535,7 +535,7 @@ size_t pvo_ba_workspace_bytes(int E, int P, int nframes, int HW);
  * rows, or 1 row which is then broadcast; dz_rows >= K unless dz_out is NULL.
  * status_out (device int[4], may be NULL): [0]=0 ok / 1 non-SPD in some iteration
  * (that step's dx is 0, as droid_kernels.cu:1186-1189), [1]=K found on device,
- * [2]=1 if K_eta mismatched K, [3] reserved.
+ * [2]=1 if K_eta mismatched K (the call then updates NOTHING and [0] is 1 as well), [3] reserved.
  * The depth back-substitution reproduces EvT6x1_kernel's skip of window pose 0
  * (droid_kernels.cu:1084).  expSE3 uses xi[5] where the reference reads xi[45] (:154).
  * No host synchronisation: the factor-graph index structures are built on the

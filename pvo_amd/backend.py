@@ -28,7 +28,8 @@ class DroidBackend:
         self.edge_rule = dict(rad=args.backend_radius, nms=args.backend_nms, thresh=args.backend_thresh, beta=args.beta)
         self.beta, self.backend_radius = args.beta, args.backend_radius
         self.backend_nms, self.backend_thresh = args.backend_nms, args.backend_thresh
-        self.corr_impl = getattr(args, "backend_corr", "auto")
+        self.corr_impl = getattr(args, "backend_corr", "auto")      # "alt" = the reference's formulation (parity runs), "auto" = the fast one that fits
+        self.last_corr_impl = None                                  # what the last pass ran on ("alt" / "volume"): results record it
 
     def _volumes_fit(self, n_edges):
         """resident correlation volumes + per-edge operator state for n_edges, against the free HBM (288 GB on MI355X): the 4-level
@@ -61,10 +62,19 @@ class DroidBackend:
         ii = [i for k, i in enumerate(whole[0]) if mask is None or mask[k]]
         jj = [j for k, j in enumerate(whole[1]) if mask is None or mask[k]]
         probe = self._graph("volume")
-        if ii and probe._static_ok() and self._volumes_fit(len(ii)):
+        fits = bool(ii) and probe._static_ok() and self._volumes_fit(len(ii))
+        if keep is not None:
+            # edge sharding: every rank judges the fit from ITS OWN free memory and edge count, but all ranks must run the same
+            # formulation of the same collective solve (fp16 resident volumes and fp32 alt-corr differ numerically): the choice is
+            # "volume" only if it fits on EVERY rank (MIN over ranks)
+            flag = torch.tensor([1 if fits else 0], dtype=torch.int32, device=self.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            fits = bool(int(flag.item()))
+        if fits:
             first.clear_edges()
             probe.add_factors(ii, jj)
             if probe._fused_ok() and probe.P_zr is not None:
+                self.last_corr_impl = "volume"
                 return probe, whole
             probe.clear_edges()
             first = self._graph("alt")
@@ -85,7 +95,10 @@ class DroidBackend:
             from .parallel import ShardedBA, partition_by_source
             rank = torch.distributed.get_rank()
             keep = lambda ii, jj: [o == rank for o in partition_by_source(ii, torch.distributed.get_world_size())[0]]
+        self.last_corr_impl = "alt"
         graph, whole = self._connect_all(keep)
+        if self.corr_impl != "auto":
+            self.last_corr_impl = self.corr_impl
         if keep is not None:
             sharded, before = ShardedBA(structure=whole), self.video.disps.clone()   # `whole`: the structure of the all-reduced pose system
         if len(graph._ii_h) > 65535:

@@ -187,6 +187,10 @@ __global__ __launch_bounds__(256) void ba_plan_kernel(
     pl.meta[1] = 0;
     pl.meta[3] = 0;
     pl.meta[4] = 0;
+    // eta must have one row per depth frame (or one row, broadcast).  Anything else is a caller error the host cannot see
+    // without a synchronisation (K is found here): flagged, and the step becomes a NO-OP - the Schur grid is sized by the caller's
+    // row count, so depth frames beyond it would keep stale Q / w; the solve reports failure (dx = 0, poses untouched) and the
+    // back-substitution leaves every depth map alone (status_out[0] = 1, [2] = 1).
     pl.meta[2] = (!motion_only && K_eta != K && K_eta != 1) ? 1 : 0;
   }
 }
@@ -701,7 +705,9 @@ __device__ __forceinline__ void ba_schur_body(
       // 105 us, bench.py `sequence`; two edges a workgroup apart in the edge list shared nothing.)
       const int t = threadIdx.x;
       const int wgi = (blockIdx.y - (gridDim.y - deal_rows)) * gridDim.x + blockIdx.x;
-      const int p0 = wgi * kDealEdges, p1 = (p0 + kDealEdges < E) ? p0 + kDealEdges : E;
+      // (the plan lists only edges whose source frame lies in [0, F): eidx[eptr[K] ..) is not initialised - bound by the plan's count)
+      const int Epl = pl.eptr[pl.meta[0]];
+      const int p0 = wgi * kDealEdges, p1 = (p0 + kDealEdges < Epl) ? p0 + kDealEdges : Epl;
       long long pend_idx[2] = {-1, -1}, pend_acc[2] = {0, 0};
       for (int pos = p0; pos < p1; ++pos) {
         const int e = pl.eidx[pos];
@@ -2058,7 +2064,7 @@ __global__ __launch_bounds__(256) PVO_SOLVE_ATTR void ba_solve_kernel(
   }
   __syncthreads();
   BA_PROBE(4);
-  const int failed = fail | meta[4];
+  const int failed = fail | meta[4] | meta[2];      // (meta[2]: eta's row count != K - the whole step is a no-op, see ba_plan_kernel)
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
     const float v = failed ? 0.0f : static_cast<float>(xrow[idx]);    // zeros on failure (:1186-1189)
     dx_ws[idx] = v;
@@ -2137,7 +2143,7 @@ __global__ __launch_bounds__(256) void ba_solve_twin_kernel(
   __shared__ unsigned short act_rows[2][kMaxActiveRows];
   __shared__ PipeCtl pipe_ctl;
   __shared__ int blocks_s, got_s;
-  const int meta4 = meta[4];
+  const int meta4 = meta[4] | meta[2];      // (meta[2]: eta's row count != K - the whole step is a no-op)
   if (threadIdx.x == 0) {
     fail = 0;
     pipe_ctl.panel = -1; pipe_ctl.done[0] = pipe_ctl.done[1] = pipe_ctl.done[2] = -1; pipe_ctl.abort = 0; pipe_ctl.total = 0;
@@ -2429,7 +2435,7 @@ __device__ __forceinline__ void ba_backsub_body(
   // row_of() walked eptr -> eidx -> jj per row and pixel, three dependent loads in front of every row's six products
   __shared__ int s_edge[256], s_pose[256];
   __shared__ float s_dx[256][6];
-  const bool live = k < pl.meta[0];                       // (uniform)
+  const bool live = k < pl.meta[0] && !pl.meta[2];        // (uniform; meta[2]: eta's row count != K - nothing is updated)
   const int e0 = live ? pl.eptr[k] : 0, deg = live ? pl.eptr[k + 1] - e0 : 0;
   const bool in_lds = deg <= 255;
   const int lo = (flags & 1) ? 0 : 1;                     // EvT6x1_kernel returns early for pose index <= 0 (:1084): window pose 0 never reaches dz

@@ -300,8 +300,11 @@ extern "C" int pvo_corr_encode(const void* corr, const void* enc_weight, const f
   return PVO_OK;
 }
 
-extern "C" int pvo_segment_hist(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
-                                int E, int HW, int S, float dy_thresh, int dtype, void* stream) {
+// `own_gap`: tot and dyn were carved from ONE workspace by the caller (pvo_graph_update, update_exec.hip carve_up) and the bytes between
+// them are that workspace's padding - one fill clears both tables.  The public entry point never assumes that: two tensors of a caching
+// allocator may have a live stranger between them.
+static int segment_hist_impl(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
+                             int E, int HW, int S, float dy_thresh, int dtype, void* stream, bool own_gap) {
   if (E < 0 || HW < 0 || S <= 0) return PVO_EINVAL;
   const long long n = static_cast<long long>(E) * HW;
   if (n == 0) return PVO_OK;
@@ -309,7 +312,7 @@ extern "C" int pvo_segment_hist(const int* segm, const float* raw_mask, const vo
   hipStream_t st = pvo_stream(stream);
   const size_t tbytes = sizeof(int) * static_cast<size_t>(E) * S;
   const char *t0 = reinterpret_cast<const char*>(tot), *d0 = reinterpret_cast<const char*>(dyn);
-  if (d0 >= t0 + tbytes && static_cast<size_t>(d0 - t0) <= tbytes + 4096) {      // neighbours in one workspace (pvo_graph_update's): one fill
+  if (own_gap && d0 >= t0 + tbytes && static_cast<size_t>(d0 - t0) <= tbytes + 4096) {
     if (hipMemsetAsync(tot, 0, static_cast<size_t>(d0 - t0) + tbytes, st) != hipSuccess) return PVO_ELAUNCH;
   } else {
     if (hipMemsetAsync(tot, 0, tbytes, st) != hipSuccess) return PVO_ELAUNCH;
@@ -323,4 +326,15 @@ extern "C" int pvo_segment_hist(const int* segm, const float* raw_mask, const vo
   else return PVO_EUNSUPPORTED;
   PVO_CHECK_LAUNCH();
   return PVO_OK;
+}
+
+extern "C" int pvo_segment_hist(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
+                                int E, int HW, int S, float dy_thresh, int dtype, void* stream) {
+  return segment_hist_impl(segm, raw_mask, heads, tot, dyn, E, HW, S, dy_thresh, dtype, stream, false);
+}
+
+// internal (update_exec.hip): both tables lie in pvo_graph_update's workspace, separated by its alignment padding only
+int pvo_segment_hist_ws(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
+                        int E, int HW, int S, float dy_thresh, int dtype, void* stream) {
+  return segment_hist_impl(segm, raw_mask, heads, tot, dyn, E, HW, S, dy_thresh, dtype, stream, true);
 }

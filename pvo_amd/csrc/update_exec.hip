@@ -15,6 +15,10 @@
 #include "graph_post.h"
 #include <stdlib.h>
 
+// operator_small.hip: pvo_segment_hist for two tables carved from one workspace (one fill for both; not part of the C ABI)
+int pvo_segment_hist_ws(const int* segm, const float* raw_mask, const void* heads, int* tot, int* dyn,
+                        int E, int HW, int S, float dy_thresh, int dtype, void* stream);
+
 namespace {
 
 struct SideCtx { hipStream_t side; hipEvent_t fork, join, mid; bool ok; };
@@ -366,7 +370,7 @@ extern "C" int pvo_graph_update(const pvo_update_weights* w, const pvo_graph_upd
   int post_fused = 0;
   RUN(run_operator(w, &a, b, stream, &pending, nullptr, false, ctx_ready, post_in_gather ? &gpa : nullptr, &post_fused));
   if (u->segm)
-    RUN(pvo_segment_hist(u->segm, u->raw_mask, s.heads, s.vote_tot, s.vote_dyn, E, HW, S, u->dy_thresh, dt, stream));
+    RUN(pvo_segment_hist_ws(u->segm, u->raw_mask, s.heads, s.vote_tot, s.vote_dyn, E, HW, S, u->dy_thresh, dt, stream));
   if (!post_fused)
     RUN(pvo_graph_post(s.coords, s.heads, u->raw_mask, u->target, u->delta_dy, u->weight, tba, wba,
                        u->full_flow, E, H, W, u->dy_thresh, u->segm, u->segm ? s.vote_tot : nullptr, u->segm ? s.vote_dyn : nullptr,

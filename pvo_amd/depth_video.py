@@ -42,8 +42,14 @@ class DepthVideo:
         # feature maps of EVERY tracked frame by time stamp (keyframe or not): the motion filter computes them anyway, the
         # trajectory filler needs them again at the end (trajectory_filler.py:32-38 re-encodes every image).  0.78 MB per
         # 240 x 808 frame: a 10 000-frame sequence is 7.8 GB of the 288 GB - kept resident instead of recomputed, up to this budget
+        # Every entry carries a fingerprint of the frame it was computed from (`frame_fingerprint`), which the filler checks: a
+        # terminate() stream that reuses time stamps with other images (another stride, resize, sequence) is re-encoded, as the
+        # reference always does.  The budget is a tenth of the device memory (at most 32 GiB); entries are released as the filler
+        # consumes them and the rest when it is done (`forget_features`).
         self.frame_fmaps = {}
         self.frame_fmaps_budget = 32 << 30
+        if torch.device(device).type == "cuda" and torch.cuda.is_available():
+            self.frame_fmaps_budget = min(self.frame_fmaps_budget, torch.cuda.mem_get_info(torch.device(device))[1] // 10)
         self._frame_fmaps_bytes = 0
 
     # ------------------------------------------------------------------ bookkeeping
@@ -76,13 +82,42 @@ class DepthVideo:
         self._segments_seen = max(self._segments_seen, n)
         return inv.to(torch.int32).reshape(seg.shape)
 
-    def remember_features(self, tstamp, fmap):
-        """keep a tracked frame's feature map [..,128,h,w] (a copy) for the trajectory filler"""
+    @staticmethod
+    def frame_fingerprint(image):
+        """what identifies a frame for the feature cache: its shape, dtype and the sum of a ~100-pixel lattice of its values, taken
+        where the frame lies (a few hundred elements: no OpenMP team is woken on the host, no kernel worth naming on the device)"""
+        if not isinstance(image, torch.Tensor):
+            return None
+        h, w = image.shape[-2], image.shape[-1]
+        sample = image[..., h // 11::max(1, h // 7), w // 13::max(1, w // 11)]
+        return (tuple(image.shape), str(image.dtype), float(sample.double().sum()))
+
+    def remember_features(self, tstamp, fmap, image=None):
+        """keep a tracked frame's feature map [..,128,h,w] (a copy) for the trajectory filler; `image`: the frame it came from"""
         n = fmap.numel() * fmap.element_size()
         if self.frame_fmaps_budget <= 0 or self._frame_fmaps_bytes + n > self.frame_fmaps_budget:
             return
-        self.frame_fmaps[float(tstamp)] = fmap.detach().clone()
+        old = self.frame_fmaps.pop(float(tstamp), None)
+        if old is not None:
+            self._frame_fmaps_bytes -= old[0].numel() * old[0].element_size()
+        self.frame_fmaps[float(tstamp)] = (fmap.detach().clone(), self.frame_fingerprint(image) if image is not None else None)
         self._frame_fmaps_bytes += n
+
+    def recall_features(self, tstamp, image=None):
+        """the kept feature map of the frame tracked under `tstamp` if `image` is that frame (same fingerprint), else None.  The
+        entry is released either way: a frame's pose is filled once."""
+        hit = self.frame_fmaps.pop(float(tstamp), None)
+        if hit is None:
+            return None
+        fmap, fp = hit
+        self._frame_fmaps_bytes -= fmap.numel() * fmap.element_size()
+        if fp is None or image is None or fp != self.frame_fingerprint(image):
+            return None
+        return fmap
+
+    def forget_features(self):
+        self.frame_fmaps.clear()
+        self._frame_fmaps_bytes = 0
 
     def segments_bound(self):
         """the histogram width the panoptic vote needs: a power of two above every dense label stored so far (at least 16, at most

@@ -1181,7 +1181,14 @@ def update_operator(weights, net, motion, inp=None, P=None, pool=None, coords=No
     _fill_operator_args(a, E, H, W, levels, slots, num_slots, coords, corr, motion, net, net_out, inp, P_zr, P_q, agg, heads,
                         eta_rows, eta, upmask)
     lib = _lib.load()
-    ws = _op_workspace(("op", dev.index), dev, lib.pvo_operator_workspace_bytes(E, K, H, W))
+    nbytes = lib.pvo_operator_workspace_bytes(E, K, H, W)
+    if torch.cuda.is_current_stream_capturing():
+        # a call being captured into a HIP graph (pvo_amd/graphs.py) gets a workspace of its own, allocated from the capture's private
+        # memory pool: the shared scratch below is re-allocated whenever a later eager call needs more, and a replay would then
+        # write into freed memory
+        ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=dev)
+    else:
+        ws = _op_workspace(("op", dev.index), dev, nbytes)
     with torch.cuda.device(dev):
         check(lib.pvo_update_operator(ctypes.byref(weights.struct), ctypes.byref(a), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
                                       _stream(dev)), "update_operator")

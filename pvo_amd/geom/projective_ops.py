@@ -117,7 +117,7 @@ def projective_transform(poses, depths, intrinsics, ii, jj, jacobian=False, retu
     Returns coords [B, N, H, W, 2(3)], valid [B, N, H, W, 1] and, with ``jacobian``, the tuple
     (Ji [B,N,H,W,2,6], Jj [B,N,H,W,2,6], Jz [B,N,H,W,2,1]).
     Device tensors (fp32 / fp64) take one fused kernel per direction; the formulation below is its reference, what CPU tensors
-    use, and what ``PVO_SE3_TORCH=1`` selects everywhere.
+    use, and what `pvo_amd.config.debug_config("se3_torch", True)` selects everywhere.
     """
     if _fused(poses, depths, intrinsics):
         dev = depths.device

@@ -12,7 +12,7 @@ True broadcasting is used (lietorch materialises the pose once per pixel with
     since round 4, ONE kernel for its backward pass (`pvo_se3_*_vjp` behind torch.autograd.Function: lietorch's backward
     kernels), where the torch formulation costs ~25 element-wise launches forward and ~50 backward per operation - 46 % of the
     operators a training step dispatches (profiles/r04_train_step_stats.txt);
-  * otherwise (CPU, general broadcasting, PVO_SE3_TORCH=1) the torch ops below, whose autograd is also the reference the
+  * otherwise (CPU, general broadcasting, config knob "se3_torch") the torch ops below, whose autograd is also the reference the
     backward kernels are tested against (tests/test_se3.py).
 The native BA / reprojection kernels do not go through this class; it serves the
 differentiable Python path (geom/ba.py, DroidNet.forward) and host-side bookkeeping.
@@ -22,9 +22,7 @@ import torch
 EPS = 1e-6  # lietorch include/common.h:7
 
 
-import os
-
-FORCE_TORCH = os.environ.get("PVO_SE3_TORCH") == "1"      # tests: the torch formulation everywhere
+FORCE_TORCH = False      # tests: the torch formulation everywhere (also pvo_amd.config "se3_torch"; nothing is read from the environment)
 
 
 def _native(*ts):

@@ -8,13 +8,11 @@ buffers, the outputs are the capture's static buffers (a caller that keeps one a
 
 Safe by construction: the first `warmup` calls run eagerly (MIOpen picks its kernels there), the first replay is compared with
 an eager run of the same input, and any failure - capture not supported, mismatch - switches the instance back to eager for good.
-`PVO_HIP_GRAPHS=0` in the environment disables capture process-wide.
+`pvo_amd.config.debug_config("hip_graphs", False)` disables capture process-wide (nothing is read from the environment).
 """
-import os
-
 import torch
 
-ENABLED = os.environ.get("PVO_HIP_GRAPHS", "1") != "0"
+from . import config
 
 
 def _version(t):
@@ -29,23 +27,28 @@ def _flat(out):
 
 
 class GraphedCall:
-    def __init__(self, fn, warmup=2, rtol=2e-3, name=None, guard=None):
+    def __init__(self, fn, warmup=2, rtol=2e-3, name=None, guard=None, frozen=()):
         """fn(*tensors) -> tensor or tuple of tensors; no host synchronisation and no data-dependent shapes inside.
         guard() (optional) -> a hashable that must be unchanged for a capture to stay valid (e.g. the storage of the weights).
-        An argument that is the same tensor object as at the previous call with an unchanged version counter is not copied again:
-        arguments must therefore only ever be written through torch (a native kernel writing through data_ptr() does not count as
-        a write) - the callers here pass frames, clones and convolution outputs that nothing writes afterwards."""
+        frozen: which arguments the CALLER declares immutable for as long as it keeps passing the same tensor object - a set of
+        positions, or a callable position -> bool.  Only those may skip the copy into the capture's static buffer when they are the
+        same object with an unchanged version counter as at the previous replay.  Every other argument is copied on every call: a
+        version counter says nothing about tensors this library's kernels write through data_ptr(), so the skip is
+        the caller's explicit promise, never inferred.  `config.debug_config("graph_check_skipped", True)` compares every skipped
+        argument with the static buffer (a device synchronisation per call) and raises on a difference."""
         self.fn, self.warmup, self.rtol, self.name = fn, warmup, rtol, name or getattr(fn, "__name__", "call")
         self.guard = guard
+        self.frozen = frozen if callable(frozen) else (lambda i, _s=frozenset(frozen): i in _s)
         self.cache = {}
-        self.disabled = not ENABLED
+        self.disabled = False
         self.replays = 0
+        self.copies = self.skipped = 0
 
     def _key(self, args):
         return tuple((tuple(a.shape), a.dtype, a.device, a.stride()) for a in args) + ((self.guard(),) if self.guard else ())
 
     def __call__(self, *args):
-        if self.disabled or not args or not all(isinstance(a, torch.Tensor) and a.is_cuda for a in args) or torch.is_grad_enabled():
+        if self.disabled or not config.get("hip_graphs") or not args or not all(isinstance(a, torch.Tensor) and a.is_cuda for a in args) or torch.is_grad_enabled():
             return self.fn(*args)
         key = self._key(args)
         st = self.cache.get(key)
@@ -66,19 +69,24 @@ class GraphedCall:
                 return self.fn(*args)
             if self.disabled:
                 return self.fn(*args)
-        # an argument that is the SAME tensor object as at the previous replay and has not been written since (its version counter)
+        # an argument the caller declared FROZEN that is the same tensor object as at the previous replay (version counter unchanged)
         # is already in the capture's static buffer: the motion filter hands its reference keyframe's maps - five to seven tensors -
         # to every frame's replay, and each device-to-device blit is ~48 us of host time in front of the launch (bench.py `sequence`).
         # (Identity, not address: the previous argument is kept alive here, so no new tensor can take its place in memory.)
         held = st["held"]
         dst, src = [], []
+        check = config.get("graph_check_skipped")
         for i, (s, a) in enumerate(zip(st["in"], args)):
             h = held[i]
-            ver = _version(a)
+            ver = _version(a) if self.frozen(i) else None
             if h is not None and h[0] is a and ver is not None and h[1] == ver:
+                if check and not torch.equal(s, a):
+                    raise RuntimeError("GraphedCall %s: argument %d was declared frozen, was not copied, and differs from the capture's buffer" % (self.name, i))
+                self.skipped += 1
                 continue
             dst.append(s); src.append(a)
             held[i] = (a, ver)
+        self.copies += len(dst)
         if len(dst) == 1:
             dst[0].copy_(src[0])
         elif dst:

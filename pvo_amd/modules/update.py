@@ -60,16 +60,14 @@ def scatter_mean(src, index, dim, dim_size=None):
     return out / cnt.clamp(min=1).view(view)
 
 
-import os as _os
+from .. import config as _config
 
-# A/B switches of the fused path (read once)
-_CONV128_WIDE = _os.environ.get("PVO_CONV128_WIDE", "1") == "1"       # corr_encoder[2] / agg.conv1 on the wide-layer kernel
-# The aggregation branch (conv1 over the edges, mean per source frame, then small kernels over the K keyframes that leave most
-# of the chip idle) runs on a second HIP stream beside the heads, which only share its input.  "0": one stream.
-_AGG_SIDE_STREAM = _os.environ.get("PVO_AGG_SIDE_STREAM", "1") != "0"
-# the flow encoder, the global-context reduction and the gate context do not depend on the correlation features: second
-# stream beside the HBM-bound lookup and corr_encoder[2]
-_ENC_SIDE_STREAM = _os.environ.get("PVO_ENC_SIDE_STREAM", "1") != "0"
+# A/B switches of the fused path (pvo_amd.config, set by code; part of packed_weights()' cache key):
+#   conv128_wide      corr_encoder[2] / agg.conv1 on the wide-layer kernel
+#   agg_side_stream   the aggregation branch (conv1 over the edges, mean per source frame, then small kernels over the K keyframes that
+#                     leave most of the chip idle) on a second HIP stream beside the heads, which only share its input
+#   enc_side_stream   the flow encoder, the global-context reduction and the gate context do not depend on the correlation features:
+#                     second stream beside the HBM-bound lookup and corr_encoder[2]
 
 
 class PoolLookup:
@@ -203,6 +201,7 @@ class DynamicUpdateModule(nn.Module):
         ps = self.__dict__.get("_param_list")
         if ps is None:
             ps = self.__dict__["_param_list"] = list(self.parameters())
+        _CONV128_WIDE, _AGG_SIDE_STREAM, _ENC_SIDE_STREAM = (_config.get(k) for k in ("conv128_wide", "agg_side_stream", "enc_side_stream"))
         key = (dt, ps[0].device, tuple(p._version for p in ps), _CONV128_WIDE, _AGG_SIDE_STREAM, _ENC_SIDE_STREAM)
         hit = self.__dict__.get("_packed")
         if hit is not None and hit[0] == key and hit[1] is not None:

@@ -26,6 +26,18 @@ def _weights_guard(module):
     return guard
 
 
+def _operator_guard(module):
+    """what a captured graph that runs the UPDATE OPERATOR stays valid for: the operator's re-arranged weights
+    (DynamicUpdateModule.packed_weights) are rebuilt - and the old pack freed - whenever a parameter's version counter moves, an
+    in-place load_state_dict included, and a capture has the old pack's addresses baked in: every parameter's version is part of the key"""
+    def guard():
+        ps = module.__dict__.get("_param_list") if hasattr(module, "__dict__") else None
+        if ps is None:
+            ps = list(module.parameters()) if hasattr(module, "parameters") else []
+        return None if not ps else (ps[0].data_ptr(), ps[0].dtype, tuple(p._version for p in ps))
+    return guard
+
+
 def upload_frame(image, device):
     """pageable host tensor -> device, a plain blocking copy on the current stream.
     Measured on an MI355X box (2.3 MB int32 frame, 1.7 ms of kernels queued on the stream in front of it): this form 1.78 ms per
@@ -47,12 +59,15 @@ class MotionFilter:
         self.fused_encoders = True         # BasicEncoder.forward_inference: bias / instance norm / ReLU / residual add as one kernel per layer
         self.keep_features = True          # every frame's feature map stays resident for the trajectory filler (DepthVideo.remember_features)
         self._coords0 = None
+        self._coords0_by_shape = {}        # identity grids, one per map size, never released: a captured frame graph has its grid's address baked in
         self._features_g = GraphedCall(self._features_dev, name="fnet", guard=_weights_guard(self.fnet))
         self._context_g = GraphedCall(self._context_dev, name="cnet", guard=_weights_guard(self.cnet))
         # a whole tracked frame - encoder, 1-edge volume, lookup, one operator pass, the mean flow norm - as ONE captured launch:
         # issued eagerly the ~25 launches behind the encoder left the device idle for 0.4 of a frame's 1.4 ms (bench.py `sequence`)
         self._frame_g = GraphedCall(self._frame_dev, name="motion filter frame",
-                                    guard=lambda: (_weights_guard(self.fnet)(), _weights_guard(self.update)()))
+                                    guard=lambda: (_weights_guard(self.fnet)(), _operator_guard(self.update)()),
+                                    frozen=lambda i: i >= 1)       # the reference keyframe's maps / static terms: written once in _new_reference
+                                                                   # (fresh tensors per keyframe), read-only until the next one replaces them
         self._static = None                # conv(W[:, inp], inp) of the reference keyframe's context: constant until the next keyframe
 
     def _upload(self, image):
@@ -131,17 +146,19 @@ class MotionFilter:
         img = self._upload(image)
         if self.video.counter == 0:
             gmap = self._features_g(img)                                       # [1,128,h,w]
-            self._remember(tstamp, gmap)
+            self._remember(tstamp, gmap, image)
             ident = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0], device=self.device)
             net, inp = self._context_g(img)
             self._new_reference(gmap, net, inp)
             self._append(tstamp, image, ident, 1.0, intrinsics.to(self.device), gmap, net, inp, segments)
             return True
         if self._coords0 is None or self._coords0.shape[-3:-1] != (ht, wd):
-            with self._autocast():
-                self._coords0 = coords_grid(ht, wd, device=self.device)[None, None]
+            if (ht, wd) not in self._coords0_by_shape:
+                with self._autocast():
+                    self._coords0_by_shape[(ht, wd)] = coords_grid(ht, wd, device=self.device)[None, None]
+            self._coords0 = self._coords0_by_shape[(ht, wd)]
         gmap, mag = self._frame_g(img, self.fmap, self.net, self.inp, *(self._static or ()))
-        self._remember(tstamp, gmap)
+        self._remember(tstamp, gmap, image)
         if mag.item() > self.thresh:
             self.count = 0
             net, inp = self._context_g(img)
@@ -151,9 +168,9 @@ class MotionFilter:
         self.count += 1
         return False
 
-    def _remember(self, tstamp, gmap):
+    def _remember(self, tstamp, gmap, image):
         if self.keep_features and hasattr(self.video, "remember_features"):
-            self.video.remember_features(tstamp, gmap)
+            self.video.remember_features(tstamp, gmap, image)
 
     @torch.no_grad()
     def track_vo(self, tstamp, image, depth=None, intrinsics=None, segments=None):

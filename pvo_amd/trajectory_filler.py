@@ -62,10 +62,14 @@ class PoseTrajectoryFiller:
 
         # the motion filter encoded every one of these frames when it was tracked and the video kept the maps (same time stamp =
         # same frame: test_vo.py hands terminate() the stream it tracked; `reuse_features = False` re-encodes as the reference does)
-        kept = getattr(v, "frame_fmaps", None) if self.reuse_features else None
-        cached = [kept.get(float(t)) for t in tstamps] if kept else [None]
+        # ... checked per frame by a fingerprint of the image (DepthVideo.recall_features): a stream that reuses time stamps with
+        # other images is re-encoded; entries are released as they are consumed
+        recall = getattr(v, "recall_features", None) if self.reuse_features and getattr(v, "frame_fmaps", None) else None
+        cached = [recall(t, im) for t, im in zip(tstamps, images)] if recall else [None]
         if all(c is not None for c in cached):
             fmap = torch.cat(cached, 0)
+        elif self.device.type == "cuda" and any(c is not None for c in cached):
+            fmap = torch.cat([c if c is not None else self._features([im]) for c, im in zip(cached, images)], 0)
         else:
             fmap = self._features(images)
         v.counter += M
@@ -92,4 +96,6 @@ class PoseTrajectoryFiller:
                 tstamps, images, intrinsics = [], [], []
         if tstamps:
             pose_list += self._fill(tstamps, images, intrinsics)
+        if hasattr(self.video, "forget_features"):
+            self.video.forget_features()          # (frames tracked but not in this stream: nothing will ask for them any more)
         return lie.cat(pose_list, 0)

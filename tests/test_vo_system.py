@@ -368,29 +368,49 @@ def test_motion_filter_graph_replay_and_fused_encoders_match_the_eager_path(cuda
 
 
 @pytest.mark.gpu
-def test_graphed_call_skips_only_arguments_that_cannot_have_changed():
-    """pvo_amd.graphs.GraphedCall copies an argument into the capture's static buffer unless it is the same tensor object, unwritten
-    since the previous replay - an in-place write, a new tensor at any address, or new values must all be seen"""
+def test_graphed_call_skips_only_arguments_the_caller_froze():
+    """pvo_amd.graphs.GraphedCall copies every argument into the capture's static buffer on every call, except those the CALLER
+    declared frozen - and of those only the same tensor object with an unchanged version counter.  In particular a tensor a
+    kernel of this library rewrote through data_ptr() (no version bump) and that is passed again is NOT skipped; if a
+    caller freezes such a tensor wrongly, the debug knob finds it."""
+    from pvo_amd import config, droid_backends as db
     from pvo_amd.graphs import GraphedCall
     dev = torch.device("cuda:0")
-    g = GraphedCall(lambda a, b: a * 2.0 + b, warmup=1)
+    g = GraphedCall(lambda a, b: a * 2.0 + b, warmup=1, frozen=(1,))
     a, b = torch.arange(8.0, device=dev), torch.ones(8, device=dev)
     with torch.no_grad():
         for _ in range(3):
             out = g(a, b).clone()                      # eager, capture, replay
         assert g.replays >= 1 and torch.equal(out, a * 2 + b)
-        b.add_(1.0)                                    # same object, written in place
+        n_skip = g.skipped
+        assert torch.equal(g(a, b), a * 2 + b) and g.skipped == n_skip + 1      # b frozen, same object, same version: not copied
+        b.add_(1.0)                                    # same object, written in place through torch
         assert torch.equal(g(a, b), a * 2 + b)
         for k in range(4):                             # a fresh tensor per call (freed ones may come back at the same address)
             c = torch.full((8,), float(k), device=dev)
             assert torch.equal(g(a, c), a * 2 + c)
             del c
-        a2 = a.clone()
-        assert torch.equal(g(a2, b), a2 * 2 + b)
-        a2.mul_(3.0)
-        assert torch.equal(g(a2, b), a2 * 2 + b)
-        n = g.replays
-        assert torch.equal(g(a2, b), a2 * 2 + b) and g.replays == n + 1      # nothing changed: still replayed, same result
+        # argument 0 is not frozen: rewritten behind torch's back (a library kernel writes through data_ptr(): no version bump)
+        x = torch.zeros(1, 16, 4, 4, dtype=torch.float16, device=dev)
+        y = torch.ones(1, 16, 4, 4, dtype=torch.float16, device=dev)
+        h = GraphedCall(lambda u, v: u.float() + v.float(), warmup=1, frozen=(1,))
+        for _ in range(3):
+            h(x, y)
+        ver = x._version
+        db.bias_norm_act(torch.full_like(x, 3.0), out=x)           # the library writes x in place
+        torch.cuda.synchronize()
+        assert x._version == ver and float(x.float().mean()) == 3.0
+        assert torch.equal(h(x, y), x.float() + y.float())          # seen: x is copied on every call
+        # the same write into a FROZEN argument is the caller breaking its promise; the debug knob reports it
+        db.bias_norm_act(torch.full_like(y, 5.0), out=y)
+        torch.cuda.synchronize()
+        assert not torch.equal(h(x, y), x.float() + y.float())
+        config.debug_config("graph_check_skipped", True)
+        try:
+            with pytest.raises(RuntimeError, match="declared frozen"):
+                h(x, y)
+        finally:
+            config.debug_config("graph_check_skipped", False)
 
 
 def test_graphed_call_is_a_plain_call_off_the_gpu():
