@@ -573,9 +573,26 @@ def edge_sharded_leg(device, rank, world, steps=3):
         sync(collective)
         ba_ms = (time.perf_counter() - t0) / 10 * 1e3
         msg_bytes = sharded.last_message_bytes
+        # the part of those two steps that SHARDS (assembly + Schur elimination of this rank's edges: pvo_ba_local) timed alone; the
+        # rest - envelope, conversion, the pose solve, back-substitution of the pose update - every rank repeats
+        local_ms = None
+        if world == 1 or not collective:
+            from pvo_amd import droid_backends as db
+            sysb, wsb = sharded._sys, sharded._ws[1]
+            pi, pj = sharded._plan_edges
+
+            def loc():
+                db.ba_local(video.poses, video.disps, video.intrinsics[0], target, weight, eta, pi, pj, 1, nkf, False, sysb, wsb)      # (clears sys itself)
+            loc(); sync(False)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                loc()
+            sync(False)
+            local_ms = 2.0 * (time.perf_counter() - t0) / 20 * 1e3
+            sysb.zero_()
         del graph, video
         torch.cuda.empty_cache()
-        return el, ba_ms, poses_after, msg_bytes
+        return el, ba_ms, poses_after, msg_bytes, local_ms
 
     whole = None
     if world > 1:
@@ -584,7 +601,7 @@ def edge_sharded_leg(device, rank, world, steps=3):
     ii_l, jj_l, _ = shard_edges(ii, jj, world, rank)
     if not ii_l:
         raise RuntimeError("rank %d owns no edges" % rank)
-    el, ba_ms, poses_after, msg_bytes = run(ii_l, jj_l, True)
+    el, ba_ms, poses_after, msg_bytes, local_ms = run(ii_l, jj_l, True)
     # the collective alone: the envelope message, 50 all-reduces
     P = nkf - 1
     dense_bytes = 8 * ((6 * P) ** 2 + 6 * P)
@@ -667,6 +684,16 @@ def edge_sharded_leg(device, rank, world, steps=3):
            "ba_2_steps_ms": ba_ms, "allreduce_us": ar_us, "allreduce_bytes": int(msg_bytes) if world > 1 else None,
            "allreduce_bytes_dense": dense_bytes, "allreduce_message": "envelope blocks of the lower triangle + rhs, int64 fixed point",
            "backend": dist.get_backend() if world > 1 else None, "world_size": world, "poses_bitwise_equal_across_ranks": same}
+    one_ba, one_local = (ba_ms, local_ms) if world == 1 else (whole[1], whole[4])
+    if one_local is not None and one_ba > 0:
+        rep = max(one_ba - one_local, 0.0)
+        out["ba_only_ceiling"] = {
+            "one_gpu_ba_2_steps_ms": one_ba, "sharded_part_ms": one_local, "replicated_part_ms": rep,
+            "speedup_bound_at_n_gpus": {str(n): one_ba / (one_local / n + rep) for n in (2, 4, 8)},
+            "note": "BA alone CANNOT reach north_star's >= 6x at 8 GPUs with a replicated pose solve: assembly + Schur elimination shard by "
+                    "edge (sharded_part), the envelope / conversion / pose solve / retraction run on every rank (replicated_part), and each "
+                    "step adds one latency-bound all-reduce that this bound leaves out.  The >= 6x figure to read is "
+                    "speedup_vs_one_gpu.global_update (lookup + operator + BA), measured at N > 1 in the same job"}
     if one_rank is not None:
         out["rccl_one_rank"] = one_rank
     if world > 1:
@@ -874,6 +901,24 @@ def emit(obj):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
 
 
+def self_launch(n):
+    """run this script as n ranks of one node and return the launcher's exit status"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: RCCL between processes needs it on these hosts)
+    if env.get("PVO_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        sys.stderr.write("bench.py --gpus %d: this node shows %d GPU(s); RCCL needs one device per rank "
+                         "(PVO_BENCH_BACKEND=gloo runs the ranks as a dry run on the devices there are)\n" % (n, torch.cuda.device_count()))
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -891,12 +936,17 @@ def main():
     args = ap.parse_args()
     # (behind the parser: --help and argument errors keep the real stdout.  Descriptor 1 is NOT handed back afterwards: RCCL's
     # banner sits in a C stdio buffer that is flushed at exit, and must not land behind the result line)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: re-launch as N ranks, one per GPU, through torch.distributed.run (static rendezvous on
+        # 127.0.0.1 - the container's host name may not resolve); rank 0 of the children prints the ONE line, this process only
+        # forwards their output and exit status (non-zero if any rank failed).
+        raise SystemExit(self_launch(args.gpus))
     _own_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py --gpus %d inside a job of WORLD_SIZE=%d" % (args.gpus, world))
     local = local % max(torch.cuda.device_count(), 1)      # (a 2-process dry run on a 1-GPU box shares device 0)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -929,6 +979,13 @@ def main():
         keyframe_update(video, graph, snap)
     updates_per_step = 6
     elapsed, host_issue, in_step_lookup = timed_steps(video, graph, snap, args.steps, world)
+    # the same K steps four more times (each bracketed like the first): `value` is the FIRST block, as the contract defines it;
+    # the five block times say whether a 3 % move between two runs is the code or the box
+    block_ms = [elapsed / args.steps * 1e3]
+    if not args.steps_only:
+        for _ in range(4):
+            el_b, _, _ = timed_steps(video, graph, snap, args.steps, world, probe_stage=None)
+            block_ms.append(el_b / args.steps * 1e3)
 
     if args.steps_only:
         if rank == 0:
@@ -1066,6 +1123,9 @@ def main():
                        "edges": E, "graph_updates_per_step": updates_per_step, "parallelism": "independent window per GPU",
                        "update_path": "pvo_graph_update: one native call per graph update, no MIOpen / hipBLASLt"},
             "graph_updates_per_s": world * args.steps * updates_per_step / elapsed,
+            "step_ms_blocks": {"blocks_of_steps": args.steps, "ms_per_step": block_ms, "median": sorted(block_ms)[len(block_ms) // 2],
+                               "min": min(block_ms), "max": max(block_ms), "spread_pct": 100.0 * (max(block_ms) - min(block_ms)) / min(block_ms),
+                               "note": "five consecutive blocks of K steps, each barrier + synchronize bracketed; `value` is the first"},
             "host": {"issue_ms_per_step_median": 1e3 * hi[len(hi) // 2], "issue_ms_per_step_max": 1e3 * hi[-1],
                      "priming_blocks_of_8_steps": blocks},
             "roofline": dict(lookup_roofline(E, HW, in_step_lookup, traffic, stage_us.pop("empty", None)), isolated_cold_us=lookup_cold_us,
