@@ -2421,6 +2421,296 @@ __global__ __launch_bounds__(256) void ba_solve_twin_kernel(
   }
 }
 
+// ---- the DENSE pose solve on the fp64 matrix cores (round 6): windows up to kDenseMaxPoses free poses, one launch ---------------
+// A frontend window's pose system is DENSE: 21-25 free poses whose ~400 inactive edges couple almost every pair
+// (factor_graph.py:281-291; bench.py `sequence.ba_windows_sampled`).  The envelope forms above gain nothing there and paid for it:
+// beyond 21 poses env + prepare + partitioned solve = three launches, 16 + 100 us per Gauss-Newton step, the partition finding no
+// separator and one workgroup walking a 25-column chain at ~9 k cycles per block column - most of them the rank-6 trailing update
+// read and written through LDS (27 LDS operations per 36 multiply-adds).
+// Here the whole lower triangle lives in the REGISTERS of one workgroup, as 16 x 16 accumulator tiles of
+// v_mfma_f64_16x16x4_f64 dealt round-robin over the four waves (a 26-pose system: 55 tiles, 14 per wave, 112 VGPRs):
+//   per step of EIGHT columns (20 steps for 156 rows; a panel never straddles a tile column):
+//     1. the tiles of the panel's tile column write its eight columns to the panel's place in LDS (+ the 8 x 8 diagonal block apart)
+//     2. one lane per row: the 8 x 8 Cholesky redundantly in registers, then its own row of the panel (forward substitution
+//        against the diagonal block) - in place; the finished panels ARE the factor L, kept for the back-substitution
+//     3. every tile right of / below the panel: C -= L_rows(i) L_rows(j)^T, two MFMAs (K = 8), operands straight from the panel
+//   two barriers per step; the trailing matrix never touches LDS.  The right-hand side rides as row n of the matrix (as in the
+//   forms above), so the forward substitution is part of step 2; the back-substitution is wave 0's: one lane per column, the
+//   panel's eight unknowns by v_readlane, no LDS exchange of the vector.
+// Loads the fixed-point system itself (lower block triangle + right-hand side; zeroes ALL of it for the next step), damping as
+// droid_kernels.cu:1176, failure -> zero update (:1186-1189).  Deterministic: a fixed order of fp64 operations on an integer
+// system, so every rank of an edge-sharded run that takes this path gets the same bits; against the envelope forms the order of
+// the additions differs: equal to fp64 rounding, not bit for bit (tests: oracle parity at 1e-4 in fp32 outputs, and agreement
+// with the pipelined form to 4e-7 relative).
+constexpr int kDenseMaxPoses = 29;      // N = 16 ceil((6 P + 1) / 16) <= 176: 66 tiles (17 per wave), 129.5 KB of panels in LDS
+typedef double pvo_d4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ __forceinline__ int dense_N(int n) { return ((n + 1 + 15) / 16) * 16; }
+__host__ __device__ __forceinline__ int dense_panel_off(int kb8, int N) { return kb8 * N - 4 * kb8 * (kb8 - 1); }      // rows in front of panel kb8
+__host__ __forceinline__ size_t dense_lds_bytes(int n) {
+  const int N = dense_N(n), nb = N / 8;
+  return 16 + sizeof(double) * (8 * static_cast<size_t>(dense_panel_off(nb, N)) + 64 + 2 * static_cast<size_t>(N));
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_solve_dense_kernel(
+    long long* __restrict__ sys, const long long* __restrict__ msg, const int* __restrict__ first_s,
+    float* __restrict__ poses, float* __restrict__ dx_ws, float* __restrict__ dx_out,
+    int* __restrict__ meta, int* __restrict__ status_out, int P, int t0, float lm, float ep, Riders riders) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [16 B flags | panels | diagonal block | 1 / L_jj | x]
+  if (blockIdx.x > 0) {                                                  // rider workgroups (launched only with riders)
+    ride(smem, riders, blockIdx.x - 1);
+    return;
+  }
+  // msg != NULL: the system arrives as the packed envelope message of an edge-sharded step (ba_pack_kernel's layout: block row b =
+  // blocks first[b] .. b of 36, then the right-hand side) instead of the dense image - same values into the same tiles, so a
+  // sharded run gets the bits of the whole graph on one GPU at these sizes too
+  __shared__ int mfirst[kDenseMaxPoses + 1], mbase[kDenseMaxPoses + 2];
+  if (msg) {
+    if (threadIdx.x == 0) {
+      int run = 0;
+      for (int b = 0; b < P; ++b) {
+        const int e = first_s[b];
+        const int f = e < b ? (e < 0 ? 0 : e) : b;                       // (clamped as env_layout does)
+        mfirst[b] = f; mbase[b] = run; run += (b - f + 1) * 36;
+      }
+      mbase[P] = run;
+    }
+    __syncthreads();
+  }
+  int& fail = *reinterpret_cast<int*>(smem);
+  const int n = 6 * P, N = dense_N(n), T = N / 16, nb = (n + 7) / 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: the tile tables below live in scalar registers)
+  const int lr = lane >> 4, lc = lane & 15;                              // C / D: row lr + 4 r, column lc; A / B: index lc, k = lr
+  double* Lp = reinterpret_cast<double*>(smem + 16);
+  double* Dg = Lp + 8 * dense_panel_off(N / 8, N);
+  double* rdg = Dg + 64;
+  double* xs = rdg + N;
+  if (tid == 0) fail = 0;
+
+  // ---- this wave's tiles: q = 4 slot + wave -> (ti, tj), tj <= ti
+  int tti[SLOTS], ttj[SLOTS];
+  const int ntiles = T * (T + 1) / 2;
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    const int q = 4 * sl + wave;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+    tti[sl] = q < ntiles ? ti : -1;
+    ttj[sl] = q - ti * (ti + 1) / 2;
+  }
+  // ---- load: fixed point -> fp64 (+ damping on the diagonal, droid_kernels.cu:1176) straight into the accumulator tiles
+  pvo_d4 C[SLOTS];
+#pragma unroll
+  for (int s0 = 0; s0 < SLOTS; s0 += 4) {                               // sixteen loads in flight per lane
+    long long raw[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sl = s0 + u < SLOTS ? s0 + u : SLOTS - 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tti[sl] + lr + 4 * r, col = 16 * ttj[sl] + lc;
+        long long v = 0;
+        if (tti[sl] >= 0 && col < n) {
+          if (msg) {
+            if (row < n && col <= row) {
+              const int rb = row / 6, cb = col / 6;
+              if (cb >= mfirst[rb]) v = msg[mbase[rb] + (cb - mfirst[rb]) * 36 + (row - 6 * rb) * 6 + (col - 6 * cb)];
+            } else if (row == n) v = msg[mbase[P] + col];
+          } else {
+            if (row < n && col <= row) v = sys[static_cast<long long>(row) * n + col];
+            else if (row == n) v = sys[static_cast<long long>(n) * n + col];
+          }
+        }
+        raw[u][r] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + u >= SLOTS) continue;
+      const int sl = s0 + u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tti[sl] + lr + 4 * r, col = 16 * ttj[sl] + lc;
+        double v = static_cast<double>(raw[u][r]) * kInvFix;
+        if (row == col && row < n) v += static_cast<double>(ep) + static_cast<double>(lm) * v;
+        C[sl][r] = v;
+      }
+    }
+  }
+  // (every entry the assembly / Schur kernels or an all-reduce may have written: ready for the next step's accumulation.  Behind a
+  // barrier: a wave with few tiles would otherwise zero entries another wave has not loaded yet)
+  __syncthreads();
+  if (!msg) for (int idx = tid; idx < n * n + n; idx += 256) sys[idx] = 0LL;      // (ba_pack_kernel has zeroed the image a message came from)
+  __syncthreads();
+
+  // ---- factorisation, eight columns per step
+  for (int kb8 = 0; kb8 < nb; ++kb8) {
+    const int tc = kb8 >> 1, h = kb8 & 1, c0 = 8 * kb8;
+    double* pan = Lp + 8 * dense_panel_off(kb8, N);                      // rows c0 .. N-1 of columns c0 .. c0+7, 8 doubles per row
+    // (the lane's coordinates, opaque to the optimiser inside this loop: it otherwise hoists every tile's LDS addresses out of the
+    // loop - ten registers per tile, 140 of the 14-tile instantiation's budget - to save one addition per use)
+    int lcv = lc, lrv = lr;
+    asm volatile("" : "+v"(lcv), "+v"(lrv));
+    // 1. the panel's columns out of the accumulators
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      if (tti[sl] < 0 || ttj[sl] != tc) continue;                        // (uniform per wave)
+      if ((lcv >> 3) == h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * tti[sl] + lrv + 4 * r;
+          if (row >= c0) {
+            pan[(row - c0) * 8 + (lcv & 7)] = C[sl][r];
+            if (row < c0 + 8) Dg[(row - c0) * 8 + (lcv & 7)] = C[sl][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // 2. one lane per row of the panel
+    const int nv = (n - c0 < 8) ? n - c0 : 8;                           // columns of this panel that belong to the system (the rest: padding)
+    if (tid < N - c0) {
+      // the 8 x 8 Cholesky IN PLACE on the block's lower triangle; a diagonal slot ends up holding 1 / L_jj (L_jj itself is never
+      // needed: the diagonal rows leave as d * rs through the row formula below) - registers are what bounds this kernel's occupancy
+      double L[36];
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Dg[i * 8 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        double d = L[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+        const bool real = j < nv;
+        ok = ok && (!real || d > 0.0);
+        const double rs = (real && ok) ? rsqrt_nr(d) : 0.0;
+        L[j * (j + 1) / 2 + j] = rs;
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) {
+          double v = L[i * (i + 1) / 2 + j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+          L[i * (i + 1) / 2 + j] = v * rs;
+        }
+      }
+      double a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = pan[tid * 8 + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        double v = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= a[k] * L[j * (j + 1) / 2 + k];
+        v *= L[j * (j + 1) / 2 + j];
+        if (tid < 8 && j > tid) v = 0.0;                                 // (the diagonal block's rows: L is lower triangular)
+        a[j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pan[tid * 8 + j] = a[j];
+      if (tid < 8) {
+        double r = L[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) r = (tid == j) ? L[j * (j + 1) / 2 + j] : r;
+        rdg[c0 + tid] = r;
+      }
+      if (tid == 0 && !ok) fail = 1;
+    }
+    __syncthreads();
+    // 3. trailing update of every tile with a column beyond the panel
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+      const int ti = tti[sl], tj = ttj[sl];
+      if (ti < 0 || !(tj > tc || (tj == tc && h == 0))) continue;        // (uniform per wave)
+      const double* ra = pan + (16 * ti + lcv - c0) * 8 + lrv;
+      const double* rb = pan + (16 * tj + lcv - c0) * 8 + lrv;
+      const double a0 = ra[0], a1 = ra[4], b0 = rb[0], b1 = rb[4];
+      C[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, C[sl], 0, 0, 0);
+      C[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, C[sl], 0, 0, 0);
+      if ((sl & 3) == 3) __builtin_amdgcn_sched_barrier(0);              // (operand loads of at most four tiles in flight: registers)
+    }
+  }
+  __syncthreads();
+
+  // ---- back-substitution L^T x = y (y = row n of L), wave 0: lane holds columns lane, lane + 64, lane + 128
+  if (wave == 0) {
+    double z[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int c = lane + 64 * m;
+      z[m] = c < n ? Lp[8 * (dense_panel_off(c >> 3, N) + n - 8 * (c >> 3)) + (c & 7)] : 0.0;
+    }
+    for (int kb8 = nb - 1; kb8 >= 0; --kb8) {
+      const int c0 = 8 * kb8, m0 = c0 >> 6, l0 = c0 & 63;
+      const int nv = (n - c0 < 8) ? n - c0 : 8;
+      const double* pan = Lp + 8 * dense_panel_off(kb8, N);
+      const double zsel = m0 == 0 ? z[0] : (m0 == 1 ? z[1] : z[2]);
+      double x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int lo = __builtin_amdgcn_readlane(static_cast<int>(__double_as_longlong(zsel) & 0xffffffffLL), l0 + j);
+        const int hi = __builtin_amdgcn_readlane(static_cast<int>(__double_as_longlong(zsel) >> 32), l0 + j);
+        x[j] = __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+      }
+#pragma unroll
+      for (int j = 7; j >= 0; --j) {
+        double v = x[j];
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) v -= pan[i * 8 + j] * x[i];      // L[c0 + i][c0 + j]
+        x[j] = (j < nv) ? v * rdg[c0 + j] : 0.0;
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int c = lane + 64 * m;
+        if (c < c0) {
+          const double* col = Lp + 8 * (dense_panel_off(c >> 3, N) + c0 - 8 * (c >> 3)) + (c & 7);      // L[c0 + i][c], i = 0 ..
+          double v = z[m];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v -= col[8 * i] * x[i];
+          z[m] = v;
+        } else if (c < c0 + 8) {
+          double v = x[0];
+#pragma unroll
+          for (int j = 1; j < 8; ++j) v = (c - c0 == j) ? x[j] : v;
+          z[m] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int c = lane + 64 * m;
+      if (c < n) xs[c] = z[m];
+    }
+  }
+  __syncthreads();
+  const int failed = fail | meta[4] | meta[2];      // (meta[2]: eta's row count != K - the whole step is a no-op, see ba_plan_kernel)
+  for (int idx = tid; idx < n; idx += 256) {
+    double xv = xs[idx];
+    const float v = (failed || !(xv == xv)) ? 0.0f : static_cast<float>(xv);    // zeros on failure (:1186-1189)
+    dx_ws[idx] = v;
+    if (dx_out) dx_out[idx] = v;
+  }
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {               // pose_retr_kernel (:877-910)
+    float xi[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xi[c] = dx_ws[6 * p + c];
+    float* ps = poses + 7 * static_cast<long long>(t0 + p);
+    const Pose Tn = retract(xi, load_pose(ps));
+    ps[0] = Tn.t.x; ps[1] = Tn.t.y; ps[2] = Tn.t.z;
+    ps[3] = Tn.q.x; ps[4] = Tn.q.y; ps[5] = Tn.q.z; ps[6] = Tn.q.w;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    meta[4] = 0;
+    if (failed) meta[1] = 1;
+    if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // backsub: dz = Q (w - sum_r E_r^T dx[pose(r)]), disps += dz
 // ---------------------------------------------------------------------------
@@ -2726,6 +3016,40 @@ static int ba_finish_impl(float* poses, float* disps, void* sys_, const long lon
   Ws w = carve(ws_base(workspace), E, P, nframes, HW);
   hipStream_t st = pvo_stream(stream);
   const int n6 = 6 * P;
+  // Round 6: a window's system (up to kDenseMaxPoses free poses; dense image or packed message) is factorised DENSE in the registers of one
+  // workgroup on the fp64 matrix cores (ba_solve_dense_kernel) - one launch where the envelope forms took three beyond 21 poses.
+  // pvo_debug_config(PVO_KNOB_BA_SOLVER, 1..4) selects the older forms (tests compare them), 5 names this one.
+  const int solver_env = pvo_knob(PVO_KNOB_BA_SOLVER) - 1;      // (pvo_debug_config: -1 = the choice by size below)
+  if (P > 0 && P <= kDenseMaxPoses && (solver_env < 0 || solver_env == 4)) {
+    const size_t dl = dense_lds_bytes(n6);
+    const size_t lds_d = dl > rider_lds ? dl : rider_lds;
+    const int Td = dense_N(n6) / 16;                            // tiles per side: 4 slots per wave up to 5 (15 tiles), 14 up to 10 (55: 26 poses), 17 up to 11
+    static bool dense_attr_set = false;
+    if (!dense_attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_dense_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 142000) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_dense_kernel<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 142000) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_dense_kernel<17>), hipFuncAttributeMaxDynamicSharedMemorySize, 142000) != hipSuccess)
+        return PVO_ELAUNCH;
+      dense_attr_set = true;
+    }
+    if (Td <= 5)
+      hipLaunchKernelGGL(ba_solve_dense_kernel<4>, dim3(1 + rider_blocks), dim3(256), lds_d, st, sys, msg, first_s, poses, w.dx, dx_out, w.plan.meta, status_out,
+                         P, t0, lm, ep, rider);
+    else if (Td <= 10)
+      hipLaunchKernelGGL(ba_solve_dense_kernel<14>, dim3(1 + rider_blocks), dim3(256), lds_d, st, sys, msg, first_s, poses, w.dx, dx_out, w.plan.meta, status_out,
+                         P, t0, lm, ep, rider);
+    else
+      hipLaunchKernelGGL(ba_solve_dense_kernel<17>, dim3(1 + rider_blocks), dim3(256), lds_d, st, sys, msg, first_s, poses, w.dx, dx_out, w.plan.meta, status_out,
+                         P, t0, lm, ep, rider);
+    PVO_CHECK_LAUNCH();
+    if (!motion_only && E + P > 0) {
+      const int Kmax = (nframes < P + E) ? nframes : (P + E);
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3((HW + 255) / 256, Kmax > clamp_frames ? Kmax : clamp_frames), dim3(256), 0, st,
+                         w.plan, jj, w.Ei, w.Eij, w.Q, w.w, w.dx, disps, dz_out, dz_rows, HW, t0, P, 0, clamp_frames, disp_min);
+      PVO_CHECK_LAUNCH();
+    }
+    return PVO_OK;
+  }
   const int use_lds = n6 <= kLdsCholMax && !msg;               // (a packed message is factorised from the compact image at every size)
   constexpr size_t kSolveLdsMax = 142000;      // dynamic LDS of the solve: the CU's 163840 B minus its 20528 B of static tables (envelope, reach, active rows, scan buffers)
   size_t lds = use_lds ? 16 + sizeof(double) * (static_cast<size_t>(n6) * n6 + n6 + 27 * P + 24) : kSolveLdsMax;
@@ -2746,8 +3070,7 @@ static int ba_finish_impl(float* poses, float* disps, void* sys_, const long lon
   // the three bit for bit).
   // Beyond the dense LDS path a fourth form, the PARTITIONED solve (ba_solve_twin_kernel: two workgroups eliminate the pose
   // chain from both ends, tools/ba_solve_timeline.py), is the default; its result equals the others' to fp64 rounding.
-  const int solver_env = pvo_knob(PVO_KNOB_BA_SOLVER) - 1;      // (pvo_debug_config: -1 = the choice by size below)
-  const int solver_pick = solver_env >= 0 ? solver_env : (use_lds ? (P > 12 ? 2 : 0) : 3);      // 0 blocked | 1 wave | 2 pipe | 3 partitioned
+  const int solver_pick = (solver_env >= 0 && solver_env < 4) ? solver_env : (use_lds ? (P > 12 ? 2 : 0) : 3);      // 0 blocked | 1 wave | 2 pipe | 3 partitioned
   const bool twin = solver_pick == 3 && !use_lds;
   const int solver_wave = solver_pick == 3 ? 2 : solver_pick;
   if (msg) {
@@ -2796,6 +3119,10 @@ extern "C" int pvo_ba_last_partition(void* workspace, size_t workspace_bytes, in
   if (workspace_bytes < pvo_ba_workspace_bytes(E, P, nframes, HW)) return PVO_EWORKSPACE;
   out[0] = out[1] = 0;
   if (6 * P <= kLdsCholMax) return PVO_OK;
+  {
+    const int k = pvo_knob(PVO_KNOB_BA_SOLVER);
+    if (P <= kDenseMaxPoses && (k == 0 || k == 5)) return PVO_OK;      // (the dense solve: nothing to partition; a packed message never asks here)
+  }
   Ws w = carve(ws_base(workspace), E, P, nframes, HW);
   int host[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(host, w.xchg, sizeof(host), hipMemcpyDeviceToHost, pvo_stream(stream)) != hipSuccess) return PVO_ELAUNCH;

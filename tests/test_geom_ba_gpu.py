@@ -147,6 +147,93 @@ def test_ba_edges_that_repeat_a_frame_pair_match_oracle(cuda, copies, ht, wd):
     assert np.array_equal(poses, again[0]) and np.array_equal(disps, again[1])
 
 
+def _frontend_window(P=26, ht=30, wd=101, copies=4, seed=4242):
+    """the BA of a real frontend update (factor_graph.py:281-291: the window's inactive edges enter the BA with the active ones;
+    bench.py `sequence.ba_windows_sampled`: 22-26 poses, 48 active + 270-430 inactive edges, 15-19 neighbours per frame, the same
+    frame pair several times, 30 x 101 maps = 3030 pixels = 5 chunks of 512 + 470): every |i - j| <= 2 pair `copies` times in
+    interleaved order, each copy with its own target and weight, + the 48 active edges |i - j| <= 3 of the last ten frames"""
+    s = _scene(seed, P, ht, wd, 2, 1)
+    g = torch.Generator().manual_seed(seed + 1)
+    E = s["ii"].shape[0]
+    order = torch.cat([torch.randperm(E, generator=g) for _ in range(copies)])
+    act = [(i, j) for i in range(P - 10, P) for j in range(P - 10, P) if i != j and abs(i - j) <= 3]
+    assert len(act) == 48
+    ai, aj = torch.tensor([a for a, _ in act]), torch.tensor([b for _, b in act])
+    c, _ = O.reproject(s["poses_gt"].numpy(), s["disps_gt"].numpy(), s["intr"][None].repeat(P, 1).numpy(), ai.numpy(), aj.numpy())
+    t_act = (torch.from_numpy(c) + 0.1 * torch.randn(48, ht, wd, 2, generator=g)).permute(0, 3, 1, 2)
+    tgt = torch.cat([s["target"][order] + 0.2 * torch.randn(order.shape[0], 2, ht, wd, generator=g), t_act])
+    wgt = torch.cat([0.3 * torch.rand(order.shape[0], 2, ht, wd, generator=g), torch.rand(48, 2, ht, wd, generator=g)])
+    return dict(s, ii=torch.cat([s["ii"][order], ai]).contiguous(), jj=torch.cat([s["jj"][order], aj]).contiguous(),
+                target=tgt.contiguous(), weight=wgt.contiguous())
+
+
+def _two_virtual_ranks(s, cuda, iters=2, lm=1e-4, ep=0.1):
+    """the same BA as two edge shards (by source keyframe) that take turns on the device, their integer systems added as the
+    all-reduce would: (poses of rank 0, poses of rank 1, merged depth maps)"""
+    from pvo_amd import droid_backends as db
+    from pvo_amd.parallel import local_eta_rows, partition_by_source
+    d = lambda t: t.to(cuda)
+    owner, _ = partition_by_source(s["ii"].tolist(), 2)
+    F, ht, wd = s["disps"].shape
+    P = s["t1"] - s["t0"]
+    shards = []
+    for r in range(2):
+        m = torch.tensor([o == r for o in owner])
+        rows = local_eta_rows(s["ii"].tolist(), s["ii"][m].tolist(), s["t0"], s["t1"])
+        sh = dict(ii=d(s["ii"][m].contiguous()), jj=d(s["jj"][m].contiguous()), target=d(s["target"][m].contiguous()),
+                  weight=d(s["weight"][m].contiguous()), eta=d(s["eta"][rows].contiguous()),
+                  poses=d(s["poses"].clone()), disps=d(s["disps"].clone()))
+        sh["ws"] = db.ba_workspace(sh["ii"].shape[0], P, F, ht * wd, cuda)
+        sh["sys"] = torch.zeros((6 * P) ** 2 + 6 * P, dtype=torch.int64, device=cuda)
+        db.ba_plan(sh["ii"], sh["jj"], F, ht * wd, sh["eta"].shape[0], s["t0"], s["t1"], sh["ws"])
+        shards.append(sh)
+    for _ in range(iters):
+        for sh in shards:
+            db.ba_local(sh["poses"], sh["disps"], d(s["intr"]), sh["target"], sh["weight"], sh["eta"], sh["ii"], sh["jj"],
+                        s["t0"], s["t1"], False, sh["sys"], sh["ws"])
+        total = shards[0]["sys"] + shards[1]["sys"]
+        for sh in shards:
+            db.ba_finish(sh["poses"], sh["disps"], total.clone(), sh["ii"], sh["jj"], s["t0"], s["t1"], lm, ep, False, sh["ws"])
+            sh["sys"].zero_()
+    merged = d(s["disps"].clone()) + sum(sh["disps"] - d(s["disps"]) for sh in shards)
+    return shards[0]["poses"], shards[1]["poses"], merged
+
+
+@pytest.mark.parametrize("kind", ["radius8", "repeats"])
+def test_ba_of_a_real_frontend_window_matches_oracle_at_full_size(cuda, kind):
+    """The BA the full sequence really runs: 26 poses at 30 x 101 - 512-pixel chunks (3030 = 5 x 512 + 470, not a
+    multiple of four after chunking), four z-slices, the row-pass path, merged repeated targets, the packed row table, the
+    partitioned / window pose solve - against the oracle at 1e-4, twice for bitwise repeatability, and once through two virtual
+    ranks.  "radius8": 344 edges, 16 distinct neighbours per frame; "repeats": 440 edges, every inactive pair four times in
+    interleaved order + 48 active edges (the shape `sequence.ba_windows_sampled` reports)."""
+    P, ht, wd = 26, 30, 101
+    s = _scene(8801, P, ht, wd, 8, 1) if kind == "radius8" else _frontend_window(P, ht, wd)
+    assert s["ii"].shape[0] == (344 if kind == "radius8" else 440)
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
+    assert status[0] == 0 and status[1] == want["K"] == P and status[2] == 0 and status[3] == 0
+    assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
+    assert np.abs(dx - want["dx"]).max() < 1e-4 and np.abs(dz - want["dz"]).max() < 1e-4
+    again = _run_ba(s, cuda, 2)
+    assert np.array_equal(poses, again[0]) and np.array_equal(disps, again[1])          # fixed summation order: bitwise repeatable
+    p0, p1, merged = _two_virtual_ranks(s, cuda)
+    assert torch.equal(p0, p1)                                                          # replicas bit-identical
+    assert np.array_equal(p0.cpu().numpy(), poses)                                      # ... and equal to the whole graph on one GPU
+    assert np.abs(merged.cpu().numpy() - disps).max() < 2e-6
+
+
+def test_ba_with_a_wrong_eta_row_count_updates_nothing(cuda):
+    """eta must have one row per depth frame (or one, broadcast).  K is found on the device, so the host cannot refuse the call:
+    the mismatch is reported in the status words and the call changes neither poses nor depths (include/pvo_hip.h pvo_ba)"""
+    P, ht, wd = 8, 12, 16
+    s = _scene(31, P, ht, wd, 3, 1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2, eta=s["eta"][:5])
+    assert status[0] == 1 and status[2] == 1 and status[1] == P
+    assert np.array_equal(poses, s["poses"].numpy()) and np.array_equal(disps, s["disps"].numpy())
+    assert not dx.any()
+
+
 def test_ba_matches_oracle_at_SA_size(cuda):
     """S-A: 30x101 maps, 10 keyframes, 48 edges - the window shape of the reference's own driver"""
     P, ht, wd = 10, 30, 101
@@ -217,7 +304,7 @@ def test_ba_fixed_source_frame_and_broadcast_eta(cuda):
     assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
 
 
-@pytest.mark.parametrize("P,radius", [(64, 3), (40, 2), (23, 3)])
+@pytest.mark.parametrize("P,radius", [(64, 3), (40, 2), (31, 3)])
 def test_partitioned_pose_solve_partitions_a_chain_and_matches_the_oracle(cuda, P, radius):
     """the pose solve beyond the dense LDS path (ba_solve_twin_kernel): a keyframe chain is eliminated from both ends by two
     workgroups, the separator last - the partition is reported, balanced, and the result is the oracle's (dense fp64 solve)"""
@@ -240,7 +327,7 @@ def test_partitioned_pose_solve_declines_a_wide_separator(cuda):
     """loop closures from the far end back to the first poses couple everything below the cut with the end of the chain: the
     separator would be wider than the exchange buffer allows, the solve stays one chain (and is still the oracle's)"""
     from pvo_amd import droid_backends as db
-    P, ht, wd = 30, 8, 10
+    P, ht, wd = 32, 8, 10            # (31 free poses: beyond the dense matrix-core solve, which takes windows up to 29)
     s = _scene(77, P, ht, wd, 2, 1)
     far = list(range(P - 14, P - 1))
     extra_i, extra_j = torch.tensor([1] * len(far) + far), torch.tensor(far + [1] * len(far))
