@@ -36,6 +36,7 @@
 #include "conv1x1_tile.h"
 #include "glo_tile.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -2452,6 +2453,21 @@ __host__ __forceinline__ size_t dense_lds_bytes(int n) {
   return 16 + sizeof(double) * (8 * static_cast<size_t>(dense_panel_off(nb, N)) + 64 + 2 * static_cast<size_t>(N));
 }
 
+#ifdef PVO_BA_PROBE
+#define DENSE_STEP_PROBE(slot) do { if (g_ba_probe && threadIdx.x == 0 && kb8 == nb / 2) g_ba_probe[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DENSE_STEP_PROBE(slot)
+#endif
+// element (row t of a panel, column k of its eight) sits at t * 8 + (k ^ ((t >> 1) & 7)): the matrix-core operand reads take ONE
+// column of 16 consecutive rows per 16 lanes - at a plain 64-byte row pitch that is an 8-way bank conflict on every read
+__device__ __forceinline__ int dense_swz(int t, int k) { return t * 8 + (k ^ ((t >> 1) & 7)); }
+// 1 / sqrt(d): hardware estimate + ONE Newton step (the estimate carries ~26 bits: ~1.5 ulp after the step; the outputs are fp32).
+// The second step of rsqrt_nr was 4 of the ~12 dependent fp64 operations per column on this kernel's critical chain.
+__device__ __forceinline__ double rsqrt_nr1(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  return y * (1.5 - 0.5 * d * y * y);
+}
+
 template <int SLOTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_solve_dense_kernel(
     long long* __restrict__ sys, const long long* __restrict__ msg, const int* __restrict__ first_s,
@@ -2487,99 +2503,127 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   double* rdg = Dg + 64;
   double* xs = rdg + N;
   if (tid == 0) fail = 0;
+  BA_PROBE(0);
+#ifdef PVO_BA_PROBE
+  if (g_ba_probe && tid == 0) g_ba_probe[15] = 0xD15E;                    // (tools/ba_solve_timeline.py: the step stamps below are this kernel's)
+#endif
 
-  // ---- this wave's tiles: q = 4 slot + wave -> (ti, tj), tj <= ti
+  // ---- this wave's tiles: the lower triangle's tiles in COLUMN-major order (tile column 0 top to bottom, then column 1, ...),
+  // q = 4 slot + wave.  The tiles a step still has to update are then a SUFFIX of every wave's slots and the tiles of one tile
+  // column a short run of them: the unrolled slot code is entered through one jump instead of one branch per slot
   int tti[SLOTS], ttj[SLOTS];
   const int ntiles = T * (T + 1) / 2;
+  auto colstart = [&](int c) { return c * T - c * (c - 1) / 2; };         // index of tile (c, c)
+  auto first_slot = [&](int c) { const int q0 = colstart(c) - wave; return q0 > 0 ? (q0 + 3) >> 2 : 0; };      // this wave's first slot with tj >= c
 #pragma unroll
   for (int sl = 0; sl < SLOTS; ++sl) {
     const int q = 4 * sl + wave;
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
-    tti[sl] = q < ntiles ? ti : -1;
-    ttj[sl] = q - ti * (ti + 1) / 2;
+    int tj = 0;
+    while (tj + 1 < T && colstart(tj + 1) <= q) ++tj;
+    tti[sl] = q < ntiles ? tj + (q - colstart(tj)) : -1;
+    ttj[sl] = tj;
   }
-  // ---- load: fixed point -> fp64 (+ damping on the diagonal, droid_kernels.cu:1176) straight into the accumulator tiles
+  const int nsl = ntiles > wave ? (ntiles - wave + 3) >> 2 : 0;           // this wave's slots in use
+  // ---- load: fixed point -> fp64 (+ damping on the diagonal, droid_kernels.cu:1176) straight into the accumulator tiles.  Every
+  // load unconditional on a clamped index (a guarded load is a branch of its own; these are 32 in flight per lane)
   pvo_d4 C[SLOTS];
+  auto load_tiles = [&](auto from_message) {
+    constexpr bool MSG = decltype(from_message)::value;
+    const long long* __restrict__ src = MSG ? msg : sys;
+    constexpr int B = MSG ? 4 : SLOTS;       // slots per batch of loads: the dense image's addresses are cheap - all 4 SLOTS loads in flight at once (a round trip to the
+                                             // memory side, where the atomics left the system, is ~3 us: four batches were 14 us of this kernel)
 #pragma unroll
-  for (int s0 = 0; s0 < SLOTS; s0 += 4) {                               // sixteen loads in flight per lane
-    long long raw[4][4];
+    for (int s0 = 0; s0 < SLOTS; s0 += B) {
+      long long raw[B][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int sl = s0 + u < SLOTS ? s0 + u : SLOTS - 1;
+      for (int u = 0; u < B; ++u) {
+        const int sl = s0 + u < SLOTS ? s0 + u : SLOTS - 1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * tti[sl] + lr + 4 * r, col = 16 * ttj[sl] + lc;
-        long long v = 0;
-        if (tti[sl] >= 0 && col < n) {
-          if (msg) {
-            if (row < n && col <= row) {
-              const int rb = row / 6, cb = col / 6;
-              if (cb >= mfirst[rb]) v = msg[mbase[rb] + (cb - mfirst[rb]) * 36 + (row - 6 * rb) * 6 + (col - 6 * cb)];
-            } else if (row == n) v = msg[mbase[P] + col];
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * tti[sl] + lr + 4 * r, col = 16 * ttj[sl] + lc;
+          int idx = -1;
+          const bool in = tti[sl] >= 0 && col < n;
+          if (MSG) {
+            const int rw = row < n ? row : 0;
+            const int rb = rw / 6, cb = col / 6;
+            const int body = mbase[rb] + (cb - mfirst[rb]) * 36 + (rw - 6 * rb) * 6 + (col - 6 * cb);
+            idx = (in && row < n && col <= row && cb >= mfirst[rb]) ? body : ((in && row == n) ? mbase[P] + col : -1);
           } else {
-            if (row < n && col <= row) v = sys[static_cast<long long>(row) * n + col];
-            else if (row == n) v = sys[static_cast<long long>(n) * n + col];
+            idx = (in && row < n && col <= row) ? row * n + col : ((in && row == n) ? n * n + col : -1);
+          }
+          const long long v = src[idx < 0 ? 0 : idx];
+          raw[u][r] = idx < 0 ? 0LL : v;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        if (s0 + u >= SLOTS) continue;
+        const int sl = s0 + u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * tti[sl] + lr + 4 * r, col = 16 * ttj[sl] + lc;
+          double v = static_cast<double>(raw[u][r]) * kInvFix;
+          if (row == col && row < n) v += static_cast<double>(ep) + static_cast<double>(lm) * v;
+          C[sl][r] = v;
+        }
+      }
+    }
+  };
+  if (msg) load_tiles(std::true_type{}); else load_tiles(std::false_type{});
+  // the first panel's columns out of the accumulators (afterwards every step extracts the NEXT panel behind its own update)
+  auto extract = [&](int kb8x) {
+    const int tcx = kb8x >> 1, hx = kb8x & 1, c0x = 8 * kb8x;
+    double* panx = Lp + 8 * dense_panel_off(kb8x, N);
+    const int e0 = first_slot(tcx), e1x = first_slot(tcx + 1), e1 = e1x < nsl ? e1x : nsl;
+    auto one = [&](const pvo_d4& Cs, int ti) {
+      if ((lc >> 3) == hx) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * ti + lr + 4 * r;
+          if (row >= c0x) {
+            panx[dense_swz(row - c0x, lc & 7)] = Cs[r];
+            if (row < c0x + 8) Dg[(row - c0x) * 8 + (lc & 7)] = Cs[r];
           }
         }
-        raw[u][r] = v;
       }
+    };
+    switch (e0) {                                                         // (the column's slots are consecutive: one jump, then straight down)
+#define PVO_DENSE_CASE(K) case K: if (K < SLOTS) { if (K >= e1) break; one(C[K < SLOTS ? K : 0], tti[K < SLOTS ? K : 0]); } [[fallthrough]];
+      PVO_DENSE_CASE(0) PVO_DENSE_CASE(1) PVO_DENSE_CASE(2) PVO_DENSE_CASE(3) PVO_DENSE_CASE(4) PVO_DENSE_CASE(5)
+      PVO_DENSE_CASE(6) PVO_DENSE_CASE(7) PVO_DENSE_CASE(8) PVO_DENSE_CASE(9) PVO_DENSE_CASE(10) PVO_DENSE_CASE(11)
+      PVO_DENSE_CASE(12) PVO_DENSE_CASE(13) PVO_DENSE_CASE(14) PVO_DENSE_CASE(15) PVO_DENSE_CASE(16)
+#undef PVO_DENSE_CASE
+      default: break;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (s0 + u >= SLOTS) continue;
-      const int sl = s0 + u;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * tti[sl] + lr + 4 * r, col = 16 * ttj[sl] + lc;
-        double v = static_cast<double>(raw[u][r]) * kInvFix;
-        if (row == col && row < n) v += static_cast<double>(ep) + static_cast<double>(lm) * v;
-        C[sl][r] = v;
-      }
-    }
-  }
+  };
+  extract(0);
   // (every entry the assembly / Schur kernels or an all-reduce may have written: ready for the next step's accumulation.  Behind a
   // barrier: a wave with few tiles would otherwise zero entries another wave has not loaded yet)
   __syncthreads();
   if (!msg) for (int idx = tid; idx < n * n + n; idx += 256) sys[idx] = 0LL;      // (ba_pack_kernel has zeroed the image a message came from)
-  __syncthreads();
+  BA_PROBE(1);
 
-  // ---- factorisation, eight columns per step
+  // ---- factorisation, eight columns per step.  At the head of a step the panel's columns (as the updates so far left them) and
+  // its diagonal block are in LDS.
   for (int kb8 = 0; kb8 < nb; ++kb8) {
     const int tc = kb8 >> 1, h = kb8 & 1, c0 = 8 * kb8;
-    double* pan = Lp + 8 * dense_panel_off(kb8, N);                      // rows c0 .. N-1 of columns c0 .. c0+7, 8 doubles per row
-    // (the lane's coordinates, opaque to the optimiser inside this loop: it otherwise hoists every tile's LDS addresses out of the
-    // loop - ten registers per tile, 140 of the 14-tile instantiation's budget - to save one addition per use)
-    int lcv = lc, lrv = lr;
-    asm volatile("" : "+v"(lcv), "+v"(lrv));
-    // 1. the panel's columns out of the accumulators
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      if (tti[sl] < 0 || ttj[sl] != tc) continue;                        // (uniform per wave)
-      if ((lcv >> 3) == h) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * tti[sl] + lrv + 4 * r;
-          if (row >= c0) {
-            pan[(row - c0) * 8 + (lcv & 7)] = C[sl][r];
-            if (row < c0 + 8) Dg[(row - c0) * 8 + (lcv & 7)] = C[sl][r];
-          }
-        }
-      }
-    }
-    __syncthreads();
+    double* pan = Lp + 8 * dense_panel_off(kb8, N);                      // rows c0 .. N-1 of columns c0 .. c0+7, 8 doubles per row (swizzled)
+    DENSE_STEP_PROBE(8);
     // 2. one lane per row of the panel
     const int nv = (n - c0 < 8) ? n - c0 : 8;                           // columns of this panel that belong to the system (the rest: padding)
     if (tid < N - c0) {
       // the 8 x 8 Cholesky IN PLACE on the block's lower triangle; a diagonal slot ends up holding 1 / L_jj (L_jj itself is never
       // needed: the diagonal rows leave as d * rs through the row formula below) - registers are what bounds this kernel's occupancy
-      double L[36];
-      bool ok = true;
+      double L[36], a[8];
+      const int sw = (tid >> 1) & 7;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = pan[tid * 8 + (j ^ sw)];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Dg[i * 8 + j];
       }
+      bool ok = true;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         double d = L[j * (j + 1) / 2 + j];
@@ -2587,7 +2631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
         const bool real = j < nv;
         ok = ok && (!real || d > 0.0);
-        const double rs = (real && ok) ? rsqrt_nr(d) : 0.0;
+        const double rs = (real && ok) ? rsqrt_nr1(d) : 0.0;
         L[j * (j + 1) / 2 + j] = rs;
 #pragma unroll
         for (int i = j + 1; i < 8; ++i) {
@@ -2596,21 +2640,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int k = 0; k < j; ++k) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
           L[i * (i + 1) / 2 + j] = v * rs;
         }
-      }
-      double a[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = pan[tid * 8 + j];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
+        // this row's entry of column j as soon as the column's reciprocal pivot exists (the row's chain runs beside the block's)
         double v = a[j];
 #pragma unroll
         for (int k = 0; k < j; ++k) v -= a[k] * L[j * (j + 1) / 2 + k];
-        v *= L[j * (j + 1) / 2 + j];
+        v *= rs;
         if (tid < 8 && j > tid) v = 0.0;                                 // (the diagonal block's rows: L is lower triangular)
         a[j] = v;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pan[tid * 8 + j] = a[j];
+      for (int j = 0; j < 8; ++j) pan[tid * 8 + (j ^ sw)] = a[j];
       if (tid < 8) {
         double r = L[0];
 #pragma unroll
@@ -2619,21 +2658,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       if (tid == 0 && !ok) fail = 1;
     }
+    DENSE_STEP_PROBE(9);
     __syncthreads();
-    // 3. trailing update of every tile with a column beyond the panel
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-      const int ti = tti[sl], tj = ttj[sl];
-      if (ti < 0 || !(tj > tc || (tj == tc && h == 0))) continue;        // (uniform per wave)
-      const double* ra = pan + (16 * ti + lcv - c0) * 8 + lrv;
-      const double* rb = pan + (16 * tj + lcv - c0) * 8 + lrv;
-      const double a0 = ra[0], a1 = ra[4], b0 = rb[0], b1 = rb[4];
-      C[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, C[sl], 0, 0, 0);
-      C[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, C[sl], 0, 0, 0);
-      if ((sl & 3) == 3) __builtin_amdgcn_sched_barrier(0);              // (operand loads of at most four tiles in flight: registers)
+    DENSE_STEP_PROBE(10);
+    // 3. trailing update C -= L_rows(i) L_rows(j)^T of every tile with a column beyond the panel: this wave's slots from `u0` on,
+    // two slots per block of straight-line code (eight operand reads in flight, the two tiles' MFMA pairs interleaved), entered
+    // through one jump
+    {
+      const int u0 = first_slot(h == 0 ? tc : tc + 1);
+      auto pair = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        constexpr int K1 = K + 1 < SLOTS ? K + 1 : K;
+        const bool on0 = K >= u0 && K < nsl, on1 = K + 1 < SLOTS && K + 1 >= u0 && K + 1 < nsl;
+        const int ta0 = on0 ? 16 * tti[K] + lc - c0 : 0, tb0 = on0 ? 16 * ttj[K] + lc - c0 : 0;
+        const int ta1 = on1 ? 16 * tti[K1] + lc - c0 : 0, tb1 = on1 ? 16 * ttj[K1] + lc - c0 : 0;
+        double a00 = pan[dense_swz(ta0, lr)], b00 = pan[dense_swz(tb0, lr)], a01 = pan[dense_swz(ta0, 4 + lr)], b01 = pan[dense_swz(tb0, 4 + lr)];
+        double a10 = pan[dense_swz(ta1, lr)], b10 = pan[dense_swz(tb1, lr)], a11 = pan[dense_swz(ta1, 4 + lr)], b11 = pan[dense_swz(tb1, 4 + lr)];
+        if (!on0) { a00 = 0.0; a01 = 0.0; }                              // (a slot below u0 in its pair / beyond this wave's tiles: C += 0)
+        if (!on1) { a10 = 0.0; a11 = 0.0; }
+        C[K] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a00, b00, C[K], 0, 0, 0);
+        if (K + 1 < SLOTS) C[K1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a10, b10, C[K1], 0, 0, 0);
+        C[K] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a01, b01, C[K], 0, 0, 0);
+        if (K + 1 < SLOTS) C[K1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a11, b11, C[K1], 0, 0, 0);
+      };
+      switch (u0 >> 1) {
+#define PVO_DENSE_PAIR(K) case K / 2: if (K < SLOTS) { if (K >= nsl) break; pair(std::integral_constant<int, (K < SLOTS ? K : 0)>{}); } [[fallthrough]];
+        PVO_DENSE_PAIR(0) PVO_DENSE_PAIR(2) PVO_DENSE_PAIR(4) PVO_DENSE_PAIR(6) PVO_DENSE_PAIR(8) PVO_DENSE_PAIR(10) PVO_DENSE_PAIR(12)
+        PVO_DENSE_PAIR(14) PVO_DENSE_PAIR(16)
+#undef PVO_DENSE_PAIR
+        default: break;
+      }
     }
+    DENSE_STEP_PROBE(11);
+    if (kb8 + 1 < nb) extract(kb8 + 1);
+    DENSE_STEP_PROBE(12);
+    DENSE_STEP_PROBE(13);
+    __syncthreads();
+    DENSE_STEP_PROBE(14);
   }
-  __syncthreads();
+  BA_PROBE(2);
 
   // ---- back-substitution L^T x = y (y = row n of L), wave 0: lane holds columns lane, lane + 64, lane + 128
   if (wave == 0) {
@@ -2641,12 +2704,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       const int c = lane + 64 * m;
-      z[m] = c < n ? Lp[8 * (dense_panel_off(c >> 3, N) + n - 8 * (c >> 3)) + (c & 7)] : 0.0;
+      z[m] = c < n ? Lp[8 * dense_panel_off(c >> 3, N) + dense_swz(n - 8 * (c >> 3), c & 7)] : 0.0;
     }
     for (int kb8 = nb - 1; kb8 >= 0; --kb8) {
       const int c0 = 8 * kb8, m0 = c0 >> 6, l0 = c0 & 63;
       const int nv = (n - c0 < 8) ? n - c0 : 8;
       const double* pan = Lp + 8 * dense_panel_off(kb8, N);
+      // everything this step reads from LDS is independent of the unknowns: requested up front
+      double Lk[28], rdv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        rdv[j] = rdg[c0 + j];
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) Lk[i * (i - 1) / 2 + j] = pan[dense_swz(i, j)];      // L[c0 + i][c0 + j]
+      }
       const double zsel = m0 == 0 ? z[0] : (m0 == 1 ? z[1] : z[2]);
       double x[8];
 #pragma unroll
@@ -2659,17 +2730,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 7; j >= 0; --j) {
         double v = x[j];
 #pragma unroll
-        for (int i = j + 1; i < 8; ++i) v -= pan[i * 8 + j] * x[i];      // L[c0 + i][c0 + j]
-        x[j] = (j < nv) ? v * rdg[c0 + j] : 0.0;
+        for (int i = 7; i > j; --i) v -= Lk[i * (i - 1) / 2 + j] * x[i];
+        x[j] = (j < nv) ? v * rdv[j] : 0.0;
       }
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         const int c = lane + 64 * m;
         if (c < c0) {
-          const double* col = Lp + 8 * (dense_panel_off(c >> 3, N) + c0 - 8 * (c >> 3)) + (c & 7);      // L[c0 + i][c], i = 0 ..
+          const double* pc = Lp + 8 * dense_panel_off(c >> 3, N);
           double v = z[m];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v -= col[8 * i] * x[i];
+          for (int i = 0; i < 8; ++i) v -= pc[dense_swz(c0 + i - 8 * (c >> 3), c & 7)] * x[i];          // L[c0 + i][c]
           z[m] = v;
         } else if (c < c0 + 8) {
           double v = x[0];
@@ -2686,6 +2757,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   __syncthreads();
+  BA_PROBE(4);
   const int failed = fail | meta[4] | meta[2];      // (meta[2]: eta's row count != K - the whole step is a no-op, see ba_plan_kernel)
   for (int idx = tid; idx < n; idx += 256) {
     double xv = xs[idx];
@@ -2704,6 +2776,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ps[3] = Tn.q.x; ps[4] = Tn.q.y; ps[5] = Tn.q.z; ps[6] = Tn.q.w;
   }
   __syncthreads();
+  BA_PROBE(5);
   if (tid == 0) {
     meta[4] = 0;
     if (failed) meta[1] = 1;

@@ -21,11 +21,11 @@ from pvo_amd import droid_backends as db
 from test_geom_ba_gpu import _scene
 dev = torch.device("cuda:0")
 nf = int(os.environ.get("NF", "8"))
-s = _scene(0, nf, 48, 64, 3, 1)
+s = _scene(0, nf, int(os.environ.get("HT", "48")), int(os.environ.get("WD", "64")), int(os.environ.get("RAD", "3")), 1)      # RAD=8: a dense window
 d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()}
 lib = _lib.load()
 lib.pvo_debug_ba_probe.restype = ctypes.c_int; lib.pvo_debug_ba_probe.argtypes = [ctypes.c_void_p]
-buf = torch.zeros(64, dtype=torch.int64, device=dev)
+buf = torch.zeros(64, dtype=torch.int64, device=dev)      # (slot 15: which kernel wrote the step stamps)
 run = lambda: db.ba(d["poses"].clone(), d["disps"].clone(), d["intr"], d["target"], d["weight"], d["eta"], d["ii"], d["jj"], 1, nf, 2, 1e-4, 0.1, False)
 for _ in range(3):
     run()
@@ -36,11 +36,14 @@ assert lib.pvo_debug_ba_probe(None) == 0
 t = buf.cpu().tolist()
 print("P = %d free poses: load + convert %.1f k cycles | factorisation %.1f | substitution %.1f | dx out + retraction %.1f | total %.1f"
       % (nf - 1, (t[1] - t[0]) / 1e3, (t[2] - t[1]) / 1e3, (t[4] - t[2]) / 1e3, (t[5] - t[4]) / 1e3, (t[5] - t[0]) / 1e3))
-if t[14]:
+if t[15] == 0xD15E:        # the dense matrix-core solve (ba_solve_dense_kernel): one step of eight columns, the middle one, thread 0
+    names = ["8x8 Cholesky + row solve", "barrier", "trailing update (MFMA issue)", "next panel out of the accumulators", "-", "barrier"]
+    print("   dense solve, step nb/2: " + " | ".join("%s %d" % (nm, t[9 + i] - t[8 + i]) for i, nm in enumerate(names)) + " | step %d cycles" % (t[14] - t[8]))
+if t[14] and t[15] != 0xD15E:
     names = ["operand loads issued", "6x6 Cholesky", "panel + store of the factored block", "publish", "wait for the workers", "look-ahead update"]
     print("   pipelined factorisation, wave 0, block column P/2: " + " | ".join("%s %d" % (nm, t[9 + i] - t[8 + i]) for i, nm in enumerate(names)) + " | step %d cycles" % (t[14] - t[8]))
 if t[32]:
-    part = db.ba_last_partition(d["ii"].shape[0], nf - 1, nf, 48 * 64, dev)
+    part = db.ba_last_partition(d["ii"].shape[0], nf - 1, nf, s["disps"].shape[1] * s["disps"].shape[2], dev)
     names = ["", "tables, local layout, zero fill", "load", "active-row lists", "own columns", "top: wait for the terms | bottom: terms written", "top: terms added | bottom: wait for x",
              "top: separator columns | bottom: (none)", "top: back substitution", "top: x handed over", "back substitution (bottom) / idle", "dx out + retraction"]
     base = min(t[32], t[48])
