@@ -47,4 +47,12 @@ for _ in range(4):
     poses, disps = d(s["poses"].clone()), d(s["disps"].clone())
     db.ba(poses, disps, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]), 1, 8, 2, 1e-4, 0.1, False)
 torch.cuda.synchronize()
+# the BA of a real frontend update (round 6): 26 poses, 440 edges (every inactive pair four times + 48 active), 30 x 101 maps -
+# ba_schur_mfma_kernel<false, 512> with its row passes / merged targets, ba_solve_dense_kernel<14>
+from test_geom_ba_gpu import _frontend_window
+s = _frontend_window()
+for _ in range(4):
+    poses, disps = d(s["poses"].clone()), d(s["disps"].clone())
+    db.ba(poses, disps, d(s["intr"]), d(s["target"]), d(s["weight"]), d(s["eta"]), d(s["ii"]), d(s["jj"]), 1, 26, 2, 1e-4, 0.1, False)
+torch.cuda.synchronize()
 print("done")
