@@ -249,29 +249,45 @@ def cpu_baseline():
             "parts_s": {"build_6_edges": t_build, "lookup_36_edges": t_lookup, "update_operator": t_upd, "ba_2_iters": t_ba}}
 
 
-def synthetic_ate(device):
-    """The ATE half of BASELINE.json's metric, on the only sequence available here: a synthetic plane scene tracked by
-    the frontend + HIP BA with ground-truth correspondences (+ fixed noise) standing in for the learned operator (no
-    checkpoint or dataset exists in this environment).  Sim(3)-aligned translation RMSE, as test_vo.py:162-163 computes."""
+def synthetic_ate(device, n_frames=120):
+    """The ATE half of BASELINE.json's metric, on the only kind of sequence available here (no checkpoint, no dataset): a synthetic
+    plane scene at the reference driver's map size (30 x 101 = 240 x 808 / 8) tracked by the REAL DroidFrontend (window of 25 with its
+    inactive edges, proximity factors, the keyframe test with its removal branch) and optimised by the REAL DroidBackend (global BA x 2),
+    on the HIP kernels, with ground-truth correspondences (+ fixed noise) standing in for the learned operator.  Every third frame of
+    the scene barely moves, so the frontend's keyframe test removes it again (droid_frontend.py:54-58).  Sim(3)-aligned translation
+    RMSE as test_vo.py:162-163 computes, before and after the global BA.  The same loop against the CPU-oracle path (same keyframe
+    decisions, ATE within 1e-3): tests/test_synthetic_vo.py, at 26 frames (the oracle's BA takes ~0.5 s per call at this size)."""
     import numpy as np
+    from argparse import Namespace
     from pvo_amd import droid_backends as db
+    from pvo_amd.backend import DroidBackend
     from pvo_amd.depth_video import DepthVideo
     from pvo_amd.frontend import DroidFrontend
     from pvo_amd.synthetic import OracleFlowOperator, PlaneScene, run_sequence
     from pvo_amd.trajectory import ate_rmse, camera_centres
-    scene = PlaneScene(ht=24, wd=32, n_frames=14, seed=0)
-    video = DepthVideo(image_size=(scene.ht * 8, scene.wd * 8), buffer=32, device=device)
+    scene = PlaneScene(ht=30, wd=101, n_frames=n_frames, seed=0, step=0.06, pattern=(1.0, 1.0, 0.15))
+    video = DepthVideo(image_size=(scene.ht * 8, scene.wd * 8), buffer=n_frames + 8, device=device)
     op = OracleFlowOperator(scene, video, lambda p, d, k, i, j: db.reproject(p, d, k, i, j)[0])
-    fe = DroidFrontend(op, video, device=device, warmup=8, keyframe_thresh=0.5, frontend_thresh=16.0, frontend_window=20,
+    fe = DroidFrontend(op, video, device=device, warmup=8, keyframe_thresh=0.6, frontend_thresh=16.0, frontend_window=25,
                        frontend_radius=2, frontend_nms=1)
-    poses, frames = run_sequence(scene, video, fe, op)
+    be = DroidBackend(Namespace(update=op), video, Namespace(device=str(device), backend_radius=2, backend_nms=3, backend_thresh=15.0,
+                                                             beta=0.3, backend_corr="alt"))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    before, after, frames = run_sequence(scene, video, fe, op, backend=be)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
     gt = camera_centres(scene.poses[frames].numpy())
-    return {"value": float(ate_rmse(camera_centres(poses.numpy()), gt)), "unit": "scene units",
-            "trajectory_length": float(np.linalg.norm(gt[-1] - gt[0])), "keyframes": len(frames),
-            "sequence": "synthetic plane scene, 24x32 maps, 14 frames, ground-truth correspondences + 0.05 px noise in place of the learned operator"}
+    length = float(np.abs(np.diff(gt, axis=0)).sum()) if len(frames) > 1 else 0.0
+    return {"value": float(ate_rmse(camera_centres(after.numpy()), gt)), "unit": "scene units",
+            "ate_rmse_frontend_only": float(ate_rmse(camera_centres(before.numpy()), gt)),
+            "trajectory_path_length": float(np.linalg.norm(np.diff(gt, axis=0), axis=1).sum()), "frames": n_frames, "keyframes_kept": len(frames),
+            "keyframes_removed_by_the_frontend": int(fe.keyframes_removed), "seconds": el, "finite": bool(torch.isfinite(after).all()),
+            "sequence": "synthetic plane scene, 30x101 maps, %d frames (every third barely moves), ground-truth correspondences + 0.05 px noise in "
+                        "place of the learned operator; real DroidFrontend (window 25, inactive edges, proximity factors, keyframe removal) + "
+                        "DroidBackend (global BA, 7 + 12 steps), HIP BA throughout" % n_frames}
 
 
 PROBE_EVERY = 5
+REMOVAL_RATE = 0.25      # share of the sequence leg's keyframe updates that end in rm_keyframe (seeded schedule)
 
 
 def timed_steps(video, graph, snap, steps, world, probe_stage="lookup", updates_per_step=6):
@@ -737,7 +753,7 @@ class _Split:
         setattr(obj, name, timed)
 
 
-def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None, record=None, terminate=True, seed=0):
+def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None, record=None, terminate=True, seed=0, removal_rate=0.0):
     """tools/test_vo.py's loop (evaluation_scripts/test_vo.py:88-108) on the synthetic stream: Droid.track per frame, then
     terminate (backend x2 + trajectory filler)"""
     from pvo_amd.droid import Droid, default_args
@@ -758,6 +774,14 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
         counts["keyframes_removed"] += 1
         return rmk(ix)
     fe._update, fe.graph.rm_keyframe = _upd, _rmk
+    if removal_rate > 0:
+        # the frontend's keyframe test compares distances between poses a RANDOM network produced (chaotic): its branch is driven by a
+        # seeded schedule instead - decision k is fixed for the k-th keyframe update of every pass (DroidFrontend.keyframe_decision);
+        # the distance is still computed and read back
+        import random
+        rng = random.Random(1234 + seed)
+        sched = [rng.random() < removal_rate for _ in range(4 * n_frames + 64)]
+        fe.keyframe_decision = lambda k, dist: sched[k]
     gupd = fe.graph.update
 
     windows = []
@@ -832,8 +856,7 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
             out["backend_graphs"] = backend_graphs
     finally:
         _FG.update_lowmem = lowmem
-    del droid
-    torch.cuda.empty_cache()
+    del droid      # (the allocator keeps its blocks: the next pass's volume pools come out of the cache, as a second sequence in one process would)
     return out
 
 
@@ -845,7 +868,8 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
     magnitudes of the two kinds form two tight clusters (0.2005 +- 0.0008 / 0.2045 +- 0.0006 with the seeded weights) - the motion
     filter's threshold is put half way between them on a 48-frame warm-up pass, so a quarter of the frames is dropped by the filter and
     three quarters become keyframes.  The frontend's keyframe test compares distances of poses a random network produced (0.04 .. 3,
-    chaotic): its threshold is 0, every keyframe is kept and gets its 4 + 2 graph updates, as in the replayed S-B / S-A step.  Three
+    chaotic): its outcome follows a SEEDED schedule instead (REMOVAL_RATE of the keyframe updates end in rm_keyframe + the counter /
+    t1 roll-back, droid_frontend.py:54-58; the others get their 4 + 2 graph updates) - the distance is still computed and read back.  Three
     passes: warm-up + calibration, plain (the rates), instrumented (the split; device synchronisations around every component)."""
     rec = {"motion": [], "keyframe_distance": []}
     _sequence_pass(device, min(n_frames, 48), 0.0, 0.0, record=rec, terminate=True)
@@ -856,7 +880,7 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
         import cProfile, io, pstats
         pr = cProfile.Profile()
         pr.enable()
-    plain = _sequence_pass(device, n_frames, f_th, k_th)
+    plain = _sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE)
     if cprofile:
         pr.disable()
         buf = io.StringIO()
@@ -867,14 +891,18 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
         with open(cprofile, "w") as f:
             f.write(buf.getvalue())
     sp = _Split()
-    inst = _sequence_pass(device, n_frames, f_th, k_th, split=sp) if instrumented else {"track_s": float("nan")}
+    inst = _sequence_pass(device, n_frames, f_th, k_th, split=sp, removal_rate=REMOVAL_RATE) if instrumented else {"track_s": float("nan")}
     total = sum(sp.t.values())
     return {"workload": "synthetic 240x808 stream (30x101 maps), %d frames, panoptic segments (segm_filter), random-init weights; "
                         "tools/test_vo.py's loop: Droid.track per frame, terminate = backend(7) + backend(12) + trajectory filler" % n_frames,
             "calibration": {"motion_first_32": [round(x, 4) for x in rec["motion"][:32]], "keyframe_distance": [round(x, 4) for x in rec["keyframe_distance"][:24]]},
             "thresholds": {"filter_thresh": f_th, "keyframe_thresh": k_th,
-                           "how": "filter: half way between the two clusters of one-step flow magnitudes on a 48-frame warm-up pass (1-pixel and 9-pixel frames); keyframe test: 0 = every keyframe kept"},
-            "frames_per_s": plain["frames"] / plain["track_s"], "keyframe_updates_per_s": plain["keyframe_updates"] / plain["track_s"],
+                           "how": "filter: half way between the two clusters of one-step flow magnitudes on a 48-frame warm-up pass (1-pixel and 9-pixel frames); keyframe test: seeded schedule, see keyframe_removal"},
+            "frames_per_s": plain["frames"] / plain["track_s"],
+            "frames_per_s_end_to_end": plain["frames"] / (plain["track_s"] + plain.get("terminate_s", 0.0)),
+            "keyframe_removal": {"rate_scheduled": REMOVAL_RATE, "removed": plain["keyframes_removed"], "keyframe_updates": plain["keyframe_updates"],
+                                 "how": "seeded decision per keyframe update through DroidFrontend.keyframe_decision (the distance is still computed and read back): rm_keyframe + the counter / t1 roll-back of droid_frontend.py:54-58 are in the timed loop"},
+            "keyframe_updates_per_s": plain["keyframe_updates"] / plain["track_s"],
             "graph_updates_per_s": plain["graph_updates"] / plain["track_s"],
             "ms_per_keyframe_update_all_in": 1e3 * plain["track_s"] / max(plain["keyframe_updates"], 1),
             "ba_windows_sampled": plain.get("ba_windows_sampled"), "terminate_s": plain.get("terminate_s"), "backend_graphs": plain.get("backend_graphs"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},

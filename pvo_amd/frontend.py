@@ -22,6 +22,8 @@ class DroidFrontend:
         self.warmup, self.beta, self.frontend_nms = warmup, beta, frontend_nms
         self.keyframe_thresh, self.frontend_window = keyframe_thresh, frontend_window
         self.frontend_thresh, self.frontend_radius = frontend_thresh, frontend_radius
+        self.keyframe_decision = None
+        self.keyframes_removed = 0
 
     def _update(self):
         """add edges, optimise, decide whether the previous frame stays a keyframe (droid_frontend.py:36-70)"""
@@ -34,10 +36,16 @@ class DroidFrontend:
         for _ in range(self.iters1):
             self.graph.update(None, None, use_inactive=True)
         d = self.video.distance([self.t1 - 3], [self.t1 - 2], beta=self.beta, bidirectional=True)
-        if d.item() < self.keyframe_thresh:
+        # (keyframe_decision: measurement / test hook - a callable (update index, distance as a float) -> True to drop the keyframe.
+        # With random-init weights the distance is chaotic; bench.py and the GPU tests feed a seeded schedule so that the removal
+        # branch - rm_keyframe, the counter / t1 roll-back - runs the same way in every pass.  The scalar is read back either way.)
+        dist = d.item()
+        drop = self.keyframe_decision(self.count, dist) if self.keyframe_decision is not None else dist < self.keyframe_thresh
+        if drop:
             self.graph.rm_keyframe(self.t1 - 2)
             self.video.counter -= 1
             self.t1 -= 1
+            self.keyframes_removed += 1
         else:
             for _ in range(self.iters2):
                 self.graph.update(None, None, use_inactive=True)

@@ -17,7 +17,9 @@ from .geom.se3 import SE3
 
 
 class PlaneScene:
-    def __init__(self, ht=48, wd=64, n_frames=24, seed=0, step=0.12):
+    def __init__(self, ht=48, wd=64, n_frames=24, seed=0, step=0.12, pattern=None):
+        """pattern (optional): per-frame multipliers of `step`, repeated - e.g. (1, 1, 0.15) makes every third frame barely move, which
+        the frontend's keyframe test (droid_frontend.py:54-58) then removes again: the rm_keyframe branch in a closed loop"""
         g = torch.Generator().manual_seed(seed)
         self.ht, self.wd, self.n = ht, wd, n_frames
         self.intr = torch.tensor([wd * 0.625, wd * 0.625, wd / 2.0, ht / 2.0])
@@ -25,8 +27,10 @@ class PlaneScene:
         self.planes = [(torch.tensor([0.15, 0.05, 1.0]), 4.0), (torch.tensor([0.0, 1.0, 0.12]), 1.3),
                        (torch.tensor([1.0, 0.0, 0.35]), 3.2)]
         xi = []
+        a_run = 0.0
         for k in range(n_frames):
-            a = k * step
+            a = k * step if pattern is None else a_run
+            a_run += step * (1.0 if pattern is None else pattern[k % len(pattern)])
             xi.append(torch.tensor([-a, 0.03 * math.sin(1.3 * a), -0.25 * a, 0.02 * math.sin(a), -0.06 * a, 0.01 * a]))
         self.poses = torch.stack([SE3.exp(x).data for x in xi])         # world-to-camera, frame 0 = identity
         self.disps = torch.stack([self.render_disp(self.poses[k]) for k in range(n_frames)])
@@ -92,8 +96,10 @@ class OracleFlowOperator:
         return net, delta, weight, eta, {}, delta_m
 
 
-def run_sequence(scene, video, frontend, operator, n_frames=None):
-    """feed the scene's frames as keyframes (the motion filter is outside this path) and run the frontend"""
+def run_sequence(scene, video, frontend, operator, n_frames=None, backend=None, backend_steps=(7, 12)):
+    """feed the scene's frames as keyframes (the motion filter is outside this path) and run the frontend; with `backend` (a
+    DroidBackend over the same video / operator) the two global bundle adjustments of Droid.terminate (droid.py:84-90) follow.
+    Returns (poses of the kept keyframes, the scene frame each of them is) - with a backend: (poses before, poses after, frames)."""
     n_frames = n_frames or scene.n
     dev = video.poses.device
     h, w = scene.ht, scene.wd
@@ -109,7 +115,13 @@ def run_sequence(scene, video, frontend, operator, n_frames=None):
         if video.counter <= slot:
             operator.frame_of.pop(slot, None)
             operator.bind(video.counter - 1, k)
-    return video.poses[:video.counter].detach().cpu(), [operator.frame_of.get(s, s) for s in range(video.counter)]
+    frames = [operator.frame_of.get(s, s) for s in range(video.counter)]
+    before = video.poses[:video.counter].detach().cpu().clone()
+    if backend is None:
+        return before, frames
+    for steps in backend_steps:
+        backend(steps)
+    return before, video.poses[:video.counter].detach().cpu().clone(), frames
 
 
 class TrainClips(torch.utils.data.Dataset):

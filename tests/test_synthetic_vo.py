@@ -61,6 +61,13 @@ class OracleVideo:
             d = 0.5 * (d + O.frame_distance(*a, jj, ii, beta))
         return torch.from_numpy(d)
 
+    def normalize(self):
+        n = self.counter
+        s = self.disps[:n].mean()
+        self.disps[:n] /= s
+        self.poses[:n, :3] *= s
+        self.dirty[:n] = True
+
     def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1, motion_only=False):
         r = O.ba(self.poses.numpy(), self.disps.numpy(), self.intrinsics[0].numpy(), target.numpy(), weight.numpy(),
                  eta.numpy(), ii.numpy(), jj.numpy(), t0, t1, itrs, lm, ep, motion_only=motion_only)
@@ -98,3 +105,47 @@ def test_closed_loop_ate_hip_equals_oracle_path(cuda):
     assert abs(ate_hip - ate_cpu) < 1e-3                                 # north_star tolerance
     assert ate_hip < 0.05 * np.linalg.norm(gt[-1] - gt[0])               # and the loop actually tracks the camera
     assert np.abs(camera_centres(poses_hip.numpy()) - camera_centres(poses_cpu.numpy())).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_closed_loop_at_the_driver_map_size_with_keyframe_removal_and_global_ba(cuda, monkeypatch):
+    """The same closed loop at the reference driver's map size (30 x 101 = 240 x 808 / 8: 3030 pixels, 512-pixel Schur chunks) through
+    the REAL DroidFrontend (window with its inactive edges, proximity factors, and - every third frame barely moves - the keyframe
+    test's removal branch, droid_frontend.py:54-58) and the REAL DroidBackend (two global bundle adjustments, droid.py:84-90), once on
+    the HIP kernels and once on the CPU oracle: the same keyframe decisions, removals included; ATE within the north star's 1e-3
+    before and after the global BA."""
+    from argparse import Namespace
+    from pvo_amd import droid_backends as db
+    from pvo_amd.backend import DroidBackend
+    from pvo_amd.depth_video import DepthVideo
+    import pvo_amd.modules.corr as corr_mod
+    n = 26
+    scene = PlaneScene(ht=30, wd=101, n_frames=n, seed=0, step=0.06, pattern=(1.0, 1.0, 0.15))
+    kw = dict(warmup=8, keyframe_thresh=0.6, frontend_thresh=16.0, frontend_window=25, frontend_radius=2, frontend_nms=1)
+    bargs = lambda dev: Namespace(device=dev, backend_radius=2, backend_nms=3, backend_thresh=15.0, beta=0.3, backend_corr="alt")
+    # --- HIP path
+    video = DepthVideo(image_size=(scene.ht * 8, scene.wd * 8), buffer=n + 8, device=cuda)
+    op = OracleFlowOperator(scene, video, lambda p, d, k, i, j: db.reproject(p, d, k, i, j)[0])
+    fe = DroidFrontend(op, video, device=cuda, **kw)
+    be = DroidBackend(Namespace(update=op), video, bargs(str(cuda)))
+    hip_before, hip_after, frames_hip = run_sequence(scene, video, fe, op, backend=be, backend_steps=(2, 3))
+    # --- CPU oracle path, identical host logic (the stand-in operator reads no correlation features: none are computed there)
+    ov = OracleVideo(scene.ht, scene.wd, buffer=n + 8)
+    op2 = OracleFlowOperator(scene, ov, _oracle_reproject)
+    fe2 = DroidFrontend(op2, ov, device="cpu", **kw)
+    fe2.graph.corr_impl = "none"
+    fe2.graph.corr = type("NoVolumes", (), {"__call__": lambda self, coords, **kw: None})()
+    monkeypatch.setattr(corr_mod, "AltCorrBlock", lambda *a, **k: (lambda *a2, **k2: None))
+    be2 = DroidBackend(Namespace(update=op2), ov, bargs("cpu"))
+    cpu_before, cpu_after, frames_cpu = run_sequence(scene, ov, fe2, op2, backend=be2, backend_steps=(2, 3))
+    monkeypatch.undo()
+    assert frames_hip == frames_cpu                                      # same keyframe decisions
+    assert fe.keyframes_removed == fe2.keyframes_removed >= 4 and len(frames_hip) >= 16
+    gt = camera_centres(scene.poses[frames_hip].numpy())
+    length = np.linalg.norm(np.diff(gt, axis=0), axis=1).sum()
+    for name, a, b in (("frontend", hip_before, cpu_before), ("global BA", hip_after, cpu_after)):
+        ate_h, ate_c = ate_rmse(camera_centres(a.numpy()), gt), ate_rmse(camera_centres(b.numpy()), gt)
+        print("%s: ATE-RMSE hip %.6f cpu-oracle %.6f (path length %.2f)" % (name, ate_h, ate_c, length))
+        assert abs(ate_h - ate_c) < 1e-3                                 # north_star tolerance
+        assert ate_h < 0.05 * length
+        assert np.abs(camera_centres(a.numpy()) - camera_centres(b.numpy())).max() < 5e-3

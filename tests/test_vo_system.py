@@ -413,6 +413,50 @@ def test_graphed_call_skips_only_arguments_the_caller_froze():
             config.debug_config("graph_check_skipped", False)
 
 
+@pytest.mark.gpu
+def test_full_sequence_at_240x808_graphs_against_eager_with_segments_and_removals(cuda):
+    """BASELINE.json configs[1]'s full-sequence form at the reference driver's input size (tools/test_vo.py's loop: Droid.track per
+    frame, Droid.terminate; 240 x 808, panoptic segments, segm_filter on) - 44 frames, every frame a keyframe candidate, a quarter of the
+    keyframe updates ending in rm_keyframe by a seeded schedule (DroidFrontend.keyframe_decision): the captured HIP graphs of the
+    per-frame work (pvo_amd/graphs.py) against the eager launches of the same kernels.  Same keyframes kept, same removals, poses and
+    the filled trajectory equal within 16-bit drift; the graphs were really replayed."""
+    import random
+    from pvo_amd import config
+    from pvo_amd.droid import Droid, default_args
+    from pvo_amd.synthetic import drifting_texture_stream
+    n = 44
+    frames = list(drifting_texture_stream(n, seed=0))
+    rng = random.Random(77)
+    sched = [rng.random() < 0.25 for _ in range(4 * n)]
+    out = {}
+    for mode in ("graphs", "eager"):
+        config.debug_config("hip_graphs", mode == "graphs")
+        try:
+            torch.manual_seed(0)
+            droid = Droid(default_args(device=str(cuda), image_size=[240, 808], buffer=64, segm_filter=True, thresh=0.8,
+                                       filter_thresh=0.0, keyframe_thresh=0.0))
+            fe, mf = droid.frontend, droid.filterx
+            fe.keyframe_decision = lambda k, dist: sched[k]
+            for t, image, intr, segm in frames:
+                droid.track(t, image, intrinsics=intr, segments=segm)
+            kf = int(droid.video.counter)
+            res = dict(kept=droid.video.tstamp[:kf].cpu().clone(), removed=fe.keyframes_removed, poses=droid.video.poses[:kf].cpu().clone(),
+                       disps=droid.video.disps[:kf].cpu().clone(), replays=mf._frame_g.replays + mf._context_g.replays)
+            res["traj"] = torch.from_numpy(droid.terminate(iter(frames), need_inv=True))
+            out[mode] = res
+            del droid
+        finally:
+            config.debug_config("hip_graphs", True)
+    g, e = out["graphs"], out["eager"]
+    assert g["replays"] >= n and e["replays"] == 0
+    assert g["removed"] == e["removed"] >= 5 and torch.equal(g["kept"], e["kept"]) and 20 <= g["kept"].shape[0] < n
+    assert torch.isfinite(g["traj"]).all() and g["traj"].shape == (n, 7)
+    scale = float(e["poses"][:, :3].abs().max()) + 1e-6
+    assert float((g["poses"] - e["poses"]).abs().max()) <= 2e-3 * max(scale, 1.0), float((g["poses"] - e["poses"]).abs().max())
+    assert float((g["disps"] - e["disps"]).abs().max()) <= 2e-2 * float(e["disps"].abs().max())
+    assert float((g["traj"] - e["traj"]).abs().max()) <= 5e-3 * max(float(e["traj"][:, :3].abs().max()), 1.0)
+
+
 def test_graphed_call_is_a_plain_call_off_the_gpu():
     """CPU tensors, gradients enabled or no arguments: pvo_amd.graphs.GraphedCall just calls through (nothing is captured)"""
     from pvo_amd.graphs import GraphedCall
