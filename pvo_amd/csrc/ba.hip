@@ -51,6 +51,9 @@ constexpr float kMinDepth = 0.25f;
 constexpr double kFix = 268435456.0, kInvFix = 1.0 / 268435456.0;
 __device__ __forceinline__ void fix_add(long long* sys, long long idx, double v, int* meta) {
   if (!(fabs(v) < 3.0e10)) { meta[4] = 1; return; }
+#ifdef PVO_BA_NO_ATOMICS                 // (timing experiment only - tools/ba_kernel_timeline.py PROBE_DEFS: the sums are lost)
+  if (idx >= 0) return;
+#endif
   atomicAdd(reinterpret_cast<unsigned long long*>(sys + idx), static_cast<unsigned long long>(__double2ll_rn(v * kFix)));
 }
 constexpr int kDealEdges = 2;           // edges (consecutive in the plan's by-source order) per chunk-sum workgroup of the Schur kernel
@@ -98,8 +101,15 @@ struct Ws {
   double* chol;          // [(6P)^2 + 6P] scratch for the global-memory factorisation
   double* xchg;          // partitioned pose solve: [2 doubles = 4 ints: flags, split | separator terms | separator solution] (kXchgDoubles)
   float* Mrg;            // [E][6][HW]: the summed Eij rows of edges that share source AND target frame (Schur kernel), at the first one's index
+  // dense windows (P <= kDenseMaxPoses), two-stage Schur sums: per (depth frame, 256-pixel chunk) the tile-pair sums of the chunk,
+  // the frame's row -> system-entry table and its tile count (0 = this frame went the atomic way)
+  float* spart;          // [kSchurStageFrames(P)][ceil(HW/256)][kSchurStagePairs][256]
+  short* srow;           // [kSchurStageFrames(P)][128]
+  int* sT;               // [kSchurStageFrames(P)]
   size_t bytes;
 };
+constexpr int kSchurStagePairs = 36;     // tile pairs of up to 8 row tiles
+__host__ __device__ __forceinline__ int schur_stage_frames(int P) { return (P > 0 && P <= 29) ? P + 8 : 0; }
 
 __host__ size_t align_up(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
@@ -130,6 +140,12 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 * n6 + n6 + 27 * (n6 / 6) + 32)));
   w.xchg = reinterpret_cast<double*>(take(sizeof(double) * kXchgDoubles));
   w.Mrg = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * 6 * HW));
+  {
+    const size_t ks = static_cast<size_t>(schur_stage_frames(P));
+    w.spart = reinterpret_cast<float*>(take(sizeof(float) * ks * ((HW + 255) / 256) * kSchurStagePairs * 256));
+    w.srow = reinterpret_cast<short*>(take(sizeof(short) * ks * 128));
+    w.sT = reinterpret_cast<int*>(take(sizeof(int) * (ks + 1)));
+  }
   w.bytes = off;
   return w;
 }
@@ -554,7 +570,8 @@ __device__ __forceinline__ f32x4 load4(gfloat* __restrict__ row, int p, int HW) 
 }
 
 // scatter one reduced 16x16 tile (ti,tj) of -S into the pose system
-__device__ __forceinline__ void scatter_tile(float v, int reg, int l, int ti, int tj, const short* rowout,
+template <typename V>
+__device__ __forceinline__ void scatter_tile(V v, int reg, int l, int ti, int tj, const short* rowout,
                                              long long* __restrict__ sys, int n6, int* meta) {
   // D[i][j]: i = 4*(lane>>4)+reg (row in tile ti), j = lane&15 (row in tile tj)
   const int oi = rowout[ti * 16 + 4 * (l >> 4) + reg];
@@ -676,6 +693,70 @@ __device__ __forceinline__ void schur_rowpass(const RowTab& rt, gfloat* __restri
   __syncthreads();                        // `red` is rewritten by the next pass
 }
 
+// schur_rowpass with the depth frame's rows STAGED IN LDS (round 6: dense frontend windows).  Streaming from global memory, every row
+// tile is read once per row pass it takes part in: 26 frames x 6 chunks with 7 row tiles re-read 1.1 MB of a (frame, chunk)'s 211 KB
+// of rows - 170 MB per launch, the whole of its 75 us (tools/ba_kernel_timeline.py at NF=26 RAD=8 HT=30 WD=101: tile pairs 38-52 us
+// per workgroup against ~3 us of MFMA).  Staged once per (frame, 256-pixel chunk) the pairs read LDS.  Same operands, same chain of
+// MFMAs in the same order, same (w0 + w1) + (w2 + w3) reduction: bit-identical to the streaming form at the same chunk size.
+constexpr int kLdsRowPad = 4;            // floats between rows: 16-byte alignment of every row, rows 8 apart share a bank group (2-way)
+template <int CNT, int PIX>
+__device__ __forceinline__ void schur_rowpass_lds(const float* L, const float* Lq, int nrows, const short* rowout, float* red,
+                                                  long long* __restrict__ sys, int n6, int* meta, int ti, int tj0,
+                                                  float* __restrict__ part_out, int pair0) {
+  constexpr int pitch = PIX + kLdsRowPad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int idx = lane & 15, kq = lane >> 4;
+  const int ra_row = ti * 16 + idx;
+  const float* ra = L + static_cast<size_t>(ra_row < nrows ? ra_row : 0) * pitch;
+  const bool oka = ra_row < nrows;
+  const float* rb[CNT];
+  bool okb[CNT];
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    const int r = (tj0 + t) * 16 + idx;
+    okb[t] = r < nrows;
+    rb[t] = L + static_cast<size_t>(okb[t] ? r : 0) * pitch;
+  }
+  f32x4 acc[CNT];
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int s = 0; s < PIX / 64; ++s) {
+    const int p = wave * (PIX / 4) + s * 16 + 4 * kq;                    // (inside the chunk)
+    const f32x4 q = *reinterpret_cast<const f32x4*>(Lq + p);
+    const f32x4 a0 = oka ? *reinterpret_cast<const f32x4*>(ra + p) : zero;
+    const f32x4 a = a0 * q;
+    f32x4 b[CNT];
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) b[t] = okb[t] ? *reinterpret_cast<const f32x4*>(rb[t] + p) : zero;
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    float* r = red + (static_cast<size_t>(wave) * CNT + t) * 256;
+    r[lane] = acc[t].x; r[64 + lane] = acc[t].y; r[128 + lane] = acc[t].z; r[192 + lane] = acc[t].w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < CNT; ++t) {
+    const float* r0 = red + static_cast<size_t>(t) * 256 + tid;
+    const float v = (r0[0] + r0[static_cast<size_t>(CNT) * 256]) + (r0[static_cast<size_t>(2 * CNT) * 256] + r0[static_cast<size_t>(3 * CNT) * 256]);
+    // two-stage sums (dense windows): the chunk's tile-pair sum goes to the workspace, ba_schur_reduce_kernel adds a frame's chunks and
+    // issues ONE fixed-point atomic per entry and frame - with one per chunk the 3.3 M memory-side atomics of a window's launch were
+    // half of its 93 us (tools/ba_kernel_timeline.py with PROBE_DEFS=-DPVO_BA_NO_ATOMICS)
+    if (part_out) part_out[static_cast<size_t>(pair0 + t) * 256 + tid] = v;
+    else scatter_tile(v, tid >> 6, tid & 63, ti, tj0 + t, rowout, sys, n6, meta);
+  }
+  __syncthreads();                        // `red` is rewritten by the next pass
+}
+
 template <bool VEC4, int PIX>
 __device__ __forceinline__ void ba_schur_body(
     const Plan& pl, const int64_t* __restrict__ jj, const float* __restrict__ eta, int K_eta,
@@ -683,7 +764,7 @@ __device__ __forceinline__ void ba_schur_body(
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
     int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows,
-    float* __restrict__ Mrg) {
+    float* __restrict__ Mrg, int depth_done, int lds_floats, float* __restrict__ spart, short* __restrict__ srow, int* __restrict__ sT) {
   __shared__ int rowcode[kMaxRows];       // see RowTab
   __shared__ short rowout[kMaxRows];
   __shared__ int nrows_s;
@@ -764,7 +845,13 @@ __device__ __forceinline__ void ba_schur_body(
       if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
     }
   };
-  if (zi == 0) depth_phase();
+  // (every slice that gets here may have to stay - more than kFastTiles row tiles unless targets merge or are fixed - and then needs
+  // the rows: it issues the depth phase in front of the table like slice 0 instead of behind it; a slice that leaves after all has
+  // written the same values to the same addresses as slice 0.)
+  // depth_done: ba_depth_kernel ran in front of this launch (windows on 512-pixel chunks, round 6): at a real frontend window every
+  // one of the four slices re-read the frame's 16-18 edges x 8 rows here - 164 MB per launch instead of 41, and 20 us at the head of
+  // every workgroup (tools/ba_kernel_timeline.py, NF=26 RAD=8 HT=30 WD=101)
+  if (!depth_done) depth_phase();
   if (in_lds && deg_all <= 64) {
     // row table by wave 0, one lane per out-edge: the position of an edge's six rows = the number of free target poses before it
     // (ballot + popcount) - the same order as the sequential walk below, which took 1.9 us of this kernel at S-B
@@ -838,7 +925,6 @@ __device__ __forceinline__ void ba_schur_body(
   if (zi > 0) {
     __syncthreads();
     if (((nrows_s + 15) >> 4) <= kFastTiles) return;               // (uniform: nrows_s is the workgroup's)
-    depth_phase();
   }
   BA_WG_PROBE(1, 3);                     // row table built, depth phase issued
   __syncthreads();
@@ -867,6 +953,12 @@ __device__ __forceinline__ void ba_schur_body(
     __syncthreads();                      // (uniform: any_merged_s is the workgroup's)
   }
   BA_WG_PROBE(1, 4);                     // depth rows (and merged rows) stored
+  const bool lds_path = lds_floats > 0 && T > kFastTiles && static_cast<long long>(nrows) * (PIX + kLdsRowPad) + PIX <= lds_floats;
+  const bool staged = lds_path && spart != nullptr && T * (T + 1) / 2 <= kSchurStagePairs;
+  if (sT != nullptr && blockIdx.x == 0 && zi == 0) {          // what ba_schur_reduce_kernel needs to know about this frame
+    if (tid == 0) sT[k] = staged ? T : 0;
+    if (staged && tid < 16 * T) srow[k * 128 + tid] = rowout[tid];
+  }
   if (nrows == 0) return;
 
   gfloat* __restrict__ qrow = (gfloat*)(Q + static_cast<long long>(k) * HW);
@@ -882,7 +974,71 @@ __device__ __forceinline__ void ba_schur_body(
   }
   // any degree: one ROW TILE against up to eight others per pass (row tiles re-read from L2 once per pass)
   constexpr int kPassTiles = 8;           // 8 x 4 x 256 floats of `red` = 32 KB
-  for (int ti = zi; ti < T; ti += Z) {
+  if (lds_path) {
+    // (round 6) the frame's rows of this chunk + Q, once into LDS (dynamic segment; the host asks for it only on 256-pixel chunks of
+    // a dense window and launches ONE slice then); a frame whose rows do not fit streams them as before, a few lines down
+    extern __shared__ __attribute__((aligned(16))) float dyn_rows[];
+    constexpr int pitch = PIX + kLdsRowPad;
+    float* Lq = dyn_rows + static_cast<size_t>(nrows) * pitch;
+    const int x0 = blockIdx.x * PIX;
+    // (eight rows' loads in flight per wave before the first store: one row at a time the staging was 26 serial round trips to HBM
+    // per wave - 50 of the workgroup's 60 us)
+    static_assert(PIX == 256 || PIX == 512 || PIX == 1024, "chunk");
+    for (int r0 = wave; r0 < nrows; r0 += 32) {
+      f32x4 v[8][PIX / 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 4 * u;
+        gfloat* src = rt.ptr(r < nrows ? r : r0);
+#pragma unroll
+        for (int c = 0; c < PIX / 256; ++c) v[u][c] = load4<VEC4>(src, x0 + c * 256 + lane * 4, HW);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 4 * u;
+        if (r < nrows) {
+#pragma unroll
+          for (int c = 0; c < PIX / 256; ++c)
+            *reinterpret_cast<f32x4*>(dyn_rows + static_cast<size_t>(r) * pitch + c * 256 + lane * 4) = v[u][c];
+        }
+      }
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int c = 0; c < PIX / 256; ++c) {
+        const int px = c * 256 + lane * 4;
+        *reinterpret_cast<f32x4*>(Lq + px) = load4<VEC4>(qrow, x0 + px, HW);
+      }
+    }
+    __syncthreads();
+    float* part_out = staged ? spart + (static_cast<size_t>(k) * gridDim.x + blockIdx.x) * kSchurStagePairs * 256 : nullptr;
+    for (int ti = 0; ti < T; ++ti) {
+      const int ph = ti % (2 * Z);
+      if ((ph < Z ? ph : 2 * Z - 1 - ph) != zi) continue;
+      for (int tj0 = ti; tj0 < T; tj0 += kPassTiles) {
+        const int cnt = (T - tj0 < kPassTiles) ? T - tj0 : kPassTiles;
+        const int pair0 = ti * T - ti * (ti - 1) / 2 + (tj0 - ti);      // index of pair (ti, tj0) among the T (T + 1) / 2
+        switch (cnt) {
+          case 1: schur_rowpass_lds<1, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+          case 2: schur_rowpass_lds<2, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+          case 3: schur_rowpass_lds<3, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+          case 4: schur_rowpass_lds<4, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+          case 5: schur_rowpass_lds<5, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+          case 6: schur_rowpass_lds<6, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+          case 7: schur_rowpass_lds<7, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+          default: schur_rowpass_lds<8, PIX>(dyn_rows, Lq, nrows, rowout, red, sys, n6, pl.meta, ti, tj0, part_out, pair0); break;
+        }
+      }
+    }
+    BA_WG_PROBE(1, 7);
+    return;
+  }
+  // row tile ti costs T - ti tile pairs: the slices take them in a SNAKE (0 1 2 3 3 2 1 0 0 1 ...), so that every slice gets the same
+  // number of pairs (T = 7, four slices: 7 | 6 + 1 | 5 + 2 | 4 + 3; dealt ti = z, z + 4, .. slice 0 had 10 and slice 3 had 4, and the
+  // launch ends with its slowest slice).  Every pair is still one workgroup's chain in the same order: bit-identical.
+  for (int ti = 0; ti < T; ++ti) {
+    const int ph = ti % (2 * Z);
+    if ((ph < Z ? ph : 2 * Z - 1 - ph) != zi) continue;
     for (int tj0 = ti; tj0 < T; tj0 += kPassTiles) {
       const int cnt = (T - tj0 < kPassTiles) ? T - tj0 : kPassTiles;
       switch (cnt) {
@@ -907,8 +1063,48 @@ __global__ __launch_bounds__(256) void ba_schur_mfma_kernel(
     float* __restrict__ Ei, const float* __restrict__ Eij,
     float* __restrict__ Q, float* __restrict__ w, long long* __restrict__ sys,
     int HW, int t0, int P, const float* __restrict__ part, const int64_t* __restrict__ ii, int E, int chunksA, int deal_rows,
-    float* __restrict__ Mrg) {
-  ba_schur_body<VEC4, PIX>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA, deal_rows, Mrg);
+    float* __restrict__ Mrg, int depth_done, int lds_floats, float* __restrict__ spart, short* __restrict__ srow, int* __restrict__ sT) {
+  ba_schur_body<VEC4, PIX>(pl, jj, eta, K_eta, Eii, Cii, bz, Ei, Eij, Q, w, sys, HW, t0, P, part, ii, E, chunksA, deal_rows, Mrg, depth_done, lds_floats,
+                           spart, srow, sT);
+}
+
+// second stage of the dense-window Schur sums: tile pair p of depth frame k = the sum over the frame's chunks (fixed order, fp64: the
+// addends are fp32) -> one fixed-point atomic per entry.  Integer sums across frames as before: bitwise reproducible, and an
+// edge-sharded run gets the whole graph's bits (a frame's edges, hence its chunks, live on one rank).
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(Plan pl, const float* __restrict__ spart, const short* __restrict__ srow,
+                                                              const int* __restrict__ sT, long long* __restrict__ sys, int gx, int n6) {
+  const int k = blockIdx.y, p = blockIdx.x, tid = threadIdx.x;
+  if (k >= pl.meta[0]) return;
+  const int T = sT[k];
+  if (T == 0 || p >= T * (T + 1) / 2) return;
+  __shared__ short rowout[128];
+  if (tid < 128) rowout[tid] = tid < 16 * T ? srow[k * 128 + tid] : static_cast<short>(-1);
+  __syncthreads();
+  int ti = 0, base = 0;
+  while (base + (T - ti) <= p) { base += T - ti; ++ti; }
+  const int tj = ti + (p - base);
+  double v = 0.0;
+  for (int x = 0; x < gx; ++x) v += static_cast<double>(spart[((static_cast<size_t>(k) * gx + x) * kSchurStagePairs + p) * 256 + tid]);
+  scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6, pl.meta);
+}
+
+// the depth phase of the Schur kernel as a launch of its own (one thread per pixel and depth frame): C, w, Q and the frame's own pose
+// rows Ei, in exactly the order depth_pixel states - the values are bit for bit what the fused form writes.  Used in front of the
+// 512- / 1024-pixel Schur grids (windows beyond ~15 poses), where the Schur kernel's z-slices would each repeat it.
+__global__ __launch_bounds__(256) void ba_depth_kernel(
+    Plan pl, const float* __restrict__ eta, int K_eta, const float* __restrict__ Eii, const float* __restrict__ Cii,
+    const float* __restrict__ bz, float* __restrict__ Ei, float* __restrict__ Q, float* __restrict__ w, int HW, int t0, int P) {
+  const int k = blockIdx.y;
+  if (k >= pl.meta[0]) return;
+  __shared__ int s_edge[256];
+  const int tid = threadIdx.x;
+  const int e0 = pl.eptr[k], deg_all = pl.eptr[k + 1] - e0;
+  const int pself = pl.kx[k] - t0;
+  const bool in_lds = deg_all <= 256;
+  if (in_lds && tid < deg_all) s_edge[tid] = pl.eidx[e0 + tid];
+  __syncthreads();
+  const int x = blockIdx.x * 256 + tid;
+  if (x < HW) depth_pixel(pl, k, x, eta, K_eta, Eii, Cii, bz, Ei, Q, w, HW, t0, P, in_lds ? s_edge : pl.eidx + e0, deg_all, pself);
 }
 
 // ---------------------------------------------------------------------------
@@ -2948,20 +3144,48 @@ extern "C" int pvo_ba_local(const float* poses, const float* disps, const float*
     // full-sequence run - 21-25 poses, frames with 18 neighbours - took 86.5 us with 256-pixel chunks and 73.4 with 512: half the
     // tile-pair atomics and half the workgroups that each redo row table and depth phase per z-slice; 2 / 8 slices and 1024-pixel
     // chunks were all slower, tools/_probe sweep of a dumped window)
-    const int pix = wg256 <= 192 ? 256 : (wg256 <= 1024 ? 512 : 1024);
+    // Round 6: a DENSE window (up to kDenseMaxPoses poses whose 256-pixel grid would not fit: the frontend's window with its
+    // inactive edges) stays on 256-pixel chunks and ONE slice, with the dynamic LDS segment for a frame's rows (schur_rowpass_lds);
+    // its depth phase is ba_depth_kernel's.  By P and the map size only, like the chunk rule: the same on every rank.
+    const bool dense_window = P <= kDenseMaxPoses && wg256 > 192;
+    const int pix = (wg256 <= 192 || dense_window) ? 256 : (wg256 <= 1024 ? 512 : 1024);
     const int gx = (HW + pix - 1) / pix;
     const int deal_rows = two_stage ? (E + kDealEdges * gx - 1) / (kDealEdges * gx) : 0;      // workgroups that add up the assembly's chunk sums: kDealEdges edges each
     // rows of the grid = depth frames: the caller's eta has one row per depth frame (K_eta == K, checked by the plan kernel and
     // reported in the status words), so that is the count; only a broadcast eta (one row) leaves the host with the bound P + E -
     // which at a real window's 48 + 400 edges meant 454 grid rows x 12 chunks x 4 slices for 27 depth frames
     const int Kgrid = (K_eta > 1 && K_eta <= Kmax) ? K_eta : Kmax;
-    const dim3 sgrid(gx, Kgrid + deal_rows, 4);      // (z: slices for the row-tile passes of many-neighbour frames, see ba_schur_body)
-#define PVO_SCHUR_LAUNCH(V, PX) hipLaunchKernelGGL((ba_schur_mfma_kernel<V, PX>), sgrid, dim3(256), 0, st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, \
-                                                   w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA, deal_rows, w.Mrg)
+    const dim3 sgrid(gx, Kgrid + deal_rows, dense_window ? 1 : 4);      // (z: slices for the row-tile passes of many-neighbour frames, see ba_schur_body)
+    const int depth_done = (pix != 256 || dense_window) ? 1 : 0;       // (by map size and pose window only: the same on every rank of a sharded run)
+    // dynamic LDS of the dense-window form: what the CU's 160 KB leave beside the kernel's static tables (49.7 KB)
+    constexpr int kSchurRowsLds = 110 * 1024;
+    const size_t sdyn = dense_window ? kSchurRowsLds : 0;
+    const int lds_floats = static_cast<int>(sdyn / sizeof(float));
+    if (dense_window) {
+      static bool schur_attr_set = false;
+      if (!schur_attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, kSchurRowsLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, kSchurRowsLds) != hipSuccess)
+          return PVO_ELAUNCH;
+        schur_attr_set = true;
+      }
+    }
+    if (depth_done) {
+      hipLaunchKernelGGL(ba_depth_kernel, dim3((HW + 255) / 256, Kgrid), dim3(256), 0, st, w.plan, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, w.Q, w.w, HW, t0, P);
+      PVO_CHECK_LAUNCH();
+    }
+    const bool stage2 = dense_window && Kgrid <= schur_stage_frames(P);       // (the workspace holds the chunk sums of that many frames)
+#define PVO_SCHUR_LAUNCH(V, PX) hipLaunchKernelGGL((ba_schur_mfma_kernel<V, PX>), sgrid, dim3(256), (PX == 256 ? sdyn : 0), st, w.plan, jj, eta, K_eta, w.Eii, w.Cii, w.bz, w.Ei, \
+                                                   w.Eij, w.Q, w.w, sys, HW, t0, P, two_stage ? w.part : nullptr, ii, E, chunksA, deal_rows, w.Mrg, depth_done, (PX == 256 ? lds_floats : 0), \
+                                                   (stage2 && PX == 256) ? w.spart : nullptr, w.srow, stage2 ? w.sT : nullptr)
     if ((HW & 3) == 0) { if (pix == 256) PVO_SCHUR_LAUNCH(true, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(true, 512); else PVO_SCHUR_LAUNCH(true, 1024); }
     else { if (pix == 256) PVO_SCHUR_LAUNCH(false, 256); else if (pix == 512) PVO_SCHUR_LAUNCH(false, 512); else PVO_SCHUR_LAUNCH(false, 1024); }
 #undef PVO_SCHUR_LAUNCH
     PVO_CHECK_LAUNCH();
+    if (stage2) {
+      hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3(kSchurStagePairs, Kgrid), dim3(256), 0, st, w.plan, w.spart, w.srow, w.sT, sys, gx, 6 * P);
+      PVO_CHECK_LAUNCH();
+    }
   }
   return PVO_OK;
 }

@@ -13,7 +13,7 @@ if "--build" in sys.argv:
     build.build_hip()
     os.makedirs(PROBE_DIR, exist_ok=True)
     obj = os.path.join(PROBE_DIR, "bawg.o")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_BA_PROBE=3", "-c", os.path.join(build.CSRC, "ba.hip"), "-o", obj], stderr=subprocess.DEVNULL)
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-DPVO_BA_PROBE=3"] + os.environ.get("PROBE_DEFS", "").split() + ["-c", os.path.join(build.CSRC, "ba.hip"), "-o", obj], stderr=subprocess.DEVNULL)
     objs = [obj if s == "ba.hip" else os.path.join(build.CSRC, s.replace(".hip", ".o")) for s in build.HIP_SOURCES]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_LIB] + objs)
     print(PROBE_LIB); sys.exit(0)
