@@ -513,7 +513,7 @@ def lookup_traffic():
     of the kernel (it records the sha256 of corr_lookup.hip); otherwise None: a counter value is not carried over a code change"""
     import hashlib
     sha = hashlib.sha256(open(os.path.join(ROOT, "pvo_amd", "csrc", "corr_lookup.hip"), "rb").read()).hexdigest()
-    for name in ("r05_lookup_pmc.json", "r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json"):
+    for name in ("r06_lookup_pmc.json", "r05_lookup_pmc.json", "r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -522,6 +522,53 @@ def lookup_traffic():
             return j.get("fused_encoder", j).get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "kernel_source_sha256": j.get("kernel_source_sha256"),
                                                                             "matches_this_source": j.get("kernel_source_sha256") == sha}
     return None, None
+
+
+def measure_lookup_traffic(timeout_s=150):
+    """HBM bytes per launch of the fused lookup MEASURED IN THIS RUN: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; kernel trace
+    only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over tools/pmc_lookup.py in child processes - the S-B lookup with the
+    Infinity Cache evicted between launches, and a 512 MiB copy whose known traffic calibrates both counters (on gfx950 FETCH_SIZE
+    reports half the bytes of 16-byte-per-lane reads).  Returns (bytes per launch, details) or (None, why)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    med = lambda v: sorted(v)[len(v) // 2]
+    raw = {}
+    tmp = tempfile.mkdtemp(prefix="pvo_pmc_", dir="/tmp")
+    try:
+        for C in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, C)
+            r = subprocess.run([exe, "--pmc", C, "--kernel-trace", "-f", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_lookup.py")],
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, {"error": "rocprofv3 --pmc %s failed (rc %d)" % (C, r.returncode), "tail": r.stdout[-300:]}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != C:
+                    continue
+                k = row["Kernel_Name"]
+                name = "lookup_enc" if "corr_lookup_r3_enc_kernel" in k else ("copy" if ("copy" in k.lower() or "CatArrayBatchedCopy" in k) else None)
+                if name == "copy" and float(row["Counter_Value"]) < 1e5:
+                    name = None
+                if name:
+                    raw.setdefault(name, {}).setdefault(C, []).append(float(row["Counter_Value"]))
+    except Exception as e:                                          # noqa: BLE001 (timeout, missing tool, unreadable output)
+        return None, {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    try:
+        cf, cw = med(raw["copy"]["FETCH_SIZE"]), med(raw["copy"]["WRITE_SIZE"])
+        f, w = med(raw["lookup_enc"]["FETCH_SIZE"]), med(raw["lookup_enc"]["WRITE_SIZE"])
+    except KeyError as e:
+        return None, {"error": "counter rows missing: %r" % (e,), "kernels_seen": sorted(raw)}
+    fcorr, wcorr = 512 * 1024 / cf, 512 * 1024 / cw                 # counters in KB; the calibration copy moved 512 MiB each way
+    rd, wr = f * 1024 * fcorr, w * 1024 * wcorr
+    return rd + wr, {"measured_in_this_run": True, "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over tools/pmc_lookup.py; "
+                     "median of %d launches, Infinity Cache evicted before each; corrected by the 512 MiB calibration copy of the same passes" % len(raw["lookup_enc"]["FETCH_SIZE"]),
+                     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "fetch_correction": fcorr, "write_correction": wcorr,
+                     "read_requests_64B_per_launch": rd / 64.0, "write_requests_64B_per_launch": wr / 64.0,
+                     "FETCH_SIZE_raw_KB": f, "WRITE_SIZE_raw_KB": w}
 
 
 def edge_sharded_leg(device, rank, world, steps=3):
@@ -953,6 +1000,8 @@ def main():
     ap.add_argument("--steps", type=int, default=120, help="timed keyframe updates (default 120: a timed region of ~0.5 s; the driver passes its own)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, ~1 min); "
+                    "the committed profile of the same kernel source is reported instead")
     ap.add_argument("--no-extras", action="store_true", help="skip the S-A workload and the edge-sharded leg")
     ap.add_argument("--sequence-only", action="store_true", help="run only the full-sequence leg (Droid.track / terminate on the synthetic "
                     "240x808 stream) and print its object: the command tools/sequence_timeline.sh profiles")
@@ -1134,7 +1183,15 @@ def main():
 
     if rank == 0:
         E, HW = len(graph._ii_h), H8 * W8
-        traffic, traffic_src = lookup_traffic()
+        traffic, traffic_src = (None, None)
+        if world == 1 and not args.no_pmc:
+            torch.cuda.empty_cache()
+            traffic, traffic_src = measure_lookup_traffic()
+        if traffic is None:                                         # (no profiler here: the committed, sha-guarded profile of the same source)
+            why = traffic_src
+            traffic, traffic_src = lookup_traffic()
+            if traffic_src is not None and why is not None:
+                traffic_src = dict(traffic_src, in_run_measurement=why)
         try:
             scat = scattered_ceiling(device, traffic, E * HW * 128 * 2, 1e3 * sum(in_step_lookup) / max(len(in_step_lookup), 1))
         except Exception as e:
