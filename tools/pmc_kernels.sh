@@ -19,7 +19,7 @@ for f in sorted(glob.glob("$OUT/set*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         for key in ("conv3x3_big_kernel<pvo_half, false>", "conv3x3_big_kernel<pvo_half, true>", "corr_lookup_r3_enc_kernel",
-                    "ba_assemble_kernel", "ba_schur_mfma_kernel<true, 256>", "ba_schur_mfma_kernel<false, 512>", "ba_solve_dense_kernel<4>",
+                    "ba_assemble_kernel", "ba_schur_mfma_kernel<true, 256>", "ba_schur_mfma_kernel<false, 256>", "ba_depth_kernel", "ba_schur_reduce_kernel", "ba_solve_dense_kernel<4>",
                     "ba_solve_dense_kernel<14>", "ba_solve_kernel", "ba_backsub_kernel"):
             if key in k.replace("(anonymous namespace)::", ""):
                 res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
