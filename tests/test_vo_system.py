@@ -7,6 +7,8 @@ trajectory filler, Droid.  Two kinds of test:
     learned weights cannot be measured here)."""
 from argparse import Namespace
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -482,3 +484,76 @@ def test_graphed_call_is_a_plain_call_off_the_gpu():
         for _ in range(4):
             assert torch.equal(g(a, b), a + b)
     assert len(calls) == 4 and g.replays == 0 and not g.cache
+
+
+def test_host_knobs_are_set_by_code_not_by_the_environment(monkeypatch):
+    """pvo_amd.config: the host layer's test / A-B knobs (two ranks with different environments must not run different
+    schedules).  An environment variable of the old name changes nothing; an unknown knob raises; "se3_torch" reaches geom.se3."""
+    import importlib
+    from pvo_amd import config
+    from pvo_amd.geom import se3
+    monkeypatch.setenv("PVO_HIP_GRAPHS", "0"); monkeypatch.setenv("PVO_SE3_TORCH", "1"); monkeypatch.setenv("PVO_CONV128_WIDE", "0")
+    importlib.reload(config)
+    assert config.get("hip_graphs") is True and config.get("conv128_wide") is True and se3.FORCE_TORCH is False
+    with pytest.raises(KeyError):
+        config.debug_config("no_such_knob", 1)
+    config.debug_config("se3_torch", True)
+    try:
+        assert se3.FORCE_TORCH is True
+    finally:
+        config.debug_config("se3_torch", False)
+    assert se3.FORCE_TORCH is False
+    for mod in ("pvo_amd/graphs.py", "pvo_amd/modules/update.py", "pvo_amd/geom/se3.py", "pvo_amd/config.py"):
+        assert "os.environ" not in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), mod)).read(), mod
+
+
+def test_kept_feature_maps_are_only_reused_for_the_frame_they_came_from():
+    """DepthVideo.remember_features / recall_features: the trajectory filler reuses a tracked frame's feature map only if the
+    image it is handed under that time stamp is the image the map was computed from; an entry is released when it is asked for"""
+    from pvo_amd.depth_video import DepthVideo
+    v = DepthVideo((64, 96), buffer=4, device="cpu")
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (3, 64, 96), generator=g, dtype=torch.int32)
+    other = img.clone(); other[:, 20:40, 30:60] += 7
+    fmap = torch.randn(1, 128, 8, 12, generator=g).half()
+    v.remember_features(3.0, fmap, img)
+    assert v.recall_features(3.0, other) is None and not v.frame_fmaps            # another image under the same time stamp: re-encode
+    v.remember_features(3.0, fmap, img)
+    got = v.recall_features(3.0, img)
+    assert got is not None and torch.equal(got, fmap) and v.recall_features(3.0, img) is None and v._frame_fmaps_bytes == 0
+    v.remember_features(4.0, fmap, img); v.remember_features(5.0, fmap)
+    assert v.recall_features(5.0, img) is None                                     # kept without a fingerprint: never trusted
+    v.forget_features()
+    assert not v.frame_fmaps and v._frame_fmaps_bytes == 0
+
+
+def test_frontend_keyframe_decision_hook_overrides_the_distance_test():
+    """DroidFrontend.keyframe_decision (measurement / test hook): the removal branch of droid_frontend.py:54-58 driven by a schedule"""
+    from pvo_amd.frontend import DroidFrontend
+
+    class G:
+        corr = None
+        _ii_h = [0]
+        calls = []
+        def add_proximity_factors(self, *a, **k): pass
+        def update(self, *a, **k): self.calls.append("update")
+        def rm_keyframe(self, ix): self.calls.append(("rm", ix))
+
+    class V:
+        counter = 10
+        poses = torch.zeros(16, 7); disps = torch.ones(16, 2, 2); dirty = torch.zeros(16, dtype=torch.bool)
+        def distance(self, ii, jj, **k): return torch.tensor([5.0])
+    fe = DroidFrontend.__new__(DroidFrontend)
+    fe.video, fe.graph = V(), G()
+    fe.t0, fe.t1, fe.count, fe.is_initialized = 0, 8, 0, True
+    fe.max_age, fe.iters1, fe.iters2, fe.beta, fe.frontend_nms = 25, 4, 2, 0.3, 1
+    fe.keyframe_thresh, fe.frontend_window, fe.frontend_thresh, fe.frontend_radius = 1.0, 25, 16.0, 2
+    fe.keyframes_removed = 0
+    seen = []
+    fe.keyframe_decision = lambda k, d: (seen.append((k, d)), True)[1]
+    fe._update()
+    assert seen == [(1, 5.0)] and ("rm", 7) in fe.graph.calls and fe.video.counter == 9 and fe.t1 == 8 and fe.keyframes_removed == 1
+    fe.keyframe_decision = None                                                    # the reference's test: 5.0 >= 1.0 -> kept, two more updates
+    n = len(fe.graph.calls)
+    fe._update()
+    assert fe.graph.calls[n:].count("update") == 6 and fe.video.counter == 9 and fe.t1 == 9 and fe.keyframes_removed == 1
