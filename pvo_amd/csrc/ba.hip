@@ -1011,8 +1011,10 @@ __device__ __forceinline__ void ba_schur_body(
       }
     }
     __syncthreads();
+    BA_WG_PROBE(1, 5);                   // (LDS form: rows staged)
     float* part_out = staged ? spart + (static_cast<size_t>(k) * gridDim.x + blockIdx.x) * kSchurStagePairs * 256 : nullptr;
     for (int ti = 0; ti < T; ++ti) {
+      if (ti == 1) BA_WG_PROBE(1, 6);    // (LDS form: first row pass - the longest: T tile pairs - done)
       const int ph = ti % (2 * Z);
       if ((ph < Z ? ph : 2 * Z - 1 - ph) != zi) continue;
       for (int tj0 = ti; tj0 < T; tj0 += kPassTiles) {

@@ -67,5 +67,6 @@ def show(name, k, labels, last):
 show("ba_assemble_kernel", 0, [(0, 1, "entry -> pixel terms computed, rows stored"), (1, 2, "the waves' 90 sums (reduce-scatter) + barrier"), (2, 3, "chunk sums stored / atomics issued"), (0, 3, "whole workgroup")], 3)
 show("ba_schur_mfma_kernel", 1, [(0, 1, "entry -> meta read (the chunk sums are other workgroups' now)"), (1, 2, "edge list -> LDS"), (2, 3, "depth phase issued, row table built (wave 0; slices > 0: table, barrier, depth phase)"),
                                  (3, 4, "barrier: rows and table visible (+ merged rows)"), (4, 5, "fast path: row loads + MFMA, PIX / 64 steps (wave 0)"), (5, 6, "fast path: products -> LDS + barrier"),
-                                 (6, 7, "fast path: 4-wave sums + fixed-point atomics"), (4, 7, "all tile pairs (fast path or this slice's row passes)"), (0, 7, "whole workgroup (slice 0)")], 7)
+                                 (6, 7, "fast path: 4-wave sums + fixed-point atomics"), (4, 7, "all tile pairs (fast path or this slice's row passes)"),
+                                 (4, 5, "LDS form (dense window; same slots as the fast path's, other workgroups): rows staged"), (5, 6, "LDS form: first row pass (T pairs)"), (6, 7, "LDS form: remaining row passes"), (0, 7, "whole workgroup (slice 0)")], 7)
 show("ba_backsub_kernel", 2, [(0, 1, "rows / dx -> LDS + barrier"), (1, 2, "rows x dx, depth update"), (0, 2, "whole workgroup")], 2)
