@@ -1086,7 +1086,15 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(Plan pl, const flo
   while (base + (T - ti) <= p) { base += T - ti; ++ti; }
   const int tj = ti + (p - base);
   double v = 0.0;
-  for (int x = 0; x < gx; ++x) v += static_cast<double>(spart[((static_cast<size_t>(k) * gx + x) * kSchurStagePairs + p) * 256 + tid]);
+  const float* sp = spart + (static_cast<size_t>(k) * gx * kSchurStagePairs + p) * 256 + tid;
+  const size_t step = static_cast<size_t>(kSchurStagePairs) * 256;
+  for (int x0 = 0; x0 < gx; x0 += 8) {                     // (eight chunks' loads in flight; the additions keep the chunk order)
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = sp[static_cast<size_t>(x0 + u < gx ? x0 + u : x0) * step];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (x0 + u < gx) v += static_cast<double>(a[u]);
+  }
   scatter_tile(v, tid >> 6, tid & 63, ti, tj, rowout, sys, n6, pl.meta);
 }
 
