@@ -199,16 +199,19 @@ def _two_virtual_ranks(s, cuda, iters=2, lm=1e-4, ep=0.1):
     return shards[0]["poses"], shards[1]["poses"], merged
 
 
-@pytest.mark.parametrize("kind", ["radius8", "repeats"])
+@pytest.mark.parametrize("kind", ["radius8", "repeats", "radius13"])
 def test_ba_of_a_real_frontend_window_matches_oracle_at_full_size(cuda, kind):
     """The BA the full sequence really runs: 26 poses at 30 x 101 - 512-pixel chunks (3030 = 5 x 512 + 470, not a
     multiple of four after chunking), four z-slices, the row-pass path, merged repeated targets, the packed row table, the
     partitioned / window pose solve - against the oracle at 1e-4, twice for bitwise repeatability, and once through two virtual
     ranks.  "radius8": 344 edges, 16 distinct neighbours per frame; "repeats": 440 edges, every inactive pair four times in
-    interleaved order + 48 active edges (the shape `sequence.ba_windows_sampled` reports)."""
+    interleaved order + 48 active edges (the shape `sequence.ba_windows_sampled` reports); "radius13": 494 edges, the frames in the
+    middle of the window with 25 neighbours - 157 rows, more than the dense-window Schur form can stage in LDS: those frames stream
+    their rows and issue their atomics directly while the frames at the ends (13 neighbours) take the staged, two-stage form, in
+    one launch."""
     P, ht, wd = 26, 30, 101
-    s = _scene(8801, P, ht, wd, 8, 1) if kind == "radius8" else _frontend_window(P, ht, wd)
-    assert s["ii"].shape[0] == (344 if kind == "radius8" else 440)
+    s = _frontend_window(P, ht, wd) if kind == "repeats" else _scene(8801, P, ht, wd, 8 if kind == "radius8" else 13, 1)
+    assert s["ii"].shape[0] == {"radius8": 344, "repeats": 440, "radius13": 494}[kind]
     want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
                 s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
     poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
