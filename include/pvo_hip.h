@@ -82,7 +82,7 @@ size_t pvo_graph_update_args_size(void);
  * process-wide, not thread-safe against running calls.  A product caller never needs it: every knob defaults to 0 = "the shipped
  * choice".  Returns PVO_EINVAL for an unknown knob.  (Reference counterpart: none - droid.cpp has no such switches.) */
 enum {
-  PVO_KNOB_BA_SOLVER = 0,         /* 0 shipped choice by size | 1 blocked | 2 one wave | 3 pipelined | 4 partitioned (two workgroups) | 5 dense on the fp64 matrix cores (<= 29 poses) */
+  PVO_KNOB_BA_SOLVER = 0,         /* 0 shipped choice by size | 1 blocked | 2 one wave | 3 pipelined | 4 partitioned (two workgroups) | 5 dense on the fp64 matrix cores (<= 29 poses) | 6 dense in 48 x 48 blocks over many workgroups (beyond the LDS path) */
   PVO_KNOB_HEADS_GATHER_FLAT = 1, /* 1: pvo_heads_gather without its LDS-tiled form */
   PVO_KNOB_NO_RIDERS = 2,         /* 1: pvo_graph_update computes the upsampling mask and the next gate context as launches of their own */
   PVO_KNOB_POST_SEPARATE = 3,     /* 1: pvo_graph_update runs pvo_graph_post as a launch of its own instead of as the epilogue of the heads' gather */

@@ -100,6 +100,8 @@ struct Ws {
   long long* sys;        // [(6P)^2 + 6P] fixed point
   double* chol;          // [(6P)^2 + 6P] scratch for the global-memory factorisation
   double* xchg;          // partitioned pose solve: [2 doubles = 4 ints: flags, split | separator terms | separator solution] (kXchgDoubles)
+  double* ldiag;         // blocked multi-workgroup solve (big dense-ish systems): factored diagonal blocks [n / 48 + 1][48 x 48 + 48]
+  double* xvec;          // ... and its solution [6P]
   float* Mrg;            // [E][6][HW]: the summed Eij rows of edges that share source AND target frame (Schur kernel), at the first one's index
   // dense windows (P <= kDenseMaxPoses), two-stage Schur sums: per (depth frame, 256-pixel chunk) the tile-pair sums of the chunk,
   // the frame's row -> system-entry table and its tile count (0 = this frame went the atomic way)
@@ -139,6 +141,8 @@ __host__ Ws carve(void* base, int E, int P, int F, int HW) {
   // (both at every size: a packed envelope message - pvo_ba_finish_packed - is factorised from the compact image whatever P is)
   w.chol = reinterpret_cast<double*>(take(sizeof(double) * (n6 * n6 + n6 + 27 * (n6 / 6) + 32)));
   w.xchg = reinterpret_cast<double*>(take(sizeof(double) * kXchgDoubles));
+  w.ldiag = reinterpret_cast<double*>(take(sizeof(double) * (n6 / 48 + 2) * (48 * 48 + 48)));
+  w.xvec = reinterpret_cast<double*>(take(sizeof(double) * (n6 + 8)));
   w.Mrg = reinterpret_cast<float*>(take(sizeof(float) * static_cast<size_t>(E) * 6 * HW));
   {
     const size_t ks = static_cast<size_t>(schur_stage_frames(P));
@@ -2990,6 +2994,241 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---- BLOCKED pose solve over MANY workgroups (round 6): big systems that are not narrow-banded - the backend's global graph ---------
+// A global bundle adjustment over ~85 keyframes connected by proximity (10-15 edges per frame) has an envelope of several hundred KB:
+// it fits no compute unit's LDS, the partition finds no separator, and the one-workgroup factorisation then ran out of global memory
+// - 1.8 ms per Gauss-Newton step, 38 of them in Droid.terminate (bench.py `sequence`, profiles/r06_sequence_timeline.txt).  At that
+// point sparsity is not worth a CU's patience: the DENSE right-looking factorisation in 48 x 48 blocks, three launches per block column,
+//   dense_panel_kernel   every workgroup factors the 48 x 48 diagonal block redundantly (one wave, rows in registers) and solves its own
+//                        row block of the panel against it (one thread per row; the right-hand side rides as row n, so this is the
+//                        forward substitution too); the diagonal block's workgroup stores the factor + reciprocal pivots apart
+//   dense_update_kernel  A_ij -= L_ik L_jk^T, one workgroup per block pair of the trailing lower triangle (3 x 3 outputs per thread)
+//   dense_back_kernel    back-substitution, block column by block column from the end: x_k from the stored diagonal factor (redundantly
+//                        per workgroup), y_j -= L_kj^T x_k by the workgroup of column block j
+// and dense_finish_kernel (dx, retraction, status; the riders ride here).  ~3 n / 48 + 3 launches, no host synchronisation; 85 poses:
+// ~35 launches.  Same damping, failure -> zero update, fixed order of operations (bitwise reproducible); agrees with the other forms
+// to fp64 rounding.  Chosen on the host by size and edge density (ba_finish_impl); never for a packed message.
+constexpr int kNB = 48;
+__global__ __launch_bounds__(256) void dense_panel_kernel(double* __restrict__ A, double* __restrict__ Ldiag, int n, int kb, int* __restrict__ meta) {
+  // (everything in LDS, runtime loops: the first version kept a row per lane in 48 registers with every loop unrolled - 512 registers
+  // and 8 KB of scratch per thread, 131 us per launch)
+  __shared__ double Lk[kNB][kNB + 1];       // the diagonal block: lower triangle, factored in place (the diagonal itself stays, sqrt in ldg)
+  __shared__ double Xs[kNB][kNB + 1];       // this workgroup's rows of the panel
+  __shared__ double rinv[kNB], ldg[kNB];
+  const int tid = threadIdx.x;
+  const int c0 = kNB * kb, nc = (n - c0 < kNB) ? n - c0 : kNB;         // valid columns of this block column
+  const int rb = kb + blockIdx.x, r0 = kNB * rb;                        // this workgroup's row block
+  for (int t = tid; t < kNB * kNB; t += 256) {
+    const int r = t / kNB, c = t - r * kNB;
+    Lk[r][c] = (r < nc && c <= r) ? A[static_cast<size_t>(c0 + r) * n + c0 + c] : 0.0;
+    const int rr = r0 + r;
+    Xs[r][c] = (rr <= n && c < nc) ? A[static_cast<size_t>(rr) * n + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  // ---- factorisation of the diagonal block AND substitution of this workgroup's panel rows together, EIGHT columns per step (two
+  // barriers per step; one column per step with a thread per entry was 48 x 2 barriers + a 48-step substitution: 53 us per launch):
+  //   (a) one thread per row - rows of the diagonal block from the step's first column on, and the 48 panel rows -: the 8 x 8 Cholesky of
+  //       the step's diagonal sub-block redundantly in registers, then the row's eight entries by forward substitution against it;
+  //   (b) every entry right of the step's columns: E[r][c] -= sum_k row_r[k] L_c[k], a thread per (row, column stripe).
+  // (The diagonal block's workgroup and every panel workgroup do the same arithmetic on the diagonal block: redundant, and identical.)
+  bool ok = true;
+  for (int j0 = 0; j0 < nc; j0 += 8) {
+    const int nv = (nc - j0 < 8) ? nc - j0 : 8;
+    double L[36], av[8];
+    if (tid < 2 * kNB) {
+      const bool isx = tid >= kNB;
+      const int t = isx ? tid - kNB : tid;
+      if (isx || (t >= j0 && t < nc)) {
+        double (*Row)[kNB + 1] = isx ? Xs : Lk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) L[i * (i + 1) / 2 + j] = Lk[j0 + i][j0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = Row[t][j0 + j];
+      }
+    }
+    __syncthreads();                       // (the sub-block's own rows are rewritten below by their threads: everybody has read them)
+    if (tid < 2 * kNB) {
+      const bool isx = tid >= kNB;
+      const int t = isx ? tid - kNB : tid;
+      if (isx || (t >= j0 && t < nc)) {
+        double (*Row)[kNB + 1] = isx ? Xs : Lk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          double d = L[j * (j + 1) / 2 + j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) d -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+          const bool real = j < nv;
+          ok = ok && (!real || d > 0.0);
+          const double rs = (real && ok) ? rsqrt_nr(d) : 0.0;
+          if (!isx && t == j0 + j) { rinv[j0 + j] = rs; ldg[j0 + j] = d * rs; }
+          L[j * (j + 1) / 2 + j] = rs;
+#pragma unroll
+          for (int i = j + 1; i < 8; ++i) {
+            double v = L[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+            L[i * (i + 1) / 2 + j] = v * rs;
+          }
+          double v = av[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) v -= av[k] * L[j * (j + 1) / 2 + k];
+          av[j] = v * rs;
+        }
+        // (a row of the diagonal sub-block itself: entry j == its own column is d * rs = the pivot's square root through the same formula;
+        // entries right of its diagonal are not part of L - they are never read again)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < nv && (isx || j0 + j <= t)) Row[t][j0 + j] = av[j];
+      }
+    }
+    __syncthreads();
+    const int c1 = j0 + 8;
+    if (c1 < nc) {
+      // rows: the diagonal block's rows r >= c1 (columns c1 .. r), then the 48 panel rows (columns c1 .. nc - 1); 16 column stripes
+      const int ty = tid >> 4, tx = tid & 15;
+      for (int r = c1 + ty; r < nc + kNB; r += 16) {
+        const bool isx = r >= nc;
+        double (*Row)[kNB + 1] = isx ? Xs : Lk;
+        const int rr = isx ? r - nc : r;
+        double a8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] = Row[rr][j0 + k];
+        const int cend = isx ? nc - 1 : rr;
+        for (int c = c1 + tx; c <= cend; c += 16) {
+          double v = Row[rr][c];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v -= a8[k] * Lk[c][j0 + k];
+          Row[rr][c] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == kNB && !ok) meta[4] = 1;      // non-SPD (the first panel-row thread factors every sub-block): the finish kernel writes the zero update
+  if (tid >= nc && tid < kNB) { rinv[tid] = 0.0; ldg[tid] = 0.0; }
+  __syncthreads();
+  for (int t = tid; t < kNB * kNB; t += 256) {
+    const int r = t / kNB, c = t - r * kNB;
+    const int rr = r0 + r;
+    if (rr <= n && c < nc && (rb > kb || r >= nc)) A[static_cast<size_t>(rr) * n + c0 + c] = Xs[r][c];
+  }
+  if (blockIdx.x == 0) {                                                 // the diagonal block's workgroup keeps the factor for the back-substitution
+    double* Ld = Ldiag + static_cast<size_t>(kb) * (kNB * kNB + kNB);
+    for (int t = tid; t < kNB * kNB; t += 256) {
+      const int r = t / kNB, c = t - r * kNB;
+      Ld[t] = (r < nc && c < r) ? Lk[r][c] : ((r == c && r < nc) ? ldg[r] : 0.0);
+    }
+    if (tid < kNB) Ld[kNB * kNB + tid] = rinv[tid];
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_update_kernel(double* __restrict__ A, int n, int kb, int nrb) {
+  __shared__ double Li[kNB][kNB + 1], Lj[kNB][kNB + 1];
+  // block pair p -> (i, j), kb < j <= i < nrb
+  const int m = nrb - kb - 1;
+  int p = blockIdx.x, jj = 0;
+  while (p >= m - jj) { p -= m - jj; ++jj; }
+  const int bj = kb + 1 + jj, bi = bj + p;
+  const int tid = threadIdx.x;
+  const int c0 = kNB * kb, nc = (n - c0 < kNB) ? n - c0 : kNB;
+  for (int t = tid; t < kNB * kNB; t += 256) {
+    const int r = t / kNB, c = t - r * kNB;
+    const int ri = kNB * bi + r, rj = kNB * bj + r;
+    Li[r][c] = (ri <= n && c < nc) ? A[static_cast<size_t>(ri) * n + c0 + c] : 0.0;
+    Lj[r][c] = (rj < n && c < nc) ? A[static_cast<size_t>(rj) * n + c0 + c] : 0.0;        // (columns of the target block: rows rj < n)
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;                  // 3 x 3 outputs: rows 3 ty .., columns 3 tx ..
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 4
+  for (int k = 0; k < kNB; ++k) {
+    double a[3], b[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { a[u] = Li[3 * ty + u][k]; b[u] = Lj[3 * tx + u][k]; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) acc[u][v] += a[u] * b[v];
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int rr = kNB * bi + 3 * ty + u;
+    if (rr > n) continue;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int cc = kNB * bj + 3 * tx + v;
+      if (cc < n && (bi > bj || cc <= rr)) A[static_cast<size_t>(rr) * n + cc] -= acc[u][v];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_back_kernel(const double* __restrict__ A, const double* __restrict__ Ldiag, double* __restrict__ yrow,
+                                                         double* __restrict__ xvec, int n, int kb) {
+  __shared__ double Lk[kNB][kNB + 1];
+  __shared__ double s[kNB], xk[kNB], rinv[kNB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int c0 = kNB * kb, nc = (n - c0 < kNB) ? n - c0 : kNB;
+  const double* Ld = Ldiag + static_cast<size_t>(kb) * (kNB * kNB + kNB);
+  for (int t = tid; t < kNB * kNB; t += 256) Lk[t / kNB][t % kNB] = Ld[t];
+  if (tid < kNB) { rinv[tid] = Ld[kNB * kNB + tid]; s[tid] = tid < nc ? yrow[c0 + tid] : 0.0; }
+  __syncthreads();
+  if (tid < 64) {                                        // L_kk^T x_k = s, by one wave: x_j, then s_t -= L[j][t] x_j for t < j
+    for (int j = nc - 1; j >= 0; --j) {
+      if (lane == j) xk[j] = s[j] * rinv[j];
+      const double xj = xk[j];                           // (the wave's own LDS write just above)
+      if (lane < j) s[lane] -= Lk[j][lane] * xj;
+    }
+  }
+  __syncthreads();
+  const int bj = blockIdx.x;                             // column block j < kb: y_j -= L[rows of block kb][columns of block j]^T x_k;  bj == kb: keep x_k
+  if (bj == kb) {
+    if (tid < nc) xvec[c0 + tid] = xk[tid];
+    return;
+  }
+  if (tid < kNB) {
+    const int col = kNB * bj + tid;
+    double v = yrow[col];
+    for (int r = 0; r < nc; ++r) v -= A[static_cast<size_t>(c0 + r) * n + col] * xk[r];
+    yrow[col] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_finish_kernel(const double* __restrict__ xvec, float* __restrict__ poses, float* __restrict__ dx_ws,
+                                                           float* __restrict__ dx_out, int* __restrict__ meta, int* __restrict__ status_out,
+                                                           int P, int t0, Riders riders) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (blockIdx.x > 0) {                                                  // rider workgroups (launched only with riders)
+    ride(smem, riders, blockIdx.x - 1);
+    return;
+  }
+  const int n = 6 * P, tid = threadIdx.x;
+  const int failed = meta[4] | meta[2];
+  for (int idx = tid; idx < n; idx += 256) {
+    const double xv = xvec[idx];
+    const float v = (failed || !(xv == xv)) ? 0.0f : static_cast<float>(xv);    // zeros on failure (:1186-1189)
+    dx_ws[idx] = v;
+    if (dx_out) dx_out[idx] = v;
+  }
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {               // pose_retr_kernel (:877-910)
+    float xi[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xi[c] = dx_ws[6 * p + c];
+    float* ps = poses + 7 * static_cast<long long>(t0 + p);
+    const Pose Tn = retract(xi, load_pose(ps));
+    ps[0] = Tn.t.x; ps[1] = Tn.t.y; ps[2] = Tn.t.z;
+    ps[3] = Tn.q.x; ps[4] = Tn.q.y; ps[5] = Tn.q.z; ps[6] = Tn.q.w;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    meta[4] = 0;
+    if (failed) meta[1] = 1;
+    if (status_out) { status_out[0] = meta[1]; status_out[1] = meta[0]; status_out[2] = meta[2]; status_out[3] = meta[3]; }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // backsub: dz = Q (w - sum_r E_r^T dx[pose(r)]), disps += dz
 // ---------------------------------------------------------------------------
@@ -3377,6 +3616,45 @@ static int ba_finish_impl(float* poses, float* disps, void* sys_, const long lon
   // the three bit for bit).
   // Beyond the dense LDS path a fourth form, the PARTITIONED solve (ba_solve_twin_kernel: two workgroups eliminate the pose
   // chain from both ends, tools/ba_solve_timeline.py), is the default; its result equals the others' to fp64 rounding.
+  // Round 6: a big system that is not narrow-banded - more than 8 edges per pose, i.e. a global graph connected by proximity rather than
+  // a keyframe chain - is factorised DENSE in 48 x 48 blocks over many workgroups (dense_panel / dense_update / dense_back kernels).
+  // By P and this call's E: used for the dense image only (an edge-sharded step arrives as a packed message and keeps the forms every
+  // rank chooses alike).  pvo_debug_config(PVO_KNOB_BA_SOLVER, 6) forces it at any size beyond the LDS path.
+  if (!msg && !use_lds && P > 0 && ((solver_env < 0 && static_cast<long long>(E) > 8LL * P) || solver_env == 5)) {
+    // (no envelope pass: ba_prepare_kernel with no LDS budget writes the dense row-major image whatever `env` holds - INT_MAX between solves)
+    hipLaunchKernelGGL(ba_prepare_kernel, dim3((n6 * n6 + n6 + 2047) / 2048), dim3(256), 0, st, sys, w.chol, w.plan.env, n6, lm, ep,
+                       0LL /* no LDS budget: the dense row-major image */, static_cast<int*>(nullptr));
+    PVO_CHECK_LAUNCH();
+    if (hipMemsetAsync(w.xchg, 0, 16, st) != hipSuccess) return PVO_ELAUNCH;                                       // (pvo_ba_last_partition: no partition)
+    const int nkb = (n6 + kNB - 1) / kNB, nrb = (n6 + 1 + kNB - 1) / kNB;
+    for (int kb = 0; kb < nkb; ++kb) {
+      hipLaunchKernelGGL(dense_panel_kernel, dim3(nrb - kb), dim3(256), 0, st, w.chol, w.ldiag, n6, kb, w.plan.meta);
+      const int m = nrb - kb - 1;
+      if (m > 0) hipLaunchKernelGGL(dense_update_kernel, dim3(m * (m + 1) / 2), dim3(256), 0, st, w.chol, n6, kb, nrb);
+    }
+    PVO_CHECK_LAUNCH();
+    double* yrow = w.chol + static_cast<size_t>(n6) * n6;
+    for (int kb = nkb - 1; kb >= 0; --kb)
+      hipLaunchKernelGGL(dense_back_kernel, dim3(kb + 1), dim3(256), 0, st, w.chol, w.ldiag, yrow, w.xvec, n6, kb);
+    PVO_CHECK_LAUNCH();
+    if (rider_lds > 48 * 1024) {
+      static bool fin_attr_set = false;
+      if (!fin_attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dense_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSolveLdsMax)) != hipSuccess)
+          return PVO_ELAUNCH;
+        fin_attr_set = true;
+      }
+    }
+    hipLaunchKernelGGL(dense_finish_kernel, dim3(1 + rider_blocks), dim3(256), rider_lds, st, w.xvec, poses, w.dx, dx_out, w.plan.meta, status_out, P, t0, rider);
+    PVO_CHECK_LAUNCH();
+    if (!motion_only && E + P > 0) {
+      const int Kmax = (nframes < P + E) ? nframes : (P + E);
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3((HW + 255) / 256, Kmax > clamp_frames ? Kmax : clamp_frames), dim3(256), 0, st,
+                         w.plan, jj, w.Ei, w.Eij, w.Q, w.w, w.dx, disps, dz_out, dz_rows, HW, t0, P, 0, clamp_frames, disp_min);
+      PVO_CHECK_LAUNCH();
+    }
+    return PVO_OK;
+  }
   const int solver_pick = (solver_env >= 0 && solver_env < 4) ? solver_env : (use_lds ? (P > 12 ? 2 : 0) : 3);      // 0 blocked | 1 wave | 2 pipe | 3 partitioned
   const bool twin = solver_pick == 3 && !use_lds;
   const int solver_wave = solver_pick == 3 ? 2 : solver_pick;

@@ -1218,13 +1218,13 @@ def bias_norm_act(x, bias=None, residual=None, norm=False, eps=1e-5, relu_inner=
 
 
 def debug_config(knob, value):
-    """the library's test hook (include/pvo_hip.h pvo_debug_config): "ba_solver" = None | "blocked" | "wave" | "pipe" | "twin" | "dense",
+    """the library's test hook (include/pvo_hip.h pvo_debug_config): "ba_solver" = None | "blocked" | "wave" | "pipe" | "twin" | "dense" | "blocks",
     "heads_gather_flat" = bool, "no_riders" = bool, "post_separate" = bool.  Process-wide; tests that compare bit-identical forms call it in a process of
     their own.  (These were environment variables read inside the library until round 5.)"""
     knobs = {"ba_solver": _lib.PVO_KNOB_BA_SOLVER, "heads_gather_flat": _lib.PVO_KNOB_HEADS_GATHER_FLAT, "no_riders": _lib.PVO_KNOB_NO_RIDERS,
              "post_separate": _lib.PVO_KNOB_POST_SEPARATE}
     if knob == "ba_solver":
-        value = {None: 0, "": 0, "blocked": 1, "wave": 2, "pipe": 3, "twin": 4, "dense": 5}[value]
+        value = {None: 0, "": 0, "blocked": 1, "wave": 2, "pipe": 3, "twin": 4, "dense": 5, "blocks": 6}[value]
     check(_lib.load().pvo_debug_config(knobs[knob], int(value)), "pvo_debug_config")
 
 

@@ -383,6 +383,31 @@ def test_partitioned_and_one_chain_solves_agree(cuda):
     assert (outs["pipe"][1] - outs["twin"][1]).abs().max().item() <= 1e-6 * max(1.0, outs["pipe"][1].abs().max().item())
 
 
+@pytest.mark.parametrize("P,radius", [(40, 6), (70, 9)])
+def test_blocked_dense_pose_solve_of_a_densely_connected_global_graph_matches_the_oracle(cuda, P, radius):
+    """A global graph connected by proximity rather than as a chain (more than 8 edges per pose, beyond the dense matrix-core solve's
+    29 poses: the backend's graph of a real sequence) takes the DENSE factorisation in 48 x 48 blocks over many workgroups
+    (dense_panel / dense_update / dense_back kernels; 6 P is and is not a multiple of 48): the oracle's dense fp64 solve, bitwise
+    repeatable, no partition reported, and a non-SPD system gives the zero update and a usable workspace afterwards."""
+    from pvo_amd import droid_backends as db
+    ht, wd = 8, 10
+    s = _scene(P * 3 + radius, P, ht, wd, radius, 1)
+    assert s["ii"].shape[0] > 8 * (P - 1)
+    want = O.ba(s["poses"].numpy(), s["disps"].numpy(), s["intr"].numpy(), s["target"].numpy(), s["weight"].numpy(),
+                s["eta"].numpy(), s["ii"].numpy(), s["jj"].numpy(), 1, P, 2, 1e-4, 0.1)
+    poses, disps, dx, dz, status = _run_ba(s, cuda, 2)
+    assert db.ba_last_partition(s["ii"].shape[0], P - 1, P, ht * wd, cuda) == (0, 0)
+    assert status[0] == 0 and status[1] == want["K"]
+    assert np.abs(poses - want["poses"]).max() < 1e-4 and np.abs(disps - want["disps"]).max() < 1e-4
+    assert np.abs(dx - want["dx"]).max() < 1e-4 and np.abs(dz - want["dz"]).max() < 1e-4
+    again = _run_ba(s, cuda, 2)
+    assert np.array_equal(poses, again[0]) and np.array_equal(disps, again[1])
+    bad = _run_ba(s, cuda, 1, lm=0.0, ep=-1e9)
+    assert bad[4][0] == 1 and not bad[2].any() and np.array_equal(bad[0], s["poses"].numpy())
+    ok = _run_ba(s, cuda, 2)
+    assert np.array_equal(poses, ok[0])
+
+
 def test_ba_non_spd_gives_zero_update(cuda):
     s = _scene(10, 4, 6, 8, 2, 1)
     s["weight"] = torch.zeros_like(s["weight"])

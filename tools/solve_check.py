@@ -1,7 +1,7 @@
 """The pose solve alone (pvo_ba_finish, motion_only: no back-substitution of depths) on synthetic SPD systems of every window size,
 against numpy's fp64 solve: prints the largest relative error of dx per size and solver form.
 
-    python tools/solve_check.py [solver]        # solver: dense (default choice up to 29 poses) | blocked | wave | pipe | twin
+    python tools/solve_check.py [solver]        # solver: dense (default choice up to 29 poses) | blocked | wave | pipe | twin | blocks (48 x 48 blocks over many workgroups, beyond 21 poses)
 """
 import os
 import sys
@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pvo_amd import droid_backends as db  # noqa: E402
 
 FIX = float(1 << 28)
+LAST_US = 0.0
 
 
 def system(P, seed, coupling=1.0):
@@ -49,16 +50,29 @@ def solve(P, seed=0, lm=1e-4, ep=0.1, dev="cuda:0"):
     status = torch.zeros(4, dtype=torch.int32, device=dev)
     dx, _ = db.ba_finish(poses, disps, sysd, ii, jj, 1, P + 1, lm, ep, True, ws, status=status)
     torch.cuda.synchronize()
-    return dx.cpu().numpy().reshape(-1).astype(np.float64), want, status.cpu().numpy(), bool((sysd == 0).all())
+    zeroed = bool((sysd == 0).all())
+    global LAST_US
+    src = torch.from_numpy(sysm).to(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(5):                                   # the solve alone (the system is copied back in front of every call)
+        sysd.copy_(src); poses[:, :6] = 0; poses[:, 6] = 1
+        e0.record()
+        db.ba_finish(poses, disps, sysd, ii, jj, 1, P + 1, lm, ep, True, ws)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    LAST_US = sorted(ts)[len(ts) // 2]
+    return dx.cpu().numpy().reshape(-1).astype(np.float64), want, status.cpu().numpy(), zeroed
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         db.debug_config("ba_solver", sys.argv[1])
     worst = 0.0
-    for P in list(range(1, 33)) + [40, 63]:
+    sizes = [int(x) for x in os.environ["SIZES"].split(",")] if os.environ.get("SIZES") else list(range(1, 33)) + [40, 63, 85, 128, 200]
+    for P in sizes:
         got, want, status, zeroed = solve(P, seed=P)
         err = np.abs(got - want).max() / np.abs(want).max()
         worst = max(worst, err)
-        print("P %2d  n %3d  rel err %.2e  status %s  sys zeroed %s" % (P, 6 * P, err, status.tolist(), zeroed))
+        print("P %3d  n %4d  rel err %.2e  status %s  sys zeroed %s  %8.1f us per solve (events, incl. launch gaps)" % (P, 6 * P, err, status.tolist(), zeroed, LAST_US))
     print("worst", worst)
