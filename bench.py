@@ -896,9 +896,30 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
                edges_at_end=len(fe.graph._ii_h), finite=bool(torch.isfinite(droid.video.poses[:droid.video.counter]).all()))
     try:
         if terminate:
+            # where the HOST spends terminate (no synchronisation added: a call's time is what it blocks the host for - allocation of the
+            # global graph's volume pool, read-backs - the device work it queued may finish later, inside a later entry)
+            host = {}
+
+            def _timed(obj, name, label):
+                f = getattr(obj, name)
+
+                def g(*a, **kw):
+                    t = time.perf_counter()
+                    try:
+                        return f(*a, **kw)
+                    finally:
+                        host[label] = host.get(label, 0.0) + time.perf_counter() - t
+                setattr(obj, name, g)
+            if split is None:
+                _timed(droid.backend, "_connect_all", "backend: connect (proximity edges, volume pool)")
+                _timed(droid, "_release_cached_memory", "release cached memory")
+                _timed(droid, "traj_filler", "trajectory filler")
+                _timed(_FG, "update_lowmem", "backend: graph updates (host side)")
             t0 = time.perf_counter()
             traj = droid.terminate(iter(frames), need_inv=True)
+            host["all, to the last read-back"] = time.perf_counter() - t0
             torch.cuda.synchronize(); out["terminate_s"] = time.perf_counter() - t0
+            out["terminate_host_s"] = {k: round(v, 4) for k, v in host.items()}
             out["trajectory_rows"] = int(traj.shape[0]); out["finite"] = out["finite"] and bool((traj == traj).all())
             out["backend_graphs"] = backend_graphs
     finally:
@@ -952,7 +973,7 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
             "keyframe_updates_per_s": plain["keyframe_updates"] / plain["track_s"],
             "graph_updates_per_s": plain["graph_updates"] / plain["track_s"],
             "ms_per_keyframe_update_all_in": 1e3 * plain["track_s"] / max(plain["keyframe_updates"], 1),
-            "ba_windows_sampled": plain.get("ba_windows_sampled"), "terminate_s": plain.get("terminate_s"), "backend_graphs": plain.get("backend_graphs"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},
+            "ba_windows_sampled": plain.get("ba_windows_sampled"), "terminate_s": plain.get("terminate_s"), "terminate_host_s": plain.get("terminate_host_s"), "backend_graphs": plain.get("backend_graphs"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},
             "finite": plain["finite"],
             "split_instrumented_pass": {"note": "exclusive wall time per component with a device synchronisation on both sides of every call (this pass: %.2f s of tracking against %.2f s plain)" % (inst["track_s"], plain["track_s"]),
                                         "seconds": {k: round(v, 4) for k, v in sorted(sp.t.items(), key=lambda kv: -kv[1])},
