@@ -800,18 +800,18 @@ class _Split:
         setattr(obj, name, timed)
 
 
-def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None, record=None, terminate=True, seed=0, removal_rate=0.0):
+def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None, record=None, terminate=True, seed=0, removal_rate=0.0, pipelined=False):
     """tools/test_vo.py's loop (evaluation_scripts/test_vo.py:88-108) on the synthetic stream: Droid.track per frame, then
     terminate (backend x2 + trajectory filler)"""
     from pvo_amd.droid import Droid, default_args
     from pvo_amd.synthetic import drifting_texture_stream
     torch.manual_seed(seed)
     args = default_args(device=str(device), image_size=[240, 808], buffer=max(64, n_frames + 40), segm_filter=True, thresh=0.8,
-                        filter_thresh=filter_thresh, keyframe_thresh=keyframe_thresh)
+                        filter_thresh=filter_thresh, keyframe_thresh=keyframe_thresh, pipelined=pipelined)
     droid = Droid(args)
     fe, mf = droid.frontend, droid.filterx
     counts = {"keyframe_updates": 0, "keyframes_removed": 0, "graph_updates": 0}
-    upd, rmk = fe._update, fe.graph.rm_keyframe
+    upd, rmk = fe._update_begin, fe.graph.rm_keyframe      # (_update_begin: the first half of a keyframe update, in either order of the tracker)
 
     def _upd():
         counts["keyframe_updates"] += 1
@@ -820,7 +820,7 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
     def _rmk(ix):
         counts["keyframes_removed"] += 1
         return rmk(ix)
-    fe._update, fe.graph.rm_keyframe = _upd, _rmk
+    fe._update_begin, fe.graph.rm_keyframe = _upd, _rmk
     if removal_rate > 0:
         # the frontend's keyframe test compares distances between poses a RANDOM network produced (chaotic): its branch is driven by a
         # seeded schedule instead - decision k is fixed for the k-th keyframe update of every pass (DroidFrontend.keyframe_decision);
@@ -891,6 +891,7 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for t, image, intr, segm in frames:
         droid.track(t, image, intrinsics=intr, segments=segm)
+    droid.flush()                              # (pipelined: the last keyframe update's second half)
     torch.cuda.synchronize(); t_track = time.perf_counter() - t0
     out = dict(counts, ba_windows_sampled=windows, frames=n_frames, keyframes=int(droid.video.counter), track_s=t_track,
                edges_at_end=len(fe.graph._ii_h), finite=bool(torch.isfinite(droid.video.poses[:droid.video.counter]).all()))
@@ -921,6 +922,7 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
             torch.cuda.synchronize(); out["terminate_s"] = time.perf_counter() - t0
             out["terminate_host_s"] = {k: round(v, 4) for k, v in host.items()}
             out["trajectory_rows"] = int(traj.shape[0]); out["finite"] = out["finite"] and bool((traj == traj).all())
+            out["trajectory"] = traj
             out["backend_graphs"] = backend_graphs
     finally:
         _FG.update_lowmem = lowmem
@@ -958,6 +960,13 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
             pstats.Stats(pr, stream=buf).sort_stats("tottime").print_callers(fn)
         with open(cprofile, "w") as f:
             f.write(buf.getvalue())
+    # the same sequence through the PIPELINED tracker (Droid(args.pipelined=True): the second half of a keyframe update runs inside the
+    # next track() call, behind the next frame's encoder launch): same operations in the same dependency order - the trajectory must be
+    # bit-identical to the plain pass's
+    import numpy as np
+    pipe = _sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE, pipelined=True)
+    same = bool(plain.get("trajectory") is not None and pipe.get("trajectory") is not None and
+                np.array_equal(plain["trajectory"], pipe["trajectory"]))
     sp = _Split()
     inst = _sequence_pass(device, n_frames, f_th, k_th, split=sp, removal_rate=REMOVAL_RATE) if instrumented else {"track_s": float("nan")}
     total = sum(sp.t.values())
@@ -971,6 +980,13 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
             "keyframe_removal": {"rate_scheduled": REMOVAL_RATE, "removed": plain["keyframes_removed"], "keyframe_updates": plain["keyframe_updates"],
                                  "how": "seeded decision per keyframe update through DroidFrontend.keyframe_decision (the distance is still computed and read back): rm_keyframe + the counter / t1 roll-back of droid_frontend.py:54-58 are in the timed loop"},
             "keyframe_updates_per_s": plain["keyframe_updates"] / plain["track_s"],
+            "pipelined": {"what": "Droid(args.pipelined=True), same stream and schedule: frame t + 1's graph is launched before the second half of "
+                                  "keyframe t's frontend update; results lag by half an update between calls (flush() at the end is in the time)",
+                          "frames_per_s": pipe["frames"] / pipe["track_s"],
+                          "frames_per_s_end_to_end": pipe["frames"] / (pipe["track_s"] + pipe.get("terminate_s", 0.0)),
+                          "keyframe_updates_per_s": pipe["keyframe_updates"] / pipe["track_s"],
+                          "keyframe_updates": pipe["keyframe_updates"], "keyframes_removed": pipe["keyframes_removed"],
+                          "terminate_s": pipe.get("terminate_s"), "trajectory_identical_to_plain_pass": same},
             "graph_updates_per_s": plain["graph_updates"] / plain["track_s"],
             "ms_per_keyframe_update_all_in": 1e3 * plain["track_s"] / max(plain["keyframe_updates"], 1),
             "ba_windows_sampled": plain.get("ba_windows_sampled"), "terminate_s": plain.get("terminate_s"), "terminate_host_s": plain.get("terminate_host_s"), "backend_graphs": plain.get("backend_graphs"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},

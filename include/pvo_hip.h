@@ -319,6 +319,12 @@ int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, l
  * `dtype` or NULL.  y may alias x. */
 int pvo_bias_norm_act(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
                       int norm, float eps, int relu_inner, int relu_outer, int dtype, void* stream);
+/* The encoders' last layer, Conv2d(128, output_dim, 1) (extractor.py:139,199), on NCHW planes, bias included:
+ *   y[n][co][p] = round(round(sum_ci w[co][ci] x[n][ci][p]) + bias[co]),  products added in index order in fp32 - DETERMINISTIC (the
+ * vendor library's implicit GEMM for this shape splits K over workgroups with atomics: the same frame gave different feature maps, and
+ * a sequence a different trajectory, from run to run).  x [N,Cin,HW], w [Cout,Cin], bias [Cout] or NULL, y [N,Cout,HW], all `dtype`
+ * (PVO_F16 / PVO_BF16).  Cin a multiple of 128, Cout of 64 (PVO_EUNSUPPORTED otherwise: callers keep the library convolution). */
+int pvo_conv1x1_planes(const void* x, const void* w, const void* bias, void* y, int N, int Cin, int Cout, int HW, int dtype, void* stream);
 
 /* (pvo_graph_motion: inside pvo_graph_update the motion features are written by pvo_reproject_motion since round 3; this
  * entry point serves pvo_update_operator callers that reproject themselves, and tests) */

@@ -99,7 +99,74 @@ __global__ void bias_norm_act_kernel(const uint16_t* __restrict__ x, const uint1
   }
 }
 
+// The encoders' last layer, Conv2d(128, output_dim, 1) (extractor.py:139,199), on NCHW planes: y[n][co][p] = round16(round16(sum_ci
+// w[co][ci] x[n][ci][p]) + bias[co]).  MIOpen runs it as an NHWC implicit GEMM that splits K over workgroups and adds the partial sums
+// with atomics: three consecutive calls on the same input gave three different feature maps (tools/determinism_probe.py), and with
+// them every run of a sequence its own trajectory.  Here one thread owns 4 pixels x 4 output channels and adds the 128 products in
+// index order in fp32 - the same bits every time; no layout transposes (MIOpen: three around its kernel).
+constexpr int kC1Pix = 64, kC1Co = 64, kC1Ci = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void conv1x1_planes_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
+                                                             uint16_t* __restrict__ y, int Cin, int Cout, int HW) {
+  __shared__ uint16_t xs[kC1Ci][kC1Pix];
+  __shared__ uint16_t ws[kC1Ci][kC1Co + 4];                       // [ci][co]: a thread's four output channels are adjacent
+  const int p0 = blockIdx.x * kC1Pix, co0 = blockIdx.y * kC1Co;
+  const long long n = blockIdx.z;
+  const uint16_t* xn = x + n * Cin * static_cast<long long>(HW);
+  const int tp = (threadIdx.x & 15) * 4, tc = (threadIdx.x >> 4) * 4;
+  float acc[4][4] = {};
+  for (int c0 = 0; c0 < Cin; c0 += kC1Ci) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kC1Ci * kC1Pix; i += 256) {
+      const int ci = i / kC1Pix, p = i % kC1Pix;
+      xs[ci][p] = (p0 + p < HW) ? xn[static_cast<long long>(c0 + ci) * HW + p0 + p] : static_cast<uint16_t>(0);
+    }
+    for (int i = threadIdx.x; i < kC1Co * kC1Ci; i += 256) {
+      const int co = i / kC1Ci, ci = i % kC1Ci;
+      ws[ci][co] = w[static_cast<long long>(co0 + co) * Cin + c0 + ci];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ci = 0; ci < kC1Ci; ++ci) {
+      float xv[4], wv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { xv[k] = eo_val<T>(xs[ci][tp + k]); wv[k] = eo_val<T>(ws[ci][tc + k]); }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(wv[a], xv[b], acc[a][b]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int co = co0 + tc + a;
+    const float bv = bias ? eo_val<T>(bias[co]) : 0.0f;
+    uint16_t* yr = y + (n * Cout + co) * static_cast<long long>(HW) + p0 + tp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (p0 + tp + b < HW) yr[b] = eo_bits<T>(eo_round<T>(acc[a][b]) + bv);
+  }
+}
+
 }  // namespace
+
+extern "C" int pvo_conv1x1_planes(const void* x, const void* w, const void* bias, void* y, int N, int Cin, int Cout, int HW, int dtype, void* stream) {
+  if (N < 0 || Cin <= 0 || Cout <= 0 || HW < 0) return PVO_EINVAL;
+  if (N == 0 || HW == 0) return PVO_OK;
+  if (!x || !w || !y) return PVO_EINVAL;
+  if ((Cin % kC1Ci) != 0 || (Cout % kC1Co) != 0 || N > 65535) return PVO_EUNSUPPORTED;
+  const dim3 grid((HW + kC1Pix - 1) / kC1Pix, Cout / kC1Co, N);
+  hipStream_t st = pvo_stream(stream);
+  if (dtype == PVO_F16)
+    hipLaunchKernelGGL(conv1x1_planes_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w),
+                       static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(y), Cin, Cout, HW);
+  else if (dtype == PVO_BF16)
+    hipLaunchKernelGGL(conv1x1_planes_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w),
+                       static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(y), Cin, Cout, HW);
+  else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
 
 extern "C" int pvo_bias_norm_act(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
                                  int norm, float eps, int relu_inner, int relu_outer, int dtype, void* stream) {

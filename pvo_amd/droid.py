@@ -24,7 +24,7 @@ def default_args(**over):
     a = dict(device="cuda:0", weights=None, buffer=1024, image_size=[240, 808], disable_vis=True, use_aff_bri=False,
              beta=0.6, filter_thresh=1.75, warmup=12, keyframe_thresh=2.25, frontend_thresh=12.0, frontend_window=25,
              frontend_radius=2, frontend_nms=1, backend_thresh=15.0, backend_radius=2, backend_nms=3,
-             segm_filter=False, thresh=0.8, half_update=True)
+             segm_filter=False, thresh=0.8, half_update=True, pipelined=False)
     a.update(over)
     return Namespace(**a)
 
@@ -35,6 +35,7 @@ class Droid:
         self.load_weights(args.weights, args.use_aff_bri)
         self.video = DepthVideo(args.image_size, args.buffer, args.device, args.segm_filter, args.thresh)
         self.filterx = MotionFilter(self.net, self.video, thresh=args.filter_thresh, device=args.device)
+        self.filterx.overlap_upload = bool(getattr(args, "pipelined", False))
         self.frontend = DroidFrontend(self.net.update, self.video, args.device, warmup=args.warmup, beta=args.beta,
                                       frontend_nms=args.frontend_nms, keyframe_thresh=args.keyframe_thresh,
                                       frontend_window=args.frontend_window, frontend_thresh=args.frontend_thresh,
@@ -57,12 +58,33 @@ class Droid:
                 self.net.fnet.half(); self.net.cnet.half()
 
     def track(self, tstamp, image, depth=None, intrinsics=None, segments=None):
+        """one frame (droid.py:64-75).  args.pipelined (default False: the reference's order, the video is final for this frame when
+        the call returns): the frame's graph is launched FIRST, then the second half of the previous keyframe's frontend update (its
+        keyframe test was left in flight when the previous call returned), then the motion test is read and this frame's frontend
+        work is issued up to ITS keyframe test.  Same operations on the same data in the same dependency order - poses, depths and the
+        trajectory are bit-identical (tests/test_vo_system.py) - but the device has work queued while the host waits for a scalar
+        or books edges.  The video then lags by half a keyframe update between calls: `flush()` (called by terminate / get_*)
+        completes it."""
         with torch.no_grad():
-            self.filterx.track(tstamp, image, depth, intrinsics, segments)
-            self.frontend()
+            if not getattr(self.args, "pipelined", False):
+                self.filterx.track(tstamp, image, depth, intrinsics, segments)
+                self.frontend()
+                return
+            self.filterx.begin(tstamp, image, depth, intrinsics, segments)
+            self.frontend.finish()
+            self.filterx.finish()
+            self.frontend.begin()
+
+    def flush(self):
+        """complete a keyframe update a pipelined track() left half done"""
+        fe = getattr(self, "frontend", None)
+        if fe is not None:
+            with torch.no_grad():
+                fe.finish()
 
     def terminate(self, stream=None, need_inv=True):
         """two global BA passes, then fill in every frame's pose; returns [num_frames, 7] (t, q) (droid.py:77-98)"""
+        self.flush()
         del self.frontend
         self._release_cached_memory()
         self.backend(7)
@@ -82,11 +104,14 @@ class Droid:
             torch.cuda.empty_cache()
 
     def get_traj(self):
+        self.flush()
         return SE3(self.video.poses[:self.video.counter]).data.cpu().numpy()
 
     def get_depth(self):
+        self.flush()
         d = self.video.disps[:self.video.counter]
         return upsample_inter(d[None, ..., None]).squeeze(4).squeeze(0)
 
     def get_flow(self):
+        self.flush()
         return upsample_inter(self.video.full_flow[:self.video.counter][None] * 8)

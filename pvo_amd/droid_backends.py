@@ -1217,6 +1217,27 @@ def bias_norm_act(x, bias=None, residual=None, norm=False, eps=1e-5, relu_inner=
     return y
 
 
+def conv1x1_planes_supported(cin, cout):
+    return cin % 128 == 0 and cout % 64 == 0
+
+
+def conv1x1_planes(x, w, bias=None):
+    """Conv2d(Cin, Cout, 1) on a contiguous 16-bit NCHW tensor, deterministic (pvo_conv1x1_planes): x [N,Cin,H,W], w [Cout,Cin] or
+    [Cout,Cin,1,1], bias [Cout] or None, all of x's dtype -> [N,Cout,H,W]"""
+    dev = _dev(x, w, bias)
+    _contig(x, "x"); _contig(w, "w")
+    if x.dim() != 4 or x.dtype not in (torch.float16, torch.bfloat16) or w.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):
+        raise PvoHipError("conv1x1_planes: x contiguous 16-bit [N,Cin,H,W], w and bias of the same dtype")
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if w.numel() != Cout * Cin or (bias is not None and (bias.numel() != Cout or not bias.is_contiguous())):
+        raise PvoHipError("conv1x1_planes: w [Cout,Cin], bias [Cout]")
+    y = torch.empty(N, Cout, H, W, dtype=x.dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_conv1x1_planes(_ptr(x), _ptr(w), _vp(bias), _ptr(y), N, Cin, Cout, H * W, _dtype_code(x, "x"), _stream(dev)), "conv1x1_planes")
+    return y
+
+
 def debug_config(knob, value):
     """the library's test hook (include/pvo_hip.h pvo_debug_config): "ba_solver" = None | "blocked" | "wave" | "pipe" | "twin" | "dense" | "blocks",
     "heads_gather_flat" = bool, "no_riders" = bool, "post_separate" = bool.  Process-wide; tests that compare bit-identical forms call it in a process of

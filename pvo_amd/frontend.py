@@ -3,7 +3,9 @@
 Counterpart of the reference's DroidFrontend (VO_Module/droid_slam/droid_frontend.py:9-112): same constants
 (max_factors 48, max_age 25, iters1 4, iters2 2), same initialise / update sequence.  `video.counter` is a plain
 int here (one process per GPU) and the keyframe-distance test reads ONE scalar back per keyframe — the only
-host synchronisation left in a keyframe update.
+host synchronisation left in a keyframe update.  The update is written in two halves around that read-back (`begin` / `finish`):
+called back to back they are the reference's sequence; `Droid(args.pipelined=True)` runs the second half of keyframe t inside
+track(t + 1), behind the launch of frame t + 1's encoder graph, so the device has work queued while the host waits and books.
 """
 import torch
 
@@ -24,9 +26,18 @@ class DroidFrontend:
         self.frontend_thresh, self.frontend_radius = frontend_thresh, frontend_radius
         self.keyframe_decision = None
         self.keyframes_removed = 0
+        self.update_pending = False                 # a keyframe update whose second half has not run yet (pipelined Droid)
+        self._dist = self._dist_host = self._dist_ready = None
 
     def _update(self):
         """add edges, optimise, decide whether the previous frame stays a keyframe (droid_frontend.py:36-70)"""
+        self._update_begin()
+        self._update_finish()
+
+    def _update_begin(self):
+        """first half of a keyframe update (droid_frontend.py:36-52): edges in, four graph updates, the keyframe test's distance
+        LAUNCHED - its scalar goes to a pinned host buffer behind an event and is read in `_update_finish`.  `Droid` in pipelined
+        mode returns from track() here and runs the second half inside the next call, behind the next frame's encoder launch."""
         self.count += 1
         self.t1 += 1
         if self.graph.corr is not None:                      # droid_frontend.py:42-43
@@ -36,10 +47,30 @@ class DroidFrontend:
         for _ in range(self.iters1):
             self.graph.update(None, None, use_inactive=True)
         d = self.video.distance([self.t1 - 3], [self.t1 - 2], beta=self.beta, bidirectional=True)
+        if d.is_cuda:
+            if self._dist_host is None:
+                self._dist_host = torch.empty(1, dtype=d.dtype).pin_memory()
+                self._dist_ready = torch.cuda.Event()
+            self._dist_host.copy_(d.reshape(-1)[:1], non_blocking=True)
+            self._dist_ready.record()
+            self._dist = None
+        else:
+            self._dist = d
+        self.update_pending = True
+
+    def _update_finish(self):
+        """second half (droid_frontend.py:53-70): read the distance, drop the keyframe or refine twice more, seed the next frame"""
+        if not self.update_pending:
+            return
+        self.update_pending = False
         # (keyframe_decision: measurement / test hook - a callable (update index, distance as a float) -> True to drop the keyframe.
         # With random-init weights the distance is chaotic; bench.py and the GPU tests feed a seeded schedule so that the removal
         # branch - rm_keyframe, the counter / t1 roll-back - runs the same way in every pass.  The scalar is read back either way.)
-        dist = d.item()
+        if self._dist is None:
+            self._dist_ready.synchronize()
+            dist = float(self._dist_host[0])
+        else:
+            dist = self._dist.item()
         drop = self.keyframe_decision(self.count, dist) if self.keyframe_decision is not None else dist < self.keyframe_thresh
         if drop:
             self.graph.rm_keyframe(self.t1 - 2)
@@ -68,7 +99,20 @@ class DroidFrontend:
         self.video.dirty[:self.t1] = True
 
     def __call__(self):
+        self.finish()
         if not self.is_initialized and self.video.counter == self.warmup:
             self._initialize()
         elif self.is_initialized and self.t1 < self.video.counter:
             self._update()
+
+    def begin(self):
+        """everything of this frame's frontend work that can be issued without the keyframe test's answer"""
+        self.finish()
+        if not self.is_initialized and self.video.counter == self.warmup:
+            self._initialize()
+        elif self.is_initialized and self.t1 < self.video.counter:
+            self._update_begin()
+
+    def finish(self):
+        if self.update_pending:
+            self._update_finish()

@@ -126,5 +126,13 @@ class BasicEncoder(nn.Module):
         for layer in (self.layer1, self.layer2, self.layer3):
             for block in layer:
                 t = block.forward_inference(t, norm, act)
-        t = act(_conv(self.conv2, t), _b(self.conv2, t), None, False, False, False)
+        c2 = self.conv2
+        if c2.kernel_size == (1, 1) and c2.stride == (1, 1) and c2.padding == (0, 0) and c2.groups == 1 \
+                and db.conv1x1_planes_supported(c2.in_channels, c2.out_channels):
+            # the last layer on the library's own kernel, bias included: the vendor library's 1x1 convolution of this shape adds split-K
+            # partial sums with atomics - the same frame gave a different feature map on every call (tools/determinism_probe.py)
+            w = c2.weight if c2.weight.dtype == t.dtype else c2.weight.to(t.dtype)
+            t = db.conv1x1_planes(t.contiguous(), w, _b(c2, t))
+        else:
+            t = act(_conv(c2, t), _b(c2, t), None, False, False, False)
         return t.view(b, n, *t.shape[1:])

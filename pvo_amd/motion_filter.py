@@ -69,11 +69,42 @@ class MotionFilter:
                                     frozen=lambda i: i >= 1)       # the reference keyframe's maps / static terms: written once in _new_reference
                                                                    # (fresh tensors per keyframe), read-only until the next one replaces them
         self._static = None                # conv(W[:, inp], inp) of the reference keyframe's context: constant until the next keyframe
+        self._pending = None               # a frame between begin() and finish()
+        self.overlap_upload = False        # asynchronous upload through pinned staging (Droid sets it in pipelined mode)
+        self._up_stream, self._stage, self._stage_k = None, [None, None], 0
+        self._mag_host = self._mag_ready = None
 
     def _upload(self, image):
         """host frame -> device, as it is (the reference's stream hands over int32, test_vo.py:41): NO tensor operation on the host
         (on the 128-core hosts of the MI355X boxes every CPU tensor op on a frame - a dtype cast, the [2, 1, 0] channel gather of
         motion_filter.py:52, torch.stack in the filler - costs 2-20 ms: an OpenMP team is woken for 0.6 M elements); the copy itself: `upload_frame`."""
+        if self.overlap_upload and self.device.type == "cuda" and isinstance(image, torch.Tensor) and not image.is_cuda:
+            # pipelined tracker: the launch stream still holds the previous keyframe's graph updates (and the library's second stream their
+            # side chains); a blocking copy from pageable memory waits for them - measured 2.8 ms per frame, on either stream - and this
+            # frame's graph could only be launched into an idle device afterwards.  The frame is staged in pinned memory (one host
+            # memmove, no tensor operation: see above) and goes up asynchronously on an upload stream; the launch stream waits on the device.
+            import ctypes
+            if self._up_stream is None:
+                from .droid_backends import side_stream
+                side_stream(self.device)                                   # (created first: the operator's two streams keep their queues)
+                self._up_stream = torch.cuda.Stream(self.device)
+            k = self._stage_k = self._stage_k ^ 1
+            st = self._stage[k]
+            if st is None or st[0].shape != image.shape or st[0].dtype != image.dtype:
+                st = self._stage[k] = (torch.empty(image.shape, dtype=image.dtype).pin_memory(), torch.cuda.Event())
+            else:
+                st[1].synchronize()                                        # (the copy out of this buffer two frames ago)
+            if image.is_contiguous():
+                ctypes.memmove(st[0].data_ptr(), image.data_ptr(), image.numel() * image.element_size())
+            else:
+                st[0].copy_(image)
+            cur = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self._up_stream):
+                img = st[0].to(self.device, non_blocking=True)
+                st[1].record(self._up_stream)
+            cur.wait_stream(self._up_stream)
+            img.record_stream(cur)
+            return img
         return upload_frame(image, self.device)
 
     def _normalise_dev(self, image_dev):
@@ -142,31 +173,69 @@ class MotionFilter:
     @torch.no_grad()
     def track(self, tstamp, image, depth=None, intrinsics=None, segments=None):
         """run on every incoming frame (motion_filter.py:46-87); image [3,H,W] BGR 0..255"""
+        self.begin(tstamp, image, depth, intrinsics, segments)
+        return self.finish()
+
+    @torch.no_grad()
+    def begin(self, tstamp, image, depth=None, intrinsics=None, segments=None):
+        """first half of track(): the frame goes up and its graph (encoder, 1-edge volume, lookup, one operator pass, mean flow norm) is
+        LAUNCHED; the scalar is copied to a pinned host buffer behind an event.  Nothing here reads or writes the video."""
         ht, wd = image.shape[-2] // 8, image.shape[-1] // 8
         img = self._upload(image)
+        self._pending = (tstamp, image, img, intrinsics, segments, None, None)
         if self.video.counter == 0:
-            gmap = self._features_g(img)                                       # [1,128,h,w]
-            self._remember(tstamp, gmap, image)
-            ident = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0], device=self.device)
-            net, inp = self._context_g(img)
-            self._new_reference(gmap, net, inp)
-            self._append(tstamp, image, ident, 1.0, intrinsics.to(self.device), gmap, net, inp, segments)
-            return True
+            return
         if self._coords0 is None or self._coords0.shape[-3:-1] != (ht, wd):
             if (ht, wd) not in self._coords0_by_shape:
                 with self._autocast():
                     self._coords0_by_shape[(ht, wd)] = coords_grid(ht, wd, device=self.device)[None, None]
             self._coords0 = self._coords0_by_shape[(ht, wd)]
         gmap, mag = self._frame_g(img, self.fmap, self.net, self.inp, *(self._static or ()))
+        if mag.is_cuda:
+            if self._mag_host is None:
+                self._mag_host = torch.empty(1, dtype=mag.dtype).pin_memory()
+                self._mag_ready = torch.cuda.Event()
+            self._mag_host.copy_(mag.reshape(-1)[:1], non_blocking=True)
+            self._mag_ready.record()
+            mag = None
+        self._pending = (tstamp, image, img, intrinsics, segments, gmap, mag)
+
+    @torch.no_grad()
+    def finish(self):
+        """second half: read the motion test's scalar; a frame that moved enough gets its context features and joins the video"""
+        tstamp, image, img, intrinsics, segments, gmap, mag = self._pending
+        self._pending = None
+        if gmap is None:                                                       # the first frame: always a keyframe
+            gmap = self._features_g(img)                                       # [1,128,h,w]
+            self._remember(tstamp, gmap, image)
+            ident = torch.as_tensor([0, 0, 0, 0, 0, 0, 1.0], device=self.device)
+            net, inp = self._context_g(img)
+            self._new_reference(gmap, net, inp)
+            self._append(tstamp, image, ident, 1.0, self._small_to_device(intrinsics), gmap, net, inp, segments)
+            return True
         self._remember(tstamp, gmap, image)
-        if mag.item() > self.thresh:
+        if mag is None:
+            self._mag_ready.synchronize()
+            moved = float(self._mag_host[0])
+        else:
+            moved = mag.item()
+        if moved > self.thresh:
             self.count = 0
             net, inp = self._context_g(img)
             self._new_reference(gmap, net, inp)
-            self._append(tstamp, image, None, None, intrinsics.to(self.device), gmap, net, inp, segments)
+            self._append(tstamp, image, None, None, self._small_to_device(intrinsics), gmap, net, inp, segments)
             return True
         self.count += 1
         return False
+
+    def _small_to_device(self, t):
+        """a few host floats (the frame's intrinsics) -> device through the pinned staging ring: `.to(device)` from pageable memory is a
+        BLOCKING copy queued behind everything on the stream - in the pipelined tracker 1 ms per frame spent waiting for the previous
+        keyframe's updates"""
+        if self.device.type == "cuda" and isinstance(t, torch.Tensor) and not t.is_cuda:
+            from .droid_backends import to_device_async
+            return to_device_async(t, t.dtype, self.device)
+        return t.to(self.device)
 
     def _remember(self, tstamp, gmap, image):
         if self.keep_features and hasattr(self.video, "remember_features"):
@@ -180,6 +249,6 @@ class MotionFilter:
         gmap = self._features_g(img)
         net, inp = self._context_g(img)
         first = self.video.counter == 0
-        self._append(tstamp, image, ident if first else None, 1.0 if first else None, intrinsics.to(self.device),
+        self._append(tstamp, image, ident if first else None, 1.0 if first else None, self._small_to_device(intrinsics),
                      gmap, net, inp, segments)
         return True

@@ -474,6 +474,81 @@ def test_full_sequence_at_240x808_graphs_against_eager_with_segments_and_removal
           % (float((g["poses"] - e["poses"]).abs().max()), float(e["poses"][:, :3].abs().max())))
 
 
+@pytest.mark.gpu
+def test_encoder_head_convolution_is_deterministic_and_matches_fp32(cuda):
+    """pvo_conv1x1_planes (the encoders' Conv2d(128, C, 1), extractor.py:139,199) against the fp32 convolution of the same 16-bit operands,
+    and the whole fused encoder three times on one frame: identical bits (the vendor library's split-K kernel for this layer was not)."""
+    import torch.nn.functional as F
+    from pvo_amd import droid_backends as db
+    from pvo_amd.modules.extractor import BasicEncoder
+    g = torch.Generator().manual_seed(3)
+    for cout, hw in ((128, (30, 101)), (256, (30, 101)), (64, (7, 9))):
+        x = torch.randn(2, 128, *hw, generator=g).half().to(cuda)
+        w = (torch.randn(cout, 128, 1, 1, generator=g) * 0.1).half().to(cuda)
+        b = torch.randn(cout, generator=g).half().to(cuda)
+        y = db.conv1x1_planes(x, w, b)
+        ref = (F.conv2d(x.float(), w.float()).half().float() + b.float()[None, :, None, None]).half()
+        assert y.shape == ref.shape and float((y.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.float().abs().max()) + 2e-3
+        assert torch.equal(y, db.conv1x1_planes(x, w, b)) and torch.equal(db.conv1x1_planes(x, w, None) , db.conv1x1_planes(x, w))
+    with pytest.raises(db.PvoHipError):
+        db.conv1x1_planes(torch.zeros(1, 96, 4, 4, dtype=torch.float16, device=cuda), torch.zeros(64, 96, dtype=torch.float16, device=cuda))
+    torch.manual_seed(0)
+    for norm, dim in (("instance", 128), ("none", 256)):
+        enc = BasicEncoder(output_dim=dim, norm_fn=norm).to(cuda).half().eval()
+        img = torch.randn(1, 1, 3, 240, 808, generator=g).to(cuda)
+        with torch.no_grad():
+            outs = [enc.forward_inference(img) for _ in range(3)]
+            ref = enc(img.half())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert float((outs[0].float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())
+
+
+@pytest.mark.gpu
+def test_pipelined_tracker_gives_the_same_video_and_trajectory_bit_for_bit(cuda):
+    """Droid(args.pipelined=True) - frame t + 1's encoder graph launched before the second half of keyframe t's frontend update, the frame
+    uploaded on the second stream - against the reference's order, 240 x 808 with segments, a quarter of the keyframe updates ending in
+    rm_keyframe (seeded), a mix of filtered and kept frames: the same operations on the same data in the same dependency order, so
+    keyframes, poses, depths and the filled-in trajectory are IDENTICAL, not close.  Between calls the pipelined video lags (an update is
+    pending after a keyframe), get_traj() completes it.  (Comparing bits needs a run that repeats itself: a third pass in the reference's
+    order pins that too - it did not before the encoders' last layer left the vendor library's split-K kernel, pvo_conv1x1_planes.)"""
+    import random
+    from pvo_amd.droid import Droid, default_args
+    from pvo_amd.synthetic import drifting_texture_stream
+    n = 40
+    frames = list(drifting_texture_stream(n, seed=0))
+    rng = random.Random(5)
+    sched = [rng.random() < 0.25 for _ in range(4 * n)]
+    out = {}
+    for mode in (False, True, "again"):
+        torch.manual_seed(0)
+        droid = Droid(default_args(device=str(cuda), image_size=[240, 808], buffer=64, segm_filter=True, thresh=0.8,
+                                   filter_thresh=0.2026, keyframe_thresh=0.0, pipelined=mode is True))
+        fe = droid.frontend
+        fe.keyframe_decision = lambda k, dist: sched[k]
+        pending = 0
+        for t, image, intr, segm in frames:
+            droid.track(t, image, intrinsics=intr, segments=segm)
+            pending += int(fe.update_pending)
+        mid = torch.from_numpy(droid.get_traj()).clone()                     # (flushes)
+        assert not fe.update_pending
+        kf = int(droid.video.counter)
+        res = dict(kept=droid.video.tstamp[:kf].cpu().clone(), removed=fe.keyframes_removed, poses=droid.video.poses[:kf + 1].cpu().clone(),
+                   disps=droid.video.disps[:kf + 1].cpu().clone(), pending=pending, mid=mid, updates=fe.count)
+        res["traj"] = torch.from_numpy(droid.terminate(iter(frames), need_inv=True))
+        out[mode] = res
+        del droid
+    a, b = out[False], out["again"]
+    for k in ("kept", "poses", "disps", "mid", "traj"):                      # the sequence itself is reproducible bit for bit from run to run
+        assert torch.equal(a[k], b[k]), ("two runs in the reference's order differ", k)
+    a, b = out[False], out[True]
+    assert a["pending"] == 0 and b["pending"] >= 10                          # the pipelined tracker really left updates in flight
+    assert a["updates"] == b["updates"] >= 15 and a["removed"] == b["removed"] >= 3
+    assert torch.equal(a["kept"], b["kept"]) and a["kept"].shape[0] < n - 3  # the filter dropped frames, the same ones
+    for k in ("poses", "disps", "mid", "traj"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.isfinite(a["traj"]).all() and a["traj"].shape == (n, 7)
+
+
 def test_graphed_call_is_a_plain_call_off_the_gpu():
     """CPU tensors, gradients enabled or no arguments: pvo_amd.graphs.GraphedCall just calls through (nothing is captured)"""
     from pvo_amd.graphs import GraphedCall
