@@ -962,11 +962,27 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
             f.write(buf.getvalue())
     # the same sequence through the PIPELINED tracker (Droid(args.pipelined=True): the second half of a keyframe update runs inside the
     # next track() call, behind the next frame's encoder launch): same operations in the same dependency order - the trajectory must be
-    # bit-identical to the plain pass's
+    # bit-identical to the plain pass's.  The two orders alternate, three passes each: the boxes' hosts are shared, a pass half of
+    # whose time is host work moves by 20 % when a neighbour is busy (seen: 95 and 120 frames/s minutes apart on one box) - the MEDIAN
+    # pass of each order is reported, every sample listed.
     import numpy as np
     pipe = _sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE, pipelined=True)
     same = bool(plain.get("trajectory") is not None and pipe.get("trajectory") is not None and
                 np.array_equal(plain["trajectory"], pipe["trajectory"]))
+    plains, pipes = [plain], [pipe]
+    for _ in range(2):
+        plains.append(_sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE))
+        pipes.append(_sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE, pipelined=True))
+        same = same and np.array_equal(plains[0]["trajectory"], plains[-1]["trajectory"]) and np.array_equal(plains[0]["trajectory"], pipes[-1]["trajectory"])
+    e2e = lambda p: p["track_s"] + p.get("terminate_s", 0.0)
+    samples = {"frames_per_s": [round(p["frames"] / p["track_s"], 2) for p in plains],
+               "frames_per_s_end_to_end": [round(p["frames"] / e2e(p), 2) for p in plains],
+               "terminate_s": [round(p.get("terminate_s", 0.0), 3) for p in plains],
+               "pipelined_frames_per_s": [round(p["frames"] / p["track_s"], 2) for p in pipes],
+               "pipelined_frames_per_s_end_to_end": [round(p["frames"] / e2e(p), 2) for p in pipes],
+               "order": "plain, pipelined, plain, pipelined, plain, pipelined"}
+    plain = sorted(plains, key=e2e)[1]
+    pipe = sorted(pipes, key=e2e)[1]
     sp = _Split()
     inst = _sequence_pass(device, n_frames, f_th, k_th, split=sp, removal_rate=REMOVAL_RATE) if instrumented else {"track_s": float("nan")}
     total = sum(sp.t.values())
@@ -986,7 +1002,8 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
                           "frames_per_s_end_to_end": pipe["frames"] / (pipe["track_s"] + pipe.get("terminate_s", 0.0)),
                           "keyframe_updates_per_s": pipe["keyframe_updates"] / pipe["track_s"],
                           "keyframe_updates": pipe["keyframe_updates"], "keyframes_removed": pipe["keyframes_removed"],
-                          "terminate_s": pipe.get("terminate_s"), "trajectory_identical_to_plain_pass": same},
+                          "terminate_s": pipe.get("terminate_s"), "trajectories_identical_in_all_six_passes": bool(same)},
+            "samples": samples,
             "graph_updates_per_s": plain["graph_updates"] / plain["track_s"],
             "ms_per_keyframe_update_all_in": 1e3 * plain["track_s"] / max(plain["keyframe_updates"], 1),
             "ba_windows_sampled": plain.get("ba_windows_sampled"), "terminate_s": plain.get("terminate_s"), "terminate_host_s": plain.get("terminate_host_s"), "backend_graphs": plain.get("backend_graphs"), "counts": {k: plain[k] for k in ("frames", "keyframes", "keyframe_updates", "keyframes_removed", "graph_updates", "edges_at_end", "trajectory_rows")},

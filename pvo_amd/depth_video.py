@@ -72,6 +72,21 @@ class DepthVideo:
         """panoptic ids -> dense per-frame labels in [0, max_segments) with 0 kept as 'no segment'.  The reference keys the
         vote by lay * 1e6 + id (factor_graph.py:259), i.e. by the raw id; raw ids (R + 256 G + 65536 B, category * 1000 +
         instance, ...) do not fit a histogram, and only the grouping inside one frame matters to the vote."""
+        if isinstance(segm, torch.Tensor) and not segm.is_cuda and self.device.type == "cuda" and segm.numel() <= (1 << 16):
+            # a frame's ids arrive on the host (test_vo.py hands over numpy / CPU tensors) and are a few thousand integers: relabelled
+            # THERE and sent up through the pinned staging ring.  On the device torch.unique is ~15 launches and reads its result's size
+            # back - with the blocking upload in front of it 0.9 ms per keyframe of waiting for whatever the stream still held (1.3 ms
+            # in the pipelined tracker: the previous keyframe's graph updates).
+            import numpy as np
+            seg_h = segm.numpy().astype(np.int64, copy=False)
+            u_h, inv_h = np.unique(seg_h, return_inverse=True)
+            shift = 1 if u_h.size and int(u_h[0]) != 0 else 0
+            n = int(u_h.size) + shift
+            if n > self.max_segments:
+                raise ValueError("frame has %d panoptic segments, more than max_segments = %d" % (n, self.max_segments))
+            self._segments_seen = max(self._segments_seen, n)
+            lab = torch.from_numpy((inv_h.reshape(seg_h.shape) + shift).astype(np.int32))
+            return db.to_device_async(lab, torch.int32, self.device)
         seg = torch.as_tensor(segm, device=self.device).to(torch.int64)
         u, inv = torch.unique(seg, return_inverse=True)
         if u.numel() and int(u[0]) != 0:
@@ -130,11 +145,19 @@ class DepthVideo:
     def append(self, tstamp, pose, disp, intrinsics, fmap, net, inp, segm=None, image=None, channels_last=None):
         """store one keyframe; fmap may be [128,h,w] (reference layout) or [h,w,128] (see _fmap_cl)"""
         k = self.counter
-        self.tstamp[k] = tstamp
+        # (a Python number goes in with fill_ on a slice - a kernel argument.  `buf[k] = number` builds a host tensor and copies it with a
+        # BLOCKING transfer queued behind everything on the stream: measured 1.3 ms per keyframe in the pipelined tracker)
+        if isinstance(tstamp, torch.Tensor):
+            self.tstamp[k] = tstamp
+        else:
+            self.tstamp[k:k + 1].fill_(float(tstamp))
         if pose is not None:
             self.poses[k] = pose
         if disp is not None:
-            self.disps[k] = disp
+            if isinstance(disp, torch.Tensor):
+                self.disps[k] = disp
+            else:
+                self.disps[k:k + 1].fill_(float(disp))
         self.intrinsics[k] = intrinsics
         self.fmaps[k] = self._fmap_cl(fmap, channels_last)
         self.nets[k] = net

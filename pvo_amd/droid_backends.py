@@ -1078,6 +1078,16 @@ class PackedWeights:
             setattr(st, n, t.data_ptr())
         self.struct, self.device = st, dev
 
+    def on_one_stream(self):
+        """the same weights with the operator's side chains (aggregation branch, flow encoder) kept on the launch stream: for callers that
+        CAPTURE the operator into a HIP graph - a captured fork becomes a parallel branch the runtime runs on a stream of its own choosing"""
+        one = self.__dict__.get("_one_stream")
+        if one is None:
+            flags = (self.flags | _lib.PVO_OP_SINGLE_STREAM) & ~_lib.PVO_OP_ENC_SIDE_STREAM
+            one = self if flags == self.flags else PackedWeights(self.dtype, self.tensors, flags)
+            self.__dict__["_one_stream"] = one
+        return one
+
     # a derived cache entry: copies / pickles of the owning module rebuild it (ctypes structs with pointers cannot be copied)
     def __deepcopy__(self, memo):
         return None
@@ -1376,6 +1386,23 @@ def side_stream(device):
         with torch.cuda.device(idx):
             check(_lib.load().pvo_side_stream(ctypes.byref(out)), "side_stream")
         st = _side_streams[idx] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", idx))
+    return st
+
+
+_upload_streams = {}
+
+
+def upload_stream(device):
+    """ONE stream per device for asynchronous host-to-device frame uploads (the pipelined tracker), created once per process behind the
+    library's second stream.  The runtime hands a new stream the hardware queue with the fewest streams on it at that moment: a stream
+    created per tracker landed on a different queue in every tracker of a process - the first pipelined pass of bench.py's sequence leg
+    ran at 147 frames/s, the next two at 103 and 106 with their upload stream on a queue the operator's kernels were using."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _upload_streams.get(idx)
+    if st is None:
+        side_stream(device)
+        st = _upload_streams[idx] = torch.cuda.Stream(torch.device("cuda", idx))
     return st
 
 

@@ -294,12 +294,14 @@ class DynamicUpdateModule(nn.Module):
         both = db.to_device_async(ptr + idx, torch.int32, ii.device)
         return both[:len(ptr)], both[len(ptr):], len(frames)
 
-    def _forward_fused(self, net, inp, corr, flow, ii, agg_segments, static_terms, dt, out_dim):
+    def _forward_fused(self, net, inp, corr, flow, ii, agg_segments, static_terms, dt, out_dim, single_stream=False):
         """16-bit inference: the whole operator is ONE call into libpvo_hip (pvo_update_operator, update_exec.hip)"""
         from .. import droid_backends as db
         E, _, ht, wd = net.shape
         cl = lambda t: t.to(dt).contiguous(memory_format=torch.channels_last)
         pw = self.packed_weights(dt)
+        if single_stream:
+            pw = pw.on_one_stream()
         kw = {}
         if isinstance(corr, PoolLookup):
             kw["pool"], kw["coords"] = (corr.levels, corr.slots, corr.num_slots), corr.coords
@@ -325,7 +327,7 @@ class DynamicUpdateModule(nn.Module):
         return net, delta, weight, eta.view(batch, -1, ht, wd), upmask, delta_m
 
     def forward(self, net, inp, corr, flow=None, ii=None, jj=None, use_aff_bri=False, raw_mask=None, segments=None,
-                agg_segments=None, static_terms=None):
+                agg_segments=None, static_terms=None, single_stream=False):
         """DynamicUpdateModule.forward (droid_net.py:256-314).  agg_segments (optional): (seg_ptr int32 [K+1], seg_idx
         int32 [E], K), the CSR of edges grouped by source frame; static_terms (optional): `self.static_terms(inp)` cached
         by the caller; corr may be a `PoolLookup` (16-bit inference only)."""
@@ -347,7 +349,7 @@ class DynamicUpdateModule(nn.Module):
         fused = (net.is_cuda and not self.training and not torch.is_grad_enabled() and self.fused_gru
                  and dt in (torch.float16, torch.bfloat16) and not use_aff_bri)
         if fused:
-            return self._forward_fused(net, inp, corr, flow, ii, agg_segments, static_terms, dt, out_dim)
+            return self._forward_fused(net, inp, corr, flow, ii, agg_segments, static_terms, dt, out_dim, single_stream)
         if pooled:
             raise RuntimeError("a PoolLookup needs the 16-bit inference path")
         if pdt != torch.float32 and not torch.is_autocast_enabled("cuda"):

@@ -71,7 +71,7 @@ class MotionFilter:
         self._static = None                # conv(W[:, inp], inp) of the reference keyframe's context: constant until the next keyframe
         self._pending = None               # a frame between begin() and finish()
         self.overlap_upload = False        # asynchronous upload through pinned staging (Droid sets it in pipelined mode)
-        self._up_stream, self._stage, self._stage_k = None, [None, None], 0
+        self._up_stream, self._stage, self._stage_k, self._stage_used = None, [None, None], 0, None
         self._mag_host = self._mag_ready = None
 
     def _upload(self, image):
@@ -85,26 +85,30 @@ class MotionFilter:
             # memmove, no tensor operation: see above) and goes up asynchronously on an upload stream; the launch stream waits on the device.
             import ctypes
             if self._up_stream is None:
-                from .droid_backends import side_stream
-                side_stream(self.device)                                   # (created first: the operator's two streams keep their queues)
-                self._up_stream = torch.cuda.Stream(self.device)
+                from .droid_backends import upload_stream
+                self._up_stream = upload_stream(self.device)               # (one per process: see there)
             k = self._stage_k = self._stage_k ^ 1
             st = self._stage[k]
             if st is None or st[0].shape != image.shape or st[0].dtype != image.dtype:
-                st = self._stage[k] = (torch.empty(image.shape, dtype=image.dtype).pin_memory(), torch.cuda.Event())
+                # two (pinned host buffer, device buffer) pairs, used alternately and kept: no allocation per frame, and no tensor that one
+                # stream allocates and another reads (the caching allocator would have to track it per use)
+                st = self._stage[k] = (torch.empty(image.shape, dtype=image.dtype).pin_memory(),
+                                       torch.empty(image.shape, dtype=image.dtype, device=self.device), torch.cuda.Event(), torch.cuda.Event())
+                st[3].record(torch.cuda.current_stream(self.device))
             else:
-                st[1].synchronize()                                        # (the copy out of this buffer two frames ago)
+                st[2].synchronize()                                        # (the copy out of this host buffer two frames ago)
             if image.is_contiguous():
                 ctypes.memmove(st[0].data_ptr(), image.data_ptr(), image.numel() * image.element_size())
             else:
                 st[0].copy_(image)
             cur = torch.cuda.current_stream(self.device)
+            self._up_stream.wait_event(st[3])                              # (the launch stream's last read of this device buffer, two frames ago)
             with torch.cuda.stream(self._up_stream):
-                img = st[0].to(self.device, non_blocking=True)
-                st[1].record(self._up_stream)
+                st[1].copy_(st[0], non_blocking=True)
+                st[2].record(self._up_stream)
             cur.wait_stream(self._up_stream)
-            img.record_stream(cur)
-            return img
+            self._stage_used = st
+            return st[1]
         return upload_frame(image, self.device)
 
     def _normalise_dev(self, image_dev):
@@ -130,6 +134,11 @@ class MotionFilter:
             half = lambda t: t if t.dtype in (torch.float16, torch.bfloat16) or self.device.type != "cuda" else t.half()
             corr = CorrBlock(half(fmap_ref[None]), half(gmap[None]))(self._coords0)
             kw = {"static_terms": tuple(static)} if static else {}
+            if self.device.type == "cuda" and hasattr(self.update, "packed_weights"):
+                # (this runs inside a captured graph: the operator's side chains stay on the launch stream - one edge leaves nothing to
+                # overlap, and a captured fork is a parallel branch on a stream the runtime picks per graph instance: trackers of one
+                # process then ran 100 or 138 frames/s depending on the hardware queue that stream got)
+                kw["single_stream"] = True
             _, delta, _, _ = self.update(net_ref[None], inp_ref[None], corr, **kw)
             return gmap, delta[..., 0:2].float().norm(dim=-1).mean().reshape(1)
 
@@ -205,6 +214,18 @@ class MotionFilter:
         """second half: read the motion test's scalar; a frame that moved enough gets its context features and joins the video"""
         tstamp, image, img, intrinsics, segments, gmap, mag = self._pending
         self._pending = None
+        try:
+            return self._finish(tstamp, image, img, intrinsics, segments, gmap, mag)
+        finally:
+            self._release_stage()
+
+    def _release_stage(self):
+        """the launch stream has issued its last read of the frame's device buffer (asynchronous upload): the next upload into it waits for this"""
+        if self._stage_used is not None:
+            self._stage_used[3].record(torch.cuda.current_stream(self.device))
+            self._stage_used = None
+
+    def _finish(self, tstamp, image, img, intrinsics, segments, gmap, mag):
         if gmap is None:                                                       # the first frame: always a keyframe
             gmap = self._features_g(img)                                       # [1,128,h,w]
             self._remember(tstamp, gmap, image)
@@ -251,4 +272,5 @@ class MotionFilter:
         first = self.video.counter == 0
         self._append(tstamp, image, ident if first else None, 1.0 if first else None, self._small_to_device(intrinsics),
                      gmap, net, inp, segments)
+        self._release_stage()
         return True

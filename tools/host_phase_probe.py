@@ -46,11 +46,14 @@ for cls, names in ((fgm.FactorGraph, ("rm_factors", "add_proximity_factors", "ad
 wrap(torch.Tensor, "item", "Tensor.item (wait)")
 wrap(torch.Tensor, "cpu", "Tensor.cpu (wait)")
 wrap(torch.cuda.Event, "synchronize", "Event.synchronize (wait)")
+if os.environ.get("PROBE_TENSOR_OPS"):
+    for n in ("__setitem__", "copy_", "to", "clone", "index_select", "mean", "zero_"):
+        wrap(torch.Tensor, n, "Tensor.%s" % n)
 from pvo_amd.graphs import GraphedCall
 wrap(GraphedCall, "__call__", "GraphedCall")
 
 dev = torch.device("cuda:0")
-for rep in range(2):
+for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
     torch.manual_seed(0)
     droid = Droid(default_args(device=str(dev), image_size=[240, 808], buffer=n_frames + 40, segm_filter=True, thresh=0.8, filter_thresh=0.2026, keyframe_thresh=0.0, pipelined=pipelined))
     import random
