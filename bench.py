@@ -930,7 +930,7 @@ def _sequence_pass(device, n_frames, filter_thresh, keyframe_thresh, split=None,
     return out
 
 
-def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
+def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None, reps=3, order="both"):
     """The run the metric is named after (BASELINE.json configs[1] "full sequence"; evaluation_scripts/test_vo.py:88-164): a seeded
     synthetic 240 x 808 stream with panoptic segments through Droid.track per frame and Droid.terminate (backend x2 + filler), random-
     init weights.  No checkpoint exists here, so a random network decides which frames become keyframes.  To keep the run REPRODUCIBLE
@@ -950,7 +950,7 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
         import cProfile, io, pstats
         pr = cProfile.Profile()
         pr.enable()
-    plain = _sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE)
+    plain = _sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE, pipelined=(order == "pipelined"))   # (order != "both": profiling runs, one order only)
     if cprofile:
         pr.disable()
         buf = io.StringIO()
@@ -966,11 +966,11 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
     # whose time is host work moves by 20 % when a neighbour is busy (seen: 95 and 120 frames/s minutes apart on one box) - the MEDIAN
     # pass of each order is reported, every sample listed.
     import numpy as np
-    pipe = _sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE, pipelined=True)
+    pipe = _sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE, pipelined=True) if order == "both" else plain
     same = bool(plain.get("trajectory") is not None and pipe.get("trajectory") is not None and
                 np.array_equal(plain["trajectory"], pipe["trajectory"]))
     plains, pipes = [plain], [pipe]
-    for _ in range(2):
+    for _ in range(reps - 1 if order == "both" else 0):
         plains.append(_sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE))
         pipes.append(_sequence_pass(device, n_frames, f_th, k_th, removal_rate=REMOVAL_RATE, pipelined=True))
         same = same and np.array_equal(plains[0]["trajectory"], plains[-1]["trajectory"]) and np.array_equal(plains[0]["trajectory"], pipes[-1]["trajectory"])
@@ -981,8 +981,8 @@ def sequence_leg(device, n_frames=160, instrumented=True, cprofile=None):
                "pipelined_frames_per_s": [round(p["frames"] / p["track_s"], 2) for p in pipes],
                "pipelined_frames_per_s_end_to_end": [round(p["frames"] / e2e(p), 2) for p in pipes],
                "order": "plain, pipelined, plain, pipelined, plain, pipelined"}
-    plain = sorted(plains, key=e2e)[1]
-    pipe = sorted(pipes, key=e2e)[1]
+    plain = sorted(plains, key=e2e)[len(plains) // 2]
+    pipe = sorted(pipes, key=e2e)[len(pipes) // 2]
     sp = _Split()
     inst = _sequence_pass(device, n_frames, f_th, k_th, split=sp, removal_rate=REMOVAL_RATE) if instrumented else {"track_s": float("nan")}
     total = sum(sp.t.values())
@@ -1057,6 +1057,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, ~1 min); "
                     "the committed profile of the same kernel source is reported instead")
     ap.add_argument("--no-extras", action="store_true", help="skip the S-A workload and the edge-sharded leg")
+    ap.add_argument("--sequence-reps", type=int, default=3, help="passes per order of the full-sequence leg (the median pass is reported)")
+    ap.add_argument("--sequence-order", choices=("both", "plain", "pipelined"), default="both",
+                    help="profiling runs: trace one order of the tracker only (with --sequence-reps 1: calibration pass + one pass)")
     ap.add_argument("--sequence-only", action="store_true", help="run only the full-sequence leg (Droid.track / terminate on the synthetic "
                     "240x808 stream) and print its object: the command tools/sequence_timeline.sh profiles")
     ap.add_argument("--sequence-frames", type=int, default=160)
@@ -1095,7 +1098,8 @@ def main():
     from pvo_amd import droid_backends as db
     _lib.load()                                         # fail loudly if the HIP library is missing
     if args.sequence_only:
-        emit({"sequence": sequence_leg(device, args.sequence_frames, instrumented=not args.sequence_plain, cprofile=args.sequence_cprofile)})
+        emit({"sequence": sequence_leg(device, args.sequence_frames, instrumented=not args.sequence_plain, cprofile=args.sequence_cprofile,
+                                       reps=args.sequence_reps, order=args.sequence_order)})
         return
     video, graph = make_window(device, seed=rank)
     if not graph._fused_ok():

@@ -40,6 +40,7 @@ class Droid:
                                       frontend_nms=args.frontend_nms, keyframe_thresh=args.keyframe_thresh,
                                       frontend_window=args.frontend_window, frontend_thresh=args.frontend_thresh,
                                       frontend_radius=args.frontend_radius)
+        self.filterx.before_context = self.frontend.keyframe_ahead
         self.backend = DroidBackend(self.net, self.video, args)
         self.traj_filler = PoseTrajectoryFiller(self.net, self.video, args.device)
 
@@ -85,6 +86,7 @@ class Droid:
     def terminate(self, stream=None, need_inv=True):
         """two global BA passes, then fill in every frame's pose; returns [num_frames, 7] (t, q) (droid.py:77-98)"""
         self.flush()
+        self.filterx.before_context = None          # (a bound method of the frontend: it would keep the frontend's volumes alive)
         del self.frontend
         self._release_cached_memory()
         self.backend(7)

@@ -540,6 +540,25 @@ class FactorGraph:
         both = to_device_async(ptr + idx, torch.int32, self.device)
         return both[:len(ptr)], both[len(ptr):], n
 
+    def prefetch_proximity(self, t0, t1, t, beta):
+        """launch the distance matrix add_proximity_factors(t0, t1, beta=beta) will read once the video holds t frames, and its copy to a
+        pinned host buffer.  The frontend calls this as soon as the motion filter knows the frame becomes a keyframe - BEFORE the context
+        encoder and the keyframe's bookkeeping are queued: the distances only read poses, depths and intrinsics[0], which the previous
+        update left final (the new frame's pose / depth seed included), so the same kernel on the same inputs gives the same bits - but
+        the host's wait for them ends in front of ~0.6 ms of device work, which then runs while the host selects and adds the edges."""
+        if self.device.type != "cuda" or t - t0 <= 0 or t - t1 <= 0:
+            return
+        import numpy as np
+        nj = t - t1
+        ii, jj = np.repeat(np.arange(t0, t), nj), np.tile(np.arange(t1, t), t - t0)
+        d = self.video.distance(ii, jj, beta=beta).float().reshape(-1)
+        st = self.__dict__.get("_prox_stage")
+        if st is None or st[0].numel() < d.numel():
+            st = self.__dict__["_prox_stage"] = (torch.empty(max(4096, d.numel()), dtype=torch.float32).pin_memory(), torch.cuda.Event())
+        st[0][:d.numel()].copy_(d, non_blocking=True)
+        st[1].record()
+        self._prox_prefetch = {"key": (t0, t1, t, float(beta)), "host": st[0], "ready": st[1]}
+
     def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
         """add edges chosen by frame distance with non-maximum suppression (factor_graph.py:372-429).
         The distance matrix comes back from the device ONCE (the reference reads it element by element with
@@ -554,7 +573,12 @@ class FactorGraph:
         # the selection below is the reference's greedy loop on a [ni, nj] array: the suppression of everything near an existing
         # edge is one array operation per window offset (it was a Python loop per edge and offset: 0.57 s of a 1.75 s sequence
         # with 119 keyframes, bench.py `sequence`), the greedy pass visits only the candidates under the threshold
-        D = self.video.distance(ii, jj, beta=beta).float().cpu().numpy().astype(np.float64).reshape(ni, nj)
+        pf = self.__dict__.pop("_prox_prefetch", None)
+        if pf is not None and pf["key"] == (t0, t1, t, float(beta)):
+            pf["ready"].synchronize()                              # (launched by prefetch_proximity, in front of the keyframe's context encoder)
+            D = pf["host"][:ni * nj].numpy().astype(np.float64).reshape(ni, nj)
+        else:
+            D = self.video.distance(ii, jj, beta=beta).float().cpu().numpy().astype(np.float64).reshape(ni, nj)
         I = np.arange(t0, t)[:, None]
         J = np.arange(t1, t)[None, :]
         D = np.where((I - rad < J) | ~(D <= 100), np.inf, D)         # (~(D <= 100): values above 100 and NaN drop out)

@@ -27,6 +27,7 @@ class DroidFrontend:
         self.keyframe_decision = None
         self.keyframes_removed = 0
         self.update_pending = False                 # a keyframe update whose second half has not run yet (pipelined Droid)
+        self.prefetch = True                        # launch an update's proximity distances ahead of the keyframe's context encoder
         self._dist = self._dist_host = self._dist_ready = None
 
     def _update(self):
@@ -116,3 +117,10 @@ class DroidFrontend:
     def finish(self):
         if self.update_pending:
             self._update_finish()
+
+    def keyframe_ahead(self):
+        """the motion filter has decided that the frame in its hands becomes a keyframe (MotionFilter.before_context): if a keyframe update
+        will follow its append, launch that update's proximity distances now, in front of the context encoder (prefetch_proximity)"""
+        if self.is_initialized and not self.update_pending and self.t1 == self.video.counter and self.prefetch:
+            t1 = self.t1 + 1
+            self.graph.prefetch_proximity(t1 - 5, max(t1 - self.frontend_window, 0), self.video.counter + 1, self.beta)

@@ -70,6 +70,7 @@ class MotionFilter:
                                                                    # (fresh tensors per keyframe), read-only until the next one replaces them
         self._static = None                # conv(W[:, inp], inp) of the reference keyframe's context: constant until the next keyframe
         self._pending = None               # a frame between begin() and finish()
+        self.before_context = None         # called when a frame is known to become a keyframe, before anything is queued for it
         self.overlap_upload = False        # asynchronous upload through pinned staging (Droid sets it in pipelined mode)
         self._up_stream, self._stage, self._stage_k, self._stage_used = None, [None, None], 0, None
         self._mag_host = self._mag_ready = None
@@ -242,6 +243,8 @@ class MotionFilter:
             moved = mag.item()
         if moved > self.thresh:
             self.count = 0
+            if self.before_context is not None:
+                self.before_context()                                          # (Droid: DroidFrontend.keyframe_ahead)
             net, inp = self._context_g(img)
             self._new_reference(gmap, net, inp)
             self._append(tstamp, image, None, None, self._small_to_device(intrinsics), gmap, net, inp, segments)

@@ -519,13 +519,20 @@ def test_pipelined_tracker_gives_the_same_video_and_trajectory_bit_for_bit(cuda)
     rng = random.Random(5)
     sched = [rng.random() < 0.25 for _ in range(4 * n)]
     out = {}
-    for mode in (False, True, "again"):
+    for mode in (False, True, "again", "no prefetch"):
         torch.manual_seed(0)
         droid = Droid(default_args(device=str(cuda), image_size=[240, 808], buffer=64, segm_filter=True, thresh=0.8,
                                    filter_thresh=0.2026, keyframe_thresh=0.0, pipelined=mode is True))
         fe = droid.frontend
         fe.keyframe_decision = lambda k, dist: sched[k]
-        pending = 0
+        fe.prefetch = mode != "no prefetch"          # (the proximity distances launched ahead of the context encoder, or where the reference computes them)
+        pending, used, pf = 0, 0, fe.graph.prefetch_proximity
+
+        def spy(*a, **kw):
+            nonlocal used
+            used += 1
+            return pf(*a, **kw)
+        fe.graph.prefetch_proximity = spy
         for t, image, intr, segm in frames:
             droid.track(t, image, intrinsics=intr, segments=segm)
             pending += int(fe.update_pending)
@@ -533,13 +540,17 @@ def test_pipelined_tracker_gives_the_same_video_and_trajectory_bit_for_bit(cuda)
         assert not fe.update_pending
         kf = int(droid.video.counter)
         res = dict(kept=droid.video.tstamp[:kf].cpu().clone(), removed=fe.keyframes_removed, poses=droid.video.poses[:kf + 1].cpu().clone(),
-                   disps=droid.video.disps[:kf + 1].cpu().clone(), pending=pending, mid=mid, updates=fe.count)
+                   disps=droid.video.disps[:kf + 1].cpu().clone(), pending=pending, mid=mid, updates=fe.count, prefetched=used)
         res["traj"] = torch.from_numpy(droid.terminate(iter(frames), need_inv=True))
         out[mode] = res
         del droid
     a, b = out[False], out["again"]
     for k in ("kept", "poses", "disps", "mid", "traj"):                      # the sequence itself is reproducible bit for bit from run to run
         assert torch.equal(a[k], b[k]), ("two runs in the reference's order differ", k)
+    b = out["no prefetch"]
+    assert b["prefetched"] == 0 and a["prefetched"] >= a["updates"] - 2      # every keyframe update but the first read prefetched distances
+    for k in ("kept", "poses", "disps", "mid", "traj"):
+        assert torch.equal(a[k], b[k]), ("prefetched proximity distances change the result", k)
     a, b = out[False], out[True]
     assert a["pending"] == 0 and b["pending"] >= 10                          # the pipelined tracker really left updates in flight
     assert a["updates"] == b["updates"] >= 15 and a["removed"] == b["removed"] >= 3
