@@ -13,7 +13,8 @@ import pvo_amd.motion_filter as mfm
 import pvo_amd.frontend as fem
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-pipelined = len(sys.argv) > 2 and sys.argv[2] == "pipelined"
+pipelined = "pipelined" in sys.argv[2:]
+with_terminate = "terminate" in sys.argv[2:]
 T = collections.defaultdict(list)
 stack = []
 
@@ -43,6 +44,13 @@ for cls, names in ((fgm.FactorGraph, ("rm_factors", "add_proximity_factors", "ad
     for n in names:
         if hasattr(cls, n):
             wrap(cls, n)
+import pvo_amd.backend as bem, pvo_amd.trajectory_filler as tfm, pvo_amd.modules.corr as cm
+for cls, names in ((bem.DroidBackend, ("__call__", "_connect_all", "_volumes_fit", "_graph")), (fgm.FactorGraph, ("update_lowmem", "_update_fused", "clear_edges", "_filter_repeated")),
+                   (tfm.PoseTrajectoryFiller, ("__call__", "_fill")), (dvm.DepthVideo, ("normalize",)),
+                   (cm.CorrVolumePool, ("add", "reserve", "put", "keep", "__init__"))):
+    for n in names:
+        if hasattr(cls, n):
+            wrap(cls, n)
 wrap(torch.Tensor, "item", "Tensor.item (wait)")
 wrap(torch.Tensor, "cpu", "Tensor.cpu (wait)")
 wrap(torch.cuda.Event, "synchronize", "Event.synchronize (wait)")
@@ -69,7 +77,20 @@ for rep in range(int(os.environ.get("PROBE_REPS", "3"))):
             droid.track(t, image, intrinsics=intr, segments=segm)
         droid.flush()
     torch.cuda.synchronize(); total = time.perf_counter() - t0
+    if with_terminate:
+        track_T = {k: list(v) for k, v in T.items()}
+        for k in list(T):
+            T[k].clear()
+        t0 = time.perf_counter()
+        droid.terminate(iter(frames), need_inv=True)
+        torch.cuda.synchronize(); total_term = time.perf_counter() - t0
     del droid
+if with_terminate:
+    print("terminate: %.3f s; host time by call" % total_term)
+    for k, v in sorted(T.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+        if v:
+            print("%-44s %6d %10.1f %10.1f %12.1f" % (k, len(v), 1e3 * sum(x[0] for x in v), 1e3 * sum(x[1] for x in v), 1e6 * sum(x[1] for x in v) / len(v)))
+    T = track_T
 print("pipelined" if pipelined else "reference order"); print("tracking %d frames: %.3f s; host time by call (sum over the pass; exclusive = without the wrapped calls inside)" % (n_frames, total))
 print("%-44s %6s %10s %10s %12s" % ("call", "n", "incl ms", "excl ms", "excl us/call"))
 for k, v in sorted(T.items(), key=lambda kv: -sum(x[1] for x in kv[1])):

@@ -84,6 +84,8 @@ def parse_args(argv=None):
     p.add_argument("--segm_filter", type=bool, default=False)
     p.add_argument("--thresh", type=float, default=0.8)
     p.add_argument("--out", default="shared_data/traj")
+    p.add_argument("--pipelined", action="store_true", help="MI355X build: run the second half of a keyframe update inside the next track() call "
+                   "(same trajectory bit for bit; pvo_amd/droid.py)")
     return p.parse_args(argv)
 
 
