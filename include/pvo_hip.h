@@ -425,6 +425,17 @@ size_t pvo_graph_update_workspace_bytes(int E, int K, int R, int H, int W, int m
  * an extra stream can end up sharing a queue with one of the two that must overlap.  Ordering against the launch
  * stream is the caller's business (events).  Writes the hipStream_t to *stream_out. */
 int pvo_side_stream(void** stream_out);
+
+/* HOST function (no device work, any thread): the greedy proximity-edge selection of FactorGraph.add_proximity_factors
+ * (VO_Module/droid_slam/factor_graph.py:372-429) from a distance matrix.  dist [ni][nj] f32: distance of frames (t0 + a, t1 + b), both
+ * ranges ending at the video's counter (t0 + ni == t1 + nj).  Out of the candidates: cells with (i - rad < j) or !(d <= 100), and the
+ * diamond |di| + |dj| <= min(|i - j| - 2, nms) around every existing edge (have_i, have_j)[n_have] with |i - j| > 2.  Taken, each in both
+ * directions: the temporal neighbours i < j <= i + rad first, then the remaining cells in ascending distance (ties by index) while
+ * <= thresh, every accepted edge suppressing its own diamond.  out_i / out_j [max_out] receive *n_out edges (PVO_EWORKSPACE if they do
+ * not fit: 2 * (ni * rad + ni * nj) always does). */
+int pvo_proximity_select(const float* dist, int ni, int nj, int t0, int t1, int rad, int nms, double thresh,
+                         const long long* have_i, const long long* have_j, int n_have,
+                         long long* out_i, long long* out_j, int max_out, int* n_out);
 /* Measurement hook: HIP events recorded on the launch stream around one stage of the following pvo_graph_update /
  * pvo_update_operator calls (at most `capacity` occurrences), so a benchmark can read a kernel's duration inside its timed
  * steps.  pvo_probe_read waits for the recorded events, writes their elapsed times in milliseconds to HOST memory,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pvo_proj_transform": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pvo_proj_transform_vjp": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pvo_side_stream": (_i, [_c.POINTER(_vp)]),
+    "pvo_proximity_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _c.c_double, _vp, _vp, _i, _vp, _vp, _i, _c.POINTER(_i)]),
     "pvo_probe_arm": (_i, [_i, _i]),
     "pvo_probe_arm_every": (_i, [_i, _i, _i]),
     "pvo_probe_read": (_i, [_vp, _i]),

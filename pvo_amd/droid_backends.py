@@ -1227,6 +1227,22 @@ def bias_norm_act(x, bias=None, residual=None, norm=False, eps=1e-5, relu_inner=
     return y
 
 
+def proximity_select(dist, t0, t1, rad, nms, thresh, have_i, have_j):
+    """the greedy proximity-edge selection (pvo_proximity_select, a HOST function of the library): dist = float32 numpy array [ni, nj] of
+    frame distances (frames t0.., t1..), have_i / have_j = int64 numpy arrays of the existing edges -> (ii, jj) Python lists"""
+    import numpy as np
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    ni, nj = dist.shape
+    have_i = np.ascontiguousarray(have_i, dtype=np.int64); have_j = np.ascontiguousarray(have_j, dtype=np.int64)
+    cap = 2 * (ni * rad + ni * nj) + 2
+    out = np.empty((2, cap), dtype=np.int64)
+    n = ctypes.c_int(0)
+    check(_lib.load().pvo_proximity_select(dist.ctypes.data, ni, nj, int(t0), int(t1), int(rad), int(nms), float(thresh),
+                                           have_i.ctypes.data if have_i.size else None, have_j.ctypes.data if have_j.size else None, int(have_i.size),
+                                           out[0].ctypes.data, out[1].ctypes.data, cap, ctypes.byref(n)), "proximity_select")
+    return out[0, :n.value].tolist(), out[1, :n.value].tolist()
+
+
 def conv1x1_planes_supported(cin, cout):
     return cin % 128 == 0 and cout % 64 == 0
 

@@ -114,6 +114,7 @@ class FactorGraph:
         self._inp = None
         self._corr_ready = None     # event: the side-stream build of the most recently added edges (see add_factors)
         self.build_on_side_stream = True
+        self.native_select = True    # proximity-edge selection in the library's host code (False: the numpy form below, which tests compare it with)
         self._rows = {}             # per-edge state tensors as rows of fixed-capacity buffers (_EdgeRows)
         self._segm = None
         self.corr = self.net = self.inp = self.segm = None
@@ -576,9 +577,19 @@ class FactorGraph:
         pf = self.__dict__.pop("_prox_prefetch", None)
         if pf is not None and pf["key"] == (t0, t1, t, float(beta)):
             pf["ready"].synchronize()                              # (launched by prefetch_proximity, in front of the keyframe's context encoder)
-            D = pf["host"][:ni * nj].numpy().astype(np.float64).reshape(ni, nj)
+            D32 = pf["host"][:ni * nj].numpy().reshape(ni, nj)
         else:
-            D = self.video.distance(ii, jj, beta=beta).float().cpu().numpy().astype(np.float64).reshape(ni, nj)
+            D32 = self.video.distance(ii, jj, beta=beta).float().cpu().numpy().reshape(ni, nj)
+        if self.native_select:
+            # the selection as one call into the library's host code (pvo_proximity_select): the device has nothing queued while it runs
+            from . import droid_backends as db
+            have_i = np.array(list(self._ii_h) + self.ii_bad.tolist() + list(self._ii_inac_h), dtype=np.int64)
+            have_j = np.array(list(self._jj_h) + self.jj_bad.tolist() + list(self._jj_inac_h), dtype=np.int64)
+            ei, ej = db.proximity_select(D32, t0, t1, rad, nms, thresh, have_i, have_j)
+            if ei:
+                self.add_factors(ei, ej, remove)
+            return
+        D = D32.astype(np.float64)
         I = np.arange(t0, t)[:, None]
         J = np.arange(t1, t)[None, :]
         D = np.where((I - rad < J) | ~(D <= 100), np.inf, D)         # (~(D <= 100): values above 100 and NaN drop out)

@@ -276,6 +276,7 @@ def test_proximity_factor_selection_matches_reference():
     for n in range(3):
         t0, t1, rad, nms, thresh = [float(x) for x in z["args_%d" % n]]
         fg = FactorGraph(v, None, device="cpu")
+        fg.native_select = bool(n != 1)                  # (case 1 through the numpy form, 0 and 2 through pvo_proximity_select)
         fg._ii_h, fg._jj_h = list(have[0]), list(have[1])
         fg.ii, fg.jj = torch.tensor(have[0]), torch.tensor(have[1])
         fg.ii_bad, fg.jj_bad = torch.tensor(bad[0]), torch.tensor(bad[1])
@@ -322,10 +323,12 @@ def _greedy_selection_loops(t, t0, t1, rad, nms, thresh, d, have):
     return es
 
 
+@pytest.mark.parametrize("native", (True, False))
 @pytest.mark.parametrize("seed", range(6))
-def test_proximity_factor_selection_array_form_equals_the_loops(seed):
+def test_proximity_factor_selection_array_form_equals_the_loops(seed, native):
     """random distance matrices (ties, values above 100, windows of the frontend's and the backend's shapes) and random existing
-    edges: the array formulation selects the same edges in the same order as the reference's loops"""
+    edges: the library's host function (pvo_proximity_select, the default) and the numpy array formulation both select the same edges in
+    the same order as the reference's loops"""
     import numpy as np
     from pvo_amd.factor_graph import FactorGraph
     g = np.random.default_rng(seed)
@@ -347,6 +350,8 @@ def test_proximity_factor_selection_array_form_equals_the_loops(seed):
     dmat = torch.from_numpy(full)
     v.distance = lambda ii, jj, beta=0.3: dmat[torch.as_tensor(ii).long(), torch.as_tensor(jj).long()].clone()
     fg = FactorGraph(v, None, device="cpu")
+    assert fg.native_select
+    fg.native_select = native
     a, b, c = have[:third], have[third:2 * third], have[2 * third:]
     fg._ii_h, fg._jj_h = [e[0] for e in a], [e[1] for e in a]
     fg.ii_bad, fg.jj_bad = torch.tensor([e[0] for e in b], dtype=torch.long), torch.tensor([e[1] for e in b], dtype=torch.long)
