@@ -19,6 +19,7 @@ class PoseTrajectoryFiller:
         self.MEAN = torch.as_tensor([0.485, 0.456, 0.406], device=self.device)[:, None, None]
         self.STDV = torch.as_tensor([0.229, 0.224, 0.225], device=self.device)[:, None, None]
         self.reuse_features = True
+        self._ts_host = None
         from .motion_filter import _weights_guard
         self._one = GraphedCall(self._features_one, name="fnet (filler)", guard=_weights_guard(self.fnet))
 
@@ -45,17 +46,37 @@ class PoseTrajectoryFiller:
 
     def _fill(self, tstamps, images, intrinsics):
         v = self.video
-        tt = torch.as_tensor(tstamps, device=self.device, dtype=torch.float)
-        if self.device.type != "cuda" or getattr(self.video, "images", True) is not None:
-            images = torch.stack(images, 0)                # (on the GPU only a video that stores its frames needs them as one tensor)
-        intrinsics = torch.stack(intrinsics, 0).to(self.device)
         N, M = v.counter, len(tstamps)
+        on_gpu = self.device.type == "cuda"
+        if not on_gpu or getattr(self.video, "images", True) is not None:
+            images = torch.stack(images, 0)                # (on the GPU only a video that stores its frames needs them as one tensor)
+        if on_gpu:
+            # Nothing in a chunk reads the device back: the keyframes' time stamps come to the host ONCE per call (`_ts_host`), each
+            # frame is bracketed there, and time stamps / indices / intrinsics go up through the pinned staging ring.  A `.tolist()` of
+            # device indices (or a blocking upload) per chunk made the host wait for the previous chunk's six updates before it began
+            # to prepare the next: the device idled through every chunk's bookkeeping (13 ms per chunk for 6 ms of device work).
+            import numpy as np
+            from .droid_backends import to_device_async
+            ts_h = self._ts_host if self._ts_host is not None and len(self._ts_host) == N else v.tstamp[:N].cpu().numpy()
+            tt_h = np.asarray([float(t) for t in tstamps], dtype=np.float32)
+            t0_h = np.clip((ts_h[None, :] <= tt_h[:, None]).sum(axis=1) - 1, 0, None)
+            t1_h = np.where(t0_h < N - 1, t0_h + 1, t0_h)
+            tt = to_device_async(torch.from_numpy(tt_h), torch.float, self.device)
+            both = to_device_async(torch.from_numpy(np.concatenate([t0_h, t1_h]).astype(np.int64)), torch.long, self.device)
+            t0, t1 = both[:M], both[M:]
+            t0_e, t1_e = t0_h.tolist(), t1_h.tolist()                            # the edges' endpoints as host lists: add_factors reads nothing back
+            intrinsics = to_device_async(torch.stack(intrinsics, 0), torch.float, self.device)
+        else:
+            tt = torch.as_tensor(tstamps, device=self.device, dtype=torch.float)
+            intrinsics = torch.stack(intrinsics, 0).to(self.device)
         ts = v.tstamp[:N]
         Ps = SE3(v.poses[:N])
 
         # bracket each time stamp by keyframes t0 <= t < t1 and interpolate with constant twist
-        t0 = ((ts[None, :] <= tt[:, None]).sum(dim=1) - 1).clamp(min=0)
-        t1 = torch.where(t0 < N - 1, t0 + 1, t0)
+        if not on_gpu:
+            t0 = ((ts[None, :] <= tt[:, None]).sum(dim=1) - 1).clamp(min=0)
+            t1 = torch.where(t0 < N - 1, t0 + 1, t0)
+            t0_e, t1_e = t0, t1
         dt = ts[t1] - ts[t0] + 1e-3
         vel = (Ps[t1] * Ps[t0].inv()).log() / dt.unsqueeze(-1)
         Gs = SE3.exp(vel * (tt - ts[t0]).unsqueeze(-1)) * Ps[t0]
@@ -76,9 +97,9 @@ class PoseTrajectoryFiller:
         v[N:N + M] = (tt, images, Gs.data, 1.0, intrinsics / 8.0, fmap)
 
         graph = FactorGraph(v, self.update, self.device)
-        new = torch.arange(N, N + M, device=self.device)
-        graph.add_factors(t0, new)
-        graph.add_factors(t1, new)
+        new = list(range(N, N + M)) if on_gpu else torch.arange(N, N + M, device=self.device)
+        graph.add_factors(t0_e, new)
+        graph.add_factors(t1_e, new)
         for _ in range(6):
             graph.update(N, N + M, motion_only=True)
         Gs = SE3(v.poses[N:N + M].clone())
@@ -89,6 +110,8 @@ class PoseTrajectoryFiller:
     def __call__(self, image_stream):
         """image_stream yields (tstamp, image, intrinsics, segments); returns SE3 [num_frames]"""
         pose_list, tstamps, images, intrinsics = [], [], [], []
+        # (the keyframes' time stamps on the host, once: the one read-back of the call besides the result)
+        self._ts_host = self.video.tstamp[:self.video.counter].cpu().numpy() if self.device.type == "cuda" else None
         for (tstamp, image, intrinsic, _segments) in image_stream:
             tstamps.append(tstamp); images.append(image); intrinsics.append(intrinsic)
             if len(tstamps) == 16:

@@ -57,6 +57,23 @@ if cut_b:
     print("tracking part (to the last frontend BA): %d dispatches, %.3f s, device busy %.3f s = %.1f %% UNDER THE PROFILER (every launch costs the host "
           "more here; the same kernels against the unprofiled wall time of bench.py's sequence leg give the share of an ordinary run)" %
           (len(tr), span / 1e9, b2 / 1e9, 100.0 * b2 / span))
+if cut_b:
+    te = seg[last_fe + 8:]
+    ag2 = collections.OrderedDict()
+    for r in te:
+        a = ag2.setdefault(short(r["Kernel_Name"]), [0, 0])
+        a[0] += 1; a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    tot2 = sum(v[1] for v in ag2.values())
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in te)
+    b3, cs, ce = 0, iv[0][0], iv[0][1]
+    for s, e in iv[1:]:
+        if s > ce: b3 += ce - cs; cs, ce = s, e
+        else: ce = max(ce, e)
+    b3 += ce - cs
+    print("terminate part (backend x 2, trajectory filler): %d dispatches, %.3f s, device busy %.3f s; kernel time by name (sum %.3f s):" %
+          (len(te), (max(e for _, e in iv) - iv[0][0]) / 1e9, b3 / 1e9, tot2 / 1e9))
+    for n, (c, t) in sorted(ag2.items(), key=lambda kv: -kv[1][1])[:24]:
+        print("  %-64s x%-6d %9.2f ms  %5.1f %%  avg %7.1f us" % (n, c, t / 1e6, 100.0 * t / tot2, t / 1e3 / c))
 agg = collections.OrderedDict()
 for r in seg:
     a = agg.setdefault(short(r["Kernel_Name"]), [0, 0])
