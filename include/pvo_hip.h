@@ -319,12 +319,19 @@ int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, l
  * `dtype` or NULL.  y may alias x. */
 int pvo_bias_norm_act(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
                       int norm, float eps, int relu_inner, int relu_outer, int dtype, void* stream);
-/* The encoders' last layer, Conv2d(128, output_dim, 1) (extractor.py:139,199), on NCHW planes, bias included:
- *   y[n][co][p] = round(round(sum_ci w[co][ci] x[n][ci][p]) + bias[co]),  products added in index order in fp32 - DETERMINISTIC (the
- * vendor library's implicit GEMM for this shape splits K over workgroups with atomics: the same frame gave different feature maps, and
- * a sequence a different trajectory, from run to run).  x [N,Cin,HW], w [Cout,Cin], bias [Cout] or NULL, y [N,Cout,HW], all `dtype`
- * (PVO_F16 / PVO_BF16).  Cin a multiple of 128, Cout of 64 (PVO_EUNSUPPORTED otherwise: callers keep the library convolution). */
-int pvo_conv1x1_planes(const void* x, const void* w, const void* bias, void* y, int N, int Cin, int Cout, int HW, int dtype, void* stream);
+/* The encoders' 1 x 1 convolutions on NCHW planes, bias included - the last layer Conv2d(128, output_dim, 1) (extractor.py:139,199) and
+ * the residual blocks' strided shortcut Conv2d(in, out, 1, stride = 2) (extractor.py:31-33):
+ *   y[n][co][oy][ox] = round(round(sum_ci w[co][ci] x[n][ci][oy * stride][ox * stride]) + bias[co]),  products added in index order in
+ * fp32 - DETERMINISTIC (the vendor library's implicit GEMM for the last layer's shape splits K over workgroups with atomics: the same frame
+ * gave different feature maps, and a sequence a different trajectory, from run to run; its strided 1 x 1 form is four launches).
+ * x [N,Cin,Hin,Win], w [Cout,Cin], bias [Cout] or NULL, y [N,Cout,Hout,Wout] with Hout = (Hin - 1) / stride + 1, all `dtype` (PVO_F16 /
+ * PVO_BF16).  Cin a multiple of 32, Cout of 64 (PVO_EUNSUPPORTED otherwise: callers keep the library convolution). */
+int pvo_conv1x1_planes(const void* x, const void* w, const void* bias, void* y, int N, int Cin, int Cout, int Hin, int Win, int stride,
+                       int dtype, void* stream);
+/* A frame as the stream hands it over ([3][H][W] BGR 0..255; in_kind 0 = int32, 1 = uint8, 2 = float32) -> the encoders' input [3][H][W] RGB
+ * `dtype`: ((v / 255) - mean[c]) / std[c] in fp32, the operations and order of motion_filter.py:52-54, then rounded.  mean3 / std3: HOST
+ * pointers to three floats each. */
+int pvo_frame_normalise(const void* img, void* out, int H, int W, const float* mean3, const float* std3, int in_kind, int dtype, void* stream);
 
 /* (pvo_graph_motion: inside pvo_graph_update the motion features are written by pvo_reproject_motion since round 3; this
  * entry point serves pvo_update_operator callers that reproject themselves, and tests) */

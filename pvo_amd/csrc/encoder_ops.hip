@@ -104,22 +104,28 @@ __global__ void bias_norm_act_kernel(const uint16_t* __restrict__ x, const uint1
 // with atomics: three consecutive calls on the same input gave three different feature maps (tools/determinism_probe.py), and with
 // them every run of a sequence its own trajectory.  Here one thread owns 4 pixels x 4 output channels and adds the 128 products in
 // index order in fp32 - the same bits every time; no layout transposes (MIOpen: three around its kernel).
-constexpr int kC1Pix = 64, kC1Co = 64, kC1Ci = 128;
+constexpr int kC1Pix = 64, kC1Co = 64, kC1Ci = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void conv1x1_planes_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const uint16_t* __restrict__ bias,
-                                                             uint16_t* __restrict__ y, int Cin, int Cout, int HW) {
+                                                             uint16_t* __restrict__ y, int Cin, int Cout, int Win, int HWin, int Wout, int HWout, int stride) {
   __shared__ uint16_t xs[kC1Ci][kC1Pix];
   __shared__ uint16_t ws[kC1Ci][kC1Co + 4];                       // [ci][co]: a thread's four output channels are adjacent
+  __shared__ int src[kC1Pix];                                     // input offset of the tile's output pixels (stride: every s-th row / column)
   const int p0 = blockIdx.x * kC1Pix, co0 = blockIdx.y * kC1Co;
   const long long n = blockIdx.z;
-  const uint16_t* xn = x + n * Cin * static_cast<long long>(HW);
+  const uint16_t* xn = x + n * Cin * static_cast<long long>(HWin);
   const int tp = (threadIdx.x & 15) * 4, tc = (threadIdx.x >> 4) * 4;
+  if (threadIdx.x < kC1Pix) {
+    const int p = p0 + threadIdx.x;
+    src[threadIdx.x] = p < HWout ? (p / Wout) * stride * Win + (p % Wout) * stride : -1;
+  }
   float acc[4][4] = {};
   for (int c0 = 0; c0 < Cin; c0 += kC1Ci) {
     __syncthreads();
     for (int i = threadIdx.x; i < kC1Ci * kC1Pix; i += 256) {
       const int ci = i / kC1Pix, p = i % kC1Pix;
-      xs[ci][p] = (p0 + p < HW) ? xn[static_cast<long long>(c0 + ci) * HW + p0 + p] : static_cast<uint16_t>(0);
+      const int o = src[p];
+      xs[ci][p] = o >= 0 ? xn[static_cast<long long>(c0 + ci) * HWin + o] : static_cast<uint16_t>(0);
     }
     for (int i = threadIdx.x; i < kC1Co * kC1Ci; i += 256) {
       const int co = i / kC1Ci, ci = i % kC1Ci;
@@ -141,29 +147,66 @@ __global__ __launch_bounds__(256) void conv1x1_planes_kernel(const uint16_t* __r
   for (int a = 0; a < 4; ++a) {
     const int co = co0 + tc + a;
     const float bv = bias ? eo_val<T>(bias[co]) : 0.0f;
-    uint16_t* yr = y + (n * Cout + co) * static_cast<long long>(HW) + p0 + tp;
+    uint16_t* yr = y + (n * Cout + co) * static_cast<long long>(HWout) + p0 + tp;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
-      if (p0 + tp + b < HW) yr[b] = eo_bits<T>(eo_round<T>(acc[a][b]) + bv);
+      if (p0 + tp + b < HWout) yr[b] = eo_bits<T>(eo_round<T>(acc[a][b]) + bv);
+  }
+}
+
+// A frame as the stream hands it over - [3][H][W] BGR, 0..255, int32 / uint8 / float32 - to the encoders' input: RGB, ((v / 255) - mean) /
+// std in fp32 (the operations and their order of motion_filter.py:52-54), rounded to the 16-bit type.  One launch for the six element-wise
+// kernels PyTorch issues (flip, float, divide, subtract, divide, cast) in front of EACH encoder.
+template <typename T, typename IN>
+__global__ void frame_normalise_kernel(const IN* __restrict__ img, uint16_t* __restrict__ out, int HW, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = static_cast<float>(img[static_cast<size_t>(2 - c) * HW + p]) / 255.0f;
+    out[static_cast<size_t>(c) * HW + p] = eo_bits<T>((v - mean[c]) / stdv[c]);
   }
 }
 
 }  // namespace
 
-extern "C" int pvo_conv1x1_planes(const void* x, const void* w, const void* bias, void* y, int N, int Cin, int Cout, int HW, int dtype, void* stream) {
-  if (N < 0 || Cin <= 0 || Cout <= 0 || HW < 0) return PVO_EINVAL;
-  if (N == 0 || HW == 0) return PVO_OK;
+extern "C" int pvo_conv1x1_planes(const void* x, const void* w, const void* bias, void* y, int N, int Cin, int Cout, int Hin, int Win, int stride,
+                                  int dtype, void* stream) {
+  if (N < 0 || Cin <= 0 || Cout <= 0 || Hin < 0 || Win < 0 || stride < 1) return PVO_EINVAL;
+  if (N == 0 || Hin == 0 || Win == 0) return PVO_OK;
   if (!x || !w || !y) return PVO_EINVAL;
   if ((Cin % kC1Ci) != 0 || (Cout % kC1Co) != 0 || N > 65535) return PVO_EUNSUPPORTED;
-  const dim3 grid((HW + kC1Pix - 1) / kC1Pix, Cout / kC1Co, N);
+  const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
+  const dim3 grid((Hout * Wout + kC1Pix - 1) / kC1Pix, Cout / kC1Co, N);
   hipStream_t st = pvo_stream(stream);
   if (dtype == PVO_F16)
     hipLaunchKernelGGL(conv1x1_planes_kernel<pvo_half>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w),
-                       static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(y), Cin, Cout, HW);
+                       static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(y), Cin, Cout, Win, Hin * Win, Wout, Hout * Wout, stride);
   else if (dtype == PVO_BF16)
     hipLaunchKernelGGL(conv1x1_planes_kernel<pvo_bf16>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w),
-                       static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(y), Cin, Cout, HW);
+                       static_cast<const uint16_t*>(bias), static_cast<uint16_t*>(y), Cin, Cout, Win, Hin * Win, Wout, Hout * Wout, stride);
   else return PVO_EUNSUPPORTED;
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+// in_kind: 0 = int32, 1 = uint8, 2 = float32
+extern "C" int pvo_frame_normalise(const void* img, void* out, int H, int W, const float* mean3, const float* std3, int in_kind, int dtype, void* stream) {
+  if (H < 0 || W < 0 || !mean3 || !std3) return PVO_EINVAL;
+  if (H == 0 || W == 0) return PVO_OK;
+  if (!img || !out) return PVO_EINVAL;
+  const int HW = H * W;
+  const dim3 grid((HW + 255) / 256);
+  hipStream_t st = pvo_stream(stream);
+#define PVO_FN_LAUNCH(T, IN) hipLaunchKernelGGL((frame_normalise_kernel<T, IN>), grid, dim3(256), 0, st, static_cast<const IN*>(img), static_cast<uint16_t*>(out), HW, \
+                                                mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2])
+  if (dtype == PVO_F16) {
+    if (in_kind == 0) PVO_FN_LAUNCH(pvo_half, int); else if (in_kind == 1) PVO_FN_LAUNCH(pvo_half, uint8_t); else if (in_kind == 2) PVO_FN_LAUNCH(pvo_half, float); else return PVO_EUNSUPPORTED;
+  } else if (dtype == PVO_BF16) {
+    if (in_kind == 0) PVO_FN_LAUNCH(pvo_bf16, int); else if (in_kind == 1) PVO_FN_LAUNCH(pvo_bf16, uint8_t); else if (in_kind == 2) PVO_FN_LAUNCH(pvo_bf16, float); else return PVO_EUNSUPPORTED;
+  } else return PVO_EUNSUPPORTED;
+#undef PVO_FN_LAUNCH
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }

@@ -1244,12 +1244,12 @@ def proximity_select(dist, t0, t1, rad, nms, thresh, have_i, have_j):
 
 
 def conv1x1_planes_supported(cin, cout):
-    return cin % 128 == 0 and cout % 64 == 0
+    return cin % 32 == 0 and cout % 64 == 0
 
 
-def conv1x1_planes(x, w, bias=None):
-    """Conv2d(Cin, Cout, 1) on a contiguous 16-bit NCHW tensor, deterministic (pvo_conv1x1_planes): x [N,Cin,H,W], w [Cout,Cin] or
-    [Cout,Cin,1,1], bias [Cout] or None, all of x's dtype -> [N,Cout,H,W]"""
+def conv1x1_planes(x, w, bias=None, stride=1):
+    """Conv2d(Cin, Cout, 1, stride) on a contiguous 16-bit NCHW tensor, deterministic (pvo_conv1x1_planes): x [N,Cin,H,W], w [Cout,Cin] or
+    [Cout,Cin,1,1], bias [Cout] or None, all of x's dtype -> [N,Cout,(H-1)//stride+1,(W-1)//stride+1]"""
     dev = _dev(x, w, bias)
     _contig(x, "x"); _contig(w, "w")
     if x.dim() != 4 or x.dtype not in (torch.float16, torch.bfloat16) or w.dtype != x.dtype or (bias is not None and bias.dtype != x.dtype):
@@ -1258,10 +1258,29 @@ def conv1x1_planes(x, w, bias=None):
     Cout = w.shape[0]
     if w.numel() != Cout * Cin or (bias is not None and (bias.numel() != Cout or not bias.is_contiguous())):
         raise PvoHipError("conv1x1_planes: w [Cout,Cin], bias [Cout]")
-    y = torch.empty(N, Cout, H, W, dtype=x.dtype, device=dev)
+    stride = int(stride)
+    y = torch.empty(N, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1, dtype=x.dtype, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_conv1x1_planes(_ptr(x), _ptr(w), _vp(bias), _ptr(y), N, Cin, Cout, H * W, _dtype_code(x, "x"), _stream(dev)), "conv1x1_planes")
+        check(_lib.load().pvo_conv1x1_planes(_ptr(x), _ptr(w), _vp(bias), _ptr(y), N, Cin, Cout, H, W, stride, _dtype_code(x, "x"), _stream(dev)), "conv1x1_planes")
     return y
+
+
+_FRAME_KINDS = {torch.int32: 0, torch.uint8: 1, torch.float32: 2}
+
+
+def frame_normalise(image, mean, std, dtype=torch.float16):
+    """[3,H,W] BGR frame (int32 / uint8 / float32, 0..255) on the device -> [1,3,H,W] RGB `dtype`, ((v / 255) - mean) / std in fp32 then
+    rounded (pvo_frame_normalise); mean / std: sequences of three Python floats"""
+    dev = _dev(image)
+    _contig(image, "image")
+    if image.dim() != 3 or image.shape[0] != 3 or image.dtype not in _FRAME_KINDS:
+        raise PvoHipError("frame_normalise: a contiguous [3,H,W] int32 / uint8 / float32 frame")
+    _, H, W = image.shape
+    out = torch.empty(1, 3, H, W, dtype=dtype, device=dev)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean]); s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    with torch.cuda.device(dev):
+        check(_lib.load().pvo_frame_normalise(_ptr(image), _ptr(out), H, W, m, s, _FRAME_KINDS[image.dtype], _DT[dtype], _stream(dev)), "frame_normalise")
+    return out
 
 
 def debug_config(knob, value):

@@ -56,7 +56,15 @@ class ResidualBlock(nn.Module):
         y2 = _conv(self.conv2, y)
         if self.downsample is not None:
             d = self.downsample[0]
-            x = act(_conv(d, x), _b(d, x), None, norm, False, False)
+            from .. import droid_backends as db
+            if d.kernel_size == (1, 1) and d.padding == (0, 0) and d.stride[0] == d.stride[1] and d.groups == 1 \
+                    and db.conv1x1_planes_supported(d.in_channels, d.out_channels):
+                # the strided shortcut on the library's 1 x 1 kernel (bias included; the vendor library: a sub-tensor copy, two layout
+                # transposes and an implicit GEMM, ~30 us for 25 M multiply-adds)
+                w = d.weight if d.weight.dtype == x.dtype else d.weight.to(x.dtype)
+                x = act(db.conv1x1_planes(x.contiguous(), w, _b(d, x), stride=d.stride[0]), None, None, norm, False, False)
+            else:
+                x = act(_conv(d, x), _b(d, x), None, norm, False, False)
         return act(y2, _b(self.conv2, x), x, norm, True, True, out=y2)          # relu(x + relu(norm2(conv2(y))))
 
 

@@ -112,7 +112,15 @@ class MotionFilter:
             return st[1]
         return upload_frame(image, self.device)
 
+    _MEAN3, _STD3 = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
     def _normalise_dev(self, image_dev):
+        if self.device.type == "cuda" and self.fused_encoders and image_dev.dim() == 3 and image_dev.shape[0] == 3 and image_dev.is_contiguous() \
+                and image_dev.dtype in (torch.int32, torch.uint8, torch.float32):
+            # one launch (pvo_frame_normalise): the same fp32 operations in the same order, rounded to fp16 as the fused encoder's first
+            # cast does - bit-identical to the six element-wise kernels below, which ran in front of EACH encoder
+            from .droid_backends import frame_normalise
+            return frame_normalise(image_dev, self._MEAN3, self._STD3, torch.float16)[None]
         # (flip(0) = the reference's channel gather [2, 1, 0] without an index tensor: a list index is uploaded from the host on
         # every call, which cannot be captured into a graph)
         x = image_dev.flip(0)[None, None].float() / 255.0

@@ -26,8 +26,14 @@ class PoseTrajectoryFiller:
     def _features_one(self, image_dev):
         """one frame [3,H,W] on the device -> [1,128,h,w]"""
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.device.type == "cuda"):
+            enc = getattr(self.fnet, "forward_inference", None)
+            if enc is not None and self.device.type == "cuda" and image_dev.dim() == 3 and image_dev.is_contiguous() \
+                    and image_dev.dtype in (torch.int32, torch.uint8, torch.float32):
+                from .droid_backends import frame_normalise
+                from .motion_filter import MotionFilter
+                return enc(frame_normalise(image_dev, MotionFilter._MEAN3, MotionFilter._STD3, torch.float16)[None]).squeeze(0)
             x = image_dev.flip(0)[None, None].float() / 255.0
-            enc = getattr(self.fnet, "forward_inference", self.fnet)
+            enc = enc if enc is not None else self.fnet
             return enc((x - self.MEAN) / self.STDV).squeeze(0)
 
     def _features(self, images):

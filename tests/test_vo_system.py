@@ -490,8 +490,21 @@ def test_encoder_head_convolution_is_deterministic_and_matches_fp32(cuda):
         ref = (F.conv2d(x.float(), w.float()).half().float() + b.float()[None, :, None, None]).half()
         assert y.shape == ref.shape and float((y.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.float().abs().max()) + 2e-3
         assert torch.equal(y, db.conv1x1_planes(x, w, b)) and torch.equal(db.conv1x1_planes(x, w, None) , db.conv1x1_planes(x, w))
+    for cin, cout, hw in ((32, 64, (120, 404)), (64, 128, (60, 202)), (32, 64, (7, 9))):      # the residual blocks' strided shortcuts
+        x = torch.randn(1, cin, *hw, generator=g).half().to(cuda)
+        w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).half().to(cuda)
+        b = torch.randn(cout, generator=g).half().to(cuda)
+        y = db.conv1x1_planes(x, w, b, stride=2)
+        ref = (F.conv2d(x.float(), w.float(), stride=2).half().float() + b.float()[None, :, None, None]).half()
+        assert y.shape == ref.shape and float((y.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.float().abs().max()) + 2e-3
     with pytest.raises(db.PvoHipError):
-        db.conv1x1_planes(torch.zeros(1, 96, 4, 4, dtype=torch.float16, device=cuda), torch.zeros(64, 96, dtype=torch.float16, device=cuda))
+        db.conv1x1_planes(torch.zeros(1, 48, 4, 4, dtype=torch.float16, device=cuda), torch.zeros(64, 48, dtype=torch.float16, device=cuda))
+    # the frame's normalisation as one kernel: bit-identical to the element-wise sequence of motion_filter.py:52-54 + the encoder's cast
+    mean, std = torch.tensor([0.485, 0.456, 0.406], device=cuda)[:, None, None], torch.tensor([0.229, 0.224, 0.225], device=cuda)[:, None, None]
+    for dt in (torch.int32, torch.uint8, torch.float32):
+        img = torch.randint(0, 256, (3, 37, 53), generator=g).to(dt).to(cuda)
+        ref = (((img.flip(0)[None].float() / 255.0) - mean) / std).half()
+        assert torch.equal(db.frame_normalise(img, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)), ref)
     torch.manual_seed(0)
     for norm, dim in (("instance", 128), ("none", 256)):
         enc = BasicEncoder(output_dim=dim, norm_fn=norm).to(cuda).half().eval()
