@@ -221,6 +221,8 @@ class MotionFilter:
     @torch.no_grad()
     def finish(self):
         """second half: read the motion test's scalar; a frame that moved enough gets its context features and joins the video"""
+        if self._pending is None:
+            raise RuntimeError("MotionFilter.finish() without a begin(): no frame is in flight")
         tstamp, image, img, intrinsics, segments, gmap, mag = self._pending
         self._pending = None
         try:

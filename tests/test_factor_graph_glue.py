@@ -638,3 +638,32 @@ def test_global_update_never_applies_the_panoptic_vote(cuda):
         dd = ((res["volume"][k] - res["alt"][k]).abs() * far)
         assert dd.max().item() < 2e-2 and dd.mean().item() < 1e-3, (k, dd.max().item(), dd.mean().item())
     assert (res["volume"]["poses"] - res["alt"]["poses"]).abs().max() < 1e-3
+
+
+def test_proximity_select_host_function_argument_checks_and_corner_cases():
+    """pvo_proximity_select called directly: nothing under the threshold leaves the temporal neighbours; no existing edges; a window whose
+    two frame ranges do not end together and an output buffer that is too small are refused"""
+    import ctypes
+    import numpy as np
+    from pvo_amd import droid_backends as db
+    from pvo_amd import _lib
+    d = np.full((6, 6), 50.0, dtype=np.float32)
+    ii, jj = db.proximity_select(d, 0, 0, 2, 1, 10.0, np.zeros(0, np.int64), np.zeros(0, np.int64))
+    want = []
+    for i in range(6):
+        for j in range(i + 1, min(i + 3, 6)):
+            want += [(i, j), (j, i)]
+    assert list(zip(ii, jj)) == want
+    d[5, 1] = 3.0; d[4, 0] = 3.0                      # a tie: the lower flat index first; its diamond (radius min(|4 - 0| - 2, nms) = 2) holds (5, 1)
+    ii, jj = db.proximity_select(d, 0, 0, 2, 2, 10.0, np.zeros(0, np.int64), np.zeros(0, np.int64))
+    assert list(zip(ii, jj))[len(want):] == [(4, 0), (0, 4)]
+    ii, jj = db.proximity_select(d, 0, 0, 2, 0, 10.0, np.zeros(0, np.int64), np.zeros(0, np.int64))     # nms 0: both survive
+    assert list(zip(ii, jj))[len(want):] == [(4, 0), (0, 4), (5, 1), (1, 5)]
+    ii, jj = db.proximity_select(d, 0, 0, 2, 0, 10.0, np.array([4], np.int64), np.array([0], np.int64))  # an existing edge takes its own cell out
+    assert list(zip(ii, jj))[len(want):] == [(5, 1), (1, 5)]
+    lib = _lib.load()
+    out = np.zeros((2, 64), np.int64); n = ctypes.c_int(0)
+    call = lambda ni, nj, t0, t1, cap: lib.pvo_proximity_select(d.ctypes.data, ni, nj, t0, t1, 2, 1, 10.0, None, None, 0, out[0].ctypes.data, out[1].ctypes.data, cap, ctypes.byref(n))
+    assert call(6, 6, 0, 0, 64) == 0 and n.value == len(want) + 4     # (nms 1: both cells under the threshold are taken)
+    assert call(6, 6, 0, 1, 64) != 0                  # t0 + ni != t1 + nj
+    assert call(6, 6, 0, 0, 4) != 0                   # does not fit
