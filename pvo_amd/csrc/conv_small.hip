@@ -11,6 +11,7 @@
 //   in LDS; wave w owns output channels [32w, 32w+32) and keeps its 26 weight fragments in registers for all 16 tile rows.
 //   Weights arrive pre-arranged as [52 taps (49 + 3 zero)][128 outputs][8 channels] 16-bit.
 #include "common.h"
+#include <type_traits>
 #include "glo_tile.h"
 #include <stdlib.h>
 
@@ -453,9 +454,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
     // half-step are requested before the eight MFMAs of the current one, so a fragment has 8 MFMAs (256 matrix-pipe
     // cycles) to arrive.  Left to itself the compiler sinks each ds_read next to its first use ("read, wait lgkmcnt(0),
     // two MFMAs" - the LDS latency exposed eight times per step; SQ_WAIT_ANY was 40 % of the wave cycles).
+    // The main loop exists twice: NMT = 4 for a full tile, NMT = 2 for a tile of which only the first two 4-pixel column groups
+    // (M-tiles) lie inside the image - the right-most tile column of a map whose width is not a multiple of 16 (101 = 6 x 16 + 5: a
+    // seventh of all tiles at the reference driver's 30 x 101).  Such a workgroup issues half the MFMAs; its waves wait at the
+    // same barriers, and the matrix cores they leave idle go to the second workgroup of the CU.
+    auto main_loop = [&](auto nmt_c) {
+    constexpr int NMT = decltype(nmt_c)::value;
     auto read_half = [&](cs_u32x4 (&a)[4], const unsigned char* Ac, int toff, int ks) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const cs_u32x4*>(Ac + toff + mt * 4 * kBStride + ks * 32);
+      for (int mt = 0; mt < NMT; ++mt) a[mt] = *reinterpret_cast<const cs_u32x4*>(Ac + toff + mt * 4 * kBStride + ks * 32);
     };
 #pragma unroll 1
     for (int cc = 0; cc < nC; ++cc) {
@@ -472,37 +479,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_big_kernel(const uint16_t* __r
         read_half(a1, Ac, toff, 1);
         const cs_u32x4 (&bf)[4] = bset[t % 3];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(a0[mt], bf[nt * 2], acc[mt][nt]);
         // issue order inside the half-step: one LDS read / one global load behind each MFMA (an in-order wave hides
         // about five single-issue instructions in the 32 cycles an MFMA holds the pipe; clumped between the groups of
         // eight they are exposed)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        for (int i = 0; i < NMT; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 1, 0); }
+        for (int i = 0; i < NMT; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 4 / NMT, 0); }
         __builtin_amdgcn_sched_barrier(0);
         if (t < 8) read_half(a0, Ac, ((((t + 1) / 3) * kBPitch) + ((t + 1) % 3)) * kBStride, 0);
         if (t == 3) { store_a((cc + 1) & 1, 0); fetch_a(1); }   // (the other halo buffer was last read before the previous barrier)
         if (t == 7) store_a((cc + 1) & 1, 1);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = cs_mfma32<T>(a1[mt], bf[nt * 2 + 1], acc[mt][nt]);
-        if (t < 8) {
+        if (NMT == 4) {
+          if (t < 8) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        }
-        if (t == 3 || t == 7) {
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+          }
+          if (t == 3 || t == 7) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+            for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
+          }
+          if (t == 3) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 3, 0); }
         }
-        if (t == 3) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x20, 3, 0); }
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }
+    };
+    if (x0 + 8 >= W) main_loop(std::integral_constant<int, 2>{});
+    else main_loop(std::integral_constant<int, 4>{});
   }
   CONV_PROBE(2);
 

@@ -79,6 +79,7 @@ def _b(m, x):
 
 class BasicEncoder(nn.Module):
     """[B,N,3,H,W] -> [B,N,output_dim,H/8,W/8]  (extractor.py:183-201)."""
+    deterministic = True         # forward_inference: vendor convolutions restricted to kernels that repeat their result (see there)
 
     def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0, multidim=False):
         super().__init__()
@@ -122,6 +123,18 @@ class BasicEncoder(nn.Module):
         if not x.is_cuda or torch.is_grad_enabled() or self.training or self.norm_fn not in ("instance", "none") or self.dropout is not None:
             return self.forward(x)
         from .. import droid_backends as db
+        # The vendor library picks a convolution kernel per shape from timings taken on the box, and some of its candidates add split-K
+        # partial sums with atomics: on some boxes the 128 -> 128 3 x 3 layers at 1/8 resolution came out different on every call
+        # (tools/encoder_determinism.py), and with them every run of a sequence.  `deterministic` restricts the choice to kernels that
+        # repeat themselves; it is this process's global flag, so it is set for the duration of the call only.
+        prev = torch.backends.cudnn.deterministic
+        torch.backends.cudnn.deterministic = bool(self.deterministic) or prev
+        try:
+            return self._forward_inference(x, dtype, db)
+        finally:
+            torch.backends.cudnn.deterministic = prev
+
+    def _forward_inference(self, x, dtype, db):
         norm = self.norm_fn == "instance"
         eps = 1e-5
 

@@ -43,6 +43,17 @@ def timed(label, call, n=60):
 for g in (mf._context_g, mf._features_g, mf._frame_g):
     print(g.name, "replays", g.replays, "disabled", g.disabled, getattr(g, "error", None), "grad", torch.is_grad_enabled())
 torch.set_grad_enabled(False)
+from pvo_amd.modules.extractor import BasicEncoder
+from pvo_amd.graphs import GraphedCall
+for flag in (True, False):
+    BasicEncoder.deterministic = flag
+    gc_ = GraphedCall(mf._context_dev, name="cnet, deterministic=%s" % flag)
+    gf_ = GraphedCall(mf._features_dev, name="fnet, deterministic=%s" % flag)
+    for _ in range(4):
+        gc_(img); gf_(img)
+    timed("cnet graph, vendor deterministic=%s" % flag, lambda: gc_(img))
+    timed("fnet graph, vendor deterministic=%s" % flag, lambda: gf_(img))
+BasicEncoder.deterministic = True
 timed("cnet graph", lambda: mf._context_g(img))
 timed("fnet graph", lambda: mf._features_g(img))
 args = (img, mf.fmap, mf.net, mf.inp) + tuple(mf._static or ())
