@@ -319,6 +319,14 @@ int pvo_conv1x1_c128(const void* x, const void* w, const float* bias, void* y, l
  * `dtype` or NULL.  y may alias x. */
 int pvo_bias_norm_act(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
                       int norm, float eps, int relu_inner, int relu_outer, int dtype, void* stream);
+/* pvo_bias_norm_act for LARGE planes (the encoders' layers at 1/2 and 1/4 resolution): a plane is cut into pvo_bias_norm_act_slices(HW)
+ * slices (0: use pvo_bias_norm_act) - one launch leaves every slice's (mean, squared deviations) in ws (f32, 2 * planes * slices values;
+ * only read / written with norm != 0), a second combines a plane's slices in index order and finishes its slice.  Same operations and
+ * roundings as pvo_bias_norm_act; the instance-norm statistics differ from its two-pass sums in the last fp32 bits, deterministically.
+ * planes <= 65535.  y may alias x. */
+int pvo_bias_norm_act_slices(int HW);
+int pvo_bias_norm_act_split(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
+                            int norm, float eps, int relu_inner, int relu_outer, int dtype, float* ws, size_t ws_floats, void* stream);
 /* The encoders' 1 x 1 convolutions on NCHW planes, bias included - the last layer Conv2d(128, output_dim, 1) (extractor.py:139,199) and
  * the residual blocks' strided shortcut Conv2d(in, out, 1, stride = 2) (extractor.py:31-33):
  *   y[n][co][oy][ox] = round(round(sum_ci w[co][ci] x[n][ci][oy * stride][ox * stride]) + bias[co]),  products added in index order in

@@ -51,6 +51,8 @@ SIGNATURES = {
     "pvo_graph_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_reproject_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pvo_bias_norm_act": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _i, _f, _i, _i, _i, _vp]),
+    "pvo_bias_norm_act_slices": (_i, [_i]),
+    "pvo_bias_norm_act_split": (_i, [_vp, _vp, _vp, _vp, _c.c_longlong, _i, _i, _i, _f, _i, _i, _i, _vp, _sz, _vp]),
     "pvo_conv1x1_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pvo_frame_normalise": (_i, [_vp, _vp, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _i, _i, _vp]),
     "pvo_segment_hist": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),

@@ -99,6 +99,62 @@ __global__ void bias_norm_act_kernel(const uint16_t* __restrict__ x, const uint1
   }
 }
 
+// The same for LARGE planes (the encoders' first layers: 32 planes of 120 x 404 = 48 480 pixels per image): one workgroup per plane is 32
+// workgroups on 256 compute units, each walking its plane three times - 23 us per layer, latency.  Here a plane is cut into S slices:
+// bna_stats_kernel leaves (mean, sum of squared deviations about it) of every slice in `ws`, bna_apply_kernel combines a plane's S pairs
+// in index order (Chan et al.: exact in exact arithmetic, fp32 here - the statistics differ from the one-workgroup kernel's in the last
+// bits, deterministically) and finishes its slice.  Without normalisation only the second kernel runs.
+template <typename T>
+__global__ __launch_bounds__(256) void bna_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ bias, float* __restrict__ ws,
+                                                        int C, int HW, int S, int L) {
+  __shared__ float red[16];
+  const long long plane = blockIdx.y;
+  const int s = blockIdx.x, lo = s * L, hi = min(HW, lo + L), n = max(hi - lo, 0);
+  const uint16_t* xp = x + plane * HW;
+  const float b = bias ? eo_val<T>(bias[static_cast<int>(plane % C)]) : 0.0f;
+  float sum = 0.0f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) sum += eo_round<T>(eo_val<T>(xp[i]) + b);
+  const float mean = n > 0 ? block_sum(sum, red) / static_cast<float>(n) : 0.0f;
+  float q = 0.0f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) { const float d = eo_round<T>(eo_val<T>(xp[i]) + b) - mean; q += d * d; }
+  q = block_sum(q, red);
+  if (threadIdx.x == 0) { ws[(plane * S + s) * 2] = mean; ws[(plane * S + s) * 2 + 1] = q; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bna_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ bias, const uint16_t* __restrict__ residual,
+                                                        uint16_t* __restrict__ y, const float* __restrict__ ws, int C, int HW, int S, int L, int norm,
+                                                        float eps, int relu_inner, int relu_outer) {
+  const long long plane = blockIdx.y;
+  const int s = blockIdx.x, lo = s * L, hi = min(HW, lo + L);
+  const uint16_t* xp = x + plane * HW;
+  const uint16_t* rp = residual ? residual + plane * HW : nullptr;
+  uint16_t* yp = y + plane * HW;
+  const float b = bias ? eo_val<T>(bias[static_cast<int>(plane % C)]) : 0.0f;
+  float mean = 0.0f, invstd = 1.0f;
+  if (norm) {
+    float cnt = 0.0f, m2 = 0.0f;                       // (every thread the same S steps: no communication)
+    for (int k = 0; k < S; ++k) {
+      const float nk = static_cast<float>(max(min(HW, (k + 1) * L) - k * L, 0));
+      if (nk <= 0.0f) continue;
+      const float mk = ws[(plane * S + k) * 2], qk = ws[(plane * S + k) * 2 + 1];
+      const float tot = cnt + nk, delta = mk - mean;
+      mean += delta * (nk / tot);
+      m2 += qk + delta * delta * (cnt * nk / tot);
+      cnt = tot;
+    }
+    invstd = 1.0f / sqrtf(m2 / static_cast<float>(HW) + eps);
+  }
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    float t = eo_round<T>(eo_val<T>(xp[i]) + b);
+    if (norm) t = eo_round<T>((t - mean) * invstd);
+    if (relu_inner) t = fmaxf(t, 0.0f);
+    if (rp) t = eo_round<T>(eo_val<T>(rp[i]) + t);
+    if (relu_outer) t = fmaxf(t, 0.0f);
+    yp[i] = eo_bits<T>(t);
+  }
+}
+
 // The encoders' last layer, Conv2d(128, output_dim, 1) (extractor.py:139,199), on NCHW planes: y[n][co][p] = round16(round16(sum_ci
 // w[co][ci] x[n][ci][p]) + bias[co]).  MIOpen runs it as an NHWC implicit GEMM that splits K over workgroups and adds the partial sums
 // with atomics: three consecutive calls on the same input gave three different feature maps (tools/determinism_probe.py), and with
@@ -207,6 +263,33 @@ extern "C" int pvo_frame_normalise(const void* img, void* out, int H, int W, con
     if (in_kind == 0) PVO_FN_LAUNCH(pvo_bf16, int); else if (in_kind == 1) PVO_FN_LAUNCH(pvo_bf16, uint8_t); else if (in_kind == 2) PVO_FN_LAUNCH(pvo_bf16, float); else return PVO_EUNSUPPORTED;
   } else return PVO_EUNSUPPORTED;
 #undef PVO_FN_LAUNCH
+  PVO_CHECK_LAUNCH();
+  return PVO_OK;
+}
+
+// slices per plane of the split form (0: planes of this size keep the one-workgroup kernel)
+extern "C" int pvo_bias_norm_act_slices(int HW) { return HW >= 16384 ? 16 : (HW >= 8192 ? 4 : 0); }
+
+extern "C" int pvo_bias_norm_act_split(const void* x, const void* bias, const void* residual, void* y, long long planes, int C, int HW,
+                                       int norm, float eps, int relu_inner, int relu_outer, int dtype, float* ws, size_t ws_floats, void* stream) {
+  if (planes < 0 || C <= 0 || HW < 0 || (planes % C) != 0) return PVO_EINVAL;
+  if (planes == 0 || HW == 0) return PVO_OK;
+  const int S = pvo_bias_norm_act_slices(HW);
+  if (!x || !y || planes > 65535 || S == 0) return PVO_EINVAL;
+  if (norm && (!ws || ws_floats < static_cast<size_t>(planes) * S * 2)) return PVO_EWORKSPACE;
+  const int L = (HW + S - 1) / S;
+  const dim3 grid(S, static_cast<unsigned>(planes));
+  hipStream_t st = pvo_stream(stream);
+#define PVO_BNA_SPLIT(T)                                                                                                                        \
+  do {                                                                                                                                          \
+    if (norm) hipLaunchKernelGGL(bna_stats_kernel<T>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(bias), ws, C, HW, S, L); \
+    hipLaunchKernelGGL(bna_apply_kernel<T>, grid, dim3(256), 0, st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(bias),        \
+                       static_cast<const uint16_t*>(residual), static_cast<uint16_t*>(y), ws, C, HW, S, L, norm, eps, relu_inner, relu_outer);   \
+  } while (0)
+  if (dtype == PVO_F16) PVO_BNA_SPLIT(pvo_half);
+  else if (dtype == PVO_BF16) PVO_BNA_SPLIT(pvo_bf16);
+  else return PVO_EUNSUPPORTED;
+#undef PVO_BNA_SPLIT
   PVO_CHECK_LAUNCH();
   return PVO_OK;
 }

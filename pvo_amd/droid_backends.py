@@ -1205,9 +1205,10 @@ def update_operator(weights, net, motion, inp=None, P=None, pool=None, coords=No
     return net_out, heads, eta, upmask
 
 
-def bias_norm_act(x, bias=None, residual=None, norm=False, eps=1e-5, relu_inner=False, relu_outer=False, out=None):
+def bias_norm_act(x, bias=None, residual=None, norm=False, eps=1e-5, relu_inner=False, relu_outer=False, out=None, split=None):
     """what sits between two convolutions of an encoder layer, as one kernel (pvo_bias_norm_act): x [N,C,H,W] contiguous 16-bit ->
-    relu_outer(residual + relu_inner(instance_norm(x + bias[c]))), every step rounded to x's dtype.  `out` may be x itself."""
+    relu_outer(residual + relu_inner(instance_norm(x + bias[c]))), every step rounded to x's dtype.  `out` may be x itself.
+    split: None = large planes in slices over two launches (pvo_bias_norm_act_split), False = always the one-workgroup-per-plane kernel."""
     dev = _dev(x, bias, residual)
     _contig(x, "x")
     if x.dim() != 4 or x.dtype not in (torch.float16, torch.bfloat16):
@@ -1221,9 +1222,18 @@ def bias_norm_act(x, bias=None, residual=None, norm=False, eps=1e-5, relu_inner=
     if bias is not None and bias.numel() != C or residual is not None and residual.shape != x.shape:
         raise PvoHipError("bias_norm_act: bias [C], residual of x's shape")
     y = torch.empty_like(x) if out is None else out
+    lib = _lib.load()
+    S = lib.pvo_bias_norm_act_slices(H * W) if split is None else (lib.pvo_bias_norm_act_slices(H * W) if split else 0)
     with torch.cuda.device(dev):
-        check(_lib.load().pvo_bias_norm_act(_ptr(x), _vp(bias), _vp(residual), _ptr(y), N * C, C, H * W, 1 if norm else 0, float(eps),
-                                            1 if relu_inner else 0, 1 if relu_outer else 0, _dtype_code(x, "x"), _stream(dev)), "bias_norm_act")
+        if S > 0 and N * C <= 65535:
+            # large planes: S slices per plane over two launches instead of one workgroup per plane (pvo_bias_norm_act_split)
+            ws = torch.empty(2 * N * C * S, dtype=torch.float32, device=dev) if norm else None
+            check(lib.pvo_bias_norm_act_split(_ptr(x), _vp(bias), _vp(residual), _ptr(y), N * C, C, H * W, 1 if norm else 0, float(eps),
+                                              1 if relu_inner else 0, 1 if relu_outer else 0, _dtype_code(x, "x"), _vp(ws), ws.numel() if norm else 0,
+                                              _stream(dev)), "bias_norm_act_split")
+        else:
+            check(lib.pvo_bias_norm_act(_ptr(x), _vp(bias), _vp(residual), _ptr(y), N * C, C, H * W, 1 if norm else 0, float(eps),
+                                        1 if relu_inner else 0, 1 if relu_outer else 0, _dtype_code(x, "x"), _stream(dev)), "bias_norm_act")
     return y
 
 
